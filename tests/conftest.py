@@ -1,0 +1,20 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    """The oracle is test infrastructure: build it (gcc, seconds) before any test uses it."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "build/libpoa_oracle.so"], check=True)
+    yield
