@@ -1,0 +1,109 @@
+"""In-tree build of the native libraries (hipcc for gfx950, no GPU needed).
+
+  genomeworks_amd/lib/libgwhip.so            hand-written HIP kernels + the thin C-ABI (include/gwhip.h)
+  genomeworks_amd/lib/libgenomeworks_amd.so  host C++ (Batch / Aligner, allocator, C API include/gw_capi.h)
+
+Called by __graft_entry__.build(); also usable as `python -m genomeworks_amd.build`.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+LIB = os.path.join(PKG, "lib")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = os.path.join(ROCM, "bin", "hipcc")
+
+KERNEL_SRCS = ["csrc/gwhip_poa.hip", "csrc/gwhip_myers.hip"]
+HOST_SRCS = ["host/capi.cpp", "host/cudapoa_batch.cpp", "host/cudapoa_utils.cpp", "host/cudaaligner.cpp", "host/device_pool.cpp",
+             "host/alignment_impl.cpp", "host/runtime.cpp", "host/logging.cpp"]
+
+# no fast-math, no FMA contraction: band placement is IEEE fp32
+KERNEL_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
+                "-fhip-fp32-correctly-rounded-divide-sqrt"]
+HOST_FLAGS = ["-O2", "-g", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
+              "-D__HIP_PLATFORM_AMD__", "-pthread"]
+
+
+def _digest(paths, extra):
+    h = hashlib.sha256(repr(extra).encode())
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(p.encode())
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _deps(subdir, exts):
+    out = []
+    for base in (os.path.join(PKG, subdir), os.path.join(ROOT, "include")):
+        for d, _, fs in os.walk(base):
+            out += [os.path.join(d, f) for f in fs if f.endswith(exts)]
+    return out
+
+
+def _run(cmd):
+    print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def _stale(target, stamp_value):
+    stamp = target + ".stamp"
+    if not os.path.exists(target) or not os.path.exists(stamp):
+        return True
+    with open(stamp) as f:
+        return f.read().strip() != stamp_value
+
+
+def _mark(target, stamp_value):
+    with open(target + ".stamp", "w") as f:
+        f.write(stamp_value)
+
+
+def build_kernels(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    target = os.path.join(LIB, "libgwhip.so")
+    srcs = [os.path.join(PKG, s) for s in KERNEL_SRCS if os.path.exists(os.path.join(PKG, s))]
+    sig = _digest(_deps("csrc", (".hip", ".h", ".hpp")), KERNEL_FLAGS)
+    if force or _stale(target, sig):
+        objs = []
+        procs = []
+        for s in srcs:
+            o = os.path.join(LIB, os.path.basename(s) + ".o")
+            objs.append(o)
+            cmd = [HIPCC] + KERNEL_FLAGS + ["-I", os.path.join(ROOT, "include"), "-c", s, "-o", o]
+            print("[build]", " ".join(cmd), flush=True)
+            procs.append(subprocess.Popen(cmd))
+        for p in procs:
+            if p.wait() != 0:
+                raise RuntimeError("hipcc failed")
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs)
+        _mark(target, sig)
+    return target
+
+
+def build_host(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    target = os.path.join(LIB, "libgenomeworks_amd.so")
+    srcs = [os.path.join(PKG, s) for s in HOST_SRCS if os.path.exists(os.path.join(PKG, s))]
+    sig = _digest(_deps("host", (".cpp", ".h", ".hpp")), HOST_FLAGS)
+    if force or _stale(target, sig):
+        cmd = ["g++"] + HOST_FLAGS + ["-shared", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROCM, "include"),
+                                     "-o", target] + srcs + [
+            "-L", LIB, "-lgwhip", "-L", os.path.join(ROCM, "lib"), "-lamdhip64",
+            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+        _run(cmd)
+        _mark(target, sig)
+    return target
+
+
+def build_all(force=False):
+    k = build_kernels(force)
+    h = build_host(force)
+    return k, h
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,515 @@
+// gwhip_poa.hip -- kernels and C-ABI launchers of the POA hot path (gfx950 only).
+// Replaces generatePOA() (cudapoa/src/cudapoa_kernels.cuh:544-1076): one wavefront per window builds the
+// graph read by read; a second kernel extracts consensus (or MSA) -- see include/gwhip.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "poa_device.h"
+#include "poa_full_device.h"
+#include "poa_graph_device.h"
+#include "poa_tb_device.h"
+
+namespace gwhip
+{
+
+thread_local std::string g_last_error;
+
+static int fail(hipError_t e, const char* what)
+{
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return (int)e;
+}
+static int fail_msg(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+constexpr int kRingBytes   = 8448;  // LDS ring of recent score rows: 16 rows of a 256-band int16 row (264 x 2 B)
+constexpr int kRowInfoLds  = 3074;  // rows of the LDS row table (covers max_nodes_per_graph <= 3072)
+
+struct KernelArgs
+{
+    gwhip_poa_config cfg;
+    PoaLayout L;
+    int32_t total_windows;
+    const uint8_t* sequences;
+    const int8_t* base_weights;
+    int32_t* sequence_lengths;
+    const gwhip_window_details* window_details;
+    uint8_t* consensus;
+    uint16_t* coverage;
+    uint8_t* msa;
+    uint8_t* workspace;
+    uint8_t* full_scores; // full band: variable-width score regions after the slabs
+    uint64_t* cells;
+};
+
+template <typename IdT>
+__device__ GraphView<IdT> carve_graph(uint8_t* slab, const PoaLayout& L)
+{
+    GraphView<IdT> g;
+    g.nodes                = slab + L.nodes;
+    g.incoming_edge_count  = (uint16_t*)(slab + L.in_cnt);
+    g.outgoing_edge_count  = (uint16_t*)(slab + L.out_cnt);
+    g.node_alignment_count = (uint16_t*)(slab + L.aln_cnt);
+    g.coverage             = (uint16_t*)(slab + L.coverage);
+    g.sorted_poa           = (IdT*)(slab + L.sorted);
+    g.node_id_to_pos       = (IdT*)(slab + L.pos);
+    g.local_cnt            = (uint16_t*)(slab + L.local_cnt);
+    g.incoming_edges       = (IdT*)(slab + L.in_edges);
+    g.incoming_edge_w      = (uint16_t*)(slab + L.in_w);
+    g.outgoing_edges       = (IdT*)(slab + L.out_edges);
+    g.node_alignments      = (IdT*)(slab + L.aligned);
+    g.cons_scores          = (int32_t*)(slab + L.cons_scores);
+    g.cons_pred            = (IdT*)(slab + L.cons_pred);
+    g.marks                = slab + L.marks;
+    g.check                = slab + L.check;
+    g.to_visit             = (IdT*)(slab + L.to_visit);
+    g.out_cov              = (uint16_t*)(slab + L.out_cov);
+    g.out_cov_cnt          = (uint16_t*)(slab + L.out_cov_cnt);
+    g.msa_pos              = (IdT*)(slab + L.msa_pos);
+    g.seq_begin            = (IdT*)(slab + L.seq_begin);
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Graph-build kernel: grid = windows, block = one wavefront.
+// ------------------------------------------------------------------------------------------------
+template <typename ScoreT, typename IdT, typename TraceT, int BM, bool MSA>
+__global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane       = threadIdx.x;
+    const int32_t w      = blockIdx.x;
+    const gwhip_poa_config& c = a.cfg;
+    uint8_t* slab        = a.workspace + (size_t)w * a.L.per_window;
+    GraphView<IdT> g     = carve_graph<IdT>(slab, a.L);
+    const gwhip_window_details wd = a.window_details[w];
+    int32_t* seq_lens    = a.sequence_lengths + wd.seq_len_buffer_offset;
+    const uint8_t* sequence    = a.sequences + wd.seq_starts;
+    const int8_t* base_weights = a.base_weights + wd.seq_starts;
+    uint8_t* consensus   = a.consensus + (size_t)w * c.max_consensus_size;
+    int32_t* alignment_graph = (int32_t*)(slab + a.L.align_graph);
+    int32_t* alignment_read  = (int32_t*)(slab + a.L.align_read);
+
+    // LDS carve: [ring | rowinfo]
+    ScoreT* ring = reinterpret_cast<ScoreT*>(smem);
+    RowInfo<IdT>* rowinfo = (c.max_nodes_per_graph + 2 <= kRowInfoLds && sizeof(IdT) == 2)
+                                ? reinterpret_cast<RowInfo<IdT>*>(smem + kRingBytes)
+                                : reinterpret_cast<RowInfo<IdT>*>(slab + a.L.rowinfo);
+
+    constexpr bool TB = (BM == GWHIP_STATIC_BAND_TRACEBACK || BM == GWHIP_ADAPTIVE_BAND_TRACEBACK);
+    ScoreT* scores;
+    if (BM == GWHIP_FULL_BAND)
+        scores = reinterpret_cast<ScoreT*>(a.full_scores) + (size_t)wd.scores_offset * (size_t)c.max_nodes_per_graph;
+    else
+        scores = reinterpret_cast<ScoreT*>(slab + a.L.scores);
+    TraceT* traceback = TB ? reinterpret_cast<TraceT*>(slab + a.L.trace) : nullptr;
+    const float banded_buffer_size = __fmul_rn((float)c.max_nodes_per_graph, (float)c.matrix_sequence_dimension);
+
+    // ---- backbone from read 0 (cudapoa_kernels.cuh:200-238), lanes in parallel ----
+    const int32_t len0 = seq_lens[0];
+    for (int32_t i = lane; i < len0; i += kWave)
+    {
+        g.nodes[i]                = sequence[i];
+        g.sorted_poa[i]           = (IdT)i;
+        g.node_id_to_pos[i]       = (IdT)i;
+        g.node_alignment_count[i] = 0;
+        g.coverage[i]             = 1;
+        g.outgoing_edge_count[i]  = (i == len0 - 1) ? 0 : 1;
+        if (i < len0 - 1)
+        {
+            g.outgoing_edges[(int64_t)i * kEdges] = (IdT)(i + 1);
+            if (MSA)
+            {
+                g.out_cov[(int64_t)i * kEdges * c.max_sequences_per_poa] = 0;
+                g.out_cov_cnt[(int64_t)i * kEdges]                       = 1;
+            }
+        }
+        if (i == 0)
+        {
+            g.incoming_edge_count[0] = 0;
+            g.incoming_edge_w[0]     = (uint16_t)base_weights[0];
+            if (MSA) g.seq_begin[0] = 0;
+        }
+        else
+        {
+            g.incoming_edges[(int64_t)i * kEdges]  = (IdT)(i - 1);
+            g.incoming_edge_w[(int64_t)i * kEdges] = (uint16_t)(base_weights[i - 1] + base_weights[i]);
+            g.incoming_edge_count[i]               = 1;
+        }
+    }
+    if (lane == 0) consensus[0] = 0;
+    uint64_t cells = 0;
+    int32_t node_count = len0;
+    __syncthreads();
+
+    for (int32_t s = 1; s < (int32_t)wd.num_seqs; s++)
+    {
+        const int32_t seq_len = seq_lens[s];
+        const int32_t adv     = ((s == 1 ? len0 : seq_lens[s - 1]) + 3) & ~3; // :248-249
+        sequence += adv;
+        base_weights += adv;
+
+        if (node_count >= c.max_nodes_per_graph) // :253-265
+        {
+            if (lane == 0) { consensus[0] = kKernelError; consensus[1] = kNodeCountExceeded; }
+            break;
+        }
+        build_rowinfo<IdT>(g, node_count, rowinfo, lane);
+        __syncthreads();
+
+        int32_t alen;
+        if (BM == GWHIP_ADAPTIVE_BAND_TRACEBACK && c.alignment_band_width < kMaxAdaptiveBand)
+        {
+            alen = nw_banded_tb<ScoreT, IdT, TraceT, true>(g, rowinfo, node_count, sequence, seq_len, scores, a.L.scores_elems,
+                                                           traceback, a.L.trace_elems, banded_buffer_size, alignment_graph,
+                                                           alignment_read, c.alignment_band_width, c.max_banded_pred_distance,
+                                                           c.gap_score, c.mismatch_score, c.match_score, 0, cells);
+            if (alen == kShiftLeft || alen == kShiftRight)
+                alen = nw_banded_tb<ScoreT, IdT, TraceT, true>(g, rowinfo, node_count, sequence, seq_len, scores, a.L.scores_elems,
+                                                               traceback, a.L.trace_elems, banded_buffer_size, alignment_graph,
+                                                               alignment_read, c.alignment_band_width, c.max_banded_pred_distance,
+                                                               c.gap_score, c.mismatch_score, c.match_score, alen, cells);
+        }
+        else if (TB)
+        {
+            alen = nw_banded_tb<ScoreT, IdT, TraceT, false>(g, rowinfo, node_count, sequence, seq_len, scores, a.L.scores_elems,
+                                                            traceback, a.L.trace_elems, banded_buffer_size, alignment_graph,
+                                                            alignment_read, c.alignment_band_width, c.max_banded_pred_distance,
+                                                            c.gap_score, c.mismatch_score, c.match_score, 0, cells);
+        }
+        else if (BM == GWHIP_ADAPTIVE_BAND && c.alignment_band_width < kMaxAdaptiveBand)
+        {
+            alen = nw_banded<ScoreT, IdT, true>(g, rowinfo, node_count, sequence, seq_len, scores, ring, kRingBytes,
+                                                banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
+                                                c.gap_score, c.mismatch_score, c.match_score, 0, cells);
+            if (alen == kShiftLeft || alen == kShiftRight)
+                alen = nw_banded<ScoreT, IdT, true>(g, rowinfo, node_count, sequence, seq_len, scores, ring, kRingBytes,
+                                                    banded_buffer_size, alignment_graph, alignment_read,
+                                                    c.alignment_band_width, c.gap_score, c.mismatch_score, c.match_score,
+                                                    alen, cells);
+        }
+        else if (BM == GWHIP_STATIC_BAND || BM == GWHIP_ADAPTIVE_BAND)
+        {
+            alen = nw_banded<ScoreT, IdT, false>(g, rowinfo, node_count, sequence, seq_len, scores, ring, kRingBytes,
+                                                 banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
+                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells);
+        }
+        else
+        {
+            alen = nw_full<ScoreT, IdT>(g, rowinfo, node_count, sequence, seq_len, scores, wd.scores_width, ring, kRingBytes,
+                                        alignment_graph, alignment_read, c.gap_score, c.mismatch_score, c.match_score, cells);
+        }
+        // SizeT alignment_length in the reference: the value is narrowed to SizeT (cudapoa_kernels.cuh:268)
+        alen = (int32_t)(IdT)alen;
+
+        uint8_t err = 0;
+        if (alen == kNwLoopFailed) err = kLoopCountExceeded;
+        else if (alen == kNwAdaptiveStorageFailed) err = kExceededAdaptiveBandedMatrixSize;
+        else if (TB && alen == kNwTracebackBufferFailed) err = kExceededMaximumPredecessorDistance;
+        if (err)
+        {
+            if (lane == 0) { consensus[0] = kKernelError; consensus[1] = err; }
+            break;
+        }
+
+        int32_t status_and_count = 0;
+        if (lane == 0)
+        {
+            int32_t new_count = 0;
+            uint8_t e = add_alignment_to_graph<IdT, MSA>(new_count, g, node_count, alen, alignment_graph, sequence,
+                                                         alignment_read, base_weights, MSA ? g.seq_begin + s : nullptr,
+                                                         (uint16_t)s, (uint32_t)c.max_sequences_per_poa,
+                                                         (uint32_t)c.max_nodes_per_graph);
+            if (e != 0)
+            {
+                consensus[0]     = kKernelError;
+                consensus[1]     = e;
+                status_and_count = -1;
+            }
+            else
+            {
+                seq_lens[0] = new_count; // :506
+                if (c.spoa_accurate)
+                    topsort_racon<IdT>(g, new_count, (int32_t)(uint16_t)c.max_nodes_per_graph); // (uint16_t) cast :519
+                else
+                    topsort_kahn<IdT>(g.sorted_poa, g.node_id_to_pos, new_count, g.incoming_edge_count,
+                                      g.outgoing_edges, g.outgoing_edge_count, g.local_cnt);
+                status_and_count = new_count;
+            }
+        }
+        status_and_count = wave_first(status_and_count);
+        __syncthreads();
+        if (status_and_count < 0) break;
+        node_count = status_and_count;
+    }
+    if (lane == 0 && a.cells) a.cells[w] = cells;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Consensus kernel: one wavefront per window (the reference runs one THREAD per window,
+// cudapoa_generate_consensus.cuh:286-354, 512 per block => 2 blocks for 1024 windows).
+// ------------------------------------------------------------------------------------------------
+template <typename IdT>
+__global__ __launch_bounds__(kWave) void poa_consensus_kernel(KernelArgs a)
+{
+    const int32_t w    = blockIdx.x;
+    const gwhip_poa_config& c = a.cfg;
+    uint8_t* consensus = a.consensus + (size_t)w * c.max_consensus_size;
+    if (consensus[0] == kKernelError) return;
+    uint8_t* slab      = a.workspace + (size_t)w * a.L.per_window;
+    GraphView<IdT> g   = carve_graph<IdT>(slab, a.L);
+    const int32_t n    = a.sequence_lengths[a.window_details[w].seq_len_buffer_offset];
+    if (threadIdx.x == 0)
+        generate_consensus<IdT>(g, n, g.cons_pred, g.cons_scores, consensus, a.coverage + (size_t)w * c.max_consensus_size,
+                                c.max_consensus_size);
+}
+
+// MSA kernel: lane 0 does the racon topsort + column assignment, then one lane per sequence
+// (loops when num_seqs > 64; the reference launches max_sequences_per_poa threads, cudapoa_kernels.cuh:1025-1026).
+template <typename IdT>
+__global__ __launch_bounds__(kWave) void poa_msa_kernel(KernelArgs a)
+{
+    __shared__ int32_t msa_length;
+    const int32_t w    = blockIdx.x;
+    const gwhip_poa_config& c = a.cfg;
+    uint8_t* consensus = a.consensus + (size_t)w * c.max_consensus_size;
+    if (consensus[0] == kKernelError) return;
+    uint8_t* slab      = a.workspace + (size_t)w * a.L.per_window;
+    GraphView<IdT> g   = carve_graph<IdT>(slab, a.L);
+    const gwhip_window_details wd = a.window_details[w];
+    const int32_t n    = a.sequence_lengths[wd.seq_len_buffer_offset];
+    if (threadIdx.x == 0)
+    {
+        // static_cast<SizeT>(max_nodes_per_graph), cudapoa_generate_msa.cuh:196
+        topsort_racon<IdT>(g, n, (int32_t)(IdT)c.max_nodes_per_graph);
+        msa_length = node_id_to_msa_pos<IdT>(g, n);
+        if ((uint32_t)msa_length >= (uint32_t)c.max_consensus_size)
+        {
+            consensus[0] = kKernelError;
+            consensus[1] = kExceededMaximumSequenceSize;
+        }
+    }
+    __syncthreads();
+    if (consensus[0] == kKernelError) return;
+    uint8_t* msa = a.msa + (size_t)w * c.max_sequences_per_poa * c.max_consensus_size;
+    for (int32_t s = threadIdx.x; s < (int32_t)wd.num_seqs; s += kWave)
+        generate_msa_row<IdT>(g, (uint16_t)s, msa, msa_length, (uint32_t)c.max_sequences_per_poa, (uint32_t)c.max_consensus_size);
+}
+
+template <typename IdT>
+__global__ void poa_export_graph_kernel(KernelArgs a, uint8_t* nodes, int32_t* in_edges, uint16_t* in_w, uint16_t* in_cnt,
+                                        int32_t* out_edges, uint16_t* out_cnt)
+{
+    const int32_t w  = blockIdx.x;
+    const int32_t mn = a.cfg.max_nodes_per_graph;
+    uint8_t* slab    = a.workspace + (size_t)w * a.L.per_window;
+    GraphView<IdT> g = carve_graph<IdT>(slab, a.L);
+    const int32_t n  = a.sequence_lengths[a.window_details[w].seq_len_buffer_offset];
+    if (a.consensus[(size_t)w * a.cfg.max_consensus_size] == kKernelError) return;
+    for (int32_t i = threadIdx.x; i < n && i < mn; i += blockDim.x)
+    {
+        nodes[(size_t)w * mn + i] = g.nodes[i];
+        uint16_t ic               = g.incoming_edge_count[i];
+        in_cnt[(size_t)w * mn + i] = ic;
+        for (int32_t e = 0; e < ic && e < kEdges; e++)
+        {
+            in_edges[((size_t)w * mn + i) * kEdges + e] = g.incoming_edges[(int64_t)i * kEdges + e];
+            in_w[((size_t)w * mn + i) * kEdges + e]     = g.incoming_edge_w[(int64_t)i * kEdges + e];
+        }
+        if (out_edges && out_cnt)
+        {
+            uint16_t oc                 = g.outgoing_edge_count[i];
+            out_cnt[(size_t)w * mn + i] = oc;
+            for (int32_t e = 0; e < oc && e < kEdges; e++)
+                out_edges[((size_t)w * mn + i) * kEdges + e] = g.outgoing_edges[(int64_t)i * kEdges + e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side of the C-ABI
+// ------------------------------------------------------------------------------------------------
+static size_t full_score_bytes(const gwhip_poa_config& c, int32_t windows, uint64_t sum_scores_width)
+{
+    if (c.band_mode != GWHIP_FULL_BAND) return 0;
+    uint64_t per_window_width = (uint64_t)((c.max_sequence_size + 1 + kCellsPerLane + 3) & ~3);
+    uint64_t width_sum        = sum_scores_width ? sum_scores_width : per_window_width * (uint64_t)windows;
+    return (size_t)(width_sum * (uint64_t)c.max_nodes_per_graph * (c.score32 ? 4u : 2u)) + 256;
+}
+
+static bool validate(const gwhip_poa_args* args)
+{
+    const gwhip_poa_config& c = args->cfg;
+    if (args->total_windows < 0 || c.max_nodes_per_graph <= 0 || c.max_consensus_size < 2) return false;
+    if (c.band_mode < 0 || c.band_mode > GWHIP_ADAPTIVE_BAND_TRACEBACK) return false;
+    if (c.band_mode != GWHIP_FULL_BAND && (c.alignment_band_width % 128 != 0 || c.alignment_band_width <= 0)) return false;
+    if (!c.size32 && c.max_nodes_per_graph > 32767) return false;
+    return true;
+}
+
+template <typename ScoreT, typename IdT, typename TraceT, bool MSA>
+static hipError_t launch_window_kernel(const KernelArgs& ka, hipStream_t stream)
+{
+    const size_t lds = kRingBytes + (size_t)kRowInfoLds * 8;
+    dim3 grid(ka.total_windows), block(kWave);
+#define GW_LAUNCH(BM)                                                                                              \
+    hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA>), grid, block, lds, stream, ka);           \
+    break;
+    switch (ka.cfg.band_mode)
+    {
+    case GWHIP_FULL_BAND: GW_LAUNCH(GWHIP_FULL_BAND)
+    case GWHIP_STATIC_BAND: GW_LAUNCH(GWHIP_STATIC_BAND)
+    case GWHIP_ADAPTIVE_BAND: GW_LAUNCH(GWHIP_ADAPTIVE_BAND)
+    case GWHIP_STATIC_BAND_TRACEBACK: GW_LAUNCH(GWHIP_STATIC_BAND_TRACEBACK)
+    default: GW_LAUNCH(GWHIP_ADAPTIVE_BAND_TRACEBACK)
+    }
+#undef GW_LAUNCH
+    return hipGetLastError();
+}
+
+template <typename ScoreT, typename IdT, typename TraceT>
+static hipError_t launch_msa_split(const KernelArgs& ka, hipStream_t stream)
+{
+    if (ka.cfg.output_mask & 2) return launch_window_kernel<ScoreT, IdT, TraceT, true>(ka, stream);
+    return launch_window_kernel<ScoreT, IdT, TraceT, false>(ka, stream);
+}
+
+template <typename ScoreT, typename IdT>
+static hipError_t launch_trace_split(const KernelArgs& ka, hipStream_t stream)
+{
+    if (ka.cfg.trace16) return launch_msa_split<ScoreT, IdT, int16_t>(ka, stream);
+    return launch_msa_split<ScoreT, IdT, int8_t>(ka, stream);
+}
+
+static KernelArgs make_kernel_args(const gwhip_poa_args* args)
+{
+    KernelArgs ka{};
+    ka.cfg             = args->cfg;
+    ka.L               = make_poa_layout(args->cfg);
+    ka.total_windows   = args->total_windows;
+    ka.sequences       = args->sequences;
+    ka.base_weights    = args->base_weights;
+    ka.sequence_lengths = args->sequence_lengths;
+    ka.window_details  = args->window_details;
+    ka.consensus       = args->consensus;
+    ka.coverage        = args->coverage;
+    ka.msa             = args->msa;
+    ka.workspace       = (uint8_t*)args->workspace;
+    ka.full_scores     = ka.workspace + (size_t)args->total_windows * ka.L.per_window;
+    ka.cells           = args->cells;
+    return ka;
+}
+
+} // namespace gwhip
+
+using namespace gwhip;
+
+extern "C" {
+
+size_t gwhip_poa_workspace_bytes(const gwhip_poa_config* cfg, int32_t windows, uint64_t sum_scores_width)
+{
+    PoaLayout L = make_poa_layout(*cfg);
+    return (size_t)windows * L.per_window + full_score_bytes(*cfg, windows, sum_scores_width);
+}
+
+void gwhip_poa_bytes_per_window(const gwhip_poa_config* cfg, int64_t* per_poa, int64_t* per_matrix)
+{
+    PoaLayout L      = make_poa_layout(*cfg);
+    const bool tb    = cfg->band_mode == GWHIP_STATIC_BAND_TRACEBACK || cfg->band_mode == GWHIP_ADAPTIVE_BAND_TRACEBACK;
+    int64_t matrix   = (int64_t)cfg->matrix_sequence_dimension * (int64_t)cfg->max_nodes_per_graph *
+                     (tb ? L.trace_bytes : L.score_bytes);
+    if (cfg->band_mode == GWHIP_FULL_BAND)
+    {
+        // worst-case per-window score row: align4(max_sequence_size + 1 + 4) (cudapoa_batch.cuh:502)
+        *per_poa    = (int64_t)L.per_window;
+        *per_matrix = (int64_t)((cfg->max_sequence_size + 1 + kCellsPerLane + 3) & ~3) * (int64_t)cfg->max_nodes_per_graph * L.score_bytes;
+    }
+    else
+    {
+        *per_poa    = (int64_t)L.per_window - matrix;
+        *per_matrix = matrix;
+    }
+    // outputs + inputs the host classes allocate next to the slab
+    *per_poa += (int64_t)cfg->max_consensus_size * 3;
+    if (cfg->output_mask & 2) *per_poa += (int64_t)cfg->max_consensus_size * cfg->max_sequences_per_poa;
+    *per_poa += (int64_t)cfg->max_sequences_per_poa * cfg->max_sequence_size * 2 + (int64_t)cfg->max_sequences_per_poa * 4 + 32;
+}
+
+int gwhip_poa_generate(const gwhip_poa_args* args, gwhip_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!args || !validate(args)) return fail_msg((int)hipErrorInvalidValue, "gwhip_poa_generate: invalid arguments");
+    if (args->total_windows == 0) return 0;
+    KernelArgs ka = make_kernel_args(args);
+    size_t need   = gwhip_poa_workspace_bytes(&args->cfg, args->total_windows, 0);
+    (void)need;
+    if (!args->workspace || ((uintptr_t)args->workspace & 255) != 0)
+        return fail_msg((int)hipErrorInvalidValue, "gwhip_poa_generate: workspace must be 256-byte aligned");
+    hipError_t e;
+    const bool msa = (args->cfg.output_mask & 2) != 0;
+    if (args->cfg.score32)
+        e = args->cfg.size32 ? launch_trace_split<int32_t, int32_t>(ka, stream) : launch_trace_split<int32_t, int16_t>(ka, stream);
+    else
+        e = args->cfg.size32 ? launch_trace_split<int16_t, int32_t>(ka, stream) : launch_trace_split<int16_t, int16_t>(ka, stream);
+    if (e != hipSuccess) return fail(e, "poa_window_kernel launch");
+    if (args->event_after_graph_build)
+    {
+        e = hipEventRecord((hipEvent_t)args->event_after_graph_build, stream);
+        if (e != hipSuccess) return fail(e, "hipEventRecord");
+    }
+    dim3 grid(args->total_windows), block(kWave);
+    if (msa)
+    {
+        if (args->cfg.size32) hipLaunchKernelGGL(poa_msa_kernel<int32_t>, grid, block, 0, stream, ka);
+        else hipLaunchKernelGGL(poa_msa_kernel<int16_t>, grid, block, 0, stream, ka);
+    }
+    else
+    {
+        if (args->cfg.size32) hipLaunchKernelGGL(poa_consensus_kernel<int32_t>, grid, block, 0, stream, ka);
+        else hipLaunchKernelGGL(poa_consensus_kernel<int16_t>, grid, block, 0, stream, ka);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(e, "poa output kernel launch");
+    return 0;
+}
+
+int gwhip_poa_export_graphs(const gwhip_poa_args* args, uint8_t* nodes, int32_t* incoming_edges,
+                            uint16_t* incoming_edge_weights, uint16_t* incoming_edge_count, int32_t* outgoing_edges,
+                            uint16_t* outgoing_edge_count, gwhip_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!args || !validate(args)) return fail_msg((int)hipErrorInvalidValue, "gwhip_poa_export_graphs: invalid arguments");
+    if (args->total_windows == 0) return 0;
+    KernelArgs ka = make_kernel_args(args);
+    dim3 grid(args->total_windows), block(256);
+    if (args->cfg.size32)
+        hipLaunchKernelGGL(poa_export_graph_kernel<int32_t>, grid, block, 0, stream, ka, nodes, incoming_edges,
+                           incoming_edge_weights, incoming_edge_count, outgoing_edges, outgoing_edge_count);
+    else
+        hipLaunchKernelGGL(poa_export_graph_kernel<int16_t>, grid, block, 0, stream, ka, nodes, incoming_edges,
+                           incoming_edge_weights, incoming_edge_count, outgoing_edges, outgoing_edge_count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(e, "poa_export_graph_kernel launch");
+    return 0;
+}
+
+int gwhip_last_error_string(char* buf, size_t len)
+{
+    if (buf && len)
+    {
+        std::strncpy(buf, g_last_error.c_str(), len - 1);
+        buf[len - 1] = 0;
+    }
+    return (int)g_last_error.size();
+}
+
+const char* gwhip_build_arch(void) { return "gfx950"; }
+int gwhip_abi_version(void) { return 1; }
+
+} // extern "C"

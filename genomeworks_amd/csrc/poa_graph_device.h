@@ -1,0 +1,419 @@
+// poa_graph_device.h -- graph merge, topological sorts, consensus and MSA on the device.
+// Semantics per SURVEY.md section 8a rows P5-P8 (reference: cudapoa_add_alignment.cuh:65-285,
+// cudapoa_topsort.cuh:45-197, cudapoa_generate_consensus.cuh:35-283, cudapoa_generate_msa.cuh:35-125).
+// These phases are order-defining (node ids, edge slots, queue order, tie breaks), so the exact
+// sequential order is kept; they run on lane 0 of the window's wavefront.
+#pragma once
+#include "poa_device.h"
+
+namespace gwhip
+{
+
+// addAlignmentToGraph: walks the alignment back to front (= read order).
+template <typename IdT, bool MSA>
+__device__ uint8_t add_alignment_to_graph(int32_t& new_node_count, const GraphView<IdT>& g, int32_t node_count,
+                                          int32_t alignment_length, const int32_t* alignment_graph,
+                                          const uint8_t* read, const int32_t* alignment_read,
+                                          const int8_t* base_weights, IdT* sequence_begin_nodes_ids, uint16_t s,
+                                          uint32_t max_sequences_per_poa, uint32_t max_limit_nodes_per_window)
+{
+    int32_t head_node_id = -1;
+    int32_t curr_node_id = -1;
+    uint16_t prev_weight = 0;
+    for (int32_t pos = alignment_length - 1; pos >= 0; pos--)
+    {
+        int32_t read_pos = alignment_read[pos];
+        if (read_pos == -1) continue;
+        int8_t node_weight    = base_weights[read_pos];
+        uint8_t read_base     = read[read_pos];
+        int32_t graph_node_id = alignment_graph[pos];
+        if (graph_node_id == -1)
+        {
+            curr_node_id = node_count++;
+            if ((uint32_t)node_count >= max_limit_nodes_per_window) return kNodeCountExceeded;
+            g.nodes[curr_node_id]                = read_base;
+            g.outgoing_edge_count[curr_node_id]  = 0;
+            g.incoming_edge_count[curr_node_id]  = 0;
+            g.node_alignment_count[curr_node_id] = 0;
+            g.coverage[curr_node_id]             = 0;
+        }
+        else
+        {
+            uint8_t graph_base = g.nodes[graph_node_id];
+            if (graph_base == read_base)
+                curr_node_id = graph_node_id;
+            else
+            {
+                uint16_t num_aligned    = g.node_alignment_count[graph_node_id];
+                int32_t aligned_node_id = -1;
+                for (int32_t n = 0; n < num_aligned; n++)
+                {
+                    int32_t aid = g.node_alignments[(int64_t)graph_node_id * kAligns + n];
+                    if (g.nodes[aid] == read_base)
+                    {
+                        aligned_node_id = aid;
+                        break;
+                    }
+                }
+                if (aligned_node_id != -1)
+                    curr_node_id = aligned_node_id;
+                else
+                {
+                    curr_node_id = node_count++;
+                    if ((uint32_t)node_count >= max_limit_nodes_per_window) return kNodeCountExceeded;
+                    g.nodes[curr_node_id]                = read_base;
+                    g.outgoing_edge_count[curr_node_id]  = 0;
+                    g.incoming_edge_count[curr_node_id]  = 0;
+                    g.node_alignment_count[curr_node_id] = 0;
+                    g.coverage[curr_node_id]             = 0;
+                    int32_t new_alignments               = 0;
+                    for (int32_t n = 0; n < num_aligned; n++)
+                    {
+                        int32_t aid        = g.node_alignments[(int64_t)graph_node_id * kAligns + n];
+                        uint16_t aid_count = g.node_alignment_count[aid];
+                        g.node_alignments[(int64_t)aid * kAligns + aid_count]               = (IdT)curr_node_id;
+                        g.node_alignment_count[aid]                                         = aid_count + 1;
+                        g.node_alignments[(int64_t)curr_node_id * kAligns + new_alignments] = (IdT)aid;
+                        new_alignments++;
+                    }
+                    g.node_alignments[(int64_t)graph_node_id * kAligns + num_aligned]   = (IdT)curr_node_id;
+                    g.node_alignment_count[graph_node_id]                               = num_aligned + 1;
+                    g.node_alignments[(int64_t)curr_node_id * kAligns + new_alignments] = (IdT)graph_node_id;
+                    new_alignments++;
+                    g.node_alignment_count[curr_node_id] = (uint16_t)new_alignments;
+                }
+            }
+        }
+        if (MSA && read_pos == 0) *sequence_begin_nodes_ids = (IdT)curr_node_id;
+        if (head_node_id != -1)
+        {
+            bool edge_exists  = false;
+            uint16_t in_count = g.incoming_edge_count[curr_node_id];
+            for (int32_t e = 0; e < in_count; e++)
+            {
+                if (g.incoming_edges[(int64_t)curr_node_id * kEdges + e] == head_node_id)
+                {
+                    edge_exists = true;
+                    g.incoming_edge_w[(int64_t)curr_node_id * kEdges + e] += (uint16_t)(prev_weight + node_weight);
+                }
+            }
+            if (!edge_exists)
+            {
+                g.incoming_edges[(int64_t)curr_node_id * kEdges + in_count]  = (IdT)head_node_id;
+                g.incoming_edge_w[(int64_t)curr_node_id * kEdges + in_count] = (uint16_t)(prev_weight + node_weight);
+                g.incoming_edge_count[curr_node_id]                          = in_count + 1;
+                uint16_t out_count                                           = g.outgoing_edge_count[head_node_id];
+                g.outgoing_edges[(int64_t)head_node_id * kEdges + out_count] = (IdT)curr_node_id;
+                if (MSA)
+                {
+                    g.out_cov_cnt[(int64_t)head_node_id * kEdges + out_count] = 1;
+                    g.out_cov[((int64_t)head_node_id * kEdges + out_count) * max_sequences_per_poa] = s;
+                }
+                g.outgoing_edge_count[head_node_id] = out_count + 1;
+                if (out_count + 1 >= kEdges || in_count + 1 >= kEdges) return kEdgeCountExceeded;
+            }
+            else if (MSA)
+            {
+                uint16_t out_count = g.outgoing_edge_count[head_node_id];
+                for (int32_t e = 0; e < out_count; e++)
+                {
+                    if (g.outgoing_edges[(int64_t)head_node_id * kEdges + e] == curr_node_id)
+                    {
+                        uint16_t cc = g.out_cov_cnt[(int64_t)head_node_id * kEdges + e];
+                        g.out_cov[((int64_t)head_node_id * kEdges + e) * max_sequences_per_poa + cc] = s;
+                        g.out_cov_cnt[(int64_t)head_node_id * kEdges + e]                            = cc + 1;
+                        break;
+                    }
+                }
+            }
+        }
+        head_node_id = curr_node_id;
+        g.coverage[head_node_id]++;
+        prev_weight = (uint16_t)node_weight;
+    }
+    new_node_count = node_count;
+    return 0;
+}
+
+// Kahn order: sources by ascending node id, children in outgoing-slot order, queue == output array.
+template <typename IdT>
+__device__ void topsort_kahn(IdT* sorted_poa, IdT* node_map, int32_t node_count, const uint16_t* incoming_edge_count,
+                             const IdT* outgoing_edges, const uint16_t* outgoing_edge_count, uint16_t* local_cnt)
+{
+    int32_t position = 0;
+    for (int32_t n = 0; n < node_count; n++)
+    {
+        uint16_t c   = incoming_edge_count[n];
+        local_cnt[n] = c;
+        if (c == 0)
+        {
+            node_map[n]            = (IdT)position;
+            sorted_poa[position++] = (IdT)n;
+        }
+    }
+    for (int32_t n = 0; n < position; n++)
+    {
+        int32_t node = sorted_poa[n];
+        uint16_t oc  = outgoing_edge_count[node];
+        for (int32_t e = 0; e < oc; e++)
+        {
+            int32_t out_node = outgoing_edges[(int64_t)node * kEdges + e];
+            uint16_t c       = local_cnt[out_node];
+            if (--c == 0)
+            {
+                node_map[out_node]     = (IdT)position;
+                sorted_poa[position++] = (IdT)out_node;
+            }
+            local_cnt[out_node] = c;
+        }
+    }
+}
+
+// racon/spoa DFS order (aligned nodes adjacent)
+template <typename IdT>
+__device__ void topsort_racon(const GraphView<IdT>& g, int32_t node_count, int32_t max_nodes_per_graph)
+{
+    int32_t node_idx   = -1;
+    int32_t sorted_idx = 0;
+    for (int32_t i = 0; i < max_nodes_per_graph; i++)
+    {
+        g.marks[i] = 0;
+        g.check[i] = 1;
+    }
+    for (int32_t i = 0; i < node_count; i++)
+    {
+        if (g.marks[i] != 0) continue;
+        node_idx++;
+        g.to_visit[node_idx] = (IdT)i;
+        while (node_idx != -1)
+        {
+            int32_t node_id = g.to_visit[node_idx];
+            bool valid      = true;
+            if (g.marks[node_id] != 2)
+            {
+                for (int32_t e = 0; e < g.incoming_edge_count[node_id]; e++)
+                {
+                    int32_t begin = g.incoming_edges[(int64_t)node_id * kEdges + e];
+                    if (g.marks[begin] != 2)
+                    {
+                        node_idx++;
+                        g.to_visit[node_idx] = (IdT)begin;
+                        valid                = false;
+                    }
+                }
+                if (g.check[node_id])
+                {
+                    for (int32_t a = 0; a < g.node_alignment_count[node_id]; a++)
+                    {
+                        int32_t aid = g.node_alignments[(int64_t)node_id * kAligns + a];
+                        if (g.marks[aid] != 2)
+                        {
+                            node_idx++;
+                            g.to_visit[node_idx] = (IdT)aid;
+                            g.check[aid]         = 0;
+                            valid                = false;
+                        }
+                    }
+                }
+                if (valid)
+                {
+                    g.marks[node_id] = 2;
+                    if (g.check[node_id])
+                    {
+                        g.sorted_poa[sorted_idx]    = (IdT)node_id;
+                        g.node_id_to_pos[node_id]   = (IdT)sorted_idx;
+                        sorted_idx++;
+                        for (int32_t a = 0; a < g.node_alignment_count[node_id]; a++)
+                        {
+                            int32_t aid              = g.node_alignments[(int64_t)node_id * kAligns + a];
+                            g.sorted_poa[sorted_idx] = (IdT)aid;
+                            g.node_id_to_pos[aid]    = (IdT)sorted_idx;
+                            sorted_idx++;
+                        }
+                    }
+                }
+                else
+                    g.marks[node_id] = 1;
+            }
+            if (valid) node_idx--;
+        }
+    }
+}
+
+// heaviest bundle + branch completion. `scores` has a guard element at index -1.
+template <typename IdT>
+__device__ int32_t branch_completion(int32_t max_score_id_pos, const GraphView<IdT>& g, int32_t node_count,
+                                     int32_t* scores, IdT* predecessors)
+{
+    int32_t node_id    = g.sorted_poa[max_score_id_pos];
+    uint16_t out_edges = g.outgoing_edge_count[node_id];
+    for (int32_t oe = 0; oe < out_edges; oe++)
+    {
+        int32_t out_node_id = g.outgoing_edges[(int64_t)node_id * kEdges + oe];
+        uint16_t in_edges   = g.incoming_edge_count[out_node_id];
+        for (int32_t ie = 0; ie < in_edges; ie++)
+        {
+            int32_t id = g.incoming_edges[(int64_t)out_node_id * kEdges + ie];
+            if (id != node_id) scores[id] = -1;
+        }
+    }
+    int32_t max_score = 0, max_score_id = 0;
+    for (int32_t graph_pos = max_score_id_pos + 1; graph_pos < node_count; graph_pos++)
+    {
+        node_id               = g.sorted_poa[graph_pos];
+        int32_t pred          = -1;
+        int32_t score_node_id = -1;
+        uint16_t in_edges     = g.incoming_edge_count[node_id];
+        for (int32_t e = 0; e < in_edges; e++)
+        {
+            int32_t begin = g.incoming_edges[(int64_t)node_id * kEdges + e];
+            if (scores[begin] == -1) continue;
+            int32_t edge_w = (int32_t)g.incoming_edge_w[(int64_t)node_id * kEdges + e];
+            if (score_node_id < edge_w || (score_node_id == edge_w && scores[pred] <= scores[begin]))
+            {
+                score_node_id = edge_w;
+                pred          = begin;
+            }
+        }
+        predecessors[node_id] = (IdT)pred;
+        if (pred != -1) score_node_id += scores[pred];
+        if (max_score <= score_node_id)
+        {
+            max_score    = score_node_id;
+            max_score_id = node_id;
+        }
+        scores[node_id] = score_node_id;
+    }
+    return max_score_id;
+}
+
+template <typename IdT>
+__device__ void generate_consensus(const GraphView<IdT>& g, int32_t node_count, IdT* predecessors,
+                                   int32_t* scores_base, uint8_t* consensus, uint16_t* coverage,
+                                   int32_t max_limit_consensus_size)
+{
+    int32_t* scores = scores_base + 1;
+    scores[-1]      = -1;
+    int32_t max_score_id = 0, max_score = -1;
+    for (int32_t graph_pos = 0; graph_pos < node_count; graph_pos++)
+    {
+        int32_t node_id       = g.sorted_poa[graph_pos];
+        uint16_t in_edges     = g.incoming_edge_count[node_id];
+        int32_t score_node_id = -1;
+        int32_t pred          = -1;
+        for (int32_t e = 0; e < in_edges; e++)
+        {
+            int32_t edge_w = (int32_t)g.incoming_edge_w[(int64_t)node_id * kEdges + e];
+            int32_t begin  = g.incoming_edges[(int64_t)node_id * kEdges + e];
+            if (score_node_id < edge_w || (score_node_id == edge_w && scores[pred] <= scores[begin]))
+            {
+                score_node_id = edge_w;
+                pred          = begin;
+            }
+        }
+        predecessors[node_id] = (IdT)pred;
+        if (pred != -1) score_node_id += scores[pred];
+        if (max_score <= score_node_id)
+        {
+            max_score_id = node_id;
+            max_score    = score_node_id;
+        }
+        scores[node_id] = score_node_id;
+    }
+    int32_t loop_count = 0;
+    if (g.outgoing_edge_count[max_score_id] != 0)
+    {
+        while (g.outgoing_edge_count[max_score_id] != 0 && loop_count < node_count)
+        {
+            max_score_id = branch_completion<IdT>(g.node_id_to_pos[max_score_id], g, node_count, scores, predecessors);
+            loop_count++;
+        }
+    }
+    if (loop_count >= node_count)
+    {
+        consensus[0] = kKernelError;
+        consensus[1] = kLoopCountExceeded;
+        return;
+    }
+    int32_t consensus_pos = 0, consensus_count = 0;
+    auto cov_of = [&](int32_t id) -> uint16_t {
+        uint16_t cov = g.coverage[id];
+        for (int32_t a = 0; a < g.node_alignment_count[id]; a++)
+            cov = (uint16_t)(cov + g.coverage[g.node_alignments[(int64_t)id * kAligns + a]]);
+        return cov;
+    };
+    while (predecessors[max_score_id] != -1)
+    {
+        consensus[consensus_pos] = g.nodes[max_score_id];
+        coverage[consensus_pos]  = cov_of(max_score_id);
+        max_score_id             = predecessors[max_score_id];
+        consensus_pos            = min(consensus_pos + 1, max_limit_consensus_size - 1);
+        consensus_count++;
+    }
+    consensus[consensus_pos] = g.nodes[max_score_id];
+    coverage[consensus_pos]  = cov_of(max_score_id);
+    if (consensus_count >= (max_limit_consensus_size - 1))
+    {
+        consensus[0] = kKernelError;
+        consensus[1] = kExceededMaximumSequenceSize;
+        return;
+    }
+    consensus_pos++;
+    consensus[consensus_pos] = '\0';
+}
+
+// MSA: column index per node (aligned nodes share a column), then one lane per sequence.
+template <typename IdT>
+__device__ int32_t node_id_to_msa_pos(const GraphView<IdT>& g, int32_t node_count)
+{
+    int32_t msa_pos = 0;
+    for (int32_t rank = 0; rank < node_count; rank++)
+    {
+        int32_t node_id    = g.sorted_poa[rank];
+        g.msa_pos[node_id] = (IdT)msa_pos;
+        uint16_t ac        = g.node_alignment_count[node_id];
+        for (int32_t n = 0; n < ac; n++) g.msa_pos[g.sorted_poa[++rank]] = (IdT)msa_pos;
+        msa_pos++;
+    }
+    return msa_pos;
+}
+
+template <typename IdT>
+__device__ void generate_msa_row(const GraphView<IdT>& g, uint16_t s, uint8_t* msa, int32_t msa_length,
+                                 uint32_t max_sequences_per_poa, uint32_t max_limit_consensus_size)
+{
+    int32_t node_id      = g.seq_begin[s];
+    int32_t filled_until = 0;
+    uint8_t* row         = msa + (size_t)s * max_limit_consensus_size;
+    for (;;)
+    {
+        int32_t msa_pos = g.msa_pos[node_id];
+        row[msa_pos]    = g.nodes[node_id];
+        for (int32_t i = filled_until; i < msa_pos; i++) row[i] = '-';
+        filled_until  = msa_pos + 1;
+        bool end_node = true;
+        for (int32_t n = 0; n < g.outgoing_edge_count[node_id]; n++)
+        {
+            int32_t to_node = g.outgoing_edges[(int64_t)node_id * kEdges + n];
+            uint16_t cc     = g.out_cov_cnt[(int64_t)node_id * kEdges + n];
+            for (int32_t m = 0; m < cc; m++)
+            {
+                if (g.out_cov[((int64_t)node_id * kEdges + n) * max_sequences_per_poa + m] == s)
+                {
+                    end_node = false;
+                    node_id  = to_node;
+                    break;
+                }
+            }
+            if (!end_node) break;
+        }
+        if (end_node)
+        {
+            for (int32_t i = filled_until; i < msa_length; i++) row[i] = '-';
+            break;
+        }
+    }
+    row[msa_length] = '\0';
+}
+
+} // namespace gwhip

@@ -1,0 +1,266 @@
+"""Python mirror of pygenomeworks' genomeworks.cudapoa (cudapoa.pyx:69-334) over the object-level C API.
+
+Same class, method and argument names; status codes are the integers of cudapoa::StatusType. There is no CPU
+path: constructing a batch without the native libraries or without a GPU raises."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from .cuda import CudaStream
+
+# cudapoa::StatusType (cudapoa.hpp:34-49)
+success = 0
+exceeded_maximum_poas = 1
+exceeded_maximum_sequence_size = 2
+exceeded_maximum_sequences_per_poa = 3
+node_count_exceeded_maximum_graph_size = 4
+edge_count_exceeded_maximum_graph_size = 5
+exceeded_adaptive_banded_matrix_size = 6
+exceeded_maximum_predecessor_distance = 7
+loop_count_exceeded_upper_bound = 8
+output_type_unavailable = 9
+zero_weighted_poa_sequence = 10
+empty_poa_group = 11
+generic_error = 12
+
+_STATUS_NAMES = {
+    0: "success", 1: "exceeded_maximum_poas", 2: "exceeded_maximum_sequence_size",
+    3: "exceeded_maximum_sequences_per_poa", 4: "node_count_exceeded_maximum_graph_size",
+    5: "edge_count_exceeded_maximum_graph_size", 6: "exceeded_adaptive_banded_matrix_size",
+    7: "exceeded_maximum_predecessor_distance", 8: "loop_count_exceeded_upper_bound",
+    9: "output_type_unavailable", 10: "zero_weighted_poa_sequence", 11: "empty_poa_group", 12: "generic_error"}
+
+_BAND_MODES = {"full_band": 0, "static_band": 1, "adaptive_band": 2, "static_band_traceback": 3,
+               "adaptive_band_traceback": 4}
+
+
+def status_to_str(status):
+    """Convert status to their string representations (cudapoa.pyx:33-66)."""
+    if status not in _STATUS_NAMES:
+        raise RuntimeError("Unknown error status : " + str(status))
+    return _STATUS_NAMES[status]
+
+
+def _bind(L):
+    if getattr(L, "_gw_poa_bound", False):
+        return L
+    vp, i32 = C.c_void_p, C.c_int32
+    L.gw_poa_batch_config_full.argtypes = [C.POINTER(_native.PoaBatchConfig)] + [i32] * 8
+    L.gw_poa_batch_config_default.argtypes = [C.POINTER(_native.PoaBatchConfig), i32, i32, i32, i32, C.c_float,
+                                              C.c_float, i32]
+    L.gw_poa_create_batch.restype = vp
+    L.gw_poa_create_batch.argtypes = [i32, vp, C.c_int64, C.c_int8, C.POINTER(_native.PoaBatchConfig), C.c_int16,
+                                      C.c_int16, C.c_int16]
+    L.gw_poa_destroy_batch.argtypes = [vp]
+    L.gw_poa_add_poa_group.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]
+    for name in ("gw_poa_get_total_poas", "gw_poa_generate_poa", "gw_poa_batch_id", "gw_poa_reset", "gw_poa_max_poas",
+                 "gw_poa_relaunch"):
+        getattr(L, name).argtypes = [vp]
+    L.gw_poa_get_consensus.argtypes = [vp, C.POINTER(i32)]
+    L.gw_poa_consensus_str.restype = C.POINTER(C.c_char)
+    L.gw_poa_consensus_str.argtypes = [vp, i32, C.POINTER(i32)]
+    L.gw_poa_consensus_coverage.restype = C.POINTER(C.c_uint16)
+    L.gw_poa_consensus_coverage.argtypes = [vp, i32, C.POINTER(i32)]
+    L.gw_poa_output_status.argtypes = [vp, i32]
+    L.gw_poa_get_msa.argtypes = [vp, C.POINTER(i32)]
+    L.gw_poa_msa_rows.argtypes = [vp, i32]
+    L.gw_poa_msa_row.restype = C.POINTER(C.c_char)
+    L.gw_poa_msa_row.argtypes = [vp, i32, i32, C.POINTER(i32)]
+    L.gw_poa_get_graphs.argtypes = [vp, C.POINTER(i32)]
+    L.gw_poa_graph_num_nodes.argtypes = [vp, i32]
+    L.gw_poa_graph_num_edges.argtypes = [vp, i32]
+    L.gw_poa_graph_copy.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.gw_poa_total_cells.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.gw_poa_relaunch_timed.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L._gw_poa_bound = True
+    return L
+
+
+class CudaPoaBatch:
+    """Python API for GPU-accelerated partial order alignment (pygenomeworks CudaPoaBatch)."""
+
+    def __init__(self, max_sequences_per_poa, max_sequence_size, max_gpu_mem, output_type="consensus",
+                 band_mode="adaptive_band", device_id=0, stream=None, gap_score=-8, mismatch_score=-6, match_score=8,
+                 alignment_band_width=256, max_consensus_size=None, max_nodes_per_graph=None,
+                 matrix_sequence_dimension=None, max_banded_pred_distance=None, *args, **kwargs):
+        # unknown keyword arguments are swallowed, as in cudapoa.pyx:87-88 (its tests rely on it)
+        self._L = _bind(_native.host())
+        if stream is not None and not isinstance(stream, CudaStream):
+            raise RuntimeError("Type for stream option must be CudaStream")
+        self.stream = stream
+        if output_type == "consensus":
+            output_mask = 1
+        elif output_type == "msa":
+            output_mask = 2
+        else:
+            raise RuntimeError("Unknown output_type provided. Must be consensus/msa.")
+        if band_mode not in _BAND_MODES:
+            raise RuntimeError("Unknown band_mode provided. Must be full_band/static_band/adaptive_band.")
+        mx_consensus = 2 * max_sequence_size if max_consensus_size is None else max_consensus_size
+        # defaults of cudapoa.pyx:146-160 (4x graph length for the banded modes)
+        if band_mode == "full_band":
+            nodes = 3 * max_sequence_size if max_nodes_per_graph is None else max_nodes_per_graph
+            msd = max_sequence_size if matrix_sequence_dimension is None else matrix_sequence_dimension
+        elif band_mode in ("static_band", "static_band_traceback"):
+            nodes = 4 * max_sequence_size if max_nodes_per_graph is None else max_nodes_per_graph
+            msd = (alignment_band_width + 8) if matrix_sequence_dimension is None else matrix_sequence_dimension
+        else:
+            nodes = 4 * max_sequence_size if max_nodes_per_graph is None else max_nodes_per_graph
+            msd = 2 * (alignment_band_width + 8) if matrix_sequence_dimension is None else matrix_sequence_dimension
+        # cudapoa.pyx passes an uninitialised mx_pred_dist; we use BatchConfig's own default (2 x band width)
+        pred = 2 * ((alignment_band_width + 127) // 128 * 128) if max_banded_pred_distance is None else max_banded_pred_distance
+        cfg = _native.PoaBatchConfig()
+        if self._L.gw_poa_batch_config_full(C.byref(cfg), max_sequence_size, mx_consensus, nodes, alignment_band_width,
+                                            max_sequences_per_poa, msd, _BAND_MODES[band_mode], pred) != 0:
+            raise ValueError(self._L.gw_last_error().decode())
+        self.batch_size = cfg
+        self._h = self._L.gw_poa_create_batch(device_id, stream.stream if stream is not None else None,
+                                              int(max_gpu_mem), output_mask, C.byref(cfg), gap_score, mismatch_score,
+                                              match_score)
+        if not self._h:
+            raise RuntimeError(self._L.gw_last_error().decode())
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.gw_poa_destroy_batch(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def add_poa_group(self, poa, weights=None):
+        """Add one POA group (list of sequences). Returns (status, per-sequence statuses)."""
+        if not isinstance(poa, list):
+            poa = [poa]
+        if len(poa) < 1:
+            raise RuntimeError("At least one sequence must be present in POA group")
+        n = len(poa)
+        raw = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in poa]
+        seqs = (C.c_char_p * n)(*raw)
+        lens = (C.c_int32 * n)(*[len(b) for b in raw])
+        st = (C.c_int32 * n)()
+        wptr, keep = None, []
+        if weights is not None:
+            arr = (C.c_void_p * n)()
+            for i, w in enumerate(weights):
+                if w is None:
+                    arr[i] = None
+                else:
+                    a = np.ascontiguousarray(w, dtype=np.int8)
+                    keep.append(a)
+                    arr[i] = a.ctypes.data
+            wptr = arr
+        status = self._L.gw_poa_add_poa_group(self._h, n, seqs, wptr, lens, st)
+        if status < 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        return (status, list(st) if status not in (exceeded_maximum_poas,) else [])
+
+    @property
+    def total_poas(self):
+        return self._L.gw_poa_get_total_poas(self._h)
+
+    @property
+    def batch_id(self):
+        return self._L.gw_poa_batch_id(self._h)
+
+    @property
+    def max_poas(self):
+        return self._L.gw_poa_max_poas(self._h)
+
+    def generate_poa(self):
+        """Run asynchronous partial order alignment on all POA groups in batch."""
+        if self._L.gw_poa_generate_poa(self._h) != 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+
+    def relaunch(self):
+        """Benchmark helper: run the kernels again on the inputs already resident in HBM."""
+        if self._L.gw_poa_relaunch(self._h) != 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+
+    def relaunch_timed(self):
+        """Benchmark helper: relaunch and return (graph_build_ms, output_ms) from HIP events on the batch stream."""
+        a, b = C.c_float(0), C.c_float(0)
+        if self._L.gw_poa_relaunch_timed(self._h, C.byref(a), C.byref(b)) != 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        return a.value, b.value
+
+    def get_consensus_native(self):
+        """D2H + host unpack inside the library, without marshalling the strings to Python. Returns window count."""
+        n = C.c_int32(0)
+        err = self._L.gw_poa_get_consensus(self._h, C.byref(n))
+        if err != 0:
+            raise RuntimeError("get_consensus failed: %d" % err)
+        return n.value
+
+    def total_cells(self):
+        v = C.c_uint64(0)
+        if self._L.gw_poa_total_cells(self._h, C.byref(v)) != 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        return v.value
+
+    def get_consensus(self):
+        """Returns (consensus strings, per-base coverages, per-group status)."""
+        n = C.c_int32(0)
+        err = self._L.gw_poa_get_consensus(self._h, C.byref(n))
+        if err == output_type_unavailable:
+            raise RuntimeError("Output type not requested during batch initialization")
+        if err < 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        cons, cov, status = [], [], []
+        for i in range(n.value):
+            ln = C.c_int32(0)
+            p = self._L.gw_poa_consensus_str(self._h, i, C.byref(ln))
+            cons.append(C.string_at(p, ln.value).decode("utf-8"))
+            q = self._L.gw_poa_consensus_coverage(self._h, i, C.byref(ln))
+            cov.append([q[k] for k in range(ln.value)])
+            status.append(self._L.gw_poa_output_status(self._h, i))
+        return (cons, cov, status)
+
+    def get_msa(self):
+        """Returns (msa[group][sequence], per-group status)."""
+        n = C.c_int32(0)
+        err = self._L.gw_poa_get_msa(self._h, C.byref(n))
+        if err == output_type_unavailable:
+            raise RuntimeError("Output type not requested during batch initialization")
+        if err < 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        msa, status = [], []
+        for i in range(n.value):
+            rows = []
+            for r in range(self._L.gw_poa_msa_rows(self._h, i)):
+                ln = C.c_int32(0)
+                p = self._L.gw_poa_msa_row(self._h, i, r, C.byref(ln))
+                rows.append(C.string_at(p, ln.value).decode("utf-8"))
+            msa.append(rows)
+            status.append(self._L.gw_poa_output_status(self._h, i))
+        return (msa, status)
+
+    def get_graphs(self):
+        """Returns (networkx.DiGraph per group, per-group status)."""
+        import networkx as nx
+        n = C.c_int32(0)
+        if self._L.gw_poa_get_graphs(self._h, C.byref(n)) != 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        graphs, status = [], []
+        si = 0
+        for i in range(n.value):
+            nn = self._L.gw_poa_graph_num_nodes(self._h, i)
+            ne = self._L.gw_poa_graph_num_edges(self._h, i)
+            labels = np.zeros(max(nn, 1), np.uint8)
+            src = np.zeros(max(ne, 1), np.int32)
+            dst = np.zeros(max(ne, 1), np.int32)
+            w = np.zeros(max(ne, 1), np.int32)
+            self._L.gw_poa_graph_copy(self._h, i, labels.ctypes.data, src.ctypes.data, dst.ctypes.data, w.ctypes.data)
+            g = nx.DiGraph()
+            for e in range(ne):
+                g.add_edge(int(src[e]), int(dst[e]), weight=int(w[e]))
+            nx.set_node_attributes(g, {k: {"label": chr(labels[k])} for k in g.nodes})
+            graphs.append(g)
+            status.append(self._L.gw_poa_output_status(self._h, si) if si < n.value else 0)
+            si += 1
+        return (graphs, status)
+
+    def reset(self):
+        """Reset the batch object. Involves deleting all windows previously assigned to batch object."""
+        self._L.gw_poa_reset(self._h)

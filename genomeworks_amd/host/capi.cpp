@@ -1,0 +1,252 @@
+// capi.cpp -- object-level C-ABI (include/gw_capi.h) over the host C++ classes: what a Cython / ctypes / cgo
+// binding of cudapoa::Batch and cudaaligner::Aligner binds. Exceptions never cross the boundary.
+#include <claraparabricks/genomeworks/cudapoa/batch.hpp>
+#include <claraparabricks/genomeworks/cudapoa/cudapoa.hpp>
+
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/gw_capi.h"
+#include "host_common.hpp"
+#include "poa_batch_impl.hpp"
+
+namespace gw  = claraparabricks::genomeworks;
+namespace poa = claraparabricks::genomeworks::cudapoa;
+
+struct gw_poa_batch
+{
+    std::unique_ptr<poa::Batch> batch;
+    poa::PoaBatch* impl = nullptr;
+    std::vector<std::string> consensus;
+    std::vector<std::vector<uint16_t>> coverage;
+    std::vector<poa::StatusType> status;
+    std::vector<std::vector<std::string>> msa;
+    std::vector<gw::DirectedGraph> graphs;
+    std::vector<std::vector<std::pair<gw::Graph::edge_t, gw::Graph::edge_weight_t>>> graph_edges;
+    std::vector<int32_t> graph_nodes;
+};
+
+#define GW_TRY try {
+#define GW_CATCH(ret)                                                                                                  \
+    }                                                                                                                  \
+    catch (const std::exception& e)                                                                                    \
+    {                                                                                                                  \
+        gwhost::set_last_error(e.what());                                                                              \
+        return ret;                                                                                                    \
+    }                                                                                                                  \
+    catch (...)                                                                                                        \
+    {                                                                                                                  \
+        gwhost::set_last_error("unknown exception");                                                                   \
+        return ret;                                                                                                    \
+    }
+
+static void fill(gw_poa_batch_config* out, const poa::BatchConfig& c)
+{
+    out->max_sequence_size         = c.max_sequence_size;
+    out->max_consensus_size        = c.max_consensus_size;
+    out->max_nodes_per_graph       = c.max_nodes_per_graph;
+    out->matrix_sequence_dimension = c.matrix_sequence_dimension;
+    out->alignment_band_width      = c.alignment_band_width;
+    out->max_sequences_per_poa     = c.max_sequences_per_poa;
+    out->band_mode                 = static_cast<int32_t>(c.band_mode);
+    out->max_banded_pred_distance  = c.max_banded_pred_distance;
+}
+
+extern "C" {
+
+int gw_poa_batch_config_default(gw_poa_batch_config* out, int32_t max_seq_sz, int32_t max_seq_per_poa, int32_t band_width,
+                                int32_t band_mode, float adaptive_storage_factor, float graph_length_factor,
+                                int32_t max_pred_dist)
+{
+    GW_TRY
+    poa::BatchConfig c(max_seq_sz, max_seq_per_poa, band_width, static_cast<poa::BandMode>(band_mode),
+                       adaptive_storage_factor, graph_length_factor, max_pred_dist);
+    fill(out, c);
+    return 0;
+    GW_CATCH(-1)
+}
+
+int gw_poa_batch_config_full(gw_poa_batch_config* out, int32_t max_seq_sz, int32_t max_consensus_sz,
+                             int32_t max_nodes_per_poa, int32_t band_width, int32_t max_seq_per_poa,
+                             int32_t matrix_seq_dim, int32_t band_mode, int32_t max_pred_distance)
+{
+    GW_TRY
+    poa::BatchConfig c(max_seq_sz, max_consensus_sz, max_nodes_per_poa, band_width, max_seq_per_poa, matrix_seq_dim,
+                       static_cast<poa::BandMode>(band_mode), max_pred_distance);
+    fill(out, c);
+    return 0;
+    GW_CATCH(-1)
+}
+
+gw_poa_batch* gw_poa_create_batch(int32_t device_id, void* stream, int64_t max_mem, int8_t output_mask,
+                                  const gw_poa_batch_config* cfg, int16_t gap_score, int16_t mismatch_score,
+                                  int16_t match_score)
+{
+    GW_TRY
+    // the fields were validated when the config was built; rebuild through the explicit ctor
+    poa::BatchConfig c(cfg->max_sequence_size, cfg->max_consensus_size, cfg->max_nodes_per_graph,
+                       cfg->alignment_band_width, cfg->max_sequences_per_poa, cfg->matrix_sequence_dimension,
+                       static_cast<poa::BandMode>(cfg->band_mode), cfg->max_banded_pred_distance);
+    auto h   = std::make_unique<gw_poa_batch>();
+    h->batch = poa::create_batch(device_id, static_cast<cudaStream_t>(stream), max_mem, output_mask, c, gap_score,
+                                 mismatch_score, match_score);
+    h->impl  = dynamic_cast<poa::PoaBatch*>(h->batch.get());
+    return h.release();
+    GW_CATCH(nullptr)
+}
+
+void gw_poa_destroy_batch(gw_poa_batch* b) { delete b; }
+
+int gw_poa_add_poa_group(gw_poa_batch* b, int32_t n, const char* const* seqs, const int8_t* const* weights,
+                         const int32_t* lengths, int32_t* per_seq_status)
+{
+    GW_TRY
+    poa::Group g;
+    g.reserve(static_cast<size_t>(n));
+    for (int32_t i = 0; i < n; i++) g.push_back(poa::Entry{seqs[i], weights ? weights[i] : nullptr, lengths[i]});
+    std::vector<poa::StatusType> st;
+    poa::StatusType r = b->batch->add_poa_group(st, g);
+    if (per_seq_status)
+        for (size_t i = 0; i < st.size() && i < static_cast<size_t>(n); i++) per_seq_status[i] = static_cast<int32_t>(st[i]);
+    return static_cast<int>(r);
+    GW_CATCH(-1)
+}
+
+int32_t gw_poa_get_total_poas(gw_poa_batch* b) { return b->batch->get_total_poas(); }
+int32_t gw_poa_batch_id(gw_poa_batch* b) { return b->batch->batch_id(); }
+int32_t gw_poa_max_poas(gw_poa_batch* b) { return b->impl ? b->impl->max_poas() : -1; }
+
+int gw_poa_generate_poa(gw_poa_batch* b)
+{
+    GW_TRY
+    b->batch->generate_poa();
+    return 0;
+    GW_CATCH(-1)
+}
+
+int gw_poa_reset(gw_poa_batch* b)
+{
+    GW_TRY
+    b->batch->reset();
+    return 0;
+    GW_CATCH(-1)
+}
+
+int gw_poa_get_consensus(gw_poa_batch* b, int32_t* n_out)
+{
+    GW_TRY
+    b->consensus.clear();
+    b->coverage.clear();
+    b->status.clear();
+    poa::StatusType r = b->batch->get_consensus(b->consensus, b->coverage, b->status);
+    if (n_out) *n_out = static_cast<int32_t>(b->consensus.size());
+    return static_cast<int>(r);
+    GW_CATCH(-1)
+}
+
+const char* gw_poa_consensus_str(gw_poa_batch* b, int32_t poa_idx, int32_t* length)
+{
+    const std::string& s = b->consensus.at(static_cast<size_t>(poa_idx));
+    if (length) *length = static_cast<int32_t>(s.size());
+    return s.c_str();
+}
+
+const uint16_t* gw_poa_consensus_coverage(gw_poa_batch* b, int32_t poa_idx, int32_t* length)
+{
+    const auto& v = b->coverage.at(static_cast<size_t>(poa_idx));
+    if (length) *length = static_cast<int32_t>(v.size());
+    return v.data();
+}
+
+int32_t gw_poa_output_status(gw_poa_batch* b, int32_t poa_idx) { return static_cast<int32_t>(b->status.at(static_cast<size_t>(poa_idx))); }
+
+int gw_poa_get_msa(gw_poa_batch* b, int32_t* n_out)
+{
+    GW_TRY
+    b->msa.clear();
+    b->status.clear();
+    poa::StatusType r = b->batch->get_msa(b->msa, b->status);
+    if (n_out) *n_out = static_cast<int32_t>(b->msa.size());
+    return static_cast<int>(r);
+    GW_CATCH(-1)
+}
+
+int32_t gw_poa_msa_rows(gw_poa_batch* b, int32_t poa_idx) { return static_cast<int32_t>(b->msa.at(static_cast<size_t>(poa_idx)).size()); }
+
+const char* gw_poa_msa_row(gw_poa_batch* b, int32_t poa_idx, int32_t row, int32_t* length)
+{
+    const std::string& s = b->msa.at(static_cast<size_t>(poa_idx)).at(static_cast<size_t>(row));
+    if (length) *length = static_cast<int32_t>(s.size());
+    return s.c_str();
+}
+
+int gw_poa_get_graphs(gw_poa_batch* b, int32_t* n_out)
+{
+    GW_TRY
+    b->graphs.clear();
+    b->status.clear();
+    b->batch->get_graphs(b->graphs, b->status);
+    b->graph_edges.clear();
+    b->graph_nodes.clear();
+    for (const auto& g : b->graphs)
+    {
+        b->graph_edges.push_back(g.get_edges());
+        int32_t n = 0;
+        while (!g.get_node_label(n).empty()) n++;
+        b->graph_nodes.push_back(n);
+    }
+    if (n_out) *n_out = static_cast<int32_t>(b->graphs.size());
+    return 0;
+    GW_CATCH(-1)
+}
+
+int32_t gw_poa_graph_num_nodes(gw_poa_batch* b, int32_t poa_idx) { return b->graph_nodes.at(static_cast<size_t>(poa_idx)); }
+int32_t gw_poa_graph_num_edges(gw_poa_batch* b, int32_t poa_idx) { return static_cast<int32_t>(b->graph_edges.at(static_cast<size_t>(poa_idx)).size()); }
+
+int gw_poa_graph_copy(gw_poa_batch* b, int32_t poa_idx, char* node_labels, int32_t* edge_src, int32_t* edge_dst, int32_t* edge_weight)
+{
+    GW_TRY
+    const auto& g = b->graphs.at(static_cast<size_t>(poa_idx));
+    const int32_t n = b->graph_nodes.at(static_cast<size_t>(poa_idx));
+    for (int32_t i = 0; i < n; i++) node_labels[i] = g.get_node_label(i)[0];
+    const auto& e = b->graph_edges.at(static_cast<size_t>(poa_idx));
+    for (size_t i = 0; i < e.size(); i++)
+    {
+        edge_src[i]    = e[i].first.first;
+        edge_dst[i]    = e[i].first.second;
+        edge_weight[i] = e[i].second;
+    }
+    return 0;
+    GW_CATCH(-1)
+}
+
+int gw_poa_total_cells(gw_poa_batch* b, uint64_t* cells)
+{
+    GW_TRY
+    if (!b->impl) return -1;
+    *cells = b->impl->total_cells();
+    return 0;
+    GW_CATCH(-1)
+}
+
+int gw_poa_relaunch(gw_poa_batch* b)
+{
+    GW_TRY
+    if (!b->impl) return -1;
+    b->impl->relaunch_resident();
+    return 0;
+    GW_CATCH(-1)
+}
+
+int gw_poa_relaunch_timed(gw_poa_batch* b, float* graph_build_ms, float* output_ms)
+{
+    GW_TRY
+    if (!b->impl) return -1;
+    b->impl->relaunch_resident_timed(graph_build_ms, output_ms);
+    return 0;
+    GW_CATCH(-1)
+}
+
+} // extern "C"

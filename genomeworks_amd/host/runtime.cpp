@@ -1,0 +1,81 @@
+// runtime.cpp -- device/runtime helpers and synthetic input generators behind include/gw_capi.h.
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <random>
+#include <string>
+
+#include <claraparabricks/genomeworks/utils/genomeutils.hpp>
+
+#include "../../include/gw_capi.h"
+#include "host_common.hpp"
+
+namespace gw = claraparabricks::genomeworks;
+
+extern "C" {
+
+const char* gw_last_error(void) { return gwhost::last_error().c_str(); }
+
+int gw_device_count(int* count) { return (int)hipGetDeviceCount(count); }
+int gw_set_device(int device) { return (int)hipSetDevice(device); }
+int gw_get_device(int* device) { return (int)hipGetDevice(device); }
+int gw_mem_info(size_t* free_bytes, size_t* total_bytes) { return (int)hipMemGetInfo(free_bytes, total_bytes); }
+int gw_stream_create(void** stream) { return (int)hipStreamCreate((hipStream_t*)stream); }
+int gw_stream_sync(void* stream) { return (int)hipStreamSynchronize((hipStream_t)stream); }
+int gw_stream_destroy(void* stream) { return (int)hipStreamDestroy((hipStream_t)stream); }
+
+int64_t gw_generate_window(uint32_t seed, int32_t backbone_len, int32_t n_reads, int32_t max_mut, int32_t max_ins,
+                           int32_t max_del, char* out, int64_t out_cap, int32_t* lens)
+{
+    try
+    {
+        std::minstd_rand rng(seed);
+        const std::string backbone = gw::genomeutils::generate_random_genome(backbone_len, rng);
+        int64_t off                = 0;
+        for (int32_t i = 0; i < n_reads; i++)
+        {
+            const std::string r = (i == 0) ? backbone
+                                           : gw::genomeutils::generate_random_sequence(backbone, rng, max_mut, max_ins, max_del);
+            if (off + (int64_t)r.size() > out_cap) return -1;
+            std::memcpy(out + off, r.data(), r.size());
+            lens[i] = (int32_t)r.size();
+            off += (int64_t)r.size();
+        }
+        return off;
+    }
+    catch (const std::exception& e)
+    {
+        gwhost::set_last_error(e.what());
+        return -2;
+    }
+}
+
+int64_t gw_generate_pairs(uint32_t seed, int32_t n_pairs, int32_t len, int32_t max_mut, int32_t max_ins,
+                          int32_t max_del, char* out, int64_t out_cap, int32_t* qlens, int32_t* tlens)
+{
+    try
+    {
+        std::minstd_rand rng(seed);
+        int64_t off = 0;
+        for (int32_t i = 0; i < n_pairs; i++)
+        {
+            const std::string q = gw::genomeutils::generate_random_genome(len, rng);
+            const std::string t = gw::genomeutils::generate_random_sequence(q, rng, max_mut, max_ins, max_del);
+            if (off + (int64_t)(q.size() + t.size()) > out_cap) return -1;
+            std::memcpy(out + off, q.data(), q.size());
+            off += (int64_t)q.size();
+            std::memcpy(out + off, t.data(), t.size());
+            off += (int64_t)t.size();
+            qlens[i] = (int32_t)q.size();
+            tlens[i] = (int32_t)t.size();
+        }
+        return off;
+    }
+    catch (const std::exception& e)
+    {
+        gwhost::set_last_error(e.what());
+        return -2;
+    }
+}
+
+} // extern "C"

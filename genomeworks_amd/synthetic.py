@@ -1,0 +1,44 @@
+"""Seeded synthetic inputs with the reference generator's semantics (genomeutils.hpp:32-127), via the host library."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+
+
+def generate_window(seed, backbone_len=960, n_reads=32, max_mut=48, max_ins=24, max_del=24):
+    """One POA window: backbone + (n_reads-1) mutated copies, std::minstd_rand(seed). Returns list[bytes]."""
+    cap = (backbone_len + max_ins + 8) * n_reads
+    buf = np.zeros(cap, np.uint8)
+    lens = np.zeros(n_reads, np.int32)
+    n = _native.host().gw_generate_window(seed, backbone_len, n_reads, max_mut, max_ins, max_del,
+                                          buf.ctypes.data, cap, lens.ctypes.data)
+    if n < 0:
+        raise RuntimeError("gw_generate_window failed: %d" % n)
+    out, off = [], 0
+    for l in lens:
+        out.append(bytes(buf[off:off + l]))
+        off += int(l)
+    return out
+
+
+def config3_windows(n_windows=1024, first_seed=1000):
+    """window w uses seed 1000+w, backbone 960, 32 reads, <=48 subs / 24 ins / 24 dels."""
+    return [generate_window(first_seed + w) for w in range(n_windows)]
+
+
+def generate_pairs(seed, n_pairs, length, max_mut, max_ins, max_del):
+    cap = n_pairs * (2 * length + max_ins + 8)
+    buf = np.zeros(cap, np.uint8)
+    ql = np.zeros(n_pairs, np.int32)
+    tl = np.zeros(n_pairs, np.int32)
+    n = _native.host().gw_generate_pairs(seed, n_pairs, length, max_mut, max_ins, max_del, buf.ctypes.data, cap,
+                                         ql.ctypes.data, tl.ctypes.data)
+    if n < 0:
+        raise RuntimeError("gw_generate_pairs failed: %d" % n)
+    out, off = [], 0
+    for a, b in zip(ql, tl):
+        q = bytes(buf[off:off + a]); off += int(a)
+        t = bytes(buf[off:off + b]); off += int(b)
+        out.append((q, t))
+    return out

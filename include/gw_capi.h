@@ -1,0 +1,134 @@
+/*
+ * gw_capi.h -- object-level C-ABI over the host C++ classes (libgenomeworks_amd.so).
+ *
+ * These are the entry points a foreign-function binding of the reference's public API binds:
+ * the reference exposes cudapoa::Batch / cudaaligner::Aligner to Python through Cython
+ * (pygenomeworks/genomeworks/cudapoa/cudapoa.pxd:36-110, cudaaligner/cudaaligner.pxd:36-100);
+ * every function here flattens one method of those classes (same argument meaning, same status codes).
+ * Plain pointers and sizes only; strings are returned through caller-provided buffers or
+ * library-owned buffers that stay valid until the next call on the same handle.
+ */
+#ifndef GW_CAPI_H
+#define GW_CAPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gw_poa_batch gw_poa_batch;
+typedef struct gw_aligner gw_aligner;
+
+/* last error (exception text) of the calling thread */
+const char* gw_last_error(void);
+
+/* ---- device / runtime helpers (pygenomeworks/genomeworks/cuda/cuda.pyx) ---- */
+int gw_device_count(int* count);
+int gw_set_device(int device);
+int gw_get_device(int* device);
+int gw_mem_info(size_t* free_bytes, size_t* total_bytes);
+int gw_stream_create(void** stream);
+int gw_stream_sync(void* stream);
+int gw_stream_destroy(void* stream);
+
+/* ---- synthetic inputs (genomeutils.hpp:32-127 semantics; std::minstd_rand(seed)) ---- */
+/* Window = backbone of `backbone_len` random ACGT + (n_reads-1) x generate_random_sequence(backbone, rng,
+   max_mut, max_ins, max_del). Reads are written back to back (no padding) into `out` (capacity out_cap),
+   lengths into lens[n_reads]. Returns total bytes written, or -1 if out_cap is too small. */
+int64_t gw_generate_window(uint32_t seed, int32_t backbone_len, int32_t n_reads, int32_t max_mut, int32_t max_ins,
+                           int32_t max_del, char* out, int64_t out_cap, int32_t* lens);
+/* Aligner pair: query = random genome of `len`; target = generate_random_sequence(query, rng, mut, ins, del);
+   one rng stream (seeded once per call with `seed`) across `n_pairs` pairs, as cudaaligner/benchmarks/main.cpp:116-127. */
+int64_t gw_generate_pairs(uint32_t seed, int32_t n_pairs, int32_t len, int32_t max_mut, int32_t max_ins,
+                          int32_t max_del, char* out, int64_t out_cap, int32_t* qlens, int32_t* tlens);
+
+/* ---- cudapoa::BatchConfig (batch.hpp:60-86, batch.cu:34-104) ---- */
+typedef struct gw_poa_batch_config
+{
+    int32_t max_sequence_size;
+    int32_t max_consensus_size;
+    int32_t max_nodes_per_graph;
+    int32_t matrix_sequence_dimension;
+    int32_t alignment_band_width;
+    int32_t max_sequences_per_poa;
+    int32_t band_mode;
+    int32_t max_banded_pred_distance;
+} gw_poa_batch_config;
+
+/* BatchConfig(max_seq_sz, max_seq_per_poa, band_width, banding, adaptive_storage_factor, graph_length_factor, max_pred_dist) */
+int gw_poa_batch_config_default(gw_poa_batch_config* out, int32_t max_seq_sz, int32_t max_seq_per_poa,
+                                int32_t band_width, int32_t band_mode, float adaptive_storage_factor,
+                                float graph_length_factor, int32_t max_pred_dist);
+/* BatchConfig(max_seq_sz, max_consensus_sz, max_nodes_per_poa, band_width, max_seq_per_poa, matrix_seq_dim, banding, max_pred_distance) */
+int gw_poa_batch_config_full(gw_poa_batch_config* out, int32_t max_seq_sz, int32_t max_consensus_sz,
+                             int32_t max_nodes_per_poa, int32_t band_width, int32_t max_seq_per_poa,
+                             int32_t matrix_seq_dim, int32_t band_mode, int32_t max_pred_distance);
+
+/* create_batch(device_id, stream, max_mem, output_mask, batch_size, gap, mismatch, match)  batch.hpp:194-204.
+   Returns NULL on exception (see gw_last_error). */
+gw_poa_batch* gw_poa_create_batch(int32_t device_id, void* stream, int64_t max_mem, int8_t output_mask,
+                                  const gw_poa_batch_config* cfg, int16_t gap_score, int16_t mismatch_score,
+                                  int16_t match_score);
+void gw_poa_destroy_batch(gw_poa_batch* b);
+
+/* Batch::add_poa_group: seqs[n] pointers, weights[n] pointers (entries or the array itself may be NULL),
+   lengths[n]; per_seq_status[n] receives the per-entry StatusType. Returns the group StatusType, -1 on exception. */
+int gw_poa_add_poa_group(gw_poa_batch* b, int32_t n, const char* const* seqs, const int8_t* const* weights,
+                         const int32_t* lengths, int32_t* per_seq_status);
+int32_t gw_poa_get_total_poas(gw_poa_batch* b);
+int gw_poa_generate_poa(gw_poa_batch* b);
+int32_t gw_poa_batch_id(gw_poa_batch* b);
+int gw_poa_reset(gw_poa_batch* b);
+int32_t gw_poa_max_poas(gw_poa_batch* b);
+
+/* Batch::get_consensus: runs the D2H copy + un-reversal; results stay owned by the handle.
+   Returns the StatusType of the call (output_type_unavailable = 9), -1 on exception. */
+int gw_poa_get_consensus(gw_poa_batch* b, int32_t* n_out);
+const char* gw_poa_consensus_str(gw_poa_batch* b, int32_t poa, int32_t* length);
+const uint16_t* gw_poa_consensus_coverage(gw_poa_batch* b, int32_t poa, int32_t* length);
+int32_t gw_poa_output_status(gw_poa_batch* b, int32_t poa);
+
+/* Batch::get_msa */
+int gw_poa_get_msa(gw_poa_batch* b, int32_t* n_out);
+int32_t gw_poa_msa_rows(gw_poa_batch* b, int32_t poa);
+const char* gw_poa_msa_row(gw_poa_batch* b, int32_t poa, int32_t row, int32_t* length);
+
+/* Batch::get_graphs: per window node labels + (src, sink, weight) triples */
+int gw_poa_get_graphs(gw_poa_batch* b, int32_t* n_out);
+int32_t gw_poa_graph_num_nodes(gw_poa_batch* b, int32_t poa);
+int32_t gw_poa_graph_num_edges(gw_poa_batch* b, int32_t poa);
+int gw_poa_graph_copy(gw_poa_batch* b, int32_t poa, char* node_labels, int32_t* edge_src, int32_t* edge_dst,
+                      int32_t* edge_weight);
+
+/* timing / accounting helpers for bench.py: device cell counters of the last generate_poa() */
+int gw_poa_total_cells(gw_poa_batch* b, uint64_t* cells);
+/* device pointers + args of the last generate_poa (so a benchmark can re-launch with inputs resident in HBM) */
+int gw_poa_relaunch(gw_poa_batch* b);
+/* same, timed with HIP events on the batch's stream (ms): graph-build kernel, then consensus/MSA kernel */
+int gw_poa_relaunch_timed(gw_poa_batch* b, float* graph_build_ms, float* output_ms);
+
+/* ---- cudaaligner (aligner.hpp:76-219) ---- */
+gw_aligner* gw_aligner_create_banded(int32_t max_bandwidth, void* stream, int32_t device_id, int64_t max_device_memory);
+gw_aligner* gw_aligner_create(int32_t max_query_length, int32_t max_target_length, int32_t max_alignments,
+                              void* stream, int32_t device_id, int64_t max_device_memory);
+void gw_aligner_destroy(gw_aligner* a);
+int gw_aligner_add_alignment(gw_aligner* a, const char* query, int32_t query_length, const char* target,
+                             int32_t target_length, int reverse_complement_query, int reverse_complement_target);
+int gw_aligner_align_all(gw_aligner* a);
+int gw_aligner_sync_alignments(gw_aligner* a);
+int32_t gw_aligner_num_alignments(gw_aligner* a);
+int gw_aligner_reset(gw_aligner* a);
+/* Alignment accessors (alignment.hpp:37-112) */
+int32_t gw_alignment_status(gw_aligner* a, int32_t i);
+int32_t gw_alignment_is_optimal(gw_aligner* a, int32_t i);
+int32_t gw_alignment_edit_distance(gw_aligner* a, int32_t i);
+const char* gw_alignment_cigar(gw_aligner* a, int32_t i, int32_t extended, int32_t* length);
+int32_t gw_alignment_states(gw_aligner* a, int32_t i, int8_t* out, int32_t cap);
+int gw_aligner_relaunch(gw_aligner* a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,191 @@
+/*
+ * gwhip.h -- the thin C-ABI between host C++ (Batch / Aligner implementations, bindings, tests) and the
+ * hand-written gfx950 HIP kernels (libgwhip.so). This is the ONLY way hipcc-compiled device code is entered.
+ *
+ * Every entry point is extern "C", takes plain pointers and sizes (device pointers unless noted), returns a
+ * hipError_t as int (0 = success), never throws, launches asynchronously on the given stream and is
+ * re-entrant from multiple host threads. The caller owns all memory.
+ *
+ * Reference seams replaced (paths relative to /root/reference):
+ *   gwhip_poa_generate          <- generatePOA(...)              cudapoa/src/cudapoa_kernels.cuh:544-1076
+ *                                  (generatePOAKernel :76-542 + generateConsensusKernel / generateMSAKernel)
+ *   gwhip_poa_export_graphs     <- the device arrays CudapoaBatch::get_graphs copies back
+ *                                  cudapoa/src/cudapoa_batch.cuh:315-393
+ *   gwhip_poa_test_*            <- runNW / runNWbanded / runNWbandedTB / runTopSort / addAlignment /
+ *                                  generateConsensusTestHost  (cudapoa_nw.cuh:499, cudapoa_nw_banded.cuh:608,
+ *                                  cudapoa_nw_tb_banded.cuh:727, cudapoa_topsort.cuh:220,
+ *                                  cudapoa_add_alignment.cuh:335, cudapoa_generate_consensus.cuh:395)
+ *   gwhip_myers_banded          <- myers_banded_gpu(...)         cudaaligner/src/myers_gpu.cuh:55-74
+ *   gwhip_myers_banded_workspace<- AlignerGlobalMyersBanded workspace sizing
+ *                                  cudaaligner/src/aligner_global_myers_banded.cpp:318-360
+ */
+#ifndef GWHIP_H
+#define GWHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gwhip_stream_t; /* hipStream_t */
+
+#define GWHIP_MAX_NODE_EDGES 50      /* cudapoa_structs.cuh:24 */
+#define GWHIP_MAX_NODE_ALIGNMENTS 50 /* cudapoa_structs.cuh:27 */
+
+/* cudapoa.hpp:68-75 */
+enum gwhip_band_mode
+{
+    GWHIP_FULL_BAND = 0,
+    GWHIP_STATIC_BAND,
+    GWHIP_ADAPTIVE_BAND,
+    GWHIP_STATIC_BAND_TRACEBACK,
+    GWHIP_ADAPTIVE_BAND_TRACEBACK
+};
+
+/* WindowDetails, cudapoa_structs.cuh:70-87 (same fields; 32 bytes) */
+typedef struct gwhip_window_details
+{
+    uint16_t num_seqs;
+    int32_t seq_len_buffer_offset;
+    int32_t seq_starts;
+    uint64_t scores_offset;
+    int32_t scores_width;
+} gwhip_window_details;
+
+/* BatchConfig (batch.hpp:60-86) + scores + output mask + the type selection of cudapoa_limits.hpp:34-59 */
+typedef struct gwhip_poa_config
+{
+    int32_t max_sequence_size;
+    int32_t max_consensus_size;
+    int32_t max_nodes_per_graph;
+    int32_t matrix_sequence_dimension;
+    int32_t alignment_band_width;
+    int32_t max_sequences_per_poa;
+    int32_t band_mode;
+    int32_t max_banded_pred_distance;
+    int32_t gap_score, mismatch_score, match_score;
+    int32_t output_mask;   /* 1 consensus, 2 msa (cudapoa.hpp:81-85) */
+    int32_t score32;       /* ScoreT int32 (else int16) */
+    int32_t size32;        /* SizeT  int32 (else int16) */
+    int32_t trace16;       /* TraceT int16 (else int8) */
+    int32_t spoa_accurate; /* racon topsort inside the graph build (reference build flag SPOA_ACCURATE) */
+} gwhip_poa_config;
+
+typedef struct gwhip_poa_args
+{
+    gwhip_poa_config cfg;
+    int32_t total_windows;
+    /* inputs, device resident (the four arrays CudapoaBatch::generate_poa uploads, cudapoa_batch.cuh:171-178).
+       `sequences` / `base_weights` must be followed by >= 2048 readable zero bytes. */
+    const uint8_t* sequences;
+    const int8_t* base_weights;
+    int32_t* sequence_lengths; /* [sum num_seqs]; element [seq_len_buffer_offset] of each window is overwritten
+                                  with the final node count (cudapoa_kernels.cuh:506) */
+    const gwhip_window_details* window_details;
+    /* outputs, device: consensus[total_windows*max_consensus_size] (reversed, NUL terminated; [0]==0xFF =>
+       [1] is the StatusType), coverage likewise (uint16), msa[total_windows*max_seqs*max_consensus_size] */
+    uint8_t* consensus;
+    uint16_t* coverage;
+    uint8_t* msa;
+    /* opaque scratch of gwhip_poa_workspace_bytes() bytes, 256-byte aligned; graphs live here afterwards */
+    void* workspace;
+    size_t workspace_bytes;
+    /* optional: per-window DP cell counter (sum over reads of rows x band cells), uint64[total_windows] */
+    uint64_t* cells;
+    /* optional hipEvent_t recorded on `stream` between the graph-build kernel and the consensus/MSA kernel,
+       so a caller can time the dominant kernel with events on the launch stream */
+    void* event_after_graph_build;
+} gwhip_poa_args;
+
+/* Bytes of scratch needed for `windows` windows under cfg (host function, no GPU needed).
+   full band uses sum_scores_width = sum over windows of the per-window score row width (cudapoa_batch.cuh:502-507);
+   pass 0 to size for the worst case. */
+size_t gwhip_poa_workspace_bytes(const gwhip_poa_config* cfg, int32_t windows, uint64_t sum_scores_width);
+
+/* Device bytes per window excluding the score/trace matrix, and bytes of the matrix: the two terms of
+   max_poas = avail / (per_poa + matrix) (allocate_block.hpp:75-89), for OUR layout. Host function. */
+void gwhip_poa_bytes_per_window(const gwhip_poa_config* cfg, int64_t* per_poa, int64_t* per_matrix);
+
+int gwhip_poa_generate(const gwhip_poa_args* args, gwhip_stream_t stream);
+
+/* Export graphs in the reference's device layout for get_graphs: nodes u8[W*max_nodes],
+   incoming_edges int32[W*max_nodes*50], incoming_edge_weights u16[same], incoming_edge_count u16[W*max_nodes],
+   outgoing_edges int32[W*max_nodes*50] (may be NULL), outgoing_edge_count u16 (may be NULL). */
+int gwhip_poa_export_graphs(const gwhip_poa_args* args, uint8_t* nodes, int32_t* incoming_edges,
+                            uint16_t* incoming_edge_weights, uint16_t* incoming_edge_count, int32_t* outgoing_edges,
+                            uint16_t* outgoing_edge_count, gwhip_stream_t stream);
+
+/* ---- unit hooks (device pointers, reference array layout with SizeT=int32, 50 slots per node) ---- */
+typedef struct gwhip_poa_test_graph
+{
+    const uint8_t* nodes;
+    const int32_t* graph;          /* sorted_poa */
+    const int32_t* node_id_to_pos;
+    int32_t graph_count;
+    const uint16_t* incoming_edge_count;
+    const int32_t* incoming_edges;
+    const uint16_t* outgoing_edge_count;
+    const int32_t* outgoing_edges; /* only topsort needs it */
+} gwhip_poa_test_graph;
+
+/* mode: gwhip_band_mode. Outputs alignment_graph/alignment_read (int32, >= graph_count+read_length+2 entries)
+   and *aligned_nodes (device int32). scratch = gwhip_poa_test_nw_scratch_bytes(). */
+size_t gwhip_poa_test_nw_scratch_bytes(const gwhip_poa_config* cfg);
+int gwhip_poa_test_nw(const gwhip_poa_config* cfg, const gwhip_poa_test_graph* g, const uint8_t* read,
+                      int32_t read_length, void* scratch, int32_t* alignment_graph, int32_t* alignment_read,
+                      int32_t* aligned_nodes, gwhip_stream_t stream);
+int gwhip_poa_test_topsort(int32_t* sorted_poa, int32_t* node_id_to_pos, int32_t node_count,
+                           const uint16_t* incoming_edge_count, const int32_t* outgoing_edges,
+                           const uint16_t* outgoing_edge_count, uint16_t* local_incoming_edge_count,
+                           gwhip_stream_t stream);
+int gwhip_poa_test_add_alignment(uint8_t* nodes, int32_t* node_count, int32_t* node_alignments,
+                                 uint16_t* node_alignment_count, int32_t* incoming_edges,
+                                 uint16_t* incoming_edge_count, int32_t* outgoing_edges,
+                                 uint16_t* outgoing_edge_count, uint16_t* incoming_edge_w, int32_t alignment_length,
+                                 const int32_t* alignment_graph, const uint8_t* read, const int32_t* alignment_read,
+                                 uint16_t* node_coverage_counts, const int8_t* base_weights,
+                                 int32_t max_nodes_per_graph, int32_t* status, gwhip_stream_t stream);
+int gwhip_poa_test_consensus(const uint8_t* nodes, int32_t node_count, const int32_t* graph,
+                             const int32_t* node_id_to_pos, const int32_t* incoming_edges,
+                             const uint16_t* incoming_edge_count, const int32_t* outgoing_edges,
+                             const uint16_t* outgoing_edge_count, const uint16_t* incoming_edge_w,
+                             int32_t* predecessors, int32_t* scores, uint8_t* consensus, uint16_t* coverage,
+                             const uint16_t* node_coverage_counts, const int32_t* node_alignments,
+                             const uint16_t* node_alignment_count, int32_t max_consensus_size,
+                             gwhip_stream_t stream);
+
+/* ---- cudaaligner: banded Myers ---- */
+typedef struct gwhip_myers_args
+{
+    int32_t n_alignments;
+    const char* sequences;          /* concatenated: q0 t0 q1 t1 ... (aligner_global_myers_banded.cpp:226-232) */
+    const int64_t* sequence_starts; /* [2n+1] */
+    const int32_t* max_bandwidths;  /* [n] */
+    /* outputs (myers_gpu.cuh:55-74 contract): run-length encoded, reversed per alignment */
+    int8_t* results;        /* ops, packed */
+    int32_t* result_counts; /* run lengths, packed */
+    int32_t* result_starts; /* [n+1] offsets into results (start of alignment i; [n] = total) */
+    uint32_t* result_metadata; /* [n] bit31 = optimal, bits 0-26 = alignment index; entry i belongs to
+                                  result_starts[i] (we keep index order, which the contract leaves unspecified) */
+    int64_t results_capacity;  /* entries available in results / result_counts */
+    void* workspace;
+    size_t workspace_bytes;
+} gwhip_myers_args;
+
+size_t gwhip_myers_banded_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host,
+                                          const int32_t* max_bandwidths_host);
+int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream);
+
+/* ---- misc ---- */
+/* Copies the last error text of the calling thread (NUL terminated) and returns its length. */
+int gwhip_last_error_string(char* buf, size_t len);
+/* Compile-time facts a test can assert without a GPU. */
+const char* gwhip_build_arch(void); /* "gfx950" */
+int gwhip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

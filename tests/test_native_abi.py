@@ -1,0 +1,85 @@
+"""CPU-side checks: the C-ABI libraries load and export every symbol the headers declare (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header, prefix):
+    with open(os.path.join(ROOT, "include", header)) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def libs():
+    from genomeworks_amd import build as gb
+    gb.build_all()
+    from genomeworks_amd import _native
+    return _native.gwhip(), _native.host()
+
+
+def test_gwhip_exports_every_declared_symbol(libs):
+    gwhip, _ = libs
+    names = declared("gwhip.h", "gwhip_")
+    assert len(names) >= 7
+    missing = [n for n in names if not hasattr(gwhip, n)]
+    assert not missing, missing
+
+
+def test_host_exports_every_declared_symbol(libs):
+    _, host = libs
+    names = declared("gw_capi.h", "gw_")
+    missing = [n for n in names if not hasattr(host, n)]
+    assert not missing, missing
+
+
+def test_build_arch_is_gfx950(libs):
+    gwhip, _ = libs
+    assert gwhip.gwhip_build_arch() == b"gfx950"
+    assert gwhip.gwhip_abi_version() >= 1
+
+
+def test_workspace_sizing_matches_survey_scale(libs):
+    # config 3: <int16,int16,int16>, 3072 nodes, msd 264; host-only sizing function
+    from genomeworks_amd import _native
+    gwhip, _ = libs
+    c = _native.PoaConfig(1024, 2048, 3072, 264, 256, 32, 1, 512, -8, -6, 8, 1, 0, 0, 1, 0)
+    per_poa, per_matrix = C.c_int64(0), C.c_int64(0)
+    gwhip.gwhip_poa_bytes_per_window(C.byref(c), C.byref(per_poa), C.byref(per_matrix))
+    assert per_matrix.value == 3072 * 264 * 2
+    one = gwhip.gwhip_poa_workspace_bytes(C.byref(c), 1, 0)
+    assert gwhip.gwhip_poa_workspace_bytes(C.byref(c), 1024, 0) == 1024 * one
+    assert 2.0e6 < one < 4.5e6  # ~3 MB per window, as the reference's own carving
+
+
+def test_batch_config_math_matches_reference(libs):
+    # batch.cu:34-70: BatchConfig(1024, 32, 256, static_band) -> 3072 nodes, msd 264, consensus 2048, pred 512
+    from genomeworks_amd import _native, cudapoa
+    _, host = libs
+    cudapoa._bind(host)
+    cfg = _native.PoaBatchConfig()
+    assert host.gw_poa_batch_config_default(C.byref(cfg), 1024, 32, 256, 1, 2.0, 3.0, 0) == 0
+    assert (cfg.max_nodes_per_graph, cfg.matrix_sequence_dimension, cfg.max_consensus_size,
+            cfg.max_banded_pred_distance, cfg.alignment_band_width) == (3072, 264, 2048, 512, 256)
+    assert host.gw_poa_batch_config_default(C.byref(cfg), 1024, 100, 200, 0, 2.0, 3.0, 0) == 0  # BM_SingleBatchTest
+    assert (cfg.alignment_band_width, cfg.matrix_sequence_dimension) == (256, 1024)
+    assert host.gw_poa_batch_config_default(C.byref(cfg), 32768, 32, 256, 2, 2.0, 3.0, 0) == 0  # config 4
+    assert (cfg.max_nodes_per_graph, cfg.matrix_sequence_dimension) == (98304, 528)
+    # explicit ctor validation (batch.cu:88-98)
+    assert host.gw_poa_batch_config_full(C.byref(cfg), 1024, 512, 3072, 256, 10, 264, 1, 512) == -1
+    assert b"max_consensus_size" in host.gw_last_error()
+
+
+def test_synthetic_generator_is_seed_stable(libs):
+    from genomeworks_amd import synthetic
+    a = synthetic.generate_window(1000)
+    b = synthetic.generate_window(1000)
+    c = synthetic.generate_window(1001)
+    assert a == b and a != c
+    assert len(a) == 32 and len(a[0]) == 960 and all(900 <= len(r) <= 984 for r in a)
+    assert set(b"".join(a)) <= set(b"ACGT")
