@@ -555,7 +555,14 @@ void PoaBatch::get_graphs(std::vector<DirectedGraph>& graphs, std::vector<Status
     const size_t b_nodes = W * mn, b_cnt = W * mn * 2, b_edges = W * mn * GWHIP_MAX_NODE_EDGES * 4, b_w = W * mn * GWHIP_MAX_NODE_EDGES * 2;
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t total = up(b_nodes) + up(b_cnt) + up(b_edges) + up(b_w);
-    char* d_tmp        = allocator_.allocate(total, {stream_});
+    // the batch's pool is normally fully committed to the batch block, so these rarely-needed temporaries come
+    // straight from the runtime
+    char* d_tmp = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d_tmp), total) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        throw device_memory_allocation_exception();
+    }
     uint8_t* d_nodes   = reinterpret_cast<uint8_t*>(d_tmp);
     uint16_t* d_cnt    = reinterpret_cast<uint16_t*>(d_tmp + up(b_nodes));
     int32_t* d_edges   = reinterpret_cast<int32_t*>(d_tmp + up(b_nodes) + up(b_cnt));
@@ -574,7 +581,7 @@ void PoaBatch::get_graphs(std::vector<DirectedGraph>& graphs, std::vector<Status
     GW_CU_CHECK_ERR(hipMemcpyAsync(lens.data(), d_seq_lens_, lens.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     GW_CU_CHECK_ERR(hipMemcpyAsync(h_consensus_, d_consensus_, W * batch_size_.max_consensus_size, hipMemcpyDeviceToHost, stream_));
     GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
-    allocator_.deallocate(d_tmp, total);
+    GW_CU_CHECK_ERR(hipFree(d_tmp));
     for (int32_t poa = 0; poa < poa_count_; poa++)
     {
         const char* c = reinterpret_cast<const char*>(&h_consensus_[static_cast<size_t>(poa) * batch_size_.max_consensus_size]);
