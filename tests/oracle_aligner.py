@@ -1,0 +1,80 @@
+"""ctypes view of the aligner oracle (oracle/build/libaligner_oracle.so) and of the reference's own CPU aligner code
+built into oracle/_ref/libref_aligner.so -- TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_L = None
+_R = None
+
+OPS = "MXID"  # match, mismatch, insertion, deletion (AlignmentState order)
+
+
+def lib():
+    global _L
+    if _L is None:
+        path = os.path.join(ROOT, "oracle", "build", "libaligner_oracle.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "build/libaligner_oracle.so"], check=True)
+        _L = C.CDLL(path)
+        _L.aligner_oracle_myers_banded.restype = C.c_int32
+        _L.aligner_oracle_myers_banded.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                   C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                   C.POINTER(C.c_int64)]
+        _L.aligner_oracle_host_max_bandwidth.restype = C.c_int32
+    return _L
+
+
+def ref():
+    """The reference's own CPU code (None when oracle/_ref was not built: no /root/reference and no prebuilt .so)."""
+    global _R
+    if _R is None:
+        path = os.path.join(ROOT, "oracle", "_ref", "libref_aligner.so")
+        if not os.path.exists(path):
+            return None
+        _R = C.CDLL(path)
+        for f in (_R.ref_myers_edit_distance, _R.ref_nw_edit_distance):
+            f.restype = C.c_int32
+            f.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32]
+        _R.ref_needleman_wunsch_cpu.restype = C.c_int32
+        _R.ref_needleman_wunsch_cpu.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32]
+    return _R
+
+
+def align(query, target, max_bandwidth):
+    """Returns dict(status, optimal, runs=[(op, count)...] in forward order, states, cigar, edit_distance, cells)."""
+    q = query.encode() if isinstance(query, str) else bytes(query)
+    t = target.encode() if isinstance(target, str) else bytes(target)
+    mbw = lib().aligner_oracle_host_max_bandwidth(max_bandwidth, len(q))
+    cap = len(q) + len(t) + 4
+    ops = np.zeros(cap, np.int8)
+    cnt = np.zeros(cap, np.int32)
+    n, opt, cells = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+    rc = lib().aligner_oracle_myers_banded(q, len(q), t, len(t), mbw, ops.ctypes.data, cnt.ctypes.data, C.byref(n),
+                                           C.byref(opt), C.byref(cells))
+    runs = [(int(ops[i]), int(cnt[i])) for i in range(n.value)][::-1]  # host reverses (aligner_global_myers_banded.cpp:423)
+    out = dict(status=rc, optimal=bool(opt.value), runs=runs, cells=cells.value)
+    out["cigar"] = cigar(runs, False)
+    out["cigar_extended"] = cigar(runs, True)
+    out["edit_distance"] = sum(c for o, c in runs if o != 0)
+    return out
+
+
+def cigar(runs, extended):
+    """AlignmentImpl::convert_to_cigar (alignment_impl.cpp:70-127): basic M/I/D merges match+mismatch; extended =/X/I/D."""
+    sym = "=XID" if extended else "MMID"
+    out, last, acc = [], None, 0
+    for o, c in runs:
+        s = sym[o]
+        if s == last:
+            acc += c
+        else:
+            if last is not None:
+                out.append("%d%s" % (acc, last))
+            last, acc = s, c
+    if last is not None:
+        out.append("%d%s" % (acc, last))
+    return "".join(out)

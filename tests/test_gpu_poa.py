@@ -89,15 +89,19 @@ def test_three_identical_reads():
 def test_add_poa_group_status_codes():
     # cudapoa/tests/Test_CudapoaBatch.cu:99-153
     from genomeworks_amd import cudapoa
-    b = cudapoa.CudaPoaBatch(2, 64, 1 << 30, band_mode="full_band")
+    b = cudapoa.CudaPoaBatch(2, 256, 1 << 30, band_mode="full_band")
     st, seq = b.add_poa_group(["ACGT" * 4, "ACGT" * 4, "ACGT" * 4])
     assert st == 0 and seq == [0, 0, cudapoa.exceeded_maximum_sequences_per_poa]
     b.reset()
     assert b.total_poas == 0
-    st, seq = b.add_poa_group(["A" * 100, "ACGT"])
+    st, seq = b.add_poa_group(["A" * 300, "ACGT"])
     assert st == 0 and seq == [cudapoa.exceeded_maximum_sequence_size, 0]
+    st, seq = b.add_poa_group(["A" * 300])
+    assert st == cudapoa.empty_poa_group and seq == [cudapoa.exceeded_maximum_sequence_size]
     with pytest.raises(RuntimeError):
-        cudapoa.CudaPoaBatch(2, 64, 0, band_mode="full_band")  # zero memory -> "Requires at least ..."
+        cudapoa.CudaPoaBatch(2, 256, 0, band_mode="full_band")  # zero memory -> "Requires at least ..."
+    with pytest.raises(ValueError):
+        cudapoa.CudaPoaBatch(2, 64, 1 << 30, band_mode="full_band")  # band 256 > max_sequence_size (batch.cu:96-97)
 
 
 def test_msa_bit_exact_vs_oracle():
