@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -30,6 +31,8 @@ static int fail_msg(int code, const std::string& msg)
 
 constexpr int kRingBytes   = 8448;  // LDS ring of recent score rows: 16 rows of a 256-band int16 row (264 x 2 B)
 constexpr int kRowInfoLds  = 3074;  // rows of the LDS row table (covers max_nodes_per_graph <= 3072)
+constexpr int kRowInfoBytes = kRowInfoLds * 8;
+constexpr int kReadLds     = 2048;  // LDS copy of the current read (+ read-ahead slack)
 
 struct KernelArgs
 {
@@ -46,6 +49,8 @@ struct KernelArgs
     uint8_t* workspace;
     uint8_t* full_scores; // full band: variable-width score regions after the slabs
     uint64_t* cells;
+    uint64_t* phase_cycles; // optional [windows][kPhCount]
+    int32_t debug_flags;    // profiling ablations (GWHIP_DEBUG env var); 0 in production
 };
 
 template <typename IdT>
@@ -79,7 +84,10 @@ __device__ GraphView<IdT> carve_graph(uint8_t* slab, const PoaLayout& L)
 // ------------------------------------------------------------------------------------------------
 // Graph-build kernel: grid = windows, block = one wavefront.
 // ------------------------------------------------------------------------------------------------
-template <typename ScoreT, typename IdT, typename TraceT, int BM, bool MSA>
+// LDS_TABLES: the per-row table, the topsort working set and the current read live in LDS. It is a template
+// flag (not a runtime select) so every pointer has one address space and the row loop issues ds_* ops only:
+// a flat/global load in that loop would wait on the previous row's score store (shared in-order vmcnt).
+template <typename ScoreT, typename IdT, typename TraceT, int BM, bool MSA, bool LDS_TABLES>
 __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -96,11 +104,17 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
     int32_t* alignment_graph = (int32_t*)(slab + a.L.align_graph);
     int32_t* alignment_read  = (int32_t*)(slab + a.L.align_read);
 
-    // LDS carve: [ring | rowinfo]
+    // LDS carve: [ring | rowinfo (aliased by the topsort working set) | read]
     ScoreT* ring = reinterpret_cast<ScoreT*>(smem);
-    RowInfo<IdT>* rowinfo = (c.max_nodes_per_graph + 2 <= kRowInfoLds && sizeof(IdT) == 2)
-                                ? reinterpret_cast<RowInfo<IdT>*>(smem + kRingBytes)
-                                : reinterpret_cast<RowInfo<IdT>*>(slab + a.L.rowinfo);
+    uint8_t* lds_rowinfo_region = smem + kRingBytes;
+    uint8_t* lds_read_buf       = smem + kRingBytes + kRowInfoBytes;
+    constexpr bool graph_fits_lds = LDS_TABLES;
+    using RowT = RowInfo<LDS_TABLES>;
+    RowT* rowinfo;
+    if constexpr (LDS_TABLES)
+        rowinfo = reinterpret_cast<RowT*>(smem + kRingBytes);
+    else
+        rowinfo = reinterpret_cast<RowT*>(slab + a.L.rowinfo);
 
     constexpr bool TB = (BM == GWHIP_STATIC_BAND_TRACEBACK || BM == GWHIP_ADAPTIVE_BAND_TRACEBACK);
     ScoreT* scores;
@@ -146,7 +160,10 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
     if (lane == 0) consensus[0] = 0;
     uint64_t cells = 0;
     int32_t node_count = len0;
+    uint64_t phase_acc[kPhCount] = {0, 0, 0, 0, 0, 0};
+    PhaseClock pc{a.phase_cycles ? phase_acc : nullptr, 0};
     __syncthreads();
+    pc.start();
 
     for (int32_t s = 1; s < (int32_t)wd.num_seqs; s++)
     {
@@ -160,49 +177,61 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
             if (lane == 0) { consensus[0] = kKernelError; consensus[1] = kNodeCountExceeded; }
             break;
         }
-        build_rowinfo<IdT>(g, node_count, rowinfo, lane);
+        pc.tick(kPhOther);
+        build_rowinfo<IdT, RowT>(g, node_count, rowinfo, lane);
+        // stage the read (plus the never-consumed read-ahead) in LDS when it fits
+        constexpr bool LDS_READ = LDS_TABLES && BM != GWHIP_FULL_BAND && !TB;
+        const uint8_t* lds_read = lds_read_buf;
+        if constexpr (LDS_READ)
+        {
+            // adaptive bands may widen to 1536 columns: the staged span covers max(read, band) + read-ahead
+            const int32_t stage_bytes = min(kReadLds, ((max(seq_len, kMaxAdaptiveBand) + 8) + 3) & ~3);
+            for (int32_t i = lane * 4; i < stage_bytes; i += kWave * 4)
+                *reinterpret_cast<uint32_t*>(lds_read_buf + i) = *reinterpret_cast<const uint32_t*>(sequence + i);
+        }
         __syncthreads();
+        pc.tick(kPhRowInfo);
 
         int32_t alen;
         if (BM == GWHIP_ADAPTIVE_BAND_TRACEBACK && c.alignment_band_width < kMaxAdaptiveBand)
         {
-            alen = nw_banded_tb<ScoreT, IdT, TraceT, true>(g, rowinfo, node_count, sequence, seq_len, scores, a.L.scores_elems,
+            alen = nw_banded_tb<ScoreT, IdT, RowT, TraceT, true>(g, rowinfo, node_count, sequence, seq_len, scores, a.L.scores_elems,
                                                            traceback, a.L.trace_elems, banded_buffer_size, alignment_graph,
                                                            alignment_read, c.alignment_band_width, c.max_banded_pred_distance,
                                                            c.gap_score, c.mismatch_score, c.match_score, 0, cells);
             if (alen == kShiftLeft || alen == kShiftRight)
-                alen = nw_banded_tb<ScoreT, IdT, TraceT, true>(g, rowinfo, node_count, sequence, seq_len, scores, a.L.scores_elems,
+                alen = nw_banded_tb<ScoreT, IdT, RowT, TraceT, true>(g, rowinfo, node_count, sequence, seq_len, scores, a.L.scores_elems,
                                                                traceback, a.L.trace_elems, banded_buffer_size, alignment_graph,
                                                                alignment_read, c.alignment_band_width, c.max_banded_pred_distance,
                                                                c.gap_score, c.mismatch_score, c.match_score, alen, cells);
         }
         else if (TB)
         {
-            alen = nw_banded_tb<ScoreT, IdT, TraceT, false>(g, rowinfo, node_count, sequence, seq_len, scores, a.L.scores_elems,
+            alen = nw_banded_tb<ScoreT, IdT, RowT, TraceT, false>(g, rowinfo, node_count, sequence, seq_len, scores, a.L.scores_elems,
                                                             traceback, a.L.trace_elems, banded_buffer_size, alignment_graph,
                                                             alignment_read, c.alignment_band_width, c.max_banded_pred_distance,
                                                             c.gap_score, c.mismatch_score, c.match_score, 0, cells);
         }
         else if (BM == GWHIP_ADAPTIVE_BAND && c.alignment_band_width < kMaxAdaptiveBand)
         {
-            alen = nw_banded<ScoreT, IdT, true>(g, rowinfo, node_count, sequence, seq_len, scores, ring, kRingBytes,
+            alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, kRingBytes,
                                                 banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
-                                                c.gap_score, c.mismatch_score, c.match_score, 0, cells);
+                                                c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags);
             if (alen == kShiftLeft || alen == kShiftRight)
-                alen = nw_banded<ScoreT, IdT, true>(g, rowinfo, node_count, sequence, seq_len, scores, ring, kRingBytes,
+                alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, kRingBytes,
                                                     banded_buffer_size, alignment_graph, alignment_read,
                                                     c.alignment_band_width, c.gap_score, c.mismatch_score, c.match_score,
-                                                    alen, cells);
+                                                    alen, cells, pc, a.debug_flags);
         }
         else if (BM == GWHIP_STATIC_BAND || BM == GWHIP_ADAPTIVE_BAND)
         {
-            alen = nw_banded<ScoreT, IdT, false>(g, rowinfo, node_count, sequence, seq_len, scores, ring, kRingBytes,
+            alen = nw_banded<ScoreT, IdT, RowT, false, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, kRingBytes,
                                                  banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
-                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells);
+                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags);
         }
         else
         {
-            alen = nw_full<ScoreT, IdT>(g, rowinfo, node_count, sequence, seq_len, scores, wd.scores_width, ring, kRingBytes,
+            alen = nw_full<ScoreT, IdT, RowT>(g, rowinfo, node_count, sequence, seq_len, scores, wd.scores_width, ring, kRingBytes,
                                         alignment_graph, alignment_read, c.gap_score, c.mismatch_score, c.match_score, cells);
         }
         // SizeT alignment_length in the reference: the value is narrowed to SizeT (cudapoa_kernels.cuh:268)
@@ -218,8 +247,30 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
             break;
         }
 
+        pc.tick(kPhTraceback);
         int32_t status_and_count = 0;
-        if (lane == 0)
+        int32_t par_rc           = -1; // -1: use the serial merge
+        if constexpr (LDS_TABLES)
+        {
+            int32_t new_count = 0;
+            par_rc = add_alignment_parallel<IdT, MSA>(new_count, g, node_count, alen, alignment_graph, alignment_read,
+                                                      sequence, base_weights, seq_len, MSA ? g.seq_begin + s : nullptr,
+                                                      (uint16_t)s, (uint32_t)c.max_sequences_per_poa,
+                                                      c.max_nodes_per_graph, reinterpret_cast<int16_t*>(smem),
+                                                      reinterpret_cast<int16_t*>(smem) + 2048,
+                                                      reinterpret_cast<uint32_t*>(lds_rowinfo_region), lane);
+            if (par_rc == 0)
+            {
+                if (lane == 0) seq_lens[0] = new_count; // :506
+                status_and_count = new_count;
+            }
+            else if (par_rc > 0)
+            {
+                if (lane == 0) { consensus[0] = kKernelError; consensus[1] = (uint8_t)par_rc; }
+                status_and_count = -1;
+            }
+        }
+        if (lane == 0 && par_rc < 0)
         {
             int32_t new_count = 0;
             uint8_t e = add_alignment_to_graph<IdT, MSA>(new_count, g, node_count, alen, alignment_graph, sequence,
@@ -234,21 +285,31 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
             }
             else
             {
-                seq_lens[0] = new_count; // :506
-                if (c.spoa_accurate)
-                    topsort_racon<IdT>(g, new_count, (int32_t)(uint16_t)c.max_nodes_per_graph); // (uint16_t) cast :519
-                else
-                    topsort_kahn<IdT>(g.sorted_poa, g.node_id_to_pos, new_count, g.incoming_edge_count,
-                                      g.outgoing_edges, g.outgoing_edge_count, g.local_cnt);
+                seq_lens[0]      = new_count; // :506
                 status_and_count = new_count;
             }
         }
+        pc.tick(kPhAddAlignment);
+        if (lane == 0 && status_and_count >= 0)
+        {
+            const int32_t new_count = status_and_count;
+            if (c.spoa_accurate)
+                topsort_racon<IdT>(g, new_count, (int32_t)(uint16_t)c.max_nodes_per_graph); // (uint16_t) cast :519
+            else if (!graph_fits_lds)
+                topsort_kahn<IdT>(g.sorted_poa, g.node_id_to_pos, new_count, g.incoming_edge_count,
+                                  g.outgoing_edges, g.outgoing_edge_count, g.local_cnt);
+        }
         status_and_count = wave_first(status_and_count);
         __syncthreads();
+        if (status_and_count >= 0 && !c.spoa_accurate && graph_fits_lds)
+            topsort_kahn_lds<IdT>(g, status_and_count, lds_rowinfo_region, lane);
+        pc.tick(kPhTopsort);
         if (status_and_count < 0) break;
         node_count = status_and_count;
     }
     if (lane == 0 && a.cells) a.cells[w] = cells;
+    if (lane == 0 && a.phase_cycles)
+        for (int k = 0; k < kPhCount; k++) a.phase_cycles[(size_t)w * kPhCount + k] = phase_acc[k];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -353,13 +414,13 @@ static bool validate(const gwhip_poa_args* args)
     return true;
 }
 
-template <typename ScoreT, typename IdT, typename TraceT, bool MSA>
+template <typename ScoreT, typename IdT, typename TraceT, bool MSA, bool LDS_TABLES>
 static hipError_t launch_window_kernel(const KernelArgs& ka, hipStream_t stream)
 {
-    const size_t lds = kRingBytes + (size_t)kRowInfoLds * 8;
+    const size_t lds = kRingBytes + (LDS_TABLES ? (size_t)kRowInfoBytes + kReadLds : 0);
     dim3 grid(ka.total_windows), block(kWave);
 #define GW_LAUNCH(BM)                                                                                              \
-    hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA>), grid, block, lds, stream, ka);           \
+    hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES>), grid, block, lds, stream, ka); \
     break;
     switch (ka.cfg.band_mode)
     {
@@ -376,14 +437,26 @@ static hipError_t launch_window_kernel(const KernelArgs& ka, hipStream_t stream)
 template <typename ScoreT, typename IdT, typename TraceT>
 static hipError_t launch_msa_split(const KernelArgs& ka, hipStream_t stream)
 {
-    if (ka.cfg.output_mask & 2) return launch_window_kernel<ScoreT, IdT, TraceT, true>(ka, stream);
-    return launch_window_kernel<ScoreT, IdT, TraceT, false>(ka, stream);
+    // LDS tables need 16-bit ids, <= 3072 graph rows and a read (+ read-ahead) that fits the LDS copy
+    constexpr bool can_lds = sizeof(IdT) == 2;
+    const bool lds = can_lds && ka.cfg.max_nodes_per_graph + 2 <= kRowInfoLds && ka.cfg.max_sequence_size + 16 <= kReadLds;
+    if (ka.cfg.output_mask & 2)
+    {
+        if constexpr (can_lds)
+            if (lds) return launch_window_kernel<ScoreT, IdT, TraceT, true, true>(ka, stream);
+        return launch_window_kernel<ScoreT, IdT, TraceT, true, false>(ka, stream);
+    }
+    if constexpr (can_lds)
+        if (lds) return launch_window_kernel<ScoreT, IdT, TraceT, false, true>(ka, stream);
+    return launch_window_kernel<ScoreT, IdT, TraceT, false, false>(ka, stream);
 }
 
 template <typename ScoreT, typename IdT>
 static hipError_t launch_trace_split(const KernelArgs& ka, hipStream_t stream)
 {
-    if (ka.cfg.trace16) return launch_msa_split<ScoreT, IdT, int16_t>(ka, stream);
+    // TraceT only matters in the traceback modes; the other modes share the int8_t instantiation
+    const bool tb = ka.cfg.band_mode == GWHIP_STATIC_BAND_TRACEBACK || ka.cfg.band_mode == GWHIP_ADAPTIVE_BAND_TRACEBACK;
+    if (tb && ka.cfg.trace16) return launch_msa_split<ScoreT, IdT, int16_t>(ka, stream);
     return launch_msa_split<ScoreT, IdT, int8_t>(ka, stream);
 }
 
@@ -403,6 +476,11 @@ static KernelArgs make_kernel_args(const gwhip_poa_args* args)
     ka.workspace       = (uint8_t*)args->workspace;
     ka.full_scores     = ka.workspace + (size_t)args->total_windows * ka.L.per_window;
     ka.cells           = args->cells;
+    ka.phase_cycles    = args->phase_cycles;
+    {
+        const char* dbg = std::getenv("GWHIP_DEBUG");
+        ka.debug_flags  = dbg ? std::atoi(dbg) : 0;
+    }
     return ka;
 }
 

@@ -49,42 +49,43 @@ __global__ __launch_bounds__(kWave) void nw_hook_kernel(NwHookArgs a)
 {
     __shared__ __attribute__((aligned(16))) int16_t ring[4224];
     GraphView<int32_t> g      = view_of(a.g);
-    RowInfo<int32_t>* rowinfo = reinterpret_cast<RowInfo<int32_t>*>(a.scratch + a.rowinfo_off);
+    RowInfo<false>* rowinfo = reinterpret_cast<RowInfo<false>*>(a.scratch + a.rowinfo_off);
     int16_t* scores           = reinterpret_cast<int16_t*>(a.scratch + a.scores_off);
     TraceT* trace             = reinterpret_cast<TraceT*>(a.scratch + a.trace_off);
     const gwhip_poa_config& c = a.cfg;
     const int lane            = threadIdx.x;
-    build_rowinfo<int32_t>(g, a.g.graph_count, rowinfo, lane);
+    build_rowinfo<int32_t, RowInfo<false>>(g, a.g.graph_count, rowinfo, lane);
     __syncthreads();
     uint64_t cells  = 0;
+    PhaseClock pc{nullptr, 0};
     const float buf = __fmul_rn((float)c.max_nodes_per_graph, (float)c.matrix_sequence_dimension);
     int32_t n;
     switch (c.band_mode)
     {
     case GWHIP_FULL_BAND:
-        n = nw_full<int16_t, int32_t>(g, rowinfo, a.g.graph_count, a.read, a.read_length, scores, a.scores_width, ring,
+        n = nw_full<int16_t, int32_t, RowInfo<false>>(g, rowinfo, a.g.graph_count, a.read, a.read_length, scores, a.scores_width, ring,
                                       (int32_t)sizeof(ring), a.alignment_graph, a.alignment_read, c.gap_score,
                                       c.mismatch_score, c.match_score, cells);
         break;
     case GWHIP_STATIC_BAND:
-        n = nw_banded<int16_t, int32_t, false>(g, rowinfo, a.g.graph_count, a.read, a.read_length, scores, ring,
+        n = nw_banded<int16_t, int32_t, RowInfo<false>, false, false>(g, rowinfo, a.g.graph_count, a.read, nullptr, a.read_length, scores, ring,
                                                (int32_t)sizeof(ring), buf, a.alignment_graph, a.alignment_read,
-                                               c.alignment_band_width, c.gap_score, c.mismatch_score, c.match_score, 0, cells);
+                                               c.alignment_band_width, c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc);
         break;
     case GWHIP_ADAPTIVE_BAND:
-        n = nw_banded<int16_t, int32_t, true>(g, rowinfo, a.g.graph_count, a.read, a.read_length, scores, ring,
+        n = nw_banded<int16_t, int32_t, RowInfo<false>, true, false>(g, rowinfo, a.g.graph_count, a.read, nullptr, a.read_length, scores, ring,
                                               (int32_t)sizeof(ring), buf, a.alignment_graph, a.alignment_read,
-                                              c.alignment_band_width, c.gap_score, c.mismatch_score, c.match_score, 0, cells);
+                                              c.alignment_band_width, c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc);
         break;
     case GWHIP_STATIC_BAND_TRACEBACK:
-        n = nw_banded_tb<int16_t, int32_t, TraceT, false>(g, rowinfo, a.g.graph_count, a.read, a.read_length, scores,
+        n = nw_banded_tb<int16_t, int32_t, RowInfo<false>, TraceT, false>(g, rowinfo, a.g.graph_count, a.read, a.read_length, scores,
                                                           a.scores_elems, trace, a.trace_elems, buf, a.alignment_graph,
                                                           a.alignment_read, c.alignment_band_width,
                                                           c.max_banded_pred_distance, c.gap_score, c.mismatch_score,
                                                           c.match_score, 0, cells);
         break;
     default:
-        n = nw_banded_tb<int16_t, int32_t, TraceT, true>(g, rowinfo, a.g.graph_count, a.read, a.read_length, scores,
+        n = nw_banded_tb<int16_t, int32_t, RowInfo<false>, TraceT, true>(g, rowinfo, a.g.graph_count, a.read, a.read_length, scores,
                                                          a.scores_elems, trace, a.trace_elems, buf, a.alignment_graph,
                                                          a.alignment_read, c.alignment_band_width,
                                                          c.max_banded_pred_distance, c.gap_score, c.mismatch_score,
@@ -132,7 +133,7 @@ static void nw_hook_plan(const gwhip_poa_config& c, NwHookArgs& a, size_t& total
     const size_t mn = (size_t)c.max_nodes_per_graph;
     size_t off      = 0;
     auto take       = [&](size_t b) { size_t o = off; off = gw_align_up(off + b, 256); return o; };
-    a.rowinfo_off   = take((mn + 2) * sizeof(RowInfo<int32_t>));
+    a.rowinfo_off   = take((mn + 2) * sizeof(RowInfo<false>));
     const bool tb   = c.band_mode == GWHIP_STATIC_BAND_TRACEBACK || c.band_mode == GWHIP_ADAPTIVE_BAND_TRACEBACK;
     size_t width    = (size_t)c.matrix_sequence_dimension;
     if (c.band_mode == GWHIP_FULL_BAND)

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "poa_layout.h"
 
 namespace gwhip
@@ -28,20 +30,44 @@ template <> struct Limits<int32_t> { static constexpr int32_t min = INT32_MIN; }
 
 template <typename ScoreT> struct alignas(sizeof(ScoreT) * 4) Quad { ScoreT v[4]; };
 
-// Per-row table entry. pred[] holds score-matrix rows (node_id_to_pos + 1) of the first 3 predecessor slots.
-template <typename IdT> struct RowInfo;
-template <> struct alignas(8) RowInfo<int16_t>
+// Per-row table entry: node base, predecessor count, sink flag, the row's band start and the score-matrix rows
+// (node_id_to_pos + 1) of the first 3 predecessor slots. The LDS-resident flavour (PACKED) is bit-packed into one 64-bit
+// word (one ds_read_b64, decoded on the scalar unit): rows <= 4095, band starts <= 2044.
+template <bool PACKED> struct RowInfo;
+template <> struct alignas(8) RowInfo<true>
 {
-    uint8_t base;
-    uint8_t cnt_sink; // bits 0-6: predecessor count (<= 50), bit 7: outgoing_edge_count == 0
-    uint16_t pred[3];
+    uint64_t w; // [0:8) base  [8:14) pred count  [14] sink  [15:24) band_start/4  [24:36) [36:48) [48:60) pred rows
+    __device__ __forceinline__ int32_t base() const { return (int32_t)(w & 0xff); }
+    __device__ __forceinline__ int32_t cnt() const { return (int32_t)((w >> 8) & 0x3f); }
+    __device__ __forceinline__ bool sink() const { return ((w >> 14) & 1) != 0; }
+    __device__ __forceinline__ int32_t bs() const { return (int32_t)((w >> 15) & 0x1ff) << 2; }
+    __device__ __forceinline__ int32_t pred(int k) const { return (int32_t)((w >> (24 + 12 * k)) & 0xfff); }
+    __device__ __forceinline__ void set(int32_t base, int32_t cnt, bool sink, int32_t p0, int32_t p1, int32_t p2)
+    {
+        w = (uint64_t)(base & 0xff) | ((uint64_t)(cnt & 0x3f) << 8) | ((uint64_t)(sink ? 1 : 0) << 14) |
+            ((uint64_t)(p0 & 0xfff) << 24) | ((uint64_t)(p1 & 0xfff) << 36) | ((uint64_t)(p2 & 0xfff) << 48);
+    }
+    __device__ __forceinline__ void set_bs(int32_t bs) { w = (w & ~(0x1ffull << 15)) | ((uint64_t)((bs >> 2) & 0x1ff) << 15); }
 };
-template <> struct alignas(16) RowInfo<int32_t>
+template <> struct alignas(8) RowInfo<false>
 {
-    uint8_t base;
-    uint8_t cnt_sink;
-    uint16_t pad;
-    int32_t pred[3];
+    uint8_t base_;
+    uint8_t cnt_sink_;
+    uint16_t pad_;
+    int32_t bs_;
+    int32_t pred_[3];
+    int32_t pad2_;
+    __device__ __forceinline__ int32_t base() const { return base_; }
+    __device__ __forceinline__ int32_t cnt() const { return cnt_sink_ & 0x7f; }
+    __device__ __forceinline__ bool sink() const { return (cnt_sink_ & 0x80) != 0; }
+    __device__ __forceinline__ int32_t bs() const { return bs_; }
+    __device__ __forceinline__ int32_t pred(int k) const { return pred_[k]; }
+    __device__ __forceinline__ void set(int32_t base, int32_t cnt, bool sink, int32_t p0, int32_t p1, int32_t p2)
+    {
+        base_ = (uint8_t)base; cnt_sink_ = (uint8_t)((cnt & 0x7f) | (sink ? 0x80 : 0)); pad_ = 0; bs_ = 0;
+        pred_[0] = p0; pred_[1] = p1; pred_[2] = p2; pad2_ = 0;
+    }
+    __device__ __forceinline__ void set_bs(int32_t bs) { bs_ = bs; }
 };
 
 template <typename IdT> struct GraphView
@@ -80,9 +106,41 @@ __device__ __forceinline__ int32_t band_start_for_row(int32_t row, float gradien
     return start_pos;
 }
 
+// ---- optional per-phase cycle accounting (s_memtime), enabled by passing a non-null accumulator ----
+enum Phase { kPhRowInfo = 0, kPhForward, kPhTraceback, kPhAddAlignment, kPhTopsort, kPhOther, kPhCount };
+struct PhaseClock
+{
+    uint64_t* acc; // [kPhCount] or nullptr
+    uint64_t last;
+    __device__ void start() { if (acc) last = clock64(); }
+    __device__ void tick(int phase)
+    {
+        if (acc)
+        {
+            uint64_t now = clock64();
+            acc[phase] += now - last;
+            last = now;
+        }
+    }
+};
+
 // ---- wave-level helpers ----
 __device__ __forceinline__ int32_t wave_bcast(int32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int32_t wave_first(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ uint64_t wave_first64(uint64_t v)
+{
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)v);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+// wave-uniform copy of a row-table entry (moves the packed word into SGPRs so its decode runs on the scalar unit)
+template <typename RowT> __device__ __forceinline__ RowT uniform_row(RowT r) { return r; }
+template <> __device__ __forceinline__ RowInfo<true> uniform_row(RowInfo<true> r)
+{
+    r.w = wave_first64(r.w);
+    return r;
+}
 
 // Inclusive prefix-max across the 64 lanes with the gfx9 DPP row-shift / row-broadcast sequence.
 __device__ __forceinline__ int32_t wave_inclusive_max(int32_t v)
@@ -142,8 +200,8 @@ __device__ __forceinline__ int32_t get_score(const BandedCtx<ScoreT>& b, int32_t
 // Lane-0 traceback by recomputation, exact restatement of cudapoa_nw_banded.cuh:428-549, reading the HBM
 // score matrix and the LDS row table. Returns alignment length or an error / rerun code.
 // ------------------------------------------------------------------------------------------------
-template <typename ScoreT, typename IdT, bool ADAPTIVE>
-__device__ int32_t traceback_banded(const BandedCtx<ScoreT>& b, const GraphView<IdT>& g, const RowInfo<IdT>* rowinfo,
+template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE>
+__device__ __forceinline__ int32_t traceback_banded(const BandedCtx<ScoreT>& b, const GraphView<IdT>& g, const RowT* rowinfo,
                                     int32_t graph_count, const uint8_t* read, int32_t read_length, int32_t start_i,
                                     int32_t* alignment_graph, int32_t* alignment_read, int32_t gap_score,
                                     int32_t mismatch_score, int32_t match_score, int32_t rerun)
@@ -158,16 +216,16 @@ __device__ int32_t traceback_banded(const BandedCtx<ScoreT>& b, const GraphView<
         loop_count++;
         int32_t scores_ij = get_score(b, i, j);
         bool pred_found   = false;
-        RowInfo<IdT> ri{};
+        RowT ri{};
         int32_t pred_count = 0, node_id = 0;
         if (i != 0)
         {
             ri         = rowinfo[i];
-            pred_count = ri.cnt_sink & 0x7f;
+            pred_count = ri.cnt();
         }
         auto pred_row = [&](int32_t p) -> int32_t {
             if (pred_count == 0) return 0;
-            if (p < 3) return (int32_t)ri.pred[p];
+            if (p < 3) return ri.pred(p);
             return (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
         };
         if (i != 0 && pred_count > 3) node_id = g.sorted_poa[i - 1];
@@ -186,7 +244,7 @@ __device__ int32_t traceback_banded(const BandedCtx<ScoreT>& b, const GraphView<
                     }
                 }
             }
-            int32_t match_cost = (ri.base == read[j - 1] ? match_score : mismatch_score);
+            int32_t match_cost = (ri.base() == read[j - 1] ? match_score : mismatch_score);
             int32_t np         = max(pred_count, 1);
             for (int32_t p = 0; p < np; p++)
             {
@@ -228,24 +286,226 @@ __device__ int32_t traceback_banded(const BandedCtx<ScoreT>& b, const GraphView<
 // ------------------------------------------------------------------------------------------------
 // Per-read row table: all lanes gather (base, predecessor rows, sink flag) for rows 1..N.
 // ------------------------------------------------------------------------------------------------
-template <typename IdT>
-__device__ void build_rowinfo(const GraphView<IdT>& g, int32_t graph_count, RowInfo<IdT>* rowinfo, int lane)
+template <typename IdT, typename RowT>
+__device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t graph_count, RowT* rowinfo, int lane)
 {
     for (int32_t r = 1 + lane; r <= graph_count; r += kWave)
     {
         int32_t node = g.sorted_poa[r - 1];
-        RowInfo<IdT> ri{};
-        ri.base     = g.nodes[node];
+        RowT ri{};
         int32_t cnt = g.incoming_edge_count[node];
         int32_t oc  = g.outgoing_edge_count[node];
-        ri.cnt_sink = (uint8_t)((cnt & 0x7f) | (oc == 0 ? 0x80 : 0));
+        int32_t pr[3] = {0, 0, 0};
         for (int32_t p = 0; p < 3; p++)
-        {
-            int32_t pr = 0;
-            if (p < cnt) pr = (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node * kEdges + p]] + 1;
-            ri.pred[p] = (decltype(ri.pred[0]))pr;
-        }
+            if (p < cnt) pr[p] = (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node * kEdges + p]] + 1;
+        ri.set(g.nodes[node], cnt, oc == 0, pr[0], pr[1], pr[2]);
         rowinfo[r] = ri;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lean forward pass for bands <= 256 columns (one 64-lane pass per row), PACKED row table in LDS, read in LDS.
+// Everything wave-uniform (row table word, band starts, ring slots, carry, boundary values) lives in SGPRs;
+// per row the vector unit only does the 4-cell recurrence, the DPP prefix-max and two stores. Predecessor rows
+// come from registers (row r-1), else the LDS ring, else (far, rare) the HBM matrix after a workgroup sync.
+// Under the no-int16-wrap precondition values are kept in 32-bit registers and narrowed on store.
+// ------------------------------------------------------------------------------------------------
+template <typename ScoreT, typename IdT>
+__device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, const RowInfo<true>* rowinfo,
+                                                     int32_t graph_count, const uint8_t* lds_read, ScoreT* scores,
+                                                     ScoreT* ring, int32_t ring_rows, int32_t band_width,
+                                                     int32_t max_column, int32_t gap_score, int32_t mismatch_score,
+                                                     int32_t match_score, int32_t dbg)
+{
+    const int lane          = threadIdx.x & (kWave - 1);
+    const int32_t min_score = Limits<ScoreT>::min / 2;
+    const int32_t stride    = band_width + kRightPad;
+    const int32_t lane4     = lane * 4;
+    const bool active       = lane4 < band_width;
+    const int32_t K0 = (lane4 + 0) * gap_score, K1 = (lane4 + 1) * gap_score, K2 = (lane4 + 2) * gap_score,
+                  K3 = (lane4 + 3) * gap_score;
+    // row 0 in registers: cells rel 1+4l .. 4+4l = (rel) * gap
+    int32_t P0 = K0 + gap_score, P1 = K1 + gap_score, P2 = K2 + gap_score, P3 = K3 + gap_score;
+    int32_t prev_bs = 0, prev_rel0 = 0;
+    int32_t ring_slot = 0; // slot of row r-1 (row 0 sits in slot 0)
+    bool hbm_dirty    = false;
+    ScoreT* row_out   = scores; // advanced by stride per row
+
+    RowInfo<true> ri_next = uniform_row(rowinfo[1]);
+    for (int32_t r = 1; r <= graph_count; r++)
+    {
+        const RowInfo<true> ri = ri_next;
+        if (r < graph_count) ri_next = uniform_row(rowinfo[r + 1]);
+        const int32_t pred_count = ri.cnt();
+        const int32_t bs         = ri.bs();
+        const uint32_t base      = (uint32_t)ri.base();
+        const int32_t c          = bs + lane4;
+        row_out += stride;
+        const int32_t my_slot = (ring_slot + 1 == ring_rows) ? 0 : ring_slot + 1; // slot this row will occupy
+
+        const uint32_t rd4 = *reinterpret_cast<const uint32_t*>(lds_read + c);
+        const int32_t cp0  = ((rd4 & 0xff) == base) ? match_score : mismatch_score;
+        const int32_t cp1  = (((rd4 >> 8) & 0xff) == base) ? match_score : mismatch_score;
+        const int32_t cp2  = (((rd4 >> 16) & 0xff) == base) ? match_score : mismatch_score;
+        const int32_t cp3  = ((rd4 >> 24) == base) ? match_score : mismatch_score;
+
+        int32_t fe = 0, rel0_val = min_score;
+        int32_t s0, s1, s2, s3;
+        // candidates of the predecessor held in registers (row r-1), shifted to this row's band start
+        auto from_regs = [&](int32_t& t0, int32_t& t1, int32_t& t2, int32_t& t3) {
+            const int32_t q    = (bs - prev_bs) >> 2;
+            const int32_t pend = min(prev_bs + band_width - kCellsPerLane, max_column);
+            int32_t S0, S1, S2, S3, S4;
+            if (q == 0)
+            {
+                S0 = wave_shr1(P3, prev_rel0);
+                S1 = P0; S2 = P1; S3 = P2; S4 = P3;
+            }
+            else if (q == 1)
+            {
+                S0 = P3;
+                S1 = wave_shl1(P0, 0); S2 = wave_shl1(P1, 0); S3 = wave_shl1(P2, 0); S4 = wave_shl1(P3, 0);
+            }
+            else
+            {
+                const int src = lane + q;
+                S0 = __shfl(P3, src - 1);
+                S1 = __shfl(P0, src); S2 = __shfl(P1, src); S3 = __shfl(P2, src); S4 = __shfl(P3, src);
+            }
+            const bool valid = c <= pend; // c >= prev_bs always (band starts never decrease)
+            t0 = valid ? max(S0 + cp0, S1 + gap_score) : min_score;
+            t1 = valid ? max(S1 + cp1, S2 + gap_score) : min_score;
+            t2 = valid ? max(S2 + cp2, S3 + gap_score) : min_score;
+            t3 = valid ? max(S3 + cp3, S4 + gap_score) : min_score;
+        };
+        // candidates of an older predecessor row (LDS ring, else HBM)
+        auto from_memory = [&](int32_t prow, int32_t& t0, int32_t& t1, int32_t& t2, int32_t& t3) {
+            const int32_t pbs  = prow == 0 ? 0 : uniform_row(rowinfo[prow]).bs();
+            const int32_t pend = min(pbs + band_width - kCellsPerLane, max_column);
+            const bool valid   = !(c > pend || c < pbs);
+            const int32_t dist = r - prow;
+            const bool in_ring = dist < ring_rows;
+            int32_t S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0;
+            if (in_ring)
+            {
+                int32_t slot = my_slot - dist;
+                if (slot < 0) slot += ring_rows;
+                if (valid)
+                {
+                    const ScoreT* rowp = ring + slot * stride + (c - pbs) + kRelShift;
+                    S0 = rowp[0];
+                    const Quad<ScoreT> qd = *reinterpret_cast<const Quad<ScoreT>*>(rowp + 1);
+                    S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
+                }
+            }
+            else
+            {
+                if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
+                if (valid)
+                {
+                    const ScoreT* rowp = scores + (int64_t)prow * stride + (c - pbs) + kRelShift;
+                    S0 = rowp[0];
+                    const Quad<ScoreT> qd = *reinterpret_cast<const Quad<ScoreT>*>(rowp + 1);
+                    S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
+                }
+            }
+            t0 = valid ? max(S0 + cp0, S1 + gap_score) : min_score;
+            t1 = valid ? max(S1 + cp1, S2 + gap_score) : min_score;
+            t2 = valid ? max(S2 + cp2, S3 + gap_score) : min_score;
+            t3 = valid ? max(S3 + cp3, S4 + gap_score) : min_score;
+        };
+        // relative-0 slot of an older row
+        auto rel0_of = [&](int32_t prow) -> int32_t {
+            if (prow == r - 1) return prev_rel0;
+            const int32_t dist = r - prow;
+            if (dist < ring_rows)
+            {
+                int32_t slot = my_slot - dist;
+                if (slot < 0) slot += ring_rows;
+                return wave_first((int32_t)ring[slot * stride + kRelShift]);
+            }
+            if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
+            return wave_first((int32_t)scores[(int64_t)prow * stride + kRelShift]);
+        };
+
+        const int32_t p0row = pred_count == 0 ? 0 : ri.pred(0);
+        if ((pred_count <= 1 && p0row == r - 1) || (dbg & 4))
+        {
+            // ---- the common row: one predecessor, the previous row ----
+            if (pred_count == 0)
+            {
+                if (bs == 0) rel0_val = gap_score; // carry-in stays 0 (reference quirk)
+            }
+            else
+            {
+                fe = (bs > kCellsPerLane) ? min_score + gap_score : max(min_score, prev_rel0) + gap_score;
+                if (bs == 0) rel0_val = fe;
+            }
+            from_regs(s0, s1, s2, s3);
+        }
+        else
+        {
+            // ---- general row: any predecessor set ----
+            const int32_t node_id = (pred_count > 3) ? (int32_t)g.sorted_poa[r - 1] : 0;
+            auto pred_row = [&](int32_t p) -> int32_t {
+                if (p == 0) return p0row;
+                if (p == 1) return ri.pred(1);
+                if (p == 2) return ri.pred(2);
+                return (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
+            };
+            if (pred_count == 0)
+            {
+                if (bs == 0) rel0_val = gap_score;
+            }
+            else
+            {
+                if (bs > kCellsPerLane && pred_count == 1)
+                    fe = min_score + gap_score;
+                else
+                {
+                    int32_t penalty = min_score;
+                    for (int32_t p = 0; p < pred_count; p++) penalty = max(penalty, rel0_of(pred_row(p)));
+                    fe = penalty + gap_score;
+                }
+                if (bs == 0) rel0_val = fe;
+            }
+            const int32_t np = max(pred_count, 1);
+            for (int32_t p = 0; p < np; p++)
+            {
+                const int32_t prow = pred_row(p);
+                int32_t t0, t1, t2, t3;
+                if (prow == r - 1) from_regs(t0, t1, t2, t3);
+                else from_memory(prow, t0, t1, t2, t3);
+                if (p == 0) { s0 = t0; s1 = t1; s2 = t2; s3 = t3; }
+                else { s0 = max(s0, t0); s1 = max(s1, t1); s2 = max(s2, t2); s3 = max(s3, t3); }
+            }
+        }
+
+        // ---- horizontal max-plus scan (prefix max of u[t] = v[t] - t*gap, carry as element -1) ----
+        const int32_t u0 = s0 - K0, u1 = s1 - K1, u2 = s2 - K2, u3 = s3 - K3;
+        const int32_t m1 = max(u0, u1), m2 = max(m1, u2), m3 = max(m2, u3);
+        const int32_t incl = (dbg & 8) ? m3 : wave_inclusive_max(m3);
+        const int32_t excl = max(wave_shr1(incl, INT32_MIN), fe + gap_score);
+        P0 = max(u0, excl) + K0;
+        P1 = max(m1, excl) + K1;
+        P2 = max(m2, excl) + K2;
+        P3 = max(m3, excl) + K3;
+        if (active)
+        {
+            Quad<ScoreT> out;
+            out.v[0] = (ScoreT)P0; out.v[1] = (ScoreT)P1; out.v[2] = (ScoreT)P2; out.v[3] = (ScoreT)P3;
+            if (!(dbg & 1)) *reinterpret_cast<Quad<ScoreT>*>(row_out + lane4 + 1 + kRelShift) = out;
+            if (!(dbg & 2)) *reinterpret_cast<Quad<ScoreT>*>(ring + my_slot * stride + lane4 + 1 + kRelShift) = out;
+        }
+        if (lane == 0 && !(dbg & 16))
+        {
+            if (!(dbg & 1)) row_out[kRelShift] = (ScoreT)rel0_val;
+            if (!(dbg & 2)) ring[my_slot * stride + kRelShift] = (ScoreT)rel0_val;
+        }
+        hbm_dirty = true;
+        prev_bs   = bs;
+        prev_rel0 = rel0_val;
+        ring_slot = my_slot;
     }
 }
 
@@ -253,12 +513,12 @@ __device__ void build_rowinfo(const GraphView<IdT>& g, int32_t graph_count, RowI
 // Banded NW (score-matrix modes): forward pass wave-wide, then sink selection (wave reduction with the
 // reference's first-maximum tie rule) and the lane-0 traceback.
 // ------------------------------------------------------------------------------------------------
-template <typename ScoreT, typename IdT, bool ADAPTIVE>
-__device__ int32_t nw_banded(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, int32_t graph_count, const uint8_t* read,
-                             int32_t read_length, ScoreT* scores, ScoreT* ring_base, int32_t ring_bytes,
+template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE, bool LDS_READ>
+__device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowinfo, int32_t graph_count, const uint8_t* read,
+                             const uint8_t* lds_read, int32_t read_length, ScoreT* scores, ScoreT* ring_base, int32_t ring_bytes,
                              float max_buffer_size, int32_t* alignment_graph, int32_t* alignment_read,
                              int32_t band_width, int32_t gap_score, int32_t mismatch_score, int32_t match_score,
-                             int32_t rerun, uint64_t& cells)
+                             int32_t rerun, uint64_t& cells, PhaseClock& pc, int32_t dbg = 0)
 {
     const int lane              = threadIdx.x & (kWave - 1);
     const int32_t min_score     = Limits<ScoreT>::min / 2;
@@ -327,19 +587,36 @@ __device__ int32_t nw_banded(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, int
         P3 = (ScoreT)((c + 4) * gap_score);
         prev_rel0 = 0; // row 0, rel 0 = 0 * gap
     }
+    // band start of every row, once per read, into the row table: the row loop then does no fp math at all
+    for (int32_t r = 1 + lane; r <= graph_count; r += kWave)
+        rowinfo[r].set_bs(band_start_for_row(r, gradient, band_width, band_shift, max_column));
     bool hbm_dirty = true; // stores since the last workgroup sync (needed before reading the HBM matrix)
     __syncthreads();
     hbm_dirty = false;
+    auto bs_of = [&](int32_t row) -> int32_t { return row == 0 ? 0 : uniform_row(rowinfo[row]).bs(); };
 
-    for (int32_t r = 1; r <= graph_count; r++)
+    constexpr bool kFastOk = std::is_same<RowT, RowInfo<true>>::value && LDS_READ;
+    bool fast_done = false;
+    if constexpr (kFastOk)
     {
-        const RowInfo<IdT> ri    = rowinfo[r];
-        const int32_t pred_count = ri.cnt_sink & 0x7f;
-        const int32_t bs         = band_start_for_row(r, gradient, band_width, band_shift, max_column);
+        if (npass == 1 && b.ring_rows >= 2)
+        {
+            banded_forward_1pass<ScoreT, IdT>(g, rowinfo, graph_count, lds_read, scores, b.ring, b.ring_rows, band_width,
+                                              max_column, gap_score, mismatch_score, match_score, dbg);
+            fast_done = true;
+        }
+    }
+    RowT ri_next = uniform_row(rowinfo[1]);
+    for (int32_t r = 1; r <= graph_count && !fast_done; r++)
+    {
+        const RowT ri            = ri_next;
+        if (r < graph_count) ri_next = uniform_row(rowinfo[r + 1]); // prefetch: hides the LDS latency of the table
+        const int32_t pred_count = ri.cnt();
+        const int32_t bs         = ri.bs();
         const int32_t node_id    = (pred_count > 3) ? (int32_t)g.sorted_poa[r - 1] : 0;
         auto pred_row = [&](int32_t p) -> int32_t {
             if (pred_count == 0) return 0;
-            if (p < 3) return (int32_t)ri.pred[p];
+            if (p < 3) return ri.pred(p);
             return (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
         };
         // relative-0 slot of an arbitrary earlier row (get_score(row, -1): reads rel 0 unconditionally)
@@ -377,18 +654,21 @@ __device__ int32_t nw_banded(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, int
         {
             const int32_t c      = bs + pass * 256 + 4 * lane; // chunk anchor column (cells c+1..c+4)
             const bool active    = (pass * 256 + 4 * lane) < band_width;
-            // read characters c .. c+3 (positions past the read are never consumed; buffer has zero slack)
-            const uint32_t rd4   = *reinterpret_cast<const uint32_t*>(read + c);
-            const int32_t cp0    = ((rd4 & 0xff) == ri.base) ? match_score : mismatch_score;
-            const int32_t cp1    = (((rd4 >> 8) & 0xff) == ri.base) ? match_score : mismatch_score;
-            const int32_t cp2    = (((rd4 >> 16) & 0xff) == ri.base) ? match_score : mismatch_score;
-            const int32_t cp3    = ((rd4 >> 24) == ri.base) ? match_score : mismatch_score;
+            // read characters c .. c+3 (positions past the read are never consumed; buffer has zero slack).
+            // They come from the LDS copy when the read was staged: a global load here would make every row
+            // wait for the previous row's score store (loads and stores share the in-order vmcnt counter).
+            const uint32_t rd4   = LDS_READ ? *reinterpret_cast<const uint32_t*>(lds_read + c)
+                                            : *reinterpret_cast<const uint32_t*>(read + c);
+            const int32_t cp0    = ((rd4 & 0xff) == (uint32_t)ri.base()) ? match_score : mismatch_score;
+            const int32_t cp1    = (((rd4 >> 8) & 0xff) == (uint32_t)ri.base()) ? match_score : mismatch_score;
+            const int32_t cp2    = (((rd4 >> 16) & 0xff) == (uint32_t)ri.base()) ? match_score : mismatch_score;
+            const int32_t cp3    = ((rd4 >> 24) == (uint32_t)ri.base()) ? match_score : mismatch_score;
             int32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
             const int32_t np = max(pred_count, 1);
             for (int32_t p = 0; p < np; p++)
             {
                 const int32_t prow = (p == 0) ? pred_idx0 : pred_row(p);
-                const int32_t pbs  = band_start_for_row(prow, gradient, band_width, band_shift, max_column);
+                const int32_t pbs  = (reg_path && prow == r - 1) ? prev_bs : bs_of(prow);
                 const int32_t pend = min(pbs + band_width - kCellsPerLane, max_column);
                 const bool valid   = !(c > pend || c < pbs);
                 int32_t S0, S1, S2, S3, S4; // predecessor row columns c .. c+4
@@ -414,22 +694,27 @@ __device__ int32_t nw_banded(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, int
                 }
                 else
                 {
-                    const ScoreT* rowp;
-                    if (b.ring_rows && r - prow < b.ring_rows)
-                        rowp = b.ring + (prow % b.ring_rows) * stride;
-                    else
-                    {
-                        if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
-                        rowp = scores + (int64_t)prow * stride;
-                    }
+                    const bool in_ring = b.ring_rows && r - prow < b.ring_rows;
+                    if (!in_ring && hbm_dirty) { __syncthreads(); hbm_dirty = false; }
+                    S0 = S1 = S2 = S3 = S4 = 0;
                     if (valid)
                     {
                         const int32_t rel = c - pbs; // multiple of 4
-                        S0 = rowp[rel + kRelShift];
-                        Quad<ScoreT> qd = *reinterpret_cast<const Quad<ScoreT>*>(rowp + rel + kRelShift + 1);
-                        S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
+                        if (in_ring) // LDS ring: ds_read ops only
+                        {
+                            const ScoreT* rowp = b.ring + (prow % b.ring_rows) * stride;
+                            S0 = rowp[rel + kRelShift];
+                            Quad<ScoreT> qd = *reinterpret_cast<const Quad<ScoreT>*>(rowp + rel + kRelShift + 1);
+                            S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
+                        }
+                        else // HBM score matrix
+                        {
+                            const ScoreT* rowp = scores + (int64_t)prow * stride;
+                            S0 = rowp[rel + kRelShift];
+                            Quad<ScoreT> qd = *reinterpret_cast<const Quad<ScoreT>*>(rowp + rel + kRelShift + 1);
+                            S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
+                        }
                     }
-                    else { S0 = S1 = S2 = S3 = S4 = 0; }
                 }
                 int32_t t0, t1, t2, t3;
                 if (valid)
@@ -466,15 +751,15 @@ __device__ int32_t nw_banded(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, int
                 Quad<ScoreT> out;
                 out.v[0] = (ScoreT)N0; out.v[1] = (ScoreT)N1; out.v[2] = (ScoreT)N2; out.v[3] = (ScoreT)N3;
                 const int32_t rel = pass * 256 + 4 * lane + 1;
-                *reinterpret_cast<Quad<ScoreT>*>(scores + (int64_t)r * stride + rel + kRelShift) = out;
-                if (b.ring_rows)
+                if (!(dbg & 1)) *reinterpret_cast<Quad<ScoreT>*>(scores + (int64_t)r * stride + rel + kRelShift) = out;
+                if (b.ring_rows && !(dbg & 2))
                     *reinterpret_cast<Quad<ScoreT>*>(b.ring + (r % b.ring_rows) * stride + rel + kRelShift) = out;
             }
         }
         if (lane == 0)
         {
-            scores[(int64_t)r * stride + kRelShift] = (ScoreT)rel0_val;
-            if (b.ring_rows) b.ring[(r % b.ring_rows) * stride + kRelShift] = (ScoreT)rel0_val;
+            if (!(dbg & 1)) scores[(int64_t)r * stride + kRelShift] = (ScoreT)rel0_val;
+            if (b.ring_rows && !(dbg & 2)) b.ring[(r % b.ring_rows) * stride + kRelShift] = (ScoreT)rel0_val;
         }
         hbm_dirty = true;
         if (reg_path)
@@ -485,12 +770,13 @@ __device__ int32_t nw_banded(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, int
         }
     }
     __syncthreads(); // score matrix complete and visible to lane 0's traceback
+    pc.tick(kPhForward);
 
     // ---- sink selection (:410-426): first row with the strictly greatest H(row, L) among sink rows ----
     int32_t best = min_score, best_i = 0;
     for (int32_t idx = 1 + lane; idx <= graph_count; idx += kWave)
     {
-        if (rowinfo[idx].cnt_sink & 0x80)
+        if (rowinfo[idx].sink())
         {
             int32_t s = get_score(b, idx, read_length);
             if (best < s) { best = s; best_i = idx; }
@@ -505,10 +791,11 @@ __device__ int32_t nw_banded(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, int
 
     int32_t aligned_nodes = 0;
     if (lane == 0)
-        aligned_nodes = traceback_banded<ScoreT, IdT, ADAPTIVE>(b, g, rowinfo, graph_count, read, read_length, best_i,
+        aligned_nodes = traceback_banded<ScoreT, IdT, RowT, ADAPTIVE>(b, g, rowinfo, graph_count, read, read_length, best_i,
                                                                 alignment_graph, alignment_read, gap_score,
                                                                 mismatch_score, match_score, rerun);
     aligned_nodes = wave_first(aligned_nodes);
+    pc.tick(kPhTraceback);
     return aligned_nodes;
 }
 

@@ -9,8 +9,8 @@
 namespace gwhip
 {
 
-template <typename ScoreT, typename IdT>
-__device__ int32_t nw_full(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, int32_t graph_count, const uint8_t* read,
+template <typename ScoreT, typename IdT, typename RowT>
+__device__ __forceinline__ int32_t nw_full(const GraphView<IdT>& g, RowT* rowinfo, int32_t graph_count, const uint8_t* read,
                            int32_t read_length, ScoreT* scores, int32_t scores_width, ScoreT* ring_base,
                            int32_t ring_bytes, int32_t* alignment_graph, int32_t* alignment_read, int32_t gap_score,
                            int32_t mismatch_score, int32_t match_score, uint64_t& cells)
@@ -34,12 +34,12 @@ __device__ int32_t nw_full(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, int32
 
     for (int32_t r = 1; r <= graph_count; r++)
     {
-        const RowInfo<IdT> ri    = rowinfo[r];
-        const int32_t pred_count = ri.cnt_sink & 0x7f;
+        const RowT ri    = rowinfo[r];
+        const int32_t pred_count = ri.cnt();
         const int32_t node_id    = (pred_count > 3) ? (int32_t)g.sorted_poa[r - 1] : 0;
         auto pred_row = [&](int32_t p) -> int32_t {
             if (pred_count == 0) return 0;
-            if (p < 3) return (int32_t)ri.pred[p];
+            if (p < 3) return ri.pred(p);
             return (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
         };
         auto row_ptr = [&](int32_t row) -> const ScoreT* {
@@ -63,10 +63,10 @@ __device__ int32_t nw_full(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, int32
             const int32_t c   = pass * 256 + 4 * lane; // cells are columns c+1..c+4, read chars c..c+3
             const bool active = c < read_length;
             const uint32_t rd4 = *reinterpret_cast<const uint32_t*>(read + c);
-            const int32_t cp0 = ((rd4 & 0xff) == ri.base) ? match_score : mismatch_score;
-            const int32_t cp1 = (((rd4 >> 8) & 0xff) == ri.base) ? match_score : mismatch_score;
-            const int32_t cp2 = (((rd4 >> 16) & 0xff) == ri.base) ? match_score : mismatch_score;
-            const int32_t cp3 = ((rd4 >> 24) == ri.base) ? match_score : mismatch_score;
+            const int32_t cp0 = ((rd4 & 0xff) == (uint32_t)ri.base()) ? match_score : mismatch_score;
+            const int32_t cp1 = (((rd4 >> 8) & 0xff) == (uint32_t)ri.base()) ? match_score : mismatch_score;
+            const int32_t cp2 = (((rd4 >> 16) & 0xff) == (uint32_t)ri.base()) ? match_score : mismatch_score;
+            const int32_t cp3 = ((rd4 >> 24) == (uint32_t)ri.base()) ? match_score : mismatch_score;
             int32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
             const int32_t np = max(pred_count, 1);
             for (int32_t p = 0; p < np; p++)
@@ -129,7 +129,7 @@ __device__ int32_t nw_full(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, int32
     int32_t best = Limits<ScoreT>::min, best_i = 0;
     for (int32_t idx = 1 + lane; idx <= graph_count; idx += kWave)
     {
-        if (rowinfo[idx].cnt_sink & 0x80)
+        if (rowinfo[idx].sink())
         {
             int32_t s = H(idx, read_length);
             if (best < s) { best = s; best_i = idx; }
@@ -151,23 +151,23 @@ __device__ int32_t nw_full(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, int32
             loop_count++;
             int32_t scores_ij = H(i, j);
             bool pred_found   = false;
-            RowInfo<IdT> ri{};
+            RowT ri{};
             int32_t pred_count = 0, node_id = 0;
             if (i != 0)
             {
                 ri         = rowinfo[i];
-                pred_count = ri.cnt_sink & 0x7f;
+                pred_count = ri.cnt();
                 if (pred_count > 3) node_id = g.sorted_poa[i - 1];
             }
             auto pred_row = [&](int32_t p) -> int32_t {
                 if (pred_count == 0) return 0;
-                if (p < 3) return (int32_t)ri.pred[p];
+                if (p < 3) return ri.pred(p);
                 return (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
             };
             const int32_t np = max(pred_count, 1);
             if (i != 0 && j != 0)
             {
-                int32_t match_cost = (ri.base == read[j - 1] ? match_score : mismatch_score);
+                int32_t match_cost = (ri.base() == read[j - 1] ? match_score : mismatch_score);
                 for (int32_t p = 0; p < np; p++)
                 {
                     int32_t pi = pred_row(p);

@@ -135,6 +135,205 @@ __device__ uint8_t add_alignment_to_graph(int32_t& new_node_count, const GraphVi
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-parallel graph merge, bit-identical to add_alignment_to_graph.
+//
+// In a global alignment every read position rp = 0..L-1 appears exactly once, so the merge is a map over rp:
+//   A. classify rp (reuse the aligned graph node / reuse one of its aligned nodes / create a node), read-only;
+//   B. number the new nodes by an ordered prefix sum over rp (= the serial creation order);
+//   C. create nodes and cross-link aligned-node lists;
+//   D. for every consecutive pair (rp-1, rp) bump or append the edge, bump coverage.
+// Different rp touch different nodes as long as no two nodes on the alignment path are aligned to each other
+// (they never are in a well-formed POA); phase A verifies exactly that and returns -1, before anything was
+// modified, so the caller can fall back to the serial routine. Error precedence (first failing rp, node
+// overflow before edge overflow inside one rp) is reproduced.
+// LDS scratch: gnode[L], curr[L] (int16) and a node bitset `onpath`.
+// ------------------------------------------------------------------------------------------------
+template <typename IdT, bool MSA>
+__device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_count, const GraphView<IdT>& g,
+                                                          int32_t node_count, int32_t alen, const int32_t* ag,
+                                                          const int32_t* ar, const uint8_t* read,
+                                                          const int8_t* base_weights, int32_t read_length,
+                                                          IdT* sequence_begin_nodes_ids, uint16_t s,
+                                                          uint32_t max_sequences_per_poa, int32_t max_nodes,
+                                                          int16_t* gnode, int16_t* curr, uint32_t* onpath, int lane)
+{
+    const int32_t L = read_length;
+    for (int32_t i = lane; i < (node_count + 31) / 32; i += kWave) onpath[i] = 0;
+    for (int32_t i = lane; i < L; i += kWave) gnode[i] = -1;
+    __syncthreads();
+    int32_t covered = 0;
+    for (int32_t base = 0; base < alen; base += kWave)
+    {
+        const int32_t k  = base + lane;
+        const int32_t rp = k < alen ? ar[k] : -1;
+        if (rp >= 0)
+        {
+            const int32_t gn = ag[k];
+            gnode[rp]        = (int16_t)gn;
+            if (gn >= 0) atomicOr(&onpath[gn >> 5], 1u << (gn & 31));
+        }
+        covered += __popcll(__ballot(rp >= 0));
+    }
+    __syncthreads();
+    // The map over read positions needs a complete alignment (every read position exactly once); a degenerate
+    // traceback result (reference quirk: a walk that finds no predecessor at its first step) goes the serial way.
+    if (covered != L) return -1;
+
+    // ---- A + B: classify, detect conflicts, number new nodes in rp order ----
+    int32_t running   = 0;
+    bool conflict     = false;
+    int32_t rp_nodeerr = INT32_MAX;
+    for (int32_t base = 0; base < L; base += kWave)
+    {
+        const int32_t rp = base + lane;
+        bool is_new      = false;
+        int32_t cur      = -1;
+        if (rp < L)
+        {
+            const int32_t gn      = gnode[rp];
+            const uint8_t rbase   = read[rp];
+            if (gn < 0)
+                is_new = true;
+            else if (g.nodes[gn] == rbase)
+                cur = gn;
+            else
+            {
+                const int32_t na = g.node_alignment_count[gn];
+                for (int32_t n = 0; n < na; n++)
+                {
+                    const int32_t aid = g.node_alignments[(int64_t)gn * kAligns + n];
+                    if ((onpath[aid >> 5] >> (aid & 31)) & 1u) conflict = true;
+                    if (cur < 0 && g.nodes[aid] == rbase) cur = aid;
+                }
+                if (cur < 0) is_new = true;
+            }
+        }
+        const unsigned long long m = __ballot(is_new);
+        if (is_new)
+        {
+            cur = node_count + running + __popcll(m & ((1ull << lane) - 1));
+            if (cur + 1 >= max_nodes) rp_nodeerr = min(rp_nodeerr, rp);
+        }
+        if (rp < L) curr[rp] = (int16_t)cur;
+        running += __popcll(m);
+    }
+    if (__any(conflict)) return -1;
+    for (int off = 32; off > 0; off >>= 1) rp_nodeerr = min(rp_nodeerr, __shfl_xor(rp_nodeerr, off));
+    __syncthreads();
+
+    const int32_t first_new = node_count;
+    auto in_count_of  = [&](int32_t n) -> int32_t { return n >= first_new ? 0 : (int32_t)g.incoming_edge_count[n]; };
+    auto out_count_of = [&](int32_t n) -> int32_t { return n >= first_new ? 0 : (int32_t)g.outgoing_edge_count[n]; };
+
+    if (rp_nodeerr != INT32_MAX)
+    {
+        // node overflow at rp_nodeerr: an edge overflow at an earlier rp would have been reported first
+        int32_t rp_edgeerr = INT32_MAX;
+        for (int32_t rp = 1 + lane; rp < rp_nodeerr; rp += kWave)
+        {
+            const int32_t head = curr[rp - 1], cur = curr[rp];
+            const int32_t ic   = in_count_of(cur);
+            bool exists        = false;
+            for (int32_t e = 0; e < ic; e++)
+                if (g.incoming_edges[(int64_t)cur * kEdges + e] == head) exists = true;
+            if (!exists && (out_count_of(head) + 1 >= kEdges || ic + 1 >= kEdges)) rp_edgeerr = min(rp_edgeerr, rp);
+        }
+        for (int off = 32; off > 0; off >>= 1) rp_edgeerr = min(rp_edgeerr, __shfl_xor(rp_edgeerr, off));
+        return rp_edgeerr != INT32_MAX ? (int32_t)kEdgeCountExceeded : (int32_t)kNodeCountExceeded;
+    }
+
+    // ---- C: create nodes, cross-link aligned-node lists ----
+    for (int32_t rp = lane; rp < L; rp += kWave)
+    {
+        const int32_t cur = curr[rp];
+        if (cur < first_new) continue;
+        const int32_t gn          = gnode[rp];
+        g.nodes[cur]               = read[rp];
+        g.outgoing_edge_count[cur] = 0;
+        g.incoming_edge_count[cur] = 0;
+        g.coverage[cur]            = 0;
+        int32_t na_new             = 0;
+        if (gn >= 0)
+        {
+            const int32_t na = g.node_alignment_count[gn];
+            for (int32_t n = 0; n < na; n++)
+            {
+                const int32_t aid  = g.node_alignments[(int64_t)gn * kAligns + n];
+                const int32_t acnt = g.node_alignment_count[aid];
+                g.node_alignments[(int64_t)aid * kAligns + acnt] = (IdT)cur;
+                g.node_alignment_count[aid]                      = (uint16_t)(acnt + 1);
+                g.node_alignments[(int64_t)cur * kAligns + n]    = (IdT)aid;
+            }
+            g.node_alignments[(int64_t)gn * kAligns + na]  = (IdT)cur;
+            g.node_alignment_count[gn]                     = (uint16_t)(na + 1);
+            g.node_alignments[(int64_t)cur * kAligns + na] = (IdT)gn;
+            na_new                                         = na + 1;
+        }
+        g.node_alignment_count[cur] = (uint16_t)na_new;
+    }
+    __syncthreads();
+
+    // ---- D: edges and coverage ----
+    int32_t rp_edgeerr = INT32_MAX;
+    for (int32_t rp = lane; rp < L; rp += kWave)
+    {
+        const int32_t cur = curr[rp];
+        if (rp > 0)
+        {
+            const int32_t head = curr[rp - 1];
+            const uint16_t w   = (uint16_t)((uint16_t)base_weights[rp - 1] + base_weights[rp]);
+            const int32_t ic   = in_count_of(cur);
+            bool exists        = false;
+            for (int32_t e = 0; e < ic; e++)
+            {
+                if (g.incoming_edges[(int64_t)cur * kEdges + e] == head)
+                {
+                    exists = true;
+                    g.incoming_edge_w[(int64_t)cur * kEdges + e] += w;
+                }
+            }
+            if (!exists)
+            {
+                g.incoming_edges[(int64_t)cur * kEdges + ic]  = (IdT)head;
+                g.incoming_edge_w[(int64_t)cur * kEdges + ic] = w;
+                g.incoming_edge_count[cur]                    = (uint16_t)(ic + 1);
+                const int32_t oc                              = out_count_of(head);
+                g.outgoing_edges[(int64_t)head * kEdges + oc] = (IdT)cur;
+                if (MSA)
+                {
+                    g.out_cov_cnt[(int64_t)head * kEdges + oc]                          = 1;
+                    g.out_cov[((int64_t)head * kEdges + oc) * max_sequences_per_poa]    = s;
+                }
+                g.outgoing_edge_count[head] = (uint16_t)(oc + 1);
+                if (oc + 1 >= kEdges || ic + 1 >= kEdges) rp_edgeerr = min(rp_edgeerr, rp);
+            }
+            else if (MSA)
+            {
+                const int32_t oc = out_count_of(head);
+                for (int32_t e = 0; e < oc; e++)
+                {
+                    if (g.outgoing_edges[(int64_t)head * kEdges + e] == cur)
+                    {
+                        const uint16_t cc = g.out_cov_cnt[(int64_t)head * kEdges + e];
+                        g.out_cov[((int64_t)head * kEdges + e) * max_sequences_per_poa + cc] = s;
+                        g.out_cov_cnt[(int64_t)head * kEdges + e]                            = cc + 1;
+                        break;
+                    }
+                }
+            }
+        }
+        else if (MSA)
+            *sequence_begin_nodes_ids = (IdT)cur;
+        g.coverage[cur]++;
+    }
+    for (int off = 32; off > 0; off >>= 1) rp_edgeerr = min(rp_edgeerr, __shfl_xor(rp_edgeerr, off));
+    __syncthreads();
+    if (rp_edgeerr != INT32_MAX) return (int32_t)kEdgeCountExceeded;
+    new_node_count = node_count + running;
+    return 0;
+}
+
 // Kahn order: sources by ascending node id, children in outgoing-slot order, queue == output array.
 template <typename IdT>
 __device__ void topsort_kahn(IdT* sorted_poa, IdT* node_map, int32_t node_count, const uint16_t* incoming_edge_count,
@@ -166,6 +365,76 @@ __device__ void topsort_kahn(IdT* sorted_poa, IdT* node_map, int32_t node_count,
             }
             local_cnt[out_node] = c;
         }
+    }
+}
+
+// Kahn with its working set in LDS (node counts <= 3072, 16-bit ids): the order-defining serial loop then pays
+// LDS latency (~64 cycles) per dependent step instead of an HBM round trip. Same output as topsort_kahn.
+//   e01[n]  : first two outgoing edges (u16 | u16 << 16)      12 KB
+//   cnts[n] : outgoing count (low byte) | remaining in-degree (high byte)   6 KB
+//   queue[] : the FIFO == the sorted order                      6 KB
+template <typename IdT>
+__device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_t node_count, uint8_t* lds, int lane)
+{
+    uint32_t* e01   = reinterpret_cast<uint32_t*>(lds);
+    uint16_t* cnts  = reinterpret_cast<uint16_t*>(lds + 3072 * 4);
+    uint16_t* queue = reinterpret_cast<uint16_t*>(lds + 3072 * 6);
+    // phase 1 (all lanes): stage counts / edges; sources in ascending node id (ordered compaction per 64-chunk)
+    int32_t tail = 0;
+    for (int32_t base = 0; base < node_count; base += kWave)
+    {
+        const int32_t n = base + lane;
+        bool is_src     = false;
+        if (n < node_count)
+        {
+            const uint32_t ic = g.incoming_edge_count[n];
+            const uint32_t oc = g.outgoing_edge_count[n];
+            cnts[n]           = (uint16_t)((oc & 0xff) | (ic << 8));
+            uint32_t e        = 0;
+            if (oc > 0) e = (uint16_t)g.outgoing_edges[(int64_t)n * kEdges];
+            if (oc > 1) e |= ((uint32_t)(uint16_t)g.outgoing_edges[(int64_t)n * kEdges + 1]) << 16;
+            e01[n] = e;
+            is_src = (ic == 0);
+        }
+        const unsigned long long m = __ballot(is_src);
+        if (is_src) queue[tail + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)n;
+        tail += __popcll(m);
+    }
+    __syncthreads();
+    // phase 2 (lane 0): the FIFO loop
+    if (lane == 0)
+    {
+        int32_t head    = 0;
+        int32_t pending = -1; // value last pushed at queue[tail - 1], kept in a register
+        while (head < tail)
+        {
+            const int32_t node = (head == tail - 1 && pending >= 0) ? pending : (int32_t)queue[head];
+            const uint32_t c   = cnts[node];
+            const uint32_t e   = e01[node];
+            const int32_t oc   = (int32_t)(c & 0xff);
+            for (int32_t k = 0; k < oc; k++)
+            {
+                const int32_t child = k == 0 ? (int32_t)(e & 0xffff)
+                                      : k == 1 ? (int32_t)(e >> 16) : (int32_t)g.outgoing_edges[(int64_t)node * kEdges + k];
+                const uint32_t cc   = cnts[child];
+                const uint32_t left = ((cc >> 8) - 1) & 0xff;
+                cnts[child]         = (uint16_t)((cc & 0xff) | (left << 8));
+                if (left == 0)
+                {
+                    queue[tail++] = (uint16_t)child;
+                    pending       = child;
+                }
+            }
+            head++;
+        }
+    }
+    __syncthreads();
+    // phase 3 (all lanes): publish order and inverse map
+    for (int32_t i = lane; i < node_count; i += kWave)
+    {
+        const int32_t node    = queue[i];
+        g.sorted_poa[i]       = (IdT)node;
+        g.node_id_to_pos[node] = (IdT)i;
     }
 }
 

@@ -66,7 +66,7 @@ inline PoaLayout make_poa_layout(const gwhip_poa_config& c)
     L.id_bytes        = c.size32 ? 4 : 2;
     L.score_bytes     = c.score32 ? 4 : 2;
     L.trace_bytes     = c.trace16 ? 2 : 1;
-    L.rowinfo_bytes   = c.size32 ? 16 : 8;
+    L.rowinfo_bytes   = 24; // RowInfo<false>; the packed 8-byte flavour only ever lives in LDS
     L.align_capacity  = c.max_nodes_per_graph + c.max_sequence_size + 8;
     const bool msa    = (c.output_mask & 2) != 0;
     const bool tb     = c.band_mode == GWHIP_STATIC_BAND_TRACEBACK || c.band_mode == GWHIP_ADAPTIVE_BAND_TRACEBACK;

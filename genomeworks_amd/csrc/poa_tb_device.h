@@ -40,8 +40,8 @@ __device__ __forceinline__ void tb_set_score(const TbCtx<ScoreT>& t, int32_t row
     if (idx >= 0 && (size_t)idx < t.scores_elems) t.scores[idx] = (ScoreT)value;
 }
 
-template <typename ScoreT, typename IdT, typename TraceT, bool ADAPTIVE>
-__device__ int32_t nw_banded_tb(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, int32_t graph_count,
+template <typename ScoreT, typename IdT, typename RowT, typename TraceT, bool ADAPTIVE>
+__device__ __forceinline__ int32_t nw_banded_tb(const GraphView<IdT>& g, RowT* rowinfo, int32_t graph_count,
                                 const uint8_t* read, int32_t read_length, ScoreT* scores, size_t scores_elems,
                                 TraceT* traceback, size_t trace_elems, float max_buffer_size, int32_t* alignment_graph,
                                 int32_t* alignment_read, int32_t band_width, int32_t H, int32_t gap_score,
@@ -87,13 +87,13 @@ __device__ int32_t nw_banded_tb(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, 
 
     for (int32_t r = 1; r <= graph_count; r++)
     {
-        const RowInfo<IdT> ri    = rowinfo[r];
-        const int32_t pred_count = ri.cnt_sink & 0x7f;
+        const RowT ri    = rowinfo[r];
+        const int32_t pred_count = ri.cnt();
         const int32_t bs         = band_start_for_row(r, gradient, band_width, band_shift, max_column);
         const int32_t node_id    = (pred_count > 3) ? (int32_t)g.sorted_poa[r - 1] : 0;
         auto pred_row = [&](int32_t p) -> int32_t {
             if (pred_count == 0) return 0;
-            if (p < 3) return (int32_t)ri.pred[p];
+            if (p < 3) return ri.pred(p);
             return (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
         };
         const int32_t pred_idx0 = pred_row(0);
@@ -173,10 +173,10 @@ __device__ int32_t nw_banded_tb(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, 
             {
                 const uint32_t rd4 = *reinterpret_cast<const uint32_t*>(read + c);
                 int32_t cp[4];
-                cp[0] = ((rd4 & 0xff) == ri.base) ? match_score : mismatch_score;
-                cp[1] = (((rd4 >> 8) & 0xff) == ri.base) ? match_score : mismatch_score;
-                cp[2] = (((rd4 >> 16) & 0xff) == ri.base) ? match_score : mismatch_score;
-                cp[3] = ((rd4 >> 24) == ri.base) ? match_score : mismatch_score;
+                cp[0] = ((rd4 & 0xff) == (uint32_t)ri.base()) ? match_score : mismatch_score;
+                cp[1] = (((rd4 >> 8) & 0xff) == (uint32_t)ri.base()) ? match_score : mismatch_score;
+                cp[2] = (((rd4 >> 16) & 0xff) == (uint32_t)ri.base()) ? match_score : mismatch_score;
+                cp[3] = ((rd4 >> 24) == (uint32_t)ri.base()) ? match_score : mismatch_score;
                 const int32_t np = max(pred_count, 1);
                 for (int32_t p = 0; p < np; p++)
                 {
@@ -234,7 +234,7 @@ __device__ int32_t nw_banded_tb(const GraphView<IdT>& g, RowInfo<IdT>* rowinfo, 
     int32_t best = min_score, best_i = 0;
     for (int32_t idx = 1 + lane; idx <= graph_count; idx += kWave)
     {
-        if ((rowinfo[idx].cnt_sink & 0x80) && (graph_count - idx) < H)
+        if (rowinfo[idx].sink() && (graph_count - idx) < H)
         {
             int32_t s = tb_get_score(t, idx, read_length);
             if (best < s) { best = s; best_i = idx; }

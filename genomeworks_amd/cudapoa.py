@@ -73,6 +73,7 @@ def _bind(L):
     L.gw_poa_graph_copy.argtypes = [vp, i32, vp, vp, vp, vp]
     L.gw_poa_total_cells.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.gw_poa_relaunch_timed.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.gw_poa_profile_phases.argtypes = [vp, C.POINTER(C.c_double)]
     L._gw_poa_bound = True
     return L
 
@@ -184,6 +185,14 @@ class CudaPoaBatch:
         if self._L.gw_poa_relaunch_timed(self._h, C.byref(a), C.byref(b)) != 0:
             raise RuntimeError(self._L.gw_last_error().decode())
         return a.value, b.value
+
+    def profile_phases(self):
+        """Profiling aid: mean device ticks per window spent in each graph-build phase (one extra launch)."""
+        out = (C.c_double * 6)()
+        if self._L.gw_poa_profile_phases(self._h, out) != 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        names = ("row_table", "nw_forward", "sink_traceback", "graph_merge", "topsort", "other")
+        return dict(zip(names, [float(x) for x in out]))
 
     def get_consensus_native(self):
         """D2H + host unpack inside the library, without marshalling the strings to Python. Returns window count."""

@@ -249,4 +249,13 @@ int gw_poa_relaunch_timed(gw_poa_batch* b, float* graph_build_ms, float* output_
     GW_CATCH(-1)
 }
 
+int gw_poa_profile_phases(gw_poa_batch* b, double* out6)
+{
+    GW_TRY
+    if (!b->impl) return -1;
+    b->impl->profile_phases(out6);
+    return 0;
+    GW_CATCH(-1)
+}
+
 } // extern "C"

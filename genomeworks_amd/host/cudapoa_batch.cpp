@@ -415,10 +415,11 @@ void PoaBatch::upload_inputs()
     GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq_lens_, h_seq_lens_, static_cast<size_t>(global_sequence_idx_) * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
 }
 
-void PoaBatch::launch(void* event_after_graph_build)
+void PoaBatch::launch(void* event_after_graph_build, uint64_t* phase_cycles)
 {
     gwhip_poa_args a          = kernel_args();
     a.event_after_graph_build = event_after_graph_build;
+    a.phase_cycles            = phase_cycles;
     const int rc     = gwhip_poa_generate(&a, stream_);
     if (rc != 0)
     {
@@ -470,6 +471,24 @@ void PoaBatch::relaunch_resident_timed(float* graph_build_ms, float* output_ms)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipEventDestroy(e2);
+}
+
+void PoaBatch::profile_phases(double out[6])
+{
+    scoped_device_switch dev(device_id_);
+    for (int k = 0; k < 6; k++) out[k] = 0;
+    if (poa_count_ == 0) return;
+    const size_t n = static_cast<size_t>(poa_count_) * 6;
+    uint64_t* d    = nullptr;
+    GW_CU_CHECK_ERR(hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(uint64_t)));
+    GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq_lens_, h_seq_lens_, static_cast<size_t>(global_sequence_idx_) * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
+    launch(nullptr, d);
+    std::vector<uint64_t> h(n);
+    GW_CU_CHECK_ERR(hipMemcpyAsync(h.data(), d, n * sizeof(uint64_t), hipMemcpyDeviceToHost, stream_));
+    GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+    GW_CU_CHECK_ERR(hipFree(d));
+    for (size_t i = 0; i < n; i++) out[i % 6] += static_cast<double>(h[i]);
+    for (int k = 0; k < 6; k++) out[k] /= poa_count_;
 }
 
 void PoaBatch::log_kernel_error(StatusType error_type, std::vector<StatusType>& output_status)

@@ -36,6 +36,9 @@ public:
     void relaunch_resident();  ///< re-run the kernels on the inputs already resident in HBM (no H2D)
     /// Same, timed with HIP events on the batch's stream: graph-build kernel and output kernel (milliseconds).
     void relaunch_resident_timed(float* graph_build_ms, float* output_ms);
+    /// Profiling aid: relaunch with per-phase cycle accounting; out[6] = mean ticks per window of
+    /// {row table, NW forward, sink+traceback, graph merge, topsort, other}.
+    void profile_phases(double out[6]);
     const gwhip_poa_config& device_config() const { return cfg_; }
     cudaStream_t stream() const { return stream_; }
 
@@ -45,7 +48,7 @@ private:
     StatusType add_poa();
     StatusType add_seq_to_poa(const char* seq, const int8_t* weights, int32_t seq_len);
     void upload_inputs();
-    void launch(void* event_after_graph_build = nullptr);
+    void launch(void* event_after_graph_build = nullptr, uint64_t* phase_cycles = nullptr);
     gwhip_poa_args kernel_args() const;
     void log_kernel_error(StatusType error_type, std::vector<StatusType>& output_status);
     size_t plan(int32_t n_poas, size_t* offsets) const;

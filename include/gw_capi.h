@@ -108,6 +108,8 @@ int gw_poa_total_cells(gw_poa_batch* b, uint64_t* cells);
 int gw_poa_relaunch(gw_poa_batch* b);
 /* same, timed with HIP events on the batch's stream (ms): graph-build kernel, then consensus/MSA kernel */
 int gw_poa_relaunch_timed(gw_poa_batch* b, float* graph_build_ms, float* output_ms);
+/* profiling aid: mean s_memtime ticks per window of {row table, NW forward, sink+traceback, graph merge, topsort, other} */
+int gw_poa_profile_phases(gw_poa_batch* b, double* out6);
 
 /* ---- cudaaligner (aligner.hpp:76-219) ---- */
 gw_aligner* gw_aligner_create_banded(int32_t max_bandwidth, void* stream, int32_t device_id, int64_t max_device_memory);

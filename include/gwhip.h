@@ -97,6 +97,9 @@ typedef struct gwhip_poa_args
     /* optional hipEvent_t recorded on `stream` between the graph-build kernel and the consensus/MSA kernel,
        so a caller can time the dominant kernel with events on the launch stream */
     void* event_after_graph_build;
+    /* optional profiling aid: per-window cycle totals (s_memtime ticks) of the graph-build phases,
+       uint64[total_windows][6] = {row table, NW forward, sink+traceback, graph merge, topsort, other} */
+    uint64_t* phase_cycles;
 } gwhip_poa_args;
 
 /* Bytes of scratch needed for `windows` windows under cfg (host function, no GPU needed).
