@@ -284,6 +284,163 @@ __device__ __forceinline__ int32_t traceback_banded(const BandedCtx<ScoreT>& b, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Traceback by recomputation with the score matrix served from an LDS tile.
+// Same decision sequence as traceback_banded (cudapoa_nw_banded.cuh:428-549). The walk is executed
+// wave-uniformly (every lane follows the same (i, j)); all 64 lanes stage a tile of 64 rows x 64 columns of
+// the HBM score matrix around the current position, so a step costs LDS latency instead of HBM round trips.
+// Cells outside the tile (far predecessors) fall back to the HBM copy; the tile is re-anchored when the walk
+// approaches its edge.  tile layout in LDS: int16/int32 tile[64][64], then per tile row {band start, first column}.
+// ------------------------------------------------------------------------------------------------
+template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE>
+__device__ __forceinline__ int32_t traceback_banded_tiled(const BandedCtx<ScoreT>& b, const GraphView<IdT>& g,
+                                                          const RowT* rowinfo, int32_t graph_count,
+                                                          const uint8_t* read, int32_t read_length, int32_t start_i,
+                                                          int32_t* alignment_graph, int32_t* alignment_read,
+                                                          int32_t gap_score, int32_t mismatch_score,
+                                                          int32_t match_score, int32_t rerun, ScoreT* tile,
+                                                          int32_t* tile_meta)
+{
+    constexpr int kTileRows = 64, kTileCols = 64, kReanchor = 44;
+    const int lane      = threadIdx.x & (kWave - 1);
+    const int32_t bound = read_length + graph_count + 2;
+    int32_t aligned_nodes = 0, loop_count = 0;
+    int32_t i = start_i, j = read_length, prev_i = 0, prev_j = 0;
+    int32_t tile_top = -1; // matrix row held in tile row 0 (-1: no tile)
+
+    auto load_tile = [&](int32_t top, int32_t col) {
+        __syncthreads();
+        // lane = tile row: row = top - lane; window of 64 stored elements around column (col - lane) - 40
+        const int32_t row = top - lane;
+        int32_t bs = 0, e0 = 0;
+        if (row >= 0)
+        {
+            bs = band_start_for_row(row, b.gradient, b.band_width, b.band_shift, b.max_column);
+            e0 = (col - lane - 40) - bs + kRelShift; // stored element index of the window start
+            e0 = min(max(e0 & ~3, 0), b.stride - kTileCols);
+            const ScoreT* src = b.scores + (int64_t)row * b.stride + e0;
+            ScoreT* dst       = tile + lane * kTileCols;
+#pragma unroll
+            for (int k = 0; k < kTileCols; k += 4)
+                *reinterpret_cast<Quad<ScoreT>*>(dst + k) = *reinterpret_cast<const Quad<ScoreT>*>(src + k);
+        }
+        tile_meta[lane] = (row >= 0) ? ((bs & 0xffff) | ((e0 - kRelShift + bs) << 16)) : 0x7fff0000;
+        __syncthreads();
+    };
+    // get_score() of cudapoa_nw_banded.cuh:80-102, tile first
+    auto score_at = [&](int32_t row, int32_t column) -> int32_t {
+        const int32_t rr = tile_top - row;
+        if (tile_top >= 0 && rr >= 0 && rr < kTileRows)
+        {
+            const int32_t meta = tile_meta[rr];
+            const int32_t bs   = meta & 0xffff;
+            const int32_t lo   = meta >> 16; // column stored in tile element 0
+            const int32_t bend = min(bs + b.band_width, b.max_column);
+            if ((column > bend || column < bs) && column != -1) return b.min_score;
+            const int32_t col = column == -1 ? bs : column;
+            const int32_t off = col - lo;
+            if (off >= 0 && off < kTileCols) return tile[rr * kTileCols + off];
+        }
+        return get_score(b, row, column);
+    };
+
+    while (!(i == 0 && j == 0) && loop_count < bound)
+    {
+        // keep the current cell and its near predecessors inside the tile
+        {
+            const int32_t rr = tile_top - i;
+            bool reload      = tile_top < 0 || rr < 0 || rr >= kReanchor;
+            if (!reload)
+            {
+                const int32_t meta = tile_meta[rr];
+                const int32_t off  = j - (meta >> 16);
+                reload             = (off < 2 || off >= kTileCols);
+            }
+            if (reload && i > 0)
+            {
+                tile_top = i;
+                load_tile(i, j);
+            }
+        }
+        loop_count++;
+        const int32_t scores_ij = score_at(i, j);
+        bool pred_found         = false;
+        RowT ri{};
+        int32_t pred_count = 0, node_id = 0;
+        if (i != 0)
+        {
+            ri         = rowinfo[i];
+            pred_count = ri.cnt();
+        }
+        auto pred_row = [&](int32_t p) -> int32_t {
+            if (pred_count == 0) return 0;
+            if (p < 3) return ri.pred(p);
+            return (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
+        };
+        if (i != 0 && pred_count > 3) node_id = g.sorted_poa[i - 1];
+        bool rerun_break = false;
+        if (i != 0 && j != 0)
+        {
+            if (ADAPTIVE)
+            {
+                if (rerun == 0 && b.band_width < kMaxAdaptiveBand)
+                {
+                    int32_t threshold = max(1, b.max_column / 1024);
+                    if (j > threshold && j < b.max_column - threshold)
+                    {
+                        int32_t bs = band_start_for_row(i, b.gradient, b.band_width, b.band_shift, b.max_column);
+                        if (j <= bs + threshold) { aligned_nodes = kShiftLeft; rerun_break = true; }
+                        else if (j >= (bs + b.band_width - threshold)) { aligned_nodes = kShiftRight; rerun_break = true; }
+                    }
+                }
+            }
+            if (!rerun_break)
+            {
+                int32_t match_cost = ((uint32_t)ri.base() == read[j - 1] ? match_score : mismatch_score);
+                int32_t np         = max(pred_count, 1);
+                for (int32_t p = 0; p < np; p++)
+                {
+                    int32_t pi = pred_row(p);
+                    if (scores_ij == score_at(pi, j - 1) + match_cost)
+                    {
+                        prev_i = pi; prev_j = j - 1; pred_found = true;
+                        break;
+                    }
+                }
+            }
+        }
+        if (rerun_break) break;
+        if (!pred_found && i != 0)
+        {
+            int32_t np = max(pred_count, 1);
+            for (int32_t p = 0; p < np; p++)
+            {
+                int32_t pi = pred_row(p);
+                if (scores_ij == score_at(pi, j) + gap_score)
+                {
+                    prev_i = pi; prev_j = j; pred_found = true;
+                    break;
+                }
+            }
+        }
+        if (!pred_found && scores_ij == score_at(i, j - 1) + gap_score)
+        {
+            prev_i = i; prev_j = j - 1; pred_found = true;
+        }
+        if (lane == 0)
+        {
+            alignment_graph[aligned_nodes] = (i == prev_i ? -1 : (int32_t)g.sorted_poa[i - 1]);
+            alignment_read[aligned_nodes]  = (j == prev_j ? -1 : j - 1);
+        }
+        aligned_nodes++;
+        i = prev_i;
+        j = prev_j;
+    }
+    if (loop_count >= bound) aligned_nodes = kNwLoopFailed;
+    __syncthreads();
+    return aligned_nodes;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-read row table: all lanes gather (base, predecessor rows, sink flag) for rows 1..N.
 // ------------------------------------------------------------------------------------------------
 template <typename IdT, typename RowT>
@@ -331,11 +488,13 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
     bool hbm_dirty    = false;
     ScoreT* row_out   = scores; // advanced by stride per row
 
-    RowInfo<true> ri_next = uniform_row(rowinfo[1]);
+    // the table entry of row r+1 is loaded (raw, in a VGPR pair) while row r is computed and only moved to
+    // SGPRs at the top of the next iteration, so its LDS latency is off the critical path
+    RowInfo<true> raw_next = rowinfo[1];
     for (int32_t r = 1; r <= graph_count; r++)
     {
-        const RowInfo<true> ri = ri_next;
-        if (r < graph_count) ri_next = uniform_row(rowinfo[r + 1]);
+        const RowInfo<true> ri = uniform_row(raw_next);
+        raw_next               = rowinfo[min(r + 1, graph_count)];
         const int32_t pred_count = ri.cnt();
         const int32_t bs         = ri.bs();
         const uint32_t base      = (uint32_t)ri.base();
@@ -356,15 +515,18 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
             const int32_t q    = (bs - prev_bs) >> 2;
             const int32_t pend = min(prev_bs + band_width - kCellsPerLane, max_column);
             int32_t S0, S1, S2, S3, S4;
-            if (q == 0)
+            if (q <= 1)
             {
-                S0 = wave_shr1(P3, prev_rel0);
-                S1 = P0; S2 = P1; S3 = P2; S4 = P3;
-            }
-            else if (q == 1)
-            {
-                S0 = P3;
-                S1 = wave_shl1(P0, 0); S2 = wave_shl1(P1, 0); S3 = wave_shl1(P2, 0); S4 = wave_shl1(P3, 0);
+                // branch-free for the two common band moves (0 or +4 columns): both lane shifts are DPP moves,
+                // the wave-uniform q picks per register
+                const bool q0    = (q == 0);
+                const int32_t a0 = wave_shr1(P3, prev_rel0);
+                const int32_t b0 = wave_shl1(P0, 0), b1 = wave_shl1(P1, 0), b2 = wave_shl1(P2, 0), b3 = wave_shl1(P3, 0);
+                S0 = q0 ? a0 : P3;
+                S1 = q0 ? P0 : b0;
+                S2 = q0 ? P1 : b1;
+                S3 = q0 ? P2 : b2;
+                S4 = q0 ? P3 : b3;
             }
             else
             {
@@ -432,15 +594,10 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
         if ((pred_count <= 1 && p0row == r - 1) || (dbg & 4))
         {
             // ---- the common row: one predecessor, the previous row ----
-            if (pred_count == 0)
-            {
-                if (bs == 0) rel0_val = gap_score; // carry-in stays 0 (reference quirk)
-            }
-            else
-            {
-                fe = (bs > kCellsPerLane) ? min_score + gap_score : max(min_score, prev_rel0) + gap_score;
-                if (bs == 0) rel0_val = fe;
-            }
+            const int32_t fe1 = (bs > kCellsPerLane) ? min_score + gap_score : max(min_score, prev_rel0) + gap_score;
+            fe                = pred_count == 0 ? 0 : fe1;                   // sources: carry-in stays 0 (reference quirk)
+            const int32_t b0v = pred_count == 0 ? gap_score : fe1;
+            rel0_val          = bs == 0 ? b0v : min_score;
             from_regs(s0, s1, s2, s3);
         }
         else
@@ -494,7 +651,19 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
         {
             Quad<ScoreT> out;
             out.v[0] = (ScoreT)P0; out.v[1] = (ScoreT)P1; out.v[2] = (ScoreT)P2; out.v[3] = (ScoreT)P3;
-            if (!(dbg & 1)) *reinterpret_cast<Quad<ScoreT>*>(row_out + lane4 + 1 + kRelShift) = out;
+            if (!(dbg & 1))
+            {
+                if (dbg & 64) // experiment: streaming (non-temporal) score-row stores
+                {
+                    if constexpr (sizeof(ScoreT) == 2)
+                        __builtin_nontemporal_store(*reinterpret_cast<unsigned long long*>(&out),
+                                                    reinterpret_cast<unsigned long long*>(row_out + lane4 + 1 + kRelShift));
+                    else
+                        *reinterpret_cast<Quad<ScoreT>*>(row_out + lane4 + 1 + kRelShift) = out;
+                }
+                else
+                    *reinterpret_cast<Quad<ScoreT>*>(row_out + lane4 + 1 + kRelShift) = out;
+            }
             if (!(dbg & 2)) *reinterpret_cast<Quad<ScoreT>*>(ring + my_slot * stride + lane4 + 1 + kRelShift) = out;
         }
         if (lane == 0 && !(dbg & 16))
@@ -790,7 +959,18 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     }
 
     int32_t aligned_nodes = 0;
-    if (lane == 0)
+    const bool tile_fits = (int32_t)(64 * 64 * sizeof(ScoreT) + 64 * sizeof(int32_t)) <= ring_bytes;
+    if (LDS_READ && tile_fits && !(dbg & 32))
+    {
+        // the LDS ring is dead after the forward pass: reuse it as the traceback tile
+        ScoreT* tile       = ring_base;
+        int32_t* tile_meta = reinterpret_cast<int32_t*>(ring_base + 64 * 64);
+        aligned_nodes = traceback_banded_tiled<ScoreT, IdT, RowT, ADAPTIVE>(b, g, rowinfo, graph_count, LDS_READ ? lds_read : read,
+                                                                           read_length, best_i, alignment_graph,
+                                                                           alignment_read, gap_score, mismatch_score,
+                                                                           match_score, rerun, tile, tile_meta);
+    }
+    else if (lane == 0)
         aligned_nodes = traceback_banded<ScoreT, IdT, RowT, ADAPTIVE>(b, g, rowinfo, graph_count, read, read_length, best_i,
                                                                 alignment_graph, alignment_read, gap_score,
                                                                 mismatch_score, match_score, rerun);

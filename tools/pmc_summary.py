@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc CSVs: per kernel, mean counter value per dispatch (what we commit under profiles/)."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        if "poa_" not in k and "myers" not in k:
+            continue
+        acc[k.split("(")[0][:70]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+print("kernel,counter,mean_per_dispatch,dispatches")
+for k in sorted(acc):
+    for c in sorted(acc[k]):
+        v = acc[k][c]
+        print('"%s",%s,%.6g,%d' % (k, c, sum(v) / len(v), len(v)))
