@@ -1,0 +1,569 @@
+// gwhip_myers.hip -- banded Myers / Ukkonen global alignment for gfx950 (replaces myers_banded_gpu,
+// cudaaligner/src/myers_gpu.cu:1149-1204 and the kernel :862-1032).
+//
+// MI355X design: ONE LANE PER PAIR. The reference gives a 32-lane warp to every pair and spreads the band's
+// 32-bit words over the lanes (cross-lane add-with-carry and shifts); at the benchmark sizes the band is 1-4
+// words, so 28-31 of its 32 lanes idle. Here each lane walks its own pair with the classic blocked form of
+// Myers' algorithm: the band's words are advanced in order, chained by the horizontal delta (-1/0/+1) of the
+// previous word. Both forms compute the same DP column, hence the same pv/mv bit-vectors, scores and
+// backtrace (checked bit for bit against oracle/aligner_oracle.c, which keeps the reference's own warp
+// decomposition). 64 pairs per wavefront, no cross-lane traffic at all; pairs are scheduled longest first so
+// the lanes of a wave have similar trip counts.
+//
+// Per pair the kernel keeps pv, mv (uint32) and score (int32) for every (band word, target column) in a
+// column-major workspace because the backtrace needs every column (12 B per 32-cell word-column: the
+// algorithmic bytes of SURVEY.md 8(d)). Results are first written into the pair's own slot
+// [sequence_starts[2i], sequence_starts[2i+2]) -- a run-length encoding never exceeds |q|+|t| entries -- and a
+// second pass packs them behind an exclusive scan of the run counts, so the packed order is the input order.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <string>
+#include <vector>
+
+#include "../../include/gwhip.h"
+
+namespace gwhip
+{
+extern thread_local std::string g_last_error;
+
+namespace myers
+{
+constexpr int kWord        = 32;
+constexpr int8_t kMatch = 0, kMismatch = 1, kInsertion = 2, kDeletion = 3; // AlignmentState, cudaaligner.hpp:52-58
+
+struct Band
+{
+    uint32_t* pv;
+    uint32_t* mv;
+    int32_t* score;
+    int32_t n_rows; // words in the band
+    __device__ __forceinline__ size_t at(int32_t w, int32_t t) const { return (size_t)t * n_rows + w; }
+};
+
+__device__ __forceinline__ int32_t ceil_div(int32_t a, int32_t b) { return (a + b - 1) / b; }
+
+// bit pattern of query[offset .. offset+32) == x   (myers_gpu.cu:196-208)
+__device__ __forceinline__ uint32_t make_pattern(char x, const char* query, int32_t query_size, int32_t offset)
+{
+    const int32_t n = min(query_size - offset, kWord);
+    uint32_t r      = 0;
+    for (int32_t i = 0; i < n; ++i) r |= (uint32_t)(query[offset + i] == x) << i;
+    return r;
+}
+
+// shifted view on the pattern table (myers_gpu.cu:210-241); index (c >> 1) & 3 => A, C, T, G
+__device__ __forceinline__ uint32_t get_pattern(const uint32_t* patterns, int32_t n_words, int32_t idx, int32_t begin, char x)
+{
+    const int32_t ci     = ((unsigned char)x >> 1) & 3;
+    const int32_t io     = begin / kWord;
+    const int32_t shift  = begin % kWord;
+    uint32_t r           = (idx + io < n_words) ? patterns[(idx + io) * 4 + ci] : 0u;
+    if (shift != 0)
+    {
+        r >>= shift;
+        if (idx + io + 1 < n_words) r |= patterns[(idx + io + 1) * 4 + ci] << (kWord - shift);
+    }
+    return r;
+}
+
+// score of cell (i, j), i in [1, band rows] (myers_gpu.cu:243-255)
+__device__ __forceinline__ int32_t cell_score(const Band& b, int32_t i, int32_t j, uint32_t last_mask)
+{
+    const int32_t w   = (i - 1) / kWord;
+    const int32_t bit = (i - 1) % kWord;
+    int32_t s         = b.score[b.at(w, j)];
+    uint32_t mask     = bit == 31 ? 0u : ((~1u) << bit);
+    if (w == b.n_rows - 1) mask &= last_mask;
+    s -= __popc(mask & b.pv[b.at(w, j)]);
+    s += __popc(mask & b.mv[b.at(w, j)]);
+    return s;
+}
+
+// One word of one column. hin: horizontal delta entering the word's first row. Returns the delta at `hbit`
+// (and at hbit << 1 through out_y, used by the sliding-band step).
+__device__ __forceinline__ int32_t advance_word(uint32_t hbit, uint32_t eq, uint32_t& pv, uint32_t& mv, int32_t hin, int32_t* out_y)
+{
+    const uint32_t xv = eq | mv;
+    if (hin < 0) eq |= 1u;
+    uint32_t xh = ((eq & pv) + pv) ^ pv;
+    xh |= eq;
+    uint32_t ph = mv | ~(xh | pv);
+    uint32_t mh = pv & xh;
+    const int32_t out_x = ((ph & hbit) ? 1 : 0) - ((mh & hbit) ? 1 : 0);
+    if (out_y) *out_y = ((ph & (hbit << 1)) ? 1 : 0) - ((mh & (hbit << 1)) ? 1 : 0);
+    ph = (ph << 1) | (hin > 0 ? 1u : 0u);
+    mh = (mh << 1) | (hin < 0 ? 1u : 0u);
+    pv = mh | ~(xv | ph);
+    mv = ph & xv;
+    return out_x;
+}
+
+// horizontal stripe: columns [t_begin, t_end), fixed rows (myers_gpu.cu:629-674)
+__device__ void horizontal_band(Band& b, const uint32_t* patterns, int32_t n_words_query, const char* target,
+                                int32_t t_begin, int32_t t_end, int32_t width, int32_t n_words, int32_t pattern_offset)
+{
+    for (int32_t t = t_begin; t < t_end; ++t)
+    {
+        int32_t h = 1; // worst case for the top border of the band
+        const char tc = target[t - 1];
+        for (int32_t w = 0; w < n_words; ++w)
+        {
+            uint32_t pv = b.pv[b.at(w, t - 1)], mv = b.mv[b.at(w, t - 1)];
+            const uint32_t hbit = 1u << (w == n_words - 1 ? width - (n_words - 1) * kWord - 1 : kWord - 1);
+            const uint32_t eq   = get_pattern(patterns, n_words_query, w, pattern_offset, tc);
+            h                   = advance_word(hbit, eq, pv, mv, h, nullptr);
+            b.score[b.at(w, t)] = b.score[b.at(w, t - 1)] + h;
+            b.pv[b.at(w, t)]    = pv;
+            b.mv[b.at(w, t)]    = mv;
+        }
+    }
+}
+
+// diagonal part: the band slides one row per column (myers_gpu.cu:676-751)
+__device__ void diagonal_band(Band& b, const uint32_t* patterns, int32_t n_words_query, const char* target, int32_t t_begin,
+                              int32_t t_end, int32_t band_width, int32_t n_words, int32_t pattern_offset)
+{
+    for (int32_t t = t_begin; t < t_end; ++t)
+    {
+        int32_t h     = 1;
+        const char tc = target[t - 1];
+        for (int32_t w = 0; w < n_words; ++w)
+        {
+            uint32_t pv = b.pv[b.at(w, t - 1)] >> 1, mv = b.mv[b.at(w, t - 1)] >> 1;
+            if (w + 1 < n_words)
+            {
+                pv |= b.pv[b.at(w + 1, t - 1)] << (kWord - 1);
+                mv |= b.mv[b.at(w + 1, t - 1)] << (kWord - 1);
+            }
+            const uint32_t eq  = get_pattern(patterns, n_words_query, w, pattern_offset + t - t_begin + 1, tc);
+            const uint32_t drb = 1u << (w == n_words - 1 ? band_width - (n_words - 1) * kWord - 2 : kWord - 2);
+            const uint32_t ddb = drb << 1;
+            if (w == n_words - 1)
+            {
+                pv |= ddb; // bottom bit has no left neighbour: assume the worst case (+1)
+                mv &= ~ddb;
+            }
+            int32_t hy;
+            const int32_t hx   = advance_word(drb, eq, pv, mv, h, &hy);
+            const int32_t down = ((pv & ddb) ? 1 : 0) - ((mv & ddb) ? 1 : 0);
+            b.score[b.at(w, t)] = b.score[b.at(w, t - 1)] + hx + down;
+            b.pv[b.at(w, t)]    = pv;
+            b.mv[b.at(w, t)]    = mv;
+            h                   = hy; // the horizontal delta of the word's last row enters the next word
+        }
+    }
+}
+
+#define GW_EMIT(R)                                                                                                     \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        const int8_t r_ = (R);                                                                                         \
+        if (prev_r != r_)                                                                                              \
+        {                                                                                                              \
+            if (prev_r != -1)                                                                                          \
+            {                                                                                                          \
+                path[pos]   = prev_r;                                                                                  \
+                counts[pos] = r_count;                                                                                 \
+                ++pos;                                                                                                 \
+            }                                                                                                          \
+            prev_r  = r_;                                                                                              \
+            r_count = 0;                                                                                               \
+        }                                                                                                              \
+        ++r_count;                                                                                                     \
+    } while (0)
+
+// three-phase backtrace with the implicit worst-case row 0 (myers_gpu.cu:444-627); emits reversed RLE
+__device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b, int32_t diagonal_begin, int32_t diagonal_end,
+                                    int32_t band_width, int32_t target_size)
+{
+    const int32_t out_of_band = INT32_MAX - 1;
+    int32_t i = band_width, j = target_size;
+    const uint32_t last_mask = band_width % kWord != 0 ? ((1u << (band_width % kWord)) - 1) : ~0u;
+    const int32_t last_diag  = diagonal_end < 2 ? out_of_band : cell_score(b, 1, diagonal_end - 2, last_mask) + 2;
+    int32_t myscore          = i > 0 ? b.score[b.at((i - 1) / kWord, j)] : 0;
+    int32_t pos = 0, r_count = 0;
+    int8_t prev_r = -1;
+    while (j >= diagonal_end)
+    {
+        const int32_t above = i <= 1 ? (last_diag + j - diagonal_end) : cell_score(b, i - 1, j, last_mask);
+        const int32_t diag  = i <= 1 ? (last_diag + j - 1 - diagonal_end) : cell_score(b, i - 1, j - 1, last_mask);
+        const int32_t left  = i < 1 ? (last_diag + j - 1 - diagonal_end) : cell_score(b, i, j - 1, last_mask);
+        int8_t r;
+        if (left + 1 == myscore) { r = kInsertion; myscore = left; --j; }
+        else if (above + 1 == myscore) { r = kDeletion; myscore = above; --i; }
+        else { r = diag == myscore ? kMatch : kMismatch; myscore = diag; --i; --j; }
+        GW_EMIT(r);
+    }
+    while (j >= diagonal_begin)
+    {
+        const int32_t above = i <= 1 ? out_of_band : cell_score(b, i - 1, j, last_mask);
+        const int32_t diag  = i <= 0 ? j - 1 : cell_score(b, i, j - 1, last_mask);
+        const int32_t left  = i >= band_width ? out_of_band : cell_score(b, i + 1, j - 1, last_mask);
+        int8_t r;
+        if (left + 1 == myscore) { r = kInsertion; myscore = left; ++i; --j; }
+        else if (above + 1 == myscore) { r = kDeletion; myscore = above; --i; }
+        else { r = diag == myscore ? kMatch : kMismatch; myscore = diag; --j; }
+        GW_EMIT(r);
+    }
+    while (i > 0 && j > 0)
+    {
+        const int32_t above = i == 1 ? j : cell_score(b, i - 1, j, last_mask);
+        const int32_t diag  = i == 1 ? j - 1 : cell_score(b, i - 1, j - 1, last_mask);
+        const int32_t left  = i > band_width ? out_of_band : cell_score(b, i, j - 1, last_mask);
+        int8_t r;
+        if (left + 1 == myscore) { r = kInsertion; myscore = left; --j; }
+        else if (above + 1 == myscore) { r = kDeletion; myscore = above; --i; }
+        else { r = diag == myscore ? kMatch : kMismatch; myscore = diag; --i; --j; }
+        GW_EMIT(r);
+    }
+    if (i > 0)
+    {
+        if (prev_r != kDeletion)
+        {
+            if (prev_r != -1) { path[pos] = prev_r; counts[pos] = r_count; ++pos; }
+            prev_r  = kDeletion;
+            r_count = 0;
+        }
+        r_count += i;
+    }
+    if (j > 0)
+    {
+        if (prev_r != kInsertion)
+        {
+            if (prev_r != -1) { path[pos] = prev_r; counts[pos] = r_count; ++pos; }
+            prev_r  = kInsertion;
+            r_count = 0;
+        }
+        r_count += j;
+    }
+    if (r_count != 0) { path[pos] = prev_r; counts[pos] = r_count; ++pos; }
+    return pos;
+}
+#undef GW_EMIT
+
+struct KernelArgs
+{
+    int32_t n;
+    const char* sequences;
+    const int64_t* starts;
+    const int32_t* max_bandwidths;
+    const int32_t* order;       // scheduling order (longest first)
+    const int64_t* ws_offsets;  // per pair: first uint32 element of its workspace
+    uint32_t* ws;               // [pv | mv | score | patterns] per pair
+    int8_t* slot_ops;           // per-pair slots, indexed by sequence offset
+    int32_t* slot_counts;
+    int32_t* run_counts;        // [n] runs per pair, -1: no result
+    uint32_t* metadata;         // [n]
+    uint64_t* band_cells;       // optional [n]
+};
+
+// per-alignment body of myers_banded_kernel (myers_gpu.cu:897-1021)
+__global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
+{
+    const int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.n) return;
+    const int32_t idx        = a.order[slot];
+    const char* query        = a.sequences + a.starts[2 * idx];
+    const char* target       = a.sequences + a.starts[2 * idx + 1];
+    const int32_t query_size  = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
+    const int32_t target_size = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
+    const int32_t max_bw     = a.max_bandwidths[idx];
+    int8_t* path             = a.slot_ops + a.starts[2 * idx];
+    int32_t* counts          = a.slot_counts + a.starts[2 * idx];
+    const int32_t dlen       = abs(target_size - query_size);
+    uint64_t cells           = 0;
+
+    if (max_bw - 1 < dlen && query_size != 0 && target_size != 0)
+    {
+        a.run_counts[idx] = -1;
+        a.metadata[idx]   = (uint32_t)idx;
+        return;
+    }
+    if (target_size == 0 || query_size == 0)
+    {
+        if (query_size == 0 && target_size == 0)
+            a.run_counts[idx] = 0;
+        else
+        {
+            path[0]           = query_size == 0 ? kInsertion : kDeletion;
+            counts[0]         = query_size + target_size;
+            a.run_counts[idx] = 1;
+        }
+        a.metadata[idx] = (uint32_t)idx | (1u << 31);
+        return;
+    }
+
+    // workspace of this pair: sized by the host like compute_matrix_size_for_alignment (aligner_global_myers_banded.cpp:47-55)
+    const int32_t n_words   = ceil_div(query_size, kWord);
+    const int32_t pmax      = (max_bw + 1) / 2;
+    const int64_t max_elems = (int64_t)ceil_div(min(1 + 2 * pmax, query_size), kWord) * ((int64_t)target_size + 1);
+    uint32_t* base          = a.ws + a.ws_offsets[idx];
+    Band b;
+    b.pv            = base;
+    b.mv            = base + max_elems;
+    b.score         = reinterpret_cast<int32_t*>(base + 2 * max_elems);
+    uint32_t* patterns = base + 3 * max_elems;
+    b.n_rows        = 0;
+    for (int32_t w = 0; w < n_words; ++w)
+    {
+        patterns[w * 4 + 0] = make_pattern('A', query, query_size, w * kWord);
+        patterns[w * 4 + 1] = make_pattern('C', query, query_size, w * kWord);
+        patterns[w * 4 + 2] = make_pattern('T', query, query_size, w * kWord);
+        patterns[w * 4 + 3] = make_pattern('G', query, query_size, w * kWord);
+    }
+
+    int32_t estimate = max(1, dlen + min(target_size, query_size) / 20);
+    int32_t diagonal_begin = -1, diagonal_end = -1, band_width = 0;
+    for (;;)
+    {
+        int32_t p      = min(min(target_size, query_size), (estimate - dlen) / 2);
+        int32_t bw_new = min(1 + 2 * p + dlen, query_size);
+        if (bw_new % kWord == 1 && bw_new != query_size) // at least two bits in the last word
+        {
+            p += 1;
+            bw_new = min(1 + 2 * p + dlen, query_size);
+        }
+        if (bw_new > max_bw)
+        {
+            bw_new = max_bw;
+            p      = (bw_new - 1 - dlen) / 2;
+        }
+        const int32_t n_words_band = ceil_div(bw_new, kWord);
+        if ((int64_t)n_words_band * (int64_t)(target_size + 1) > max_elems)
+        {
+            band_width = -band_width;
+            break;
+        }
+        band_width = bw_new;
+        b.n_rows   = n_words_band;
+        cells += (uint64_t)n_words_band * kWord * (uint64_t)target_size;
+        // myers_compute_scores_edit_dist_banded (:753-846)
+        for (int32_t w = 0; w < n_words_band; ++w)
+        {
+            b.pv[b.at(w, 0)]    = ~0u;
+            b.mv[b.at(w, 0)]    = 0u;
+            b.score[b.at(w, 0)] = min((w + 1) * kWord, band_width);
+        }
+        if (band_width >= query_size)
+        {
+            diagonal_begin = target_size + 1;
+            diagonal_end   = target_size + 1;
+            horizontal_band(b, patterns, n_words, target, 1, target_size + 1, query_size, n_words_band, 0);
+        }
+        else
+        {
+            const int32_t symmetric = (band_width - min(1 + 2 * p + dlen, query_size) == 0) ? 1 : 0;
+            diagonal_begin = query_size < target_size ? target_size - query_size + p + 2 : p + 2 + (1 - symmetric);
+            diagonal_end   = query_size < target_size ? query_size - p + symmetric : query_size - (query_size - target_size) - p + 1;
+            horizontal_band(b, patterns, n_words, target, 1, diagonal_begin, band_width, n_words_band, 0);
+            diagonal_band(b, patterns, n_words, target, diagonal_begin, diagonal_end, band_width, n_words_band, 0);
+            horizontal_band(b, patterns, n_words, target, diagonal_end, target_size + 1, band_width, n_words_band, query_size - band_width);
+        }
+        const int32_t dist = n_words_band > 0 ? b.score[b.at(n_words_band - 1, target_size)] : target_size;
+        if (dist <= estimate || band_width == query_size) break;
+        if (band_width == max_bw)
+        {
+            band_width = -band_width;
+            break;
+        }
+        estimate *= 2;
+    }
+    if (band_width != 0)
+    {
+        a.run_counts[idx] = backtrace_banded(path, counts, b, diagonal_begin, diagonal_end, abs(band_width), target_size);
+        a.metadata[idx]   = (uint32_t)idx | (band_width > 0 ? (1u << 31) : 0u);
+    }
+    else
+    {
+        a.run_counts[idx] = -1;
+        a.metadata[idx]   = (uint32_t)idx;
+    }
+    if (a.band_cells) a.band_cells[idx] = cells;
+}
+
+// exclusive scan of max(run_counts, 0) into result_starts[n+1] (single workgroup, chunked)
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t* run_counts, int32_t* result_starts, int32_t n)
+{
+    __shared__ int32_t part[1024];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int32_t base = 0; base < n; base += 1024)
+    {
+        const int32_t i = base + threadIdx.x;
+        const int32_t v = i < n ? max(run_counts[i], 0) : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1)
+        {
+            int32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) result_starts[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) result_starts[n] = carry;
+}
+
+__global__ void compact_kernel(KernelArgs a, int8_t* results, int32_t* result_counts, const int32_t* result_starts)
+{
+    // one workgroup per pair: copy its runs from the slot to the packed position
+    const int32_t idx = blockIdx.x;
+    const int32_t nr  = max(a.run_counts[idx], 0);
+    const int64_t src = a.starts[2 * idx];
+    const int32_t dst = result_starts[idx];
+    for (int32_t k = threadIdx.x; k < nr; k += blockDim.x)
+    {
+        results[dst + k]       = a.slot_ops[src + k];
+        result_counts[dst + k] = a.slot_counts[src + k];
+    }
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// fixed part of the workspace (depends on n and the total sequence length only), then the per-pair matrices
+struct WsPlan
+{
+    size_t off_ws_offsets, off_run_counts, off_slot_ops, off_slot_counts, off_cells, off_identity, off_ws;
+};
+
+static WsPlan plan_fixed(int32_t n, int64_t total_len)
+{
+    WsPlan p{};
+    size_t off = 0;
+    auto take  = [&](size_t b) { size_t o = off; off = align_up(off + b, 256); return o; };
+    p.off_ws_offsets  = take(((size_t)n + 1) * 8);
+    p.off_run_counts  = take((size_t)n * 4);
+    p.off_slot_ops    = take((size_t)total_len + 16);
+    p.off_slot_counts = take(((size_t)total_len + 16) * 4);
+    p.off_cells       = take((size_t)n * 8);
+    p.off_identity    = take((size_t)n * 4);
+    p.off_ws          = off;
+    return p;
+}
+
+__host__ __device__ inline int64_t pair_ws_elems(int32_t q, int32_t t, int32_t max_bw)
+{
+    if (q == 0 || t == 0) return 0;
+    const int32_t pmax = (max_bw + 1) / 2;
+    const int32_t bw   = (1 + 2 * pmax) < q ? (1 + 2 * pmax) : q;
+    const int64_t me   = (int64_t)((bw + 31) / 32) * ((int64_t)t + 1);
+    const int64_t e    = 3 * me + (int64_t)((q + 31) / 32) * 4;
+    return (e + 3) & ~int64_t(3);
+}
+
+// per-pair workspace sizes, then an in-place exclusive scan by one workgroup
+__global__ __launch_bounds__(1024) void ws_offsets_kernel(const int64_t* starts, const int32_t* max_bws, int64_t* offsets,
+                                                          int32_t* identity, int32_t n)
+{
+    __shared__ int64_t part[1024];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int32_t base = 0; base < n; base += 1024)
+    {
+        const int32_t i = base + threadIdx.x;
+        int64_t v       = 0;
+        if (i < n)
+        {
+            v = pair_ws_elems((int32_t)(starts[2 * i + 1] - starts[2 * i]), (int32_t)(starts[2 * i + 2] - starts[2 * i + 1]), max_bws[i]);
+            identity[i] = i;
+        }
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1)
+        {
+            int64_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) offsets[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[n] = carry;
+}
+
+static int fail(hipError_t e, const char* what)
+{
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return (int)e;
+}
+
+} // namespace myers
+} // namespace gwhip
+
+using namespace gwhip;
+using namespace gwhip::myers;
+
+extern "C" {
+
+size_t gwhip_myers_banded_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host,
+                                          const int32_t* max_bandwidths_host)
+{
+    if (n_alignments <= 0) return 256;
+    const WsPlan p = plan_fixed(n_alignments, sequence_starts_host[2 * (size_t)n_alignments]);
+    int64_t elems  = 0;
+    for (int32_t i = 0; i < n_alignments; i++)
+        elems += pair_ws_elems((int32_t)(sequence_starts_host[2 * i + 1] - sequence_starts_host[2 * i]),
+                               (int32_t)(sequence_starts_host[2 * i + 2] - sequence_starts_host[2 * i + 1]),
+                               max_bandwidths_host[i]);
+    return p.off_ws + (size_t)elems * 4 + 256;
+}
+
+int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!args || args->n_alignments < 0)
+    {
+        g_last_error = "gwhip_myers_banded: invalid arguments";
+        return (int)hipErrorInvalidValue;
+    }
+    const int32_t n = args->n_alignments;
+    if (n == 0) return 0;
+    if (!args->workspace || ((uintptr_t)args->workspace & 255) != 0)
+    {
+        g_last_error = "gwhip_myers_banded: workspace must be 256-byte aligned";
+        return (int)hipErrorInvalidValue;
+    }
+    const WsPlan p = plan_fixed(n, args->total_sequence_length);
+    uint8_t* ws    = (uint8_t*)args->workspace;
+    KernelArgs ka{};
+    ka.n              = n;
+    ka.sequences      = args->sequences;
+    ka.starts         = args->sequence_starts;
+    ka.max_bandwidths = args->max_bandwidths;
+    ka.ws_offsets     = reinterpret_cast<int64_t*>(ws + p.off_ws_offsets);
+    ka.run_counts     = reinterpret_cast<int32_t*>(ws + p.off_run_counts);
+    ka.slot_ops       = reinterpret_cast<int8_t*>(ws + p.off_slot_ops);
+    ka.slot_counts    = reinterpret_cast<int32_t*>(ws + p.off_slot_counts);
+    ka.band_cells     = reinterpret_cast<uint64_t*>(ws + p.off_cells);
+    int32_t* identity = reinterpret_cast<int32_t*>(ws + p.off_identity);
+    ka.order          = args->scheduling_index ? args->scheduling_index : identity;
+    ka.ws             = reinterpret_cast<uint32_t*>(ws + p.off_ws);
+    ka.metadata       = args->result_metadata;
+
+    hipLaunchKernelGGL(ws_offsets_kernel, dim3(1), dim3(1024), 0, stream, args->sequence_starts, args->max_bandwidths,
+                       const_cast<int64_t*>(ka.ws_offsets), identity, n);
+    hipLaunchKernelGGL(myers_banded_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, ka);
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, ka.run_counts, args->result_starts, n);
+    hipLaunchKernelGGL(compact_kernel, dim3(n), dim3(64), 0, stream, ka, args->results, args->result_counts,
+                       args->result_starts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(e, "myers kernels launch");
+    if (args->band_cells)
+    {
+        e = hipMemcpyAsync(args->band_cells, ka.band_cells, (size_t)n * 8, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return fail(e, "band_cells copy");
+    }
+    return 0;
+}
+
+} // extern "C"

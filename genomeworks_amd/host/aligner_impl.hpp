@@ -1,0 +1,87 @@
+// aligner_impl.hpp -- concrete banded / unbanded Myers aligner for MI355X (see cudaaligner.cpp).
+#pragma once
+#include <claraparabricks/genomeworks/cudaaligner/aligner.hpp>
+#include <claraparabricks/genomeworks/cudaaligner/alignment.hpp>
+
+#include <string>
+#include <vector>
+
+namespace claraparabricks
+{
+namespace genomeworks
+{
+namespace cudaaligner
+{
+
+class BandedAligner : public FixedBandAligner
+{
+public:
+    /// expand_results: materialise per-position states (the fixed-stride factories) instead of run lengths.
+    /// max_query_length >= 0 switches on the fixed-stride limits (exceeded_max_length / exceeded_max_alignments).
+    BandedAligner(int64_t max_device_memory, int32_t max_bandwidth, DefaultDeviceAllocator allocator, cudaStream_t stream,
+                  int32_t device_id, bool expand_results, int32_t max_query_length, int32_t max_target_length,
+                  int32_t max_alignments);
+    ~BandedAligner() override;
+
+    StatusType align_all() override;
+    StatusType sync_alignments() override;
+    StatusType add_alignment(const char* query, int32_t query_length, const char* target, int32_t target_length,
+                             bool reverse_complement_query = false, bool reverse_complement_target = false) override;
+    StatusType add_alignment(int32_t max_bandwidth, const char* query, int32_t query_length, const char* target,
+                             int32_t target_length, bool reverse_complement_query = false,
+                             bool reverse_complement_target = false) override;
+    const std::vector<std::shared_ptr<Alignment>>& get_alignments() const override { return alignments_; }
+    DeviceAlignmentsPtrs get_alignments_device() const override;
+    void reset() override;
+    void free_temporary_device_buffers() override;
+    int32_t num_alignments() const override { return static_cast<int32_t>(seq_starts_h_.size() / 2); }
+    cudaStream_t get_stream() const override { return stream_; }
+    int32_t get_device() const override { return device_id_; }
+    DefaultDeviceAllocator get_device_allocator() const override { return allocator_; }
+    void reset_max_bandwidth(int32_t max_bandwidth) override;
+
+    // benchmark helpers (not part of the reference interface)
+    void relaunch_resident();     ///< run the kernels again on the inputs already resident in HBM
+    uint64_t total_band_cells();  ///< 32 * band words * target length, summed over band attempts and pairs
+
+private:
+    void reset_data();
+    void free_device();
+    void launch();
+
+    cudaStream_t stream_;
+    int32_t device_id_;
+    DefaultDeviceAllocator allocator_;
+    int32_t max_bandwidth_;
+    int64_t max_device_memory_;
+    bool expand_results_;
+    int32_t max_query_length_, max_target_length_, max_alignments_;
+
+    std::vector<char> seq_h_, seq_kept_;
+    std::vector<int64_t> seq_starts_h_{0};
+    std::vector<int32_t> max_bandwidths_h_;
+    std::vector<int32_t> order_h_;
+    std::vector<std::shared_ptr<Alignment>> alignments_;
+    size_t workspace_bytes_estimate_ = 0;
+    size_t workspace_bytes_          = 0;
+    bool launched_                   = false;
+    int64_t total_length_h_          = 0;
+    int32_t n_last_                  = 0;
+
+    char* device_block_        = nullptr;
+    size_t device_block_bytes_ = 0;
+    char* d_seq_               = nullptr;
+    int64_t* d_starts_         = nullptr;
+    int32_t* d_bw_             = nullptr;
+    int32_t* d_order_          = nullptr;
+    int8_t* d_results_         = nullptr;
+    int32_t* d_result_counts_  = nullptr;
+    int32_t* d_result_starts_  = nullptr;
+    uint32_t* d_metadata_      = nullptr;
+    uint64_t* d_cells_         = nullptr;
+    char* d_workspace_         = nullptr;
+};
+
+} // namespace cudaaligner
+} // namespace genomeworks
+} // namespace claraparabricks

@@ -11,9 +11,13 @@
 #include "../../include/gw_capi.h"
 #include "host_common.hpp"
 #include "poa_batch_impl.hpp"
+#include "aligner_impl.hpp"
+#include <claraparabricks/genomeworks/cudaaligner/aligner.hpp>
+#include <claraparabricks/genomeworks/cudaaligner/alignment.hpp>
 
 namespace gw  = claraparabricks::genomeworks;
 namespace poa = claraparabricks::genomeworks::cudapoa;
+namespace aln = claraparabricks::genomeworks::cudaaligner;
 
 struct gw_poa_batch
 {
@@ -26,6 +30,13 @@ struct gw_poa_batch
     std::vector<gw::DirectedGraph> graphs;
     std::vector<std::vector<std::pair<gw::Graph::edge_t, gw::Graph::edge_weight_t>>> graph_edges;
     std::vector<int32_t> graph_nodes;
+};
+
+struct gw_aligner
+{
+    std::unique_ptr<aln::Aligner> aligner;
+    aln::BandedAligner* impl = nullptr;
+    std::string cigar; // last string handed out
 };
 
 #define GW_TRY try {
@@ -254,6 +265,114 @@ int gw_poa_profile_phases(gw_poa_batch* b, double* out6)
     GW_TRY
     if (!b->impl) return -1;
     b->impl->profile_phases(out6);
+    return 0;
+    GW_CATCH(-1)
+}
+
+// ---- cudaaligner --------------------------------------------------------------------------------------
+gw_aligner* gw_aligner_create_banded(int32_t max_bandwidth, void* stream, int32_t device_id, int64_t max_device_memory)
+{
+    GW_TRY
+    auto h     = std::make_unique<gw_aligner>();
+    h->aligner = aln::create_aligner(aln::AlignmentType::global_alignment, max_bandwidth, static_cast<cudaStream_t>(stream),
+                                     device_id, max_device_memory);
+    h->impl    = dynamic_cast<aln::BandedAligner*>(h->aligner.get());
+    return h.release();
+    GW_CATCH(nullptr)
+}
+
+gw_aligner* gw_aligner_create(int32_t max_query_length, int32_t max_target_length, int32_t max_alignments, void* stream,
+                              int32_t device_id, int64_t max_device_memory)
+{
+    GW_TRY
+    auto h     = std::make_unique<gw_aligner>();
+    h->aligner = aln::create_aligner(max_query_length, max_target_length, max_alignments, aln::AlignmentType::global_alignment,
+                                     static_cast<cudaStream_t>(stream), device_id, max_device_memory);
+    h->impl    = dynamic_cast<aln::BandedAligner*>(h->aligner.get());
+    return h.release();
+    GW_CATCH(nullptr)
+}
+
+void gw_aligner_destroy(gw_aligner* a) { delete a; }
+
+int gw_aligner_add_alignment(gw_aligner* a, const char* query, int32_t query_length, const char* target,
+                             int32_t target_length, int reverse_complement_query, int reverse_complement_target)
+{
+    GW_TRY
+    return static_cast<int>(a->aligner->add_alignment(query, query_length, target, target_length, reverse_complement_query != 0,
+                                                      reverse_complement_target != 0));
+    GW_CATCH(-1)
+}
+
+int gw_aligner_align_all(gw_aligner* a)
+{
+    GW_TRY
+    return static_cast<int>(a->aligner->align_all());
+    GW_CATCH(-1)
+}
+
+int gw_aligner_sync_alignments(gw_aligner* a)
+{
+    GW_TRY
+    return static_cast<int>(a->aligner->sync_alignments());
+    GW_CATCH(-1)
+}
+
+int32_t gw_aligner_num_alignments(gw_aligner* a) { return static_cast<int32_t>(a->aligner->get_alignments().size()); }
+
+int gw_aligner_reset(gw_aligner* a)
+{
+    GW_TRY
+    a->aligner->reset();
+    return 0;
+    GW_CATCH(-1)
+}
+
+int32_t gw_alignment_status(gw_aligner* a, int32_t i) { return static_cast<int32_t>(a->aligner->get_alignments().at(static_cast<size_t>(i))->get_status()); }
+int32_t gw_alignment_is_optimal(gw_aligner* a, int32_t i) { return a->aligner->get_alignments().at(static_cast<size_t>(i))->is_optimal() ? 1 : 0; }
+int32_t gw_alignment_edit_distance(gw_aligner* a, int32_t i) { return a->aligner->get_alignments().at(static_cast<size_t>(i))->get_edit_distance(); }
+
+const char* gw_alignment_cigar(gw_aligner* a, int32_t i, int32_t extended, int32_t* length)
+{
+    a->cigar = a->aligner->get_alignments().at(static_cast<size_t>(i))->convert_to_cigar(extended ? aln::CigarFormat::extended : aln::CigarFormat::basic);
+    if (length) *length = static_cast<int32_t>(a->cigar.size());
+    return a->cigar.c_str();
+}
+
+int32_t gw_alignment_states(gw_aligner* a, int32_t i, int8_t* out, int32_t cap)
+{
+    const auto& al = *a->aligner->get_alignments().at(static_cast<size_t>(i));
+    // per-position states from whichever form the aligner filled
+    int32_t n = 0;
+    if (!al.get_actions().empty())
+    {
+        for (size_t k = 0; k < al.get_actions().size(); ++k)
+            for (int32_t r = 0; r < al.get_runlengths()[k]; ++r, ++n)
+                if (out && n < cap) out[n] = al.get_actions()[k];
+    }
+    else
+        for (auto s : al.get_alignment())
+        {
+            if (out && n < cap) out[n] = static_cast<int8_t>(s);
+            ++n;
+        }
+    return n;
+}
+
+int gw_aligner_relaunch(gw_aligner* a)
+{
+    GW_TRY
+    if (!a->impl) return -1;
+    a->impl->relaunch_resident();
+    return 0;
+    GW_CATCH(-1)
+}
+
+int gw_aligner_band_cells(gw_aligner* a, uint64_t* cells)
+{
+    GW_TRY
+    if (!a->impl) return -1;
+    *cells = a->impl->total_band_cells();
     return 0;
     GW_CATCH(-1)
 }

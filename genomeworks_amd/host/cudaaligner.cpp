@@ -1,0 +1,380 @@
+// cudaaligner.cpp -- host side of cudaaligner::Aligner on MI355X.
+//
+// Behavioural contract from the reference host code:
+//   factories                         cudaaligner/src/aligner.cpp:31-126
+//   AlignerGlobalMyersBanded          cudaaligner/src/aligner_global_myers_banded.cpp:127-543
+//   AlignerGlobal (fixed stride)      cudaaligner/src/aligner_global.cpp:50-192
+// Memory plan is ours: the kernels take one lane per pair, so the device workspace is per pair
+// (gwhip_myers_banded_workspace_bytes); a batch is refused with exceeded_max_alignments when it would not fit
+// max_device_memory, exactly where the reference's fits_device_memory() refuses.
+#include <claraparabricks/genomeworks/cudaaligner/aligner.hpp>
+#include <claraparabricks/genomeworks/cudaaligner/alignment.hpp>
+#include <claraparabricks/genomeworks/logging/logging.hpp>
+#include <claraparabricks/genomeworks/utils/genomeutils.hpp>
+#include <claraparabricks/genomeworks/utils/signed_integer_utils.hpp>
+
+#include <algorithm>
+#include <climits>
+#include <numeric>
+#include <stdexcept>
+
+#include "../../include/gwhip.h"
+#include "aligner_impl.hpp"
+#include "alignment_impl.hpp"
+
+namespace claraparabricks
+{
+namespace genomeworks
+{
+namespace cudaaligner
+{
+
+StatusType Init()
+{
+    logging::initialize_logger(logging::LogLevel::warn);
+    return StatusType::success;
+}
+
+namespace
+{
+constexpr int32_t kWordSize = 32;
+size_t up256(size_t v) { return (v + 255) & ~size_t(255); }
+} // namespace
+
+BandedAligner::BandedAligner(int64_t max_device_memory, int32_t max_bandwidth, DefaultDeviceAllocator allocator,
+                             cudaStream_t stream, int32_t device_id, bool expand_results, int32_t max_query_length,
+                             int32_t max_target_length, int32_t max_alignments)
+    : stream_(stream)
+    , device_id_(device_id)
+    , allocator_(allocator)
+    , max_bandwidth_(throw_on_negative(max_bandwidth, "max_bandwidth cannot be negative."))
+    , max_device_memory_(max_device_memory < 0 ? get_size_of_largest_free_memory_block(allocator) : max_device_memory)
+    , expand_results_(expand_results)
+    , max_query_length_(max_query_length)
+    , max_target_length_(max_target_length)
+    , max_alignments_(max_alignments)
+{
+    reset_max_bandwidth(max_bandwidth);
+}
+
+BandedAligner::~BandedAligner()
+{
+    scoped_device_switch dev(device_id_);
+    (void)hipStreamSynchronize(stream_);
+    free_device();
+}
+
+void BandedAligner::reset_max_bandwidth(int32_t max_bandwidth)
+{
+    throw_on_negative(max_bandwidth, "max_bandwidth cannot be negative.");
+    if (max_bandwidth % kWordSize == 1)
+        throw std::invalid_argument("Invalid max_bandwidth. max_bandwidth % 32 == 1 is not allowed. Please change it by +/-1.");
+    reset();
+    max_bandwidth_ = max_bandwidth;
+}
+
+void BandedAligner::free_device()
+{
+    if (device_block_ != nullptr)
+    {
+        allocator_.deallocate(device_block_, device_block_bytes_);
+        device_block_       = nullptr;
+        device_block_bytes_ = 0;
+    }
+}
+
+void BandedAligner::reset_data()
+{
+    seq_h_.clear();
+    seq_starts_h_.assign(1, 0);
+    max_bandwidths_h_.clear();
+    workspace_bytes_estimate_ = 0;
+    launched_                 = false;
+}
+
+void BandedAligner::reset()
+{
+    scoped_device_switch dev(device_id_);
+    (void)hipStreamSynchronize(stream_);
+    reset_data();
+    free_device();
+    alignments_.clear();
+}
+
+void BandedAligner::free_temporary_device_buffers()
+{
+    // everything but the packed results could go; we keep one block per batch, so this is a no-op until reset()
+}
+
+StatusType BandedAligner::add_alignment(const char* query, int32_t query_length, const char* target, int32_t target_length,
+                                        bool reverse_complement_query, bool reverse_complement_target)
+{
+    return add_alignment(max_bandwidth_, query, query_length, target, target_length, reverse_complement_query,
+                         reverse_complement_target);
+}
+
+StatusType BandedAligner::add_alignment(int32_t max_bandwidth, const char* query, int32_t query_length, const char* target,
+                                        int32_t target_length, bool reverse_complement_query, bool reverse_complement_target)
+{
+    GW_NVTX_RANGE(profiler, "BandedAligner::add_alignment");
+    if (max_bandwidth < 0 || query_length < 0 || target_length < 0 || query == nullptr || target == nullptr)
+        return StatusType::generic_error;
+    if (max_query_length_ >= 0)
+    {
+        // fixed-stride flavour (AlignerGlobal::add_alignment, aligner_global.cpp:80-112)
+        if (query_length > max_query_length_ || target_length > max_target_length_) return StatusType::exceeded_max_length;
+        if (num_alignments() >= max_alignments_) return StatusType::exceeded_max_alignments;
+    }
+    if (max_bandwidth > query_length) // keep max_bandwidth % 32 != 1 (aligner_global_myers_banded.cpp:174-178)
+        max_bandwidth = (query_length % kWordSize == 1 ? query_length + 1 : query_length);
+
+    const int32_t n_alignments = num_alignments();
+    const int64_t new_len_sum  = seq_starts_h_.back() + query_length + target_length;
+    if ((static_cast<uint32_t>(n_alignments + 1) & (~DeviceAlignmentsPtrs::index_mask)) != 0u ||
+        new_len_sum > static_cast<int64_t>(INT32_MAX))
+    {
+        if (n_alignments == 0) throw std::runtime_error("Could not fit alignment into device or host memory.");
+        return StatusType::exceeded_max_alignments;
+    }
+    // device bytes if this pair joins the batch: its matrices + its share of the fixed arrays
+    const int64_t starts2[3] = {0, query_length, static_cast<int64_t>(query_length) + target_length};
+    const size_t pair_ws      = gwhip_myers_banded_workspace_bytes(1, starts2, &max_bandwidth);
+    const size_t per_pair_io  = static_cast<size_t>(query_length + target_length) * (1 + 1 + 4) + 64;
+    const size_t new_estimate = workspace_bytes_estimate_ + pair_ws + per_pair_io;
+    if (static_cast<int64_t>(new_estimate) + (1 << 20) >= max_device_memory_)
+    {
+        if (n_alignments == 0) throw std::runtime_error("Could not fit alignment into device or host memory.");
+        return StatusType::exceeded_max_alignments;
+    }
+    const int64_t seq_start = seq_starts_h_.back();
+    seq_h_.resize(static_cast<size_t>(new_len_sum));
+    genomeutils::copy_sequence(query, query_length, seq_h_.data() + seq_start, reverse_complement_query);
+    genomeutils::copy_sequence(target, target_length, seq_h_.data() + seq_start + query_length, reverse_complement_target);
+    seq_starts_h_.push_back(seq_start + query_length);
+    seq_starts_h_.push_back(new_len_sum);
+    max_bandwidths_h_.push_back(max_bandwidth);
+    workspace_bytes_estimate_ = new_estimate;
+    return StatusType::success;
+}
+
+StatusType BandedAligner::align_all()
+{
+    GW_NVTX_RANGE(profiler, "BandedAligner::align_all");
+    const int32_t n = num_alignments();
+    if (n == 0) return StatusType::success;
+    scoped_device_switch dev(device_id_);
+    const int64_t total_len = seq_starts_h_.back();
+    // longest pairs first (aligner_global_myers_banded.cpp:306-309): lanes of one wave get similar work
+    std::vector<int32_t> order(static_cast<size_t>(n));
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        return (seq_starts_h_[2 * a + 2] - seq_starts_h_[2 * a]) > (seq_starts_h_[2 * b + 2] - seq_starts_h_[2 * b]);
+    });
+
+    workspace_bytes_ = gwhip_myers_banded_workspace_bytes(n, seq_starts_h_.data(), max_bandwidths_h_.data());
+    size_t off       = 0;
+    auto take        = [&](size_t b) { size_t o = off; off += up256(b); return o; };
+    const size_t o_seq = take(static_cast<size_t>(total_len) + 16), o_starts = take((2 * static_cast<size_t>(n) + 1) * 8);
+    const size_t o_bw = take(static_cast<size_t>(n) * 4), o_order = take(static_cast<size_t>(n) * 4);
+    const size_t o_res = take(static_cast<size_t>(total_len) + 16), o_cnt = take((static_cast<size_t>(total_len) + 16) * 4);
+    const size_t o_rs = take((static_cast<size_t>(n) + 1) * 4), o_meta = take(static_cast<size_t>(n) * 4);
+    const size_t o_cells = take(static_cast<size_t>(n) * 8);
+    const size_t o_ws = take(workspace_bytes_);
+    free_device();
+    device_block_bytes_ = off;
+    device_block_       = allocator_.allocate(device_block_bytes_, {stream_});
+    d_seq_              = device_block_ + o_seq;
+    d_starts_           = reinterpret_cast<int64_t*>(device_block_ + o_starts);
+    d_bw_               = reinterpret_cast<int32_t*>(device_block_ + o_bw);
+    d_order_            = reinterpret_cast<int32_t*>(device_block_ + o_order);
+    d_results_          = reinterpret_cast<int8_t*>(device_block_ + o_res);
+    d_result_counts_    = reinterpret_cast<int32_t*>(device_block_ + o_cnt);
+    d_result_starts_    = reinterpret_cast<int32_t*>(device_block_ + o_rs);
+    d_metadata_         = reinterpret_cast<uint32_t*>(device_block_ + o_meta);
+    d_cells_            = reinterpret_cast<uint64_t*>(device_block_ + o_cells);
+    d_workspace_        = device_block_ + o_ws;
+    order_h_            = std::move(order);
+
+    GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq_, seq_h_.data(), static_cast<size_t>(total_len), hipMemcpyHostToDevice, stream_));
+    GW_CU_CHECK_ERR(hipMemcpyAsync(d_starts_, seq_starts_h_.data(), seq_starts_h_.size() * 8, hipMemcpyHostToDevice, stream_));
+    GW_CU_CHECK_ERR(hipMemcpyAsync(d_bw_, max_bandwidths_h_.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, stream_));
+    GW_CU_CHECK_ERR(hipMemcpyAsync(d_order_, order_h_.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, stream_));
+    launch();
+    launched_ = true;
+    return StatusType::success;
+}
+
+void BandedAligner::launch()
+{
+    gwhip_myers_args a{};
+    a.n_alignments          = num_alignments();
+    a.sequences             = d_seq_;
+    a.sequence_starts       = d_starts_;
+    a.max_bandwidths        = d_bw_;
+    a.results               = d_results_;
+    a.result_counts         = d_result_counts_;
+    a.result_starts         = d_result_starts_;
+    a.result_metadata       = d_metadata_;
+    a.results_capacity      = seq_starts_h_.back();
+    a.workspace             = d_workspace_;
+    a.workspace_bytes       = workspace_bytes_;
+    a.total_sequence_length = seq_starts_h_.back();
+    a.scheduling_index      = d_order_;
+    a.band_cells            = d_cells_;
+    const int rc            = gwhip_myers_banded(&a, stream_);
+    if (rc != 0)
+    {
+        char buf[512];
+        gwhip_last_error_string(buf, sizeof(buf));
+        GW_LOG_ERROR(buf);
+        GW_CU_CHECK_ERR(static_cast<hipError_t>(rc));
+    }
+}
+
+void BandedAligner::relaunch_resident()
+{
+    if (!launched_) return;
+    scoped_device_switch dev(device_id_);
+    launch();
+}
+
+uint64_t BandedAligner::total_band_cells()
+{
+    const int32_t n = num_alignments();
+    if (!launched_ || n == 0) return 0;
+    scoped_device_switch dev(device_id_);
+    std::vector<uint64_t> h(static_cast<size_t>(n));
+    GW_CU_CHECK_ERR(hipMemcpyAsync(h.data(), d_cells_, h.size() * 8, hipMemcpyDeviceToHost, stream_));
+    GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+    uint64_t t = 0;
+    for (uint64_t v : h) t += v;
+    return t;
+}
+
+StatusType BandedAligner::sync_alignments()
+{
+    GW_NVTX_RANGE(profiler, "BandedAligner::sync");
+    const int32_t n = num_alignments();
+    alignments_.clear();
+    alignments_.resize(static_cast<size_t>(n));
+    if (n == 0) return StatusType::success;
+    scoped_device_switch dev(device_id_);
+    std::vector<int32_t> starts(static_cast<size_t>(n) + 1);
+    std::vector<uint32_t> meta(static_cast<size_t>(n));
+    GW_CU_CHECK_ERR(hipMemcpyAsync(starts.data(), d_result_starts_, starts.size() * 4, hipMemcpyDeviceToHost, stream_));
+    GW_CU_CHECK_ERR(hipMemcpyAsync(meta.data(), d_metadata_, meta.size() * 4, hipMemcpyDeviceToHost, stream_));
+    GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+    const size_t total = static_cast<size_t>(starts.back());
+    std::vector<int8_t> ops(total);
+    std::vector<int32_t> counts(total);
+    if (total > 0)
+    {
+        GW_CU_CHECK_ERR(hipMemcpyAsync(ops.data(), d_results_, total, hipMemcpyDeviceToHost, stream_));
+        GW_CU_CHECK_ERR(hipMemcpyAsync(counts.data(), d_result_counts_, total * 4, hipMemcpyDeviceToHost, stream_));
+        GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+    }
+    for (int32_t i = 0; i < n; ++i)
+    {
+        const bool is_optimal = (meta[i] >> 31) != 0;
+        const int32_t index   = static_cast<int32_t>(meta[i] & DeviceAlignmentsPtrs::index_mask);
+        const int32_t rb = starts[i], re = starts[i + 1];
+        const char* q       = seq_h_.data() + seq_starts_h_[2 * index];
+        const int32_t qlen  = static_cast<int32_t>(seq_starts_h_[2 * index + 1] - seq_starts_h_[2 * index]);
+        const char* t       = seq_h_.data() + seq_starts_h_[2 * index + 1];
+        const int32_t tlen  = static_cast<int32_t>(seq_starts_h_[2 * index + 2] - seq_starts_h_[2 * index + 1]);
+        auto alignment      = std::make_shared<AlignmentImpl>(q, qlen, t, tlen);
+        alignment->set_alignment_type(AlignmentType::global_alignment);
+        if (rb != re || (qlen == 0 && tlen == 0))
+        {
+            // the device emits each alignment back to front
+            std::vector<int8_t> a(std::make_reverse_iterator(ops.begin() + re), std::make_reverse_iterator(ops.begin() + rb));
+            std::vector<int32_t> c(std::make_reverse_iterator(counts.begin() + re), std::make_reverse_iterator(counts.begin() + rb));
+            if (expand_results_)
+            {
+                std::vector<AlignmentState> states;
+                for (size_t k = 0; k < a.size(); ++k) states.insert(states.end(), static_cast<size_t>(c[k]), static_cast<AlignmentState>(a[k]));
+                alignment->set_alignment(states, is_optimal);
+            }
+            else
+                alignment->set_alignment(std::move(a), std::move(c), is_optimal);
+            alignment->set_status(StatusType::success);
+        }
+        alignments_[static_cast<size_t>(index)] = std::move(alignment);
+    }
+    total_length_h_ = static_cast<int64_t>(total);
+    // keep the device block (device-resident results stay valid until reset()); host queues are cleared like the reference
+    seq_kept_        = std::move(seq_h_);
+    n_last_          = n;
+    reset_data();
+    return StatusType::success;
+}
+
+DeviceAlignmentsPtrs BandedAligner::get_alignments_device() const
+{
+    DeviceAlignmentsPtrs r{};
+    r.cigar_operations = d_results_;
+    r.cigar_runlengths = d_result_counts_;
+    r.cigar_offsets    = d_result_starts_;
+    r.metadata         = d_metadata_;
+    r.total_length     = total_length_h_;
+    r.n_alignments     = launched_ ? num_alignments() : n_last_;
+    return r;
+}
+
+// ---- factories (aligner.cpp:31-126) ------------------------------------------------------------------------
+std::unique_ptr<Aligner> create_aligner(int32_t max_query_length, int32_t max_target_length, int32_t max_alignments,
+                                        AlignmentType type, DefaultDeviceAllocator allocator, cudaStream_t stream,
+                                        int32_t device_id)
+{
+    if (type != AlignmentType::global_alignment) throw std::runtime_error("Aligner for specified type not implemented yet.");
+    throw_on_negative(max_query_length, "max_query_length must be non-negative.");
+    throw_on_negative(max_target_length, "max_target_length must be non-negative.");
+    throw_on_negative(max_alignments, "max_alignments must be non-negative.");
+    // The reference's default is Hirschberg + Myers (linear memory, optimal). We run the unbanded Myers kernel
+    // (band >= query length => full matrix), which is optimal as well; see DESIGN.md for the parity status.
+    int32_t bw = std::max(max_query_length, 1);
+    if (bw % kWordSize == 1) bw += 1;
+    return std::make_unique<BandedAligner>(-1, bw, allocator, stream, device_id, true, max_query_length,
+                                           max_target_length, max_alignments);
+}
+
+std::unique_ptr<Aligner> create_aligner(int32_t max_query_length, int32_t max_target_length, int32_t max_alignments,
+                                        AlignmentType type, cudaStream_t stream, int32_t device_id, int64_t max_mem)
+{
+    scoped_device_switch device(device_id);
+    if (max_mem < -1)
+        throw std::invalid_argument("max_device_memory_allocator_caching_size has to be either -1 (=all available GPU memory) or greater or equal than 0.");
+    if (max_mem == -1)
+    {
+        max_mem = cudautils::find_largest_contiguous_device_memory_section();
+        if (max_mem == 0) throw std::runtime_error("No memory available for caching");
+    }
+    DefaultDeviceAllocator allocator(static_cast<size_t>(max_mem), stream);
+    return create_aligner(max_query_length, max_target_length, max_alignments, type, allocator, stream, device_id);
+}
+
+std::unique_ptr<FixedBandAligner> create_aligner(AlignmentType type, int32_t max_bandwidth, cudaStream_t stream,
+                                                 int32_t device_id, DefaultDeviceAllocator allocator, int64_t max_device_memory)
+{
+    if (type != AlignmentType::global_alignment) throw std::runtime_error("Aligner for specified type not implemented yet.");
+    return std::make_unique<BandedAligner>(max_device_memory, max_bandwidth, allocator, stream, device_id, false, -1, -1, -1);
+}
+
+std::unique_ptr<FixedBandAligner> create_aligner(AlignmentType type, int32_t max_bandwidth, cudaStream_t stream,
+                                                 int32_t device_id, int64_t max_device_memory)
+{
+    scoped_device_switch device(device_id);
+    if (max_device_memory < -1)
+        throw std::invalid_argument("max_device_memory has to be either -1 (=all available GPU memory), or greater than or equal to 0.");
+    if (max_device_memory == -1)
+    {
+        max_device_memory = cudautils::find_largest_contiguous_device_memory_section();
+        if (max_device_memory == 0) throw std::runtime_error("No memory available for caching");
+    }
+    DefaultDeviceAllocator allocator(static_cast<size_t>(max_device_memory), stream);
+    return create_aligner(type, max_bandwidth, stream, device_id, allocator, -1);
+}
+
+} // namespace cudaaligner
+} // namespace genomeworks
+} // namespace claraparabricks

@@ -129,6 +129,8 @@ int32_t gw_alignment_edit_distance(gw_aligner* a, int32_t i);
 const char* gw_alignment_cigar(gw_aligner* a, int32_t i, int32_t extended, int32_t* length);
 int32_t gw_alignment_states(gw_aligner* a, int32_t i, int8_t* out, int32_t cap);
 int gw_aligner_relaunch(gw_aligner* a);
+/* 32 * band words * target length summed over band attempts and pairs of the last align_all() (device counters) */
+int gw_aligner_band_cells(gw_aligner* a, uint64_t* cells);
 
 #ifdef __cplusplus
 }

@@ -172,9 +172,14 @@ typedef struct gwhip_myers_args
     int32_t* result_starts; /* [n+1] offsets into results (start of alignment i; [n] = total) */
     uint32_t* result_metadata; /* [n] bit31 = optimal, bits 0-26 = alignment index; entry i belongs to
                                   result_starts[i] (we keep index order, which the contract leaves unspecified) */
-    int64_t results_capacity;  /* entries available in results / result_counts */
+    int64_t results_capacity;  /* entries available in results / result_counts (>= total_sequence_length suffices) */
     void* workspace;
     size_t workspace_bytes;
+    int64_t total_sequence_length;   /* sequence_starts[2n] (host-known), sizes the per-pair result slots */
+    const int32_t* scheduling_index; /* optional device int32[n]: processing order, longest pairs first
+                                        (aligner_global_myers_banded.cpp:306-309); NULL = input order */
+    uint64_t* band_cells;            /* optional device uint64[n]: 32*n_words_band*target_len summed over attempts */
+    int32_t* run_counts_out;         /* reserved */
 } gwhip_myers_args;
 
 size_t gwhip_myers_banded_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host,
