@@ -1,0 +1,49 @@
+"""Index-split sharding of independent work units (POA windows / alignment pairs) over the GPUs of one node.
+
+Windows and pairs never communicate, so there is no data-path collective: every rank (one process per GPU,
+`torch.distributed`) takes a contiguous slice of the unit indices, runs it through its own Batch / Aligner, and
+results are placed by GLOBAL index, so the output does not depend on the number of ranks. The only collective is
+the optional gather of result objects onto rank 0 (host side; RCCL is not involved in the data path).
+Reference context: the reference never splits one batch over devices; its tools run one worker per device pulling
+whole batches (cudamapper/src/main.cu:577-592)."""
+import os
+
+
+def shard_range(n_units, rank, world_size):
+    """Contiguous, balanced slice [lo, hi) of range(n_units) for `rank` (first n % world ranks get one more)."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    base, extra = divmod(n_units, world_size)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def dist_info():
+    """(rank, local_rank, world_size) from the torchrun environment (1 process: (0, 0, 1))."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def run_sharded(units, process_fn, gather=True):
+    """Process `units` (a list) with process_fn(list_of_units, lo) -> list of per-unit results on every rank's
+    own slice. Returns the full result list in global order on rank 0 (None elsewhere) when gather is True and a
+    process group is initialised; otherwise the local slice results."""
+    import torch.distributed as dist
+    active = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if active else 0
+    world = dist.get_world_size() if active else 1
+    lo, hi = shard_range(len(units), rank, world)
+    local = process_fn(units[lo:hi], lo)
+    if len(local) != hi - lo:
+        raise RuntimeError("process_fn must return one result per unit")
+    if not (active and gather):
+        return local
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object((lo, local), parts, dst=0)
+    if rank != 0:
+        return None
+    out = [None] * len(units)
+    for plo, res in parts:
+        out[plo:plo + len(res)] = res
+    return out
