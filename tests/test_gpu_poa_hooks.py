@@ -17,7 +17,7 @@ with open(os.path.join(HERE, "golden", "cudapoa_vectors.json")) as f:
 E = 50
 
 
-class TestGraph(C.Structure):
+class HookGraph(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("graph", C.c_void_p), ("node_id_to_pos", C.c_void_p), ("graph_count", C.c_int32),
                 ("incoming_edge_count", C.c_void_p), ("incoming_edges", C.c_void_p), ("outgoing_edge_count", C.c_void_p),
                 ("outgoing_edges", C.c_void_p)]
@@ -33,9 +33,9 @@ def lib():
     L = _native.gwhip()
     L.gwhip_poa_test_nw_scratch_bytes.restype = C.c_size_t
     L.gwhip_poa_test_nw_scratch_bytes.argtypes = [C.POINTER(_native.PoaConfig)]
-    L.gwhip_poa_test_nw.argtypes = [C.POINTER(_native.PoaConfig), C.POINTER(TestGraph), C.c_void_p, C.c_int32] + [C.c_void_p] * 5
+    L.gwhip_poa_test_nw.argtypes = [C.POINTER(_native.PoaConfig), C.POINTER(HookGraph), C.c_void_p, C.c_int32] + [C.c_void_p] * 5
     L.gwhip_poa_test_topsort.argtypes = [C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 5
-    L.gwhip_poa_test_add_alignment.argtypes = [C.c_void_p] * 9 + [C.c_int32] + [C.c_void_p] * 6 + [C.c_int32, C.c_void_p, C.c_void_p]
+    L.gwhip_poa_test_add_alignment.argtypes = [C.c_void_p] * 9 + [C.c_int32] + [C.c_void_p] * 5 + [C.c_int32, C.c_void_p, C.c_void_p]
     L.gwhip_poa_test_consensus.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 14 + [C.c_int32, C.c_void_p]
     return L
 
@@ -54,7 +54,7 @@ def run_nw_gpu(ocfg, g, read):
     cfg = device_cfg(ocfg)
     mx = ocfg.max_nodes_per_graph
     t = {k: dev(g[k]) for k in ("nodes", "graph", "pos", "incoming_count", "incoming", "outgoing_count", "outgoing")}
-    tg = TestGraph(t["nodes"].data_ptr(), t["graph"].data_ptr(), t["pos"].data_ptr(), g["count"],
+    tg = HookGraph(t["nodes"].data_ptr(), t["graph"].data_ptr(), t["pos"].data_ptr(), g["count"],
                    t["incoming_count"].data_ptr(), t["incoming"].data_ptr(), t["outgoing_count"].data_ptr(),
                    t["outgoing"].data_ptr())
     rb = np.zeros(ocfg.max_sequence_size + 4096, np.uint8)
