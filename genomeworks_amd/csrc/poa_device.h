@@ -193,6 +193,8 @@ __device__ __forceinline__ int32_t get_score(const BandedCtx<ScoreT>& b, int32_t
     int32_t bend = min(bs + b.band_width, b.max_column);
     if ((column > bend || column < bs) && column != -1) return b.min_score;
     int32_t rel = column == -1 ? 0 : column - bs;
+    // the relative-0 slot of a row whose band starts past column 0 is min_score by construction (and is not stored)
+    if (rel == 0 && bs > 0 && row > 0) return b.min_score;
     return b.scores[(int64_t)row * b.stride + rel + kRelShift];
 }
 
@@ -337,6 +339,7 @@ __device__ __forceinline__ int32_t traceback_banded_tiled(const BandedCtx<ScoreT
             const int32_t bend = min(bs + b.band_width, b.max_column);
             if ((column > bend || column < bs) && column != -1) return b.min_score;
             const int32_t col = column == -1 ? bs : column;
+            if (col == bs && bs > 0 && row > 0) return b.min_score; // relative-0 slot, see get_score
             const int32_t off = col - lo;
             if (off >= 0 && off < kTileCols) return tile[rr * kTileCols + off];
         }
@@ -463,8 +466,13 @@ __device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t g
 // ------------------------------------------------------------------------------------------------
 // Lean forward pass for bands <= 256 columns (one 64-lane pass per row), PACKED row table in LDS, read in LDS.
 // Everything wave-uniform (row table word, band starts, ring slots, carry, boundary values) lives in SGPRs;
-// per row the vector unit only does the 4-cell recurrence, the DPP prefix-max and two stores. Predecessor rows
-// come from registers (row r-1), else the LDS ring, else (far, rare) the HBM matrix after a workgroup sync.
+// per row the vector unit only does the 4-cell recurrence, the DPP prefix-max and two stores.
+//
+// Rows whose only predecessor is the previous row and whose band moved by 0 or 4 columns ("simple" rows, the
+// bulk) run in a tight inner loop with no branches besides the loop itself: the previous row is in registers
+// and is re-aligned with DPP lane shifts. All other rows take the general body (LDS ring, far rows from HBM).
+// The relative-0 slot of a row is only materialised when its band starts at column 0; for every other row it is
+// min_score by construction (cudapoa_nw_banded.cuh:158-175), so readers synthesise it.
 // Under the no-int16-wrap precondition values are kept in 32-bit registers and narrowed on store.
 // ------------------------------------------------------------------------------------------------
 template <typename ScoreT, typename IdT>
@@ -478,6 +486,7 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
     const int32_t min_score = Limits<ScoreT>::min / 2;
     const int32_t stride    = band_width + kRightPad;
     const int32_t lane4     = lane * 4;
+    const bool full_wave    = band_width == 256; // every lane owns 4 in-band cells
     const bool active       = lane4 < band_width;
     const int32_t K0 = (lane4 + 0) * gap_score, K1 = (lane4 + 1) * gap_score, K2 = (lane4 + 2) * gap_score,
                   K3 = (lane4 + 3) * gap_score;
@@ -487,122 +496,182 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
     int32_t ring_slot = 0; // slot of row r-1 (row 0 sits in slot 0)
     bool hbm_dirty    = false;
     ScoreT* row_out   = scores; // advanced by stride per row
+    ScoreT* ring_out  = ring;   // ring row of slot `ring_slot`
 
-    // the table entry of row r+1 is loaded (raw, in a VGPR pair) while row r is computed and only moved to
-    // SGPRs at the top of the next iteration, so its LDS latency is off the critical path
-    RowInfo<true> raw_next = rowinfo[1];
-    for (int32_t r = 1; r <= graph_count; r++)
-    {
-        const RowInfo<true> ri = uniform_row(raw_next);
-        raw_next               = rowinfo[min(r + 1, graph_count)];
-        const int32_t pred_count = ri.cnt();
-        const int32_t bs         = ri.bs();
-        const uint32_t base      = (uint32_t)ri.base();
-        const int32_t c          = bs + lane4;
+    // shared row tail: horizontal max-plus scan (prefix max of u[t] = v[t] - t*gap, carry-in as element -1),
+    // then the two row stores
+    auto finish_row = [&](int32_t s0, int32_t s1, int32_t s2, int32_t s3, int32_t fe, int32_t rel0_val, int32_t bs) {
+        const int32_t u0 = s0 - K0, u1 = s1 - K1, u2 = s2 - K2, u3 = s3 - K3;
+        const int32_t m1 = max(u0, u1), m2 = max(m1, u2), m3 = max(m2, u3);
+        const int32_t incl = wave_inclusive_max(m3);
+        const int32_t excl = max(wave_shr1(incl, INT32_MIN), fe + gap_score);
+        P0 = max(u0, excl) + K0;
+        P1 = max(m1, excl) + K1;
+        P2 = max(m2, excl) + K2;
+        P3 = max(m3, excl) + K3;
         row_out += stride;
-        const int32_t my_slot = (ring_slot + 1 == ring_rows) ? 0 : ring_slot + 1; // slot this row will occupy
-
-        const uint32_t rd4 = *reinterpret_cast<const uint32_t*>(lds_read + c);
-        const int32_t cp0  = ((rd4 & 0xff) == base) ? match_score : mismatch_score;
-        const int32_t cp1  = (((rd4 >> 8) & 0xff) == base) ? match_score : mismatch_score;
-        const int32_t cp2  = (((rd4 >> 16) & 0xff) == base) ? match_score : mismatch_score;
-        const int32_t cp3  = ((rd4 >> 24) == base) ? match_score : mismatch_score;
-
-        int32_t fe = 0, rel0_val = min_score;
-        int32_t s0, s1, s2, s3;
-        // candidates of the predecessor held in registers (row r-1), shifted to this row's band start
-        auto from_regs = [&](int32_t& t0, int32_t& t1, int32_t& t2, int32_t& t3) {
-            const int32_t q    = (bs - prev_bs) >> 2;
-            const int32_t pend = min(prev_bs + band_width - kCellsPerLane, max_column);
-            int32_t S0, S1, S2, S3, S4;
-            if (q <= 1)
-            {
-                // branch-free for the two common band moves (0 or +4 columns): both lane shifts are DPP moves,
-                // the wave-uniform q picks per register
-                const bool q0    = (q == 0);
-                const int32_t a0 = wave_shr1(P3, prev_rel0);
-                const int32_t b0 = wave_shl1(P0, 0), b1 = wave_shl1(P1, 0), b2 = wave_shl1(P2, 0), b3 = wave_shl1(P3, 0);
-                S0 = q0 ? a0 : P3;
-                S1 = q0 ? P0 : b0;
-                S2 = q0 ? P1 : b1;
-                S3 = q0 ? P2 : b2;
-                S4 = q0 ? P3 : b3;
-            }
-            else
-            {
-                const int src = lane + q;
-                S0 = __shfl(P3, src - 1);
-                S1 = __shfl(P0, src); S2 = __shfl(P1, src); S3 = __shfl(P2, src); S4 = __shfl(P3, src);
-            }
-            const bool valid = c <= pend; // c >= prev_bs always (band starts never decrease)
-            t0 = valid ? max(S0 + cp0, S1 + gap_score) : min_score;
-            t1 = valid ? max(S1 + cp1, S2 + gap_score) : min_score;
-            t2 = valid ? max(S2 + cp2, S3 + gap_score) : min_score;
-            t3 = valid ? max(S3 + cp3, S4 + gap_score) : min_score;
-        };
-        // candidates of an older predecessor row (LDS ring, else HBM)
-        auto from_memory = [&](int32_t prow, int32_t& t0, int32_t& t1, int32_t& t2, int32_t& t3) {
-            const int32_t pbs  = prow == 0 ? 0 : uniform_row(rowinfo[prow]).bs();
-            const int32_t pend = min(pbs + band_width - kCellsPerLane, max_column);
-            const bool valid   = !(c > pend || c < pbs);
-            const int32_t dist = r - prow;
-            const bool in_ring = dist < ring_rows;
-            int32_t S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0;
-            if (in_ring)
-            {
-                int32_t slot = my_slot - dist;
-                if (slot < 0) slot += ring_rows;
-                if (valid)
-                {
-                    const ScoreT* rowp = ring + slot * stride + (c - pbs) + kRelShift;
-                    S0 = rowp[0];
-                    const Quad<ScoreT> qd = *reinterpret_cast<const Quad<ScoreT>*>(rowp + 1);
-                    S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
-                }
-            }
-            else
-            {
-                if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
-                if (valid)
-                {
-                    const ScoreT* rowp = scores + (int64_t)prow * stride + (c - pbs) + kRelShift;
-                    S0 = rowp[0];
-                    const Quad<ScoreT> qd = *reinterpret_cast<const Quad<ScoreT>*>(rowp + 1);
-                    S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
-                }
-            }
-            t0 = valid ? max(S0 + cp0, S1 + gap_score) : min_score;
-            t1 = valid ? max(S1 + cp1, S2 + gap_score) : min_score;
-            t2 = valid ? max(S2 + cp2, S3 + gap_score) : min_score;
-            t3 = valid ? max(S3 + cp3, S4 + gap_score) : min_score;
-        };
-        // relative-0 slot of an older row
-        auto rel0_of = [&](int32_t prow) -> int32_t {
-            if (prow == r - 1) return prev_rel0;
-            const int32_t dist = r - prow;
-            if (dist < ring_rows)
-            {
-                int32_t slot = my_slot - dist;
-                if (slot < 0) slot += ring_rows;
-                return wave_first((int32_t)ring[slot * stride + kRelShift]);
-            }
-            if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
-            return wave_first((int32_t)scores[(int64_t)prow * stride + kRelShift]);
-        };
-
-        const int32_t p0row = pred_count == 0 ? 0 : ri.pred(0);
-        if ((pred_count <= 1 && p0row == r - 1) || (dbg & 4))
+        ring_slot = (ring_slot + 1 == ring_rows) ? 0 : ring_slot + 1;
+        ring_out  = (ring_slot == 0) ? ring : ring_out + stride;
+        Quad<ScoreT> out;
+        out.v[0] = (ScoreT)P0; out.v[1] = (ScoreT)P1; out.v[2] = (ScoreT)P2; out.v[3] = (ScoreT)P3;
+        if (full_wave)
         {
-            // ---- the common row: one predecessor, the previous row ----
-            const int32_t fe1 = (bs > kCellsPerLane) ? min_score + gap_score : max(min_score, prev_rel0) + gap_score;
-            fe                = pred_count == 0 ? 0 : fe1;                   // sources: carry-in stays 0 (reference quirk)
-            const int32_t b0v = pred_count == 0 ? gap_score : fe1;
-            rel0_val          = bs == 0 ? b0v : min_score;
-            from_regs(s0, s1, s2, s3);
+            if (!(dbg & 1)) *reinterpret_cast<Quad<ScoreT>*>(row_out + lane4 + 1 + kRelShift) = out;
+            *reinterpret_cast<Quad<ScoreT>*>(ring_out + lane4 + 1 + kRelShift) = out;
         }
-        else
+        else if (active)
         {
-            // ---- general row: any predecessor set ----
+            if (!(dbg & 1)) *reinterpret_cast<Quad<ScoreT>*>(row_out + lane4 + 1 + kRelShift) = out;
+            *reinterpret_cast<Quad<ScoreT>*>(ring_out + lane4 + 1 + kRelShift) = out;
+        }
+        if (bs == 0) // only rows whose band starts at column 0 have a real left-boundary value
+        {
+            if (lane == 0)
+            {
+                row_out[kRelShift]  = (ScoreT)rel0_val;
+                ring_out[kRelShift] = (ScoreT)rel0_val;
+            }
+        }
+        hbm_dirty = true;
+        prev_bs   = bs;
+        prev_rel0 = rel0_val;
+    };
+
+    // the table entry of row r+1 is loaded (raw, VGPR pair) while row r is computed and only moved to SGPRs at
+    // the top of the next iteration, so its LDS latency is off the critical path
+    RowInfo<true> raw_next = rowinfo[1];
+    int32_t r              = 1;
+    RowInfo<true> ri       = uniform_row(raw_next);
+    raw_next               = rowinfo[min(2, graph_count)];
+    while (r <= graph_count)
+    {
+        // ================= tight loop: consecutive simple rows =================
+        for (;;)
+        {
+            const int32_t pred_count = ri.cnt();
+            const int32_t bs         = ri.bs();
+            const int32_t q          = (bs - prev_bs) >> 2;
+            const bool simple        = (pred_count == 1) & (ri.pred(0) == r - 1) & (q <= 1);
+            if (!simple) break;
+            const uint32_t base = (uint32_t)ri.base();
+            const int32_t c     = bs + lane4;
+            const uint32_t rd4  = *reinterpret_cast<const uint32_t*>(lds_read + c);
+            const int32_t cp0   = ((rd4 & 0xff) == base) ? match_score : mismatch_score;
+            const int32_t cp1   = (((rd4 >> 8) & 0xff) == base) ? match_score : mismatch_score;
+            const int32_t cp2   = (((rd4 >> 16) & 0xff) == base) ? match_score : mismatch_score;
+            const int32_t cp3   = ((rd4 >> 24) == base) ? match_score : mismatch_score;
+            const int32_t fe    = (bs > kCellsPerLane) ? min_score + gap_score : max(min_score, prev_rel0) + gap_score;
+            const int32_t rel0_val = bs == 0 ? fe : min_score;
+            const int32_t pend  = min(prev_bs + band_width - kCellsPerLane, max_column);
+            const bool q0       = (q == 0);
+            const int32_t a0    = wave_shr1(P3, prev_rel0);
+            const int32_t b0 = wave_shl1(P0, 0), b1 = wave_shl1(P1, 0), b2 = wave_shl1(P2, 0), b3 = wave_shl1(P3, 0);
+            const int32_t S0 = q0 ? a0 : P3, S1 = q0 ? P0 : b0, S2 = q0 ? P1 : b1, S3 = q0 ? P2 : b2, S4 = q0 ? P3 : b3;
+            const bool valid = c <= pend;
+            const int32_t s0 = valid ? max(S0 + cp0, S1 + gap_score) : min_score;
+            const int32_t s1 = valid ? max(S1 + cp1, S2 + gap_score) : min_score;
+            const int32_t s2 = valid ? max(S2 + cp2, S3 + gap_score) : min_score;
+            const int32_t s3 = valid ? max(S3 + cp3, S4 + gap_score) : min_score;
+            finish_row(s0, s1, s2, s3, fe, rel0_val, bs);
+            r++;
+            if (r > graph_count) break;
+            ri       = uniform_row(raw_next);
+            raw_next = rowinfo[min(r + 1, graph_count)];
+        }
+        if (r > graph_count) break;
+
+        // ================= general row =================
+        {
+            const int32_t pred_count = ri.cnt();
+            const int32_t bs         = ri.bs();
+            const uint32_t base      = (uint32_t)ri.base();
+            const int32_t c          = bs + lane4;
+            const int32_t my_slot    = (ring_slot + 1 == ring_rows) ? 0 : ring_slot + 1; // slot this row will occupy
+            const uint32_t rd4 = *reinterpret_cast<const uint32_t*>(lds_read + c);
+            const int32_t cp0  = ((rd4 & 0xff) == base) ? match_score : mismatch_score;
+            const int32_t cp1  = (((rd4 >> 8) & 0xff) == base) ? match_score : mismatch_score;
+            const int32_t cp2  = (((rd4 >> 16) & 0xff) == base) ? match_score : mismatch_score;
+            const int32_t cp3  = ((rd4 >> 24) == base) ? match_score : mismatch_score;
+
+            auto from_regs = [&](int32_t& t0, int32_t& t1, int32_t& t2, int32_t& t3) {
+                const int32_t q    = (bs - prev_bs) >> 2;
+                const int32_t pend = min(prev_bs + band_width - kCellsPerLane, max_column);
+                int32_t S0, S1, S2, S3, S4;
+                if (q == 0)
+                {
+                    S0 = wave_shr1(P3, prev_rel0);
+                    S1 = P0; S2 = P1; S3 = P2; S4 = P3;
+                }
+                else if (q == 1)
+                {
+                    S0 = P3;
+                    S1 = wave_shl1(P0, 0); S2 = wave_shl1(P1, 0); S3 = wave_shl1(P2, 0); S4 = wave_shl1(P3, 0);
+                }
+                else
+                {
+                    const int src = lane + q;
+                    S0 = __shfl(P3, src - 1);
+                    S1 = __shfl(P0, src); S2 = __shfl(P1, src); S3 = __shfl(P2, src); S4 = __shfl(P3, src);
+                }
+                const bool valid = c <= pend; // c >= prev_bs always (band starts never decrease)
+                t0 = valid ? max(S0 + cp0, S1 + gap_score) : min_score;
+                t1 = valid ? max(S1 + cp1, S2 + gap_score) : min_score;
+                t2 = valid ? max(S2 + cp2, S3 + gap_score) : min_score;
+                t3 = valid ? max(S3 + cp3, S4 + gap_score) : min_score;
+            };
+            auto from_memory = [&](int32_t prow, int32_t& t0, int32_t& t1, int32_t& t2, int32_t& t3) {
+                const int32_t pbs  = prow == 0 ? 0 : uniform_row(rowinfo[prow]).bs();
+                const int32_t pend = min(pbs + band_width - kCellsPerLane, max_column);
+                const bool valid   = !(c > pend || c < pbs);
+                const int32_t dist = r - prow;
+                const bool in_ring = dist < ring_rows;
+                int32_t S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0;
+                if (in_ring)
+                {
+                    int32_t slot = my_slot - dist;
+                    if (slot < 0) slot += ring_rows;
+                    if (valid)
+                    {
+                        const ScoreT* rowp = ring + slot * stride + (c - pbs) + kRelShift;
+                        S0 = rowp[0];
+                        const Quad<ScoreT> qd = *reinterpret_cast<const Quad<ScoreT>*>(rowp + 1);
+                        S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
+                    }
+                }
+                else
+                {
+                    if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
+                    if (valid)
+                    {
+                        const ScoreT* rowp = scores + (int64_t)prow * stride + (c - pbs) + kRelShift;
+                        S0 = rowp[0];
+                        const Quad<ScoreT> qd = *reinterpret_cast<const Quad<ScoreT>*>(rowp + 1);
+                        S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
+                    }
+                }
+                if (pbs > 0 && c == pbs) S0 = min_score; // relative-0 slot of a row whose band starts past column 0
+                t0 = valid ? max(S0 + cp0, S1 + gap_score) : min_score;
+                t1 = valid ? max(S1 + cp1, S2 + gap_score) : min_score;
+                t2 = valid ? max(S2 + cp2, S3 + gap_score) : min_score;
+                t3 = valid ? max(S3 + cp3, S4 + gap_score) : min_score;
+            };
+            // relative-0 slot of an older row
+            auto rel0_of = [&](int32_t prow) -> int32_t {
+                if (prow == r - 1) return prev_rel0;
+                const int32_t pbs = prow == 0 ? 0 : uniform_row(rowinfo[prow]).bs();
+                if (pbs > 0) return min_score;
+                const int32_t dist = r - prow;
+                if (dist < ring_rows)
+                {
+                    int32_t slot = my_slot - dist;
+                    if (slot < 0) slot += ring_rows;
+                    return wave_first((int32_t)ring[slot * stride + kRelShift]);
+                }
+                if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
+                return wave_first((int32_t)scores[(int64_t)prow * stride + kRelShift]);
+            };
+
+            const int32_t p0row   = pred_count == 0 ? 0 : ri.pred(0);
             const int32_t node_id = (pred_count > 3) ? (int32_t)g.sorted_poa[r - 1] : 0;
             auto pred_row = [&](int32_t p) -> int32_t {
                 if (p == 0) return p0row;
@@ -610,9 +679,10 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
                 if (p == 2) return ri.pred(2);
                 return (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
             };
+            int32_t fe = 0, rel0_val = min_score;
             if (pred_count == 0)
             {
-                if (bs == 0) rel0_val = gap_score;
+                if (bs == 0) rel0_val = gap_score; // carry-in stays 0 (reference quirk)
             }
             else
             {
@@ -626,6 +696,7 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
                 }
                 if (bs == 0) rel0_val = fe;
             }
+            int32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
             const int32_t np = max(pred_count, 1);
             for (int32_t p = 0; p < np; p++)
             {
@@ -636,45 +707,14 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
                 if (p == 0) { s0 = t0; s1 = t1; s2 = t2; s3 = t3; }
                 else { s0 = max(s0, t0); s1 = max(s1, t1); s2 = max(s2, t2); s3 = max(s3, t3); }
             }
-        }
-
-        // ---- horizontal max-plus scan (prefix max of u[t] = v[t] - t*gap, carry as element -1) ----
-        const int32_t u0 = s0 - K0, u1 = s1 - K1, u2 = s2 - K2, u3 = s3 - K3;
-        const int32_t m1 = max(u0, u1), m2 = max(m1, u2), m3 = max(m2, u3);
-        const int32_t incl = (dbg & 8) ? m3 : wave_inclusive_max(m3);
-        const int32_t excl = max(wave_shr1(incl, INT32_MIN), fe + gap_score);
-        P0 = max(u0, excl) + K0;
-        P1 = max(m1, excl) + K1;
-        P2 = max(m2, excl) + K2;
-        P3 = max(m3, excl) + K3;
-        if (active)
-        {
-            Quad<ScoreT> out;
-            out.v[0] = (ScoreT)P0; out.v[1] = (ScoreT)P1; out.v[2] = (ScoreT)P2; out.v[3] = (ScoreT)P3;
-            if (!(dbg & 1))
+            finish_row(s0, s1, s2, s3, fe, rel0_val, bs);
+            r++;
+            if (r <= graph_count)
             {
-                if (dbg & 64) // experiment: streaming (non-temporal) score-row stores
-                {
-                    if constexpr (sizeof(ScoreT) == 2)
-                        __builtin_nontemporal_store(*reinterpret_cast<unsigned long long*>(&out),
-                                                    reinterpret_cast<unsigned long long*>(row_out + lane4 + 1 + kRelShift));
-                    else
-                        *reinterpret_cast<Quad<ScoreT>*>(row_out + lane4 + 1 + kRelShift) = out;
-                }
-                else
-                    *reinterpret_cast<Quad<ScoreT>*>(row_out + lane4 + 1 + kRelShift) = out;
+                ri       = uniform_row(raw_next);
+                raw_next = rowinfo[min(r + 1, graph_count)];
             }
-            if (!(dbg & 2)) *reinterpret_cast<Quad<ScoreT>*>(ring + my_slot * stride + lane4 + 1 + kRelShift) = out;
         }
-        if (lane == 0 && !(dbg & 16))
-        {
-            if (!(dbg & 1)) row_out[kRelShift] = (ScoreT)rel0_val;
-            if (!(dbg & 2)) ring[my_slot * stride + kRelShift] = (ScoreT)rel0_val;
-        }
-        hbm_dirty = true;
-        prev_bs   = bs;
-        prev_rel0 = rel0_val;
-        ring_slot = my_slot;
     }
 }
 
