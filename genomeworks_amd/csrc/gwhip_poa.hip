@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
         status_and_count = wave_first(status_and_count);
         __syncthreads();
         if (status_and_count >= 0 && !c.spoa_accurate && graph_fits_lds)
-            topsort_kahn_lds<IdT>(g, status_and_count, lds_rowinfo_region, lane);
+            topsort_kahn_lds<IdT>(g, status_and_count, lds_rowinfo_region, smem, lane);
         pc.tick(kPhTopsort);
         if (status_and_count < 0) break;
         node_count = status_and_count;
@@ -396,6 +396,7 @@ __global__ void poa_export_graph_kernel(KernelArgs a, uint8_t* nodes, int32_t* i
 // ------------------------------------------------------------------------------------------------
 // host side of the C-ABI
 // ------------------------------------------------------------------------------------------------
+#ifndef GWHIP_DEVICE_ONLY // tools/isa_dump.sh compiles a single kernel instantiation without the host dispatch
 static size_t full_score_bytes(const gwhip_poa_config& c, int32_t windows, uint64_t sum_scores_width)
 {
     if (c.band_mode != GWHIP_FULL_BAND) return 0;
@@ -484,8 +485,10 @@ static KernelArgs make_kernel_args(const gwhip_poa_args* args)
     return ka;
 }
 
+#endif // GWHIP_DEVICE_ONLY
 } // namespace gwhip
 
+#ifndef GWHIP_DEVICE_ONLY
 using namespace gwhip;
 
 extern "C" {
@@ -591,3 +594,4 @@ const char* gwhip_build_arch(void) { return "gfx950"; }
 int gwhip_abi_version(void) { return 1; }
 
 } // extern "C"
+#endif // GWHIP_DEVICE_ONLY

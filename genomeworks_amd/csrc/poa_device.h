@@ -444,6 +444,236 @@ __device__ __forceinline__ int32_t traceback_banded_tiled(const BandedCtx<ScoreT
 }
 
 // ------------------------------------------------------------------------------------------------
+// Traceback by recomputation, candidate-per-lane. Same decision sequence as cudapoa_nw_banded.cuh:428-549
+// (diagonal move through predecessor 0..n-1, then vertical through predecessor 0..n-1, then horizontal; first
+// equality wins), but one step evaluates every candidate at once: lanes 0..30 test the diagonal moves, lanes
+// 31..61 the vertical moves and lane 62 the horizontal move; a ballot + find-first-set reproduces the
+// reference's priority order. Rows with more than 31 predecessors take a wave-uniform sequential loop.
+//
+// The walk is latency-bound on a lone wavefront, so a step is organised as ONE LDS round trip:
+//   * the score matrix around the path is cached in an LDS tile of 60 rows x 64 ABSOLUTE columns; the window of
+//     tile row t starts at column ((anchor_col - 40 - t) & ~3) + 1 -- arithmetic, independent of the band start
+//     (band starts are multiples of 4, so the HBM source is Quad-aligned) -- and the loader applies
+//     get_score()'s band predicate (cudapoa_nw_banded.cuh:80-102) once per cached cell, so a candidate lane
+//     needs no band math at all;
+//   * every candidate lane also prefetches the row-table word and the read character its move would need
+//     next; the winner's copies are broadcast with v_readlane, so the next step starts without a dependent
+//     LDS read; the winner's score becomes the next step's H(i, j);
+//   * (position, read index) pairs are staged in LDS and flushed 64 at a time: an HBM store inside the walk
+//     would make each step wait for the previous write acknowledgement (vmcnt is shared by loads and stores).
+// Cells outside the tile (far predecessors) use the HBM copy through get_score(). alignment_graph receives
+// sorted positions during the walk and is translated to node ids by all lanes afterwards.
+// ------------------------------------------------------------------------------------------------
+template <typename ScoreT, typename IdT, bool ADAPTIVE>
+__device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT>& b, const GraphView<IdT>& g,
+                                                          const RowInfo<true>* rowinfo, int32_t graph_count,
+                                                          const uint8_t* read, int32_t read_length, int32_t start_i,
+                                                          int32_t* alignment_graph, int32_t* alignment_read,
+                                                          int32_t gap_score, int32_t mismatch_score,
+                                                          int32_t match_score, int32_t rerun, ScoreT* tile)
+{
+    constexpr int kTileRows = 60, kTileCols = 64, kTileStride = 68, kReanchor = 44, kLead = 40, kHalf = 31;
+    constexpr int kStage = 64;
+    const int lane      = threadIdx.x & (kWave - 1);
+    const int32_t bound = read_length + graph_count + 2;
+    int32_t aligned_nodes = 0, loop_count = 0;
+    int32_t i = start_i, j = read_length, prev_i = 0, prev_j = 0;
+    int32_t tile_top = -1, tile_col = 0; // matrix row in tile row 0 and the column the windows are anchored on
+    uint32_t* stage  = reinterpret_cast<uint32_t*>(tile + kTileRows * kTileStride);
+
+    auto window_lo = [&](int32_t t) -> int32_t { return ((tile_col - kLead - t) & ~3) + 1; };
+    auto load_tile = [&](int32_t top, int32_t col) {
+        __syncthreads();
+        tile_top = top;
+        tile_col = col;
+        const int32_t row = top - lane;
+        const bool ok_row = row >= 0 && lane < kTileRows;
+        int32_t e0 = 0, klo = 0, khi = -1;
+        if (ok_row)
+        {
+            const int32_t bs   = band_start_for_row(row, b.gradient, b.band_width, b.band_shift, b.max_column);
+            const int32_t bend = min(bs + b.band_width, b.max_column);
+            e0                 = window_lo(lane) - bs + kRelShift; // multiple of 4
+            // stored elements get_score() would return: columns bs (or bs + 1 when the relative-0 slot is synthetic) .. bend
+            klo = ((bs > 0 && row > 0) ? kRelShift + 1 : kRelShift) - e0;
+            khi = bend - bs + kRelShift - e0;
+        }
+        const ScoreT* src = b.scores + (int64_t)row * b.stride + e0;
+        ScoreT* dst       = tile + lane * kTileStride;
+        const bool whole  = klo <= 0 && khi >= kTileCols - 1;
+        if (__ballot(ok_row && !whole) == 0)
+        {
+            if (ok_row)
+            {
+#pragma unroll
+                for (int k = 0; k < kTileCols; k += 4)
+                    *reinterpret_cast<Quad<ScoreT>*>(dst + k) = *reinterpret_cast<const Quad<ScoreT>*>(src + k);
+            }
+        }
+        else if (ok_row) // a window reaching past a band edge: per-cell predicate
+        {
+            for (int k = 0; k < kTileCols; k++) dst[k] = (k >= klo && k <= khi) ? src[k] : (ScoreT)b.min_score;
+        }
+        __syncthreads();
+    };
+    auto flush_stage = [&](int32_t first, int32_t count) {
+        if (lane < count)
+        {
+            const uint32_t e              = stage[lane];
+            alignment_graph[first + lane] = (int32_t)(int16_t)(e & 0xffff); // sorted position; node ids are filled in below
+            alignment_read[first + lane]  = (int32_t)(int16_t)(e >> 16);
+        }
+    };
+
+    const int kind = lane < kHalf ? 0 : (lane < 2 * kHalf ? 1 : (lane == 2 * kHalf ? 2 : 3));
+    const int p    = kind == 0 ? lane : lane - kHalf;
+    const int psh  = 24 + 12 * min(p, 2);
+    // wave-uniform walk state: H(i, j), the row-table word of row i and the read character j - 1
+    int32_t scores_ij = 0;
+    uint64_t riw      = 0;
+    uint32_t rch      = 0;
+    bool have         = false;
+    while (!(i == 0 && j == 0) && loop_count < bound)
+    {
+        // keep the current cell and its near predecessors inside the tile
+        {
+            const int32_t t = tile_top - i;
+            bool reload     = tile_top < 0 || t < 0 || t >= kReanchor;
+            if (!reload)
+            {
+                const int32_t off = j - window_lo(t);
+                reload            = (off < 2 || off >= kTileCols);
+            }
+            if (reload && i > 0) load_tile(i, j);
+        }
+        loop_count++;
+        if (!have)
+        {
+            scores_ij = wave_first(get_score(b, i, j));
+            riw       = i != 0 ? wave_first64(rowinfo[i].w) : 0;
+            rch       = j > 0 ? (uint32_t)wave_first((int32_t)read[j - 1]) : 0u;
+        }
+        RowInfo<true> ri;
+        ri.w                     = riw;
+        const int32_t pred_count = ri.cnt();
+        const int32_t np         = max(pred_count, 1);
+        int32_t match_cost       = 0;
+        if (i != 0 && j != 0)
+        {
+            if (ADAPTIVE)
+            {
+                if (rerun == 0 && b.band_width < kMaxAdaptiveBand)
+                {
+                    int32_t threshold = max(1, b.max_column / 1024);
+                    if (j > threshold && j < b.max_column - threshold)
+                    {
+                        int32_t bs = band_start_for_row(i, b.gradient, b.band_width, b.band_shift, b.max_column);
+                        if (j <= bs + threshold) { aligned_nodes = kShiftLeft; break; }
+                        if (j >= (bs + b.band_width - threshold)) { aligned_nodes = kShiftRight; break; }
+                    }
+                }
+            }
+            match_cost = ((uint32_t)ri.base() == rch ? match_score : mismatch_score);
+        }
+        bool found         = false;
+        int32_t next_score = 0;
+        uint64_t next_riw  = 0;
+        uint32_t next_rch  = 0;
+        if (np <= kHalf)
+        {
+            const bool en = kind == 0 ? (i != 0 && j != 0 && p < np) : kind == 1 ? (i != 0 && p < np) : kind == 2;
+            int32_t crow  = i;
+            if (kind < 2)
+            {
+                crow = 0;
+                if (pred_count != 0)
+                {
+                    crow = (int32_t)((riw >> psh) & 0xfff);
+                    if (pred_count > 3 && en && p >= 3)
+                    {
+                        const int32_t node_id = g.sorted_poa[i - 1];
+                        crow = (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
+                    }
+                }
+            }
+            const int32_t ccol = kind == 1 ? j : j - 1;
+            const int32_t cost = kind == 0 ? match_cost : gap_score;
+            int32_t val        = 0;
+            uint64_t cw        = 0;
+            uint32_t cch       = 0;
+            if (en)
+            {
+                const int32_t t   = tile_top - crow;
+                const int32_t off = ccol - window_lo(t);
+                if ((uint32_t)t < (uint32_t)kTileRows && (uint32_t)off < (uint32_t)kTileCols)
+                    val = tile[t * kTileStride + off];
+                else
+                    val = get_score(b, crow, ccol);
+                if (crow != 0) cw = rowinfo[crow].w;
+                if (ccol > 0) cch = read[ccol - 1];
+            }
+            const bool hit   = en && (scores_ij == val + cost);
+            const uint64_t m = __ballot(hit);
+            if (m != 0)
+            {
+                const int sel = __ffsll((unsigned long long)m) - 1;
+                prev_i        = __builtin_amdgcn_readlane(crow, sel);
+                prev_j        = __builtin_amdgcn_readlane(ccol, sel);
+                next_score    = __builtin_amdgcn_readlane(val, sel);
+                next_riw      = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)cw, sel) |
+                           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)(cw >> 32), sel) << 32);
+                next_rch = (uint32_t)__builtin_amdgcn_readlane((int32_t)cch, sel);
+                found    = true;
+            }
+        }
+        else // more predecessors than candidate lanes: the reference's sequential order, wave-uniform
+        {
+            const int32_t node_id = g.sorted_poa[i - 1];
+            auto pred_row = [&](int32_t q) -> int32_t {
+                if (q < 3) return ri.pred(q);
+                return (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + q]] + 1;
+            };
+            if (j != 0)
+                for (int32_t q = 0; q < np && !found; q++)
+                {
+                    const int32_t pi = pred_row(q);
+                    if (scores_ij == wave_first(get_score(b, pi, j - 1)) + match_cost) { prev_i = pi; prev_j = j - 1; found = true; }
+                }
+            for (int32_t q = 0; q < np && !found; q++)
+            {
+                const int32_t pi = pred_row(q);
+                if (scores_ij == wave_first(get_score(b, pi, j)) + gap_score) { prev_i = pi; prev_j = j; found = true; }
+            }
+            if (!found && scores_ij == wave_first(get_score(b, i, j - 1)) + gap_score) { prev_i = i; prev_j = j - 1; found = true; }
+            found = false; // walk state is re-read at the top of the next step
+        }
+        {
+            const uint32_t e = (uint32_t)(uint16_t)(i == prev_i ? -1 : i - 1) | ((uint32_t)(uint16_t)(j == prev_j ? -1 : j - 1) << 16);
+            if (lane == 0) stage[aligned_nodes & (kStage - 1)] = e;
+        }
+        aligned_nodes++;
+        if ((aligned_nodes & (kStage - 1)) == 0) flush_stage(aligned_nodes - kStage, kStage);
+        i         = prev_i;
+        j         = prev_j;
+        scores_ij = next_score;
+        riw       = next_riw;
+        rch       = next_rch;
+        have      = found;
+    }
+    if (aligned_nodes > 0 && (aligned_nodes & (kStage - 1)) != 0)
+        flush_stage(aligned_nodes & ~(kStage - 1), aligned_nodes & (kStage - 1));
+    if (loop_count >= bound) aligned_nodes = kNwLoopFailed;
+    __syncthreads();
+    for (int32_t k = lane; k < aligned_nodes; k += kWave)
+    {
+        const int32_t pos = alignment_graph[k];
+        if (pos >= 0) alignment_graph[k] = (int32_t)g.sorted_poa[pos];
+    }
+    __syncthreads();
+    return aligned_nodes;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-read row table: all lanes gather (base, predecessor rows, sink flag) for rows 1..N.
 // ------------------------------------------------------------------------------------------------
 template <typename IdT, typename RowT>
@@ -480,12 +710,13 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
                                                      int32_t graph_count, const uint8_t* lds_read, ScoreT* scores,
                                                      ScoreT* ring, int32_t ring_rows, int32_t band_width,
                                                      int32_t max_column, int32_t gap_score, int32_t mismatch_score,
-                                                     int32_t match_score, int32_t dbg)
+                                                     int32_t match_score, int32_t dbg, uint64_t* general_row_acc)
 {
     const int lane          = threadIdx.x & (kWave - 1);
     const int32_t min_score = Limits<ScoreT>::min / 2;
     const int32_t stride    = band_width + kRightPad;
     const int32_t lane4     = lane * 4;
+    uint64_t general_acc    = 0; // profiling (GWHIP_DEBUG bit 2): cycles (or, with bit 3, count) of general rows
     const bool full_wave    = band_width == 256; // every lane owns 4 in-band cells
     const bool active       = lane4 < band_width;
     const int32_t K0 = (lane4 + 0) * gap_score, K1 = (lane4 + 1) * gap_score, K2 = (lane4 + 2) * gap_score,
@@ -582,6 +813,7 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
 
         // ================= general row =================
         {
+            const uint64_t t_general = (dbg & 4) ? clock64() : 0;
             const int32_t pred_count = ri.cnt();
             const int32_t bs         = ri.bs();
             const uint32_t base      = (uint32_t)ri.base();
@@ -714,8 +946,10 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
                 ri       = uniform_row(raw_next);
                 raw_next = rowinfo[min(r + 1, graph_count)];
             }
+            if (dbg & 4) general_acc += (dbg & 8) ? 1 : clock64() - t_general;
         }
     }
+    if ((dbg & 4) && general_row_acc) *general_row_acc += general_acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -811,7 +1045,8 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
         if (npass == 1 && b.ring_rows >= 2)
         {
             banded_forward_1pass<ScoreT, IdT>(g, rowinfo, graph_count, lds_read, scores, b.ring, b.ring_rows, band_width,
-                                              max_column, gap_score, mismatch_score, match_score, dbg);
+                                              max_column, gap_score, mismatch_score, match_score, dbg,
+                                              pc.acc ? &pc.acc[kPhOther] : nullptr);
             fast_done = true;
         }
     }
@@ -999,8 +1234,21 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     }
 
     int32_t aligned_nodes = 0;
-    const bool tile_fits = (int32_t)(64 * 64 * sizeof(ScoreT) + 64 * sizeof(int32_t)) <= ring_bytes;
-    if (LDS_READ && tile_fits && !(dbg & 32))
+    const bool tile_fits = (int32_t)(64 * 64 * sizeof(ScoreT) + 64 * sizeof(int32_t)) <= ring_bytes; // also covers the 60 x 68 + 64-word layout
+    constexpr bool kLanesOk = std::is_same<RowT, RowInfo<true>>::value && LDS_READ;
+    bool tb_done = false;
+    if constexpr (kLanesOk)
+    {
+        if (tile_fits && b.stride >= 64 && !(dbg & 32))
+        {
+            aligned_nodes = traceback_banded_lanes<ScoreT, IdT, ADAPTIVE>(b, g, rowinfo, graph_count, lds_read, read_length,
+                                                                          best_i, alignment_graph, alignment_read, gap_score,
+                                                                          mismatch_score, match_score, rerun, ring_base);
+            tb_done = true;
+        }
+    }
+    if (tb_done) {}
+    else if (LDS_READ && tile_fits && !(dbg & 128))
     {
         // the LDS ring is dead after the forward pass: reuse it as the traceback tile
         ScoreT* tile       = ring_base;

@@ -369,17 +369,17 @@ __device__ void topsort_kahn(IdT* sorted_poa, IdT* node_map, int32_t node_count,
 }
 
 // Kahn with its working set in LDS (node counts <= 3072, 16-bit ids): the order-defining serial loop then pays
-// LDS latency (~64 cycles) per dependent step instead of an HBM round trip. Same output as topsort_kahn.
-//   e01[n]  : first two outgoing edges (u16 | u16 << 16)      12 KB
-//   cnts[n] : outgoing count (low byte) | remaining in-degree (high byte)   6 KB
-//   queue[] : the FIFO == the sorted order                      6 KB
+// LDS latency per dependent step instead of an HBM round trip. Same output as topsort_kahn.
+//   ent[n]  : one 64-bit word per node (first two out-edges, out-degree, unvisited in-edges)   24 KB (row-table region)
+//   queue[] : the FIFO == the sorted order                                                       6 KB (score-ring region)
 template <typename IdT>
-__device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_t node_count, uint8_t* lds, int lane)
+__device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_t node_count, uint8_t* lds,
+                                                 uint8_t* lds_queue, int lane)
 {
-    uint32_t* e01   = reinterpret_cast<uint32_t*>(lds);
-    uint16_t* cnts  = reinterpret_cast<uint16_t*>(lds + 3072 * 4);
-    uint16_t* queue = reinterpret_cast<uint16_t*>(lds + 3072 * 6);
-    // phase 1 (all lanes): stage counts / edges; sources in ascending node id (ordered compaction per 64-chunk)
+    // per node one 64-bit LDS word: [0:16) out-edge 0  [16:32) out-edge 1  [32:40) out-degree  [40:48) unvisited in-edges
+    uint64_t* ent   = reinterpret_cast<uint64_t*>(lds);
+    uint16_t* queue = reinterpret_cast<uint16_t*>(lds_queue);
+    // phase 1 (all lanes): stage the node words; sources in ascending node id (ordered compaction per 64-chunk)
     int32_t tail = 0;
     for (int32_t base = 0; base < node_count; base += kWave)
     {
@@ -389,11 +389,10 @@ __device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_
         {
             const uint32_t ic = g.incoming_edge_count[n];
             const uint32_t oc = g.outgoing_edge_count[n];
-            cnts[n]           = (uint16_t)((oc & 0xff) | (ic << 8));
             uint32_t e        = 0;
             if (oc > 0) e = (uint16_t)g.outgoing_edges[(int64_t)n * kEdges];
             if (oc > 1) e |= ((uint32_t)(uint16_t)g.outgoing_edges[(int64_t)n * kEdges + 1]) << 16;
-            e01[n] = e;
+            ent[n] = (uint64_t)e | ((uint64_t)((oc & 0xff) | ((ic & 0xff) << 8)) << 32);
             is_src = (ic == 0);
         }
         const unsigned long long m = __ballot(is_src);
@@ -401,31 +400,59 @@ __device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_
         tail += __popcll(m);
     }
     __syncthreads();
-    // phase 2 (lane 0): the FIFO loop
-    if (lane == 0)
+    // phase 2: the FIFO loop, executed wave-uniformly (every lane runs the same scalar program, so node words land
+    // in SGPRs). A child whose last in-edge was just consumed is appended and its word kept in registers: along a
+    // chain (the common case) the next iteration needs no queue or node-word read at all, one LDS round trip per node.
     {
-        int32_t head    = 0;
-        int32_t pending = -1; // value last pushed at queue[tail - 1], kept in a register
+        int32_t head      = 0;
+        int32_t pend_node = -1;
+        uint32_t pend_lo = 0, pend_hi = 0;
         while (head < tail)
         {
-            const int32_t node = (head == tail - 1 && pending >= 0) ? pending : (int32_t)queue[head];
-            const uint32_t c   = cnts[node];
-            const uint32_t e   = e01[node];
-            const int32_t oc   = (int32_t)(c & 0xff);
-            for (int32_t k = 0; k < oc; k++)
+            int32_t node;
+            uint32_t lo, hi;
+            if (head == tail - 1 && pend_node >= 0)
             {
-                const int32_t child = k == 0 ? (int32_t)(e & 0xffff)
-                                      : k == 1 ? (int32_t)(e >> 16) : (int32_t)g.outgoing_edges[(int64_t)node * kEdges + k];
-                const uint32_t cc   = cnts[child];
-                const uint32_t left = ((cc >> 8) - 1) & 0xff;
-                cnts[child]         = (uint16_t)((cc & 0xff) | (left << 8));
-                if (left == 0)
-                {
-                    queue[tail++] = (uint16_t)child;
-                    pending       = child;
-                }
+                node = pend_node; lo = pend_lo; hi = pend_hi;
+            }
+            else
+            {
+                node             = wave_first((int32_t)queue[head]);
+                const uint64_t w = wave_first64(ent[node]);
+                lo = (uint32_t)w; hi = (uint32_t)(w >> 32);
             }
             head++;
+            const int32_t oc = (int32_t)(hi & 0xff);
+            if (oc == 0) continue;
+            // the first two children's words are fetched together
+            const int32_t c0 = (int32_t)(lo & 0xffff);
+            const int32_t c1 = oc > 1 ? (int32_t)(lo >> 16) : c0;
+            const uint64_t w0 = ent[c0];
+            const uint64_t w1 = ent[c1];
+            for (int32_t k = 0; k < oc; k++)
+            {
+                int32_t child;
+                uint64_t cw;
+                if (k == 0) { child = c0; cw = wave_first64(w0); }
+                else if (k == 1) { child = c1; cw = wave_first64(w1); }
+                else
+                {
+                    child = wave_first((int32_t)g.outgoing_edges[(int64_t)node * kEdges + k]);
+                    cw    = wave_first64(ent[child]);
+                }
+                const uint32_t chi  = (uint32_t)(cw >> 32);
+                const uint32_t left = ((chi >> 8) - 1) & 0xff;
+                if (left == 0)
+                {
+                    if (lane == 0) queue[tail] = (uint16_t)child;
+                    tail++;
+                    pend_node = child;
+                    pend_lo   = (uint32_t)cw;
+                    pend_hi   = chi & 0xff; // its in-edge count is never read again
+                }
+                else if (lane == 0)
+                    reinterpret_cast<uint8_t*>(ent + child)[5] = (uint8_t)left;
+            }
         }
     }
     __syncthreads();
