@@ -142,6 +142,25 @@ template <> __device__ __forceinline__ RowInfo<true> uniform_row(RowInfo<true> r
     return r;
 }
 
+// Single-lane LDS stores without a branch: the compiler turns `if (lane == 0) *p = v;` into an exec-mask save,
+// a skip branch and a restore; inside wave-uniform code (all 64 lanes active) narrowing exec around the store is
+// cheaper. `p` must point to LDS.
+__device__ __forceinline__ void lane0_store_u16(void* p, uint32_t v)
+{
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)p;
+    asm volatile("s_mov_b64 exec, 1\n\tds_write_b16 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lane0_store_u8(void* p, uint32_t v)
+{
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)p;
+    asm volatile("s_mov_b64 exec, 1\n\tds_write_b8 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lane0_store_u32(void* p, uint32_t v)
+{
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)p;
+    asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(v) : "memory");
+}
+
 // Inclusive prefix-max across the 64 lanes with the gfx9 DPP row-shift / row-broadcast sequence.
 __device__ __forceinline__ int32_t wave_inclusive_max(int32_t v)
 {
@@ -512,6 +531,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         }
         else if (ok_row) // a window reaching past a band edge: per-cell predicate
         {
+#pragma nounroll
             for (int k = 0; k < kTileCols; k++) dst[k] = (k >= klo && k <= khi) ? src[k] : (ScoreT)b.min_score;
         }
         __syncthreads();
@@ -525,138 +545,132 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         }
     };
 
-    const int kind = lane < kHalf ? 0 : (lane < 2 * kHalf ? 1 : (lane == 2 * kHalf ? 2 : 3));
-    const int p    = kind == 0 ? lane : lane - kHalf;
-    const int psh  = 24 + 12 * min(p, 2);
-    // wave-uniform walk state: H(i, j), the row-table word of row i and the read character j - 1
+    // lane roles (VGPR constants)
+    const int kind        = lane < kHalf ? 0 : (lane < 2 * kHalf ? 1 : (lane == 2 * kHalf ? 2 : 3));
+    const int p           = kind == 0 ? lane : lane - kHalf;
+    const int psh         = 24 + 12 * min(p, 2);
+    const bool is_diag    = kind == 0, is_vert = kind == 1, is_horiz = kind == 2;
+    const int32_t col_dec = is_vert ? 0 : 1; // candidate column = j - col_dec
+    // Wave-uniform walk state, kept in SGPRs (every update goes through readfirstlane / readlane so that the
+    // loop control stays scalar): position, H(i, j), the row-table word of row i and the read character j - 1.
     int32_t scores_ij = 0;
-    uint64_t riw      = 0;
-    uint32_t rch      = 0;
-    bool have         = false;
+    uint32_t ri_lo = 0, ri_hi = 0, rch = 0;
+    bool have = false;
     while (!(i == 0 && j == 0) && loop_count < bound)
     {
         // keep the current cell and its near predecessors inside the tile
         {
-            const int32_t t = tile_top - i;
-            bool reload     = tile_top < 0 || t < 0 || t >= kReanchor;
-            if (!reload)
-            {
-                const int32_t off = j - window_lo(t);
-                reload            = (off < 2 || off >= kTileCols);
-            }
+            const int32_t t   = tile_top - i;
+            const int32_t off = j - window_lo(t);
+            const bool reload = (tile_top < 0) | (t < 0) | (t >= kReanchor) | (off < 2) | (off >= kTileCols);
             if (reload && i > 0) load_tile(i, j);
         }
         loop_count++;
         if (!have)
         {
-            scores_ij = wave_first(get_score(b, i, j));
-            riw       = i != 0 ? wave_first64(rowinfo[i].w) : 0;
-            rch       = j > 0 ? (uint32_t)wave_first((int32_t)read[j - 1]) : 0u;
+            scores_ij        = wave_first(get_score(b, i, j));
+            const uint64_t w = i != 0 ? wave_first64(rowinfo[i].w) : 0;
+            ri_lo = (uint32_t)w; ri_hi = (uint32_t)(w >> 32);
+            rch   = j > 0 ? (uint32_t)wave_first((int32_t)read[j - 1]) : 0u;
         }
-        RowInfo<true> ri;
-        ri.w                     = riw;
-        const int32_t pred_count = ri.cnt();
+        const int32_t pred_count = (int32_t)((ri_lo >> 8) & 0x3f);
         const int32_t np         = max(pred_count, 1);
-        int32_t match_cost       = 0;
-        if (i != 0 && j != 0)
+        if (ADAPTIVE)
         {
-            if (ADAPTIVE)
+            if (i != 0 && j != 0 && rerun == 0 && b.band_width < kMaxAdaptiveBand)
             {
-                if (rerun == 0 && b.band_width < kMaxAdaptiveBand)
+                int32_t threshold = max(1, b.max_column / 1024);
+                if (j > threshold && j < b.max_column - threshold)
                 {
-                    int32_t threshold = max(1, b.max_column / 1024);
-                    if (j > threshold && j < b.max_column - threshold)
-                    {
-                        int32_t bs = band_start_for_row(i, b.gradient, b.band_width, b.band_shift, b.max_column);
-                        if (j <= bs + threshold) { aligned_nodes = kShiftLeft; break; }
-                        if (j >= (bs + b.band_width - threshold)) { aligned_nodes = kShiftRight; break; }
-                    }
+                    int32_t bs = band_start_for_row(i, b.gradient, b.band_width, b.band_shift, b.max_column);
+                    if (j <= bs + threshold) { aligned_nodes = kShiftLeft; break; }
+                    if (j >= (bs + b.band_width - threshold)) { aligned_nodes = kShiftRight; break; }
                 }
             }
-            match_cost = ((uint32_t)ri.base() == rch ? match_score : mismatch_score);
         }
+        const int32_t match_cost = ((ri_lo & 0xff) == rch ? match_score : mismatch_score);
         bool found         = false;
-        int32_t next_score = 0;
-        uint64_t next_riw  = 0;
-        uint32_t next_rch  = 0;
+        int32_t next_i = prev_i, next_j = prev_j, next_score = 0;
+        uint32_t next_lo = 0, next_hi = 0, next_rch = 0;
         if (np <= kHalf)
         {
-            const bool en = kind == 0 ? (i != 0 && j != 0 && p < np) : kind == 1 ? (i != 0 && p < np) : kind == 2;
-            int32_t crow  = i;
-            if (kind < 2)
+            // candidate of this lane: predecessor row (diag / vert) or the row itself (horiz), and its column
+            const bool en = (is_diag & (i != 0) & (j != 0) & (p < np)) | (is_vert & (i != 0) & (p < np)) | is_horiz;
+            const uint64_t riw = (uint64_t)ri_lo | ((uint64_t)ri_hi << 32);
+            int32_t crow       = pred_count != 0 ? (int32_t)((riw >> psh) & 0xfff) : 0;
+            crow               = is_horiz ? i : crow;
+            if (pred_count > 3) // predecessor slots beyond the three packed ones live in the HBM edge list
             {
-                crow = 0;
-                if (pred_count != 0)
+                if (en && !is_horiz && p >= 3)
                 {
-                    crow = (int32_t)((riw >> psh) & 0xfff);
-                    if (pred_count > 3 && en && p >= 3)
-                    {
-                        const int32_t node_id = g.sorted_poa[i - 1];
-                        crow = (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
-                    }
+                    const int32_t node_id = g.sorted_poa[i - 1];
+                    crow = (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
                 }
             }
-            const int32_t ccol = kind == 1 ? j : j - 1;
-            const int32_t cost = kind == 0 ? match_cost : gap_score;
-            int32_t val        = 0;
-            uint64_t cw        = 0;
-            uint32_t cch       = 0;
-            if (en)
+            const int32_t ccol = j - col_dec;
+            const int32_t cost = is_diag ? match_cost : gap_score;
+            const int32_t t    = tile_top - crow;
+            const int32_t off  = ccol - window_lo(t);
+            const bool in_tile = ((uint32_t)t < (uint32_t)kTileRows) & ((uint32_t)off < (uint32_t)kTileCols);
+            // three independent LDS reads, one round trip: the candidate cell, and what the next step needs if this
+            // candidate wins (its row-table word -- row 0 holds 0 -- and the read character left of its column)
+            int32_t val        = tile[in_tile ? t * kTileStride + off : 0];
+            const uint64_t cw  = rowinfo[crow].w;
+            const uint32_t cch = read[max(ccol - 1, 0)];
+            if (__ballot(en & !in_tile) != 0) // far predecessor / band edge: the HBM copy
             {
-                const int32_t t   = tile_top - crow;
-                const int32_t off = ccol - window_lo(t);
-                if ((uint32_t)t < (uint32_t)kTileRows && (uint32_t)off < (uint32_t)kTileCols)
-                    val = tile[t * kTileStride + off];
-                else
-                    val = get_score(b, crow, ccol);
-                if (crow != 0) cw = rowinfo[crow].w;
-                if (ccol > 0) cch = read[ccol - 1];
+                if (en & !in_tile) val = get_score(b, crow, ccol);
             }
-            const bool hit   = en && (scores_ij == val + cost);
+            const bool hit   = en & (scores_ij == val + cost);
             const uint64_t m = __ballot(hit);
-            if (m != 0)
-            {
-                const int sel = __ffsll((unsigned long long)m) - 1;
-                prev_i        = __builtin_amdgcn_readlane(crow, sel);
-                prev_j        = __builtin_amdgcn_readlane(ccol, sel);
-                next_score    = __builtin_amdgcn_readlane(val, sel);
-                next_riw      = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)cw, sel) |
-                           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)(cw >> 32), sel) << 32);
-                next_rch = (uint32_t)__builtin_amdgcn_readlane((int32_t)cch, sel);
-                found    = true;
-            }
+            found            = m != 0;
+            const int sel    = found ? __ffsll((unsigned long long)m) - 1 : 0;
+            const int32_t si = __builtin_amdgcn_readlane(crow, sel);
+            const int32_t sj = __builtin_amdgcn_readlane(ccol, sel);
+            next_i           = found ? si : prev_i;
+            next_j           = found ? sj : prev_j;
+            next_score       = __builtin_amdgcn_readlane(val, sel);
+            next_lo          = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)cw, sel);
+            next_hi          = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)(cw >> 32), sel);
+            next_rch         = (uint32_t)__builtin_amdgcn_readlane((int32_t)cch, sel);
         }
         else // more predecessors than candidate lanes: the reference's sequential order, wave-uniform
         {
             const int32_t node_id = g.sorted_poa[i - 1];
+            RowInfo<true> ri;
+            ri.w = (uint64_t)ri_lo | ((uint64_t)ri_hi << 32);
             auto pred_row = [&](int32_t q) -> int32_t {
                 if (q < 3) return ri.pred(q);
-                return (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + q]] + 1;
+                return wave_first((int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + q]] + 1);
             };
+            bool f = false;
             if (j != 0)
-                for (int32_t q = 0; q < np && !found; q++)
+                for (int32_t q = 0; q < np && !f; q++)
                 {
                     const int32_t pi = pred_row(q);
-                    if (scores_ij == wave_first(get_score(b, pi, j - 1)) + match_cost) { prev_i = pi; prev_j = j - 1; found = true; }
+                    if (scores_ij == wave_first(get_score(b, pi, j - 1)) + match_cost) { next_i = pi; next_j = j - 1; f = true; }
                 }
-            for (int32_t q = 0; q < np && !found; q++)
+            for (int32_t q = 0; q < np && !f; q++)
             {
                 const int32_t pi = pred_row(q);
-                if (scores_ij == wave_first(get_score(b, pi, j)) + gap_score) { prev_i = pi; prev_j = j; found = true; }
+                if (scores_ij == wave_first(get_score(b, pi, j)) + gap_score) { next_i = pi; next_j = j; f = true; }
             }
-            if (!found && scores_ij == wave_first(get_score(b, i, j - 1)) + gap_score) { prev_i = i; prev_j = j - 1; found = true; }
+            if (!f && scores_ij == wave_first(get_score(b, i, j - 1)) + gap_score) { next_i = i; next_j = j - 1; f = true; }
             found = false; // walk state is re-read at the top of the next step
         }
+        prev_i = next_i;
+        prev_j = next_j;
         {
             const uint32_t e = (uint32_t)(uint16_t)(i == prev_i ? -1 : i - 1) | ((uint32_t)(uint16_t)(j == prev_j ? -1 : j - 1) << 16);
-            if (lane == 0) stage[aligned_nodes & (kStage - 1)] = e;
+            lane0_store_u32(stage + (aligned_nodes & (kStage - 1)), e);
         }
         aligned_nodes++;
         if ((aligned_nodes & (kStage - 1)) == 0) flush_stage(aligned_nodes - kStage, kStage);
         i         = prev_i;
         j         = prev_j;
         scores_ij = next_score;
-        riw       = next_riw;
+        ri_lo     = next_lo;
+        ri_hi     = next_hi;
         rch       = next_rch;
         have      = found;
     }
@@ -679,6 +693,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
 template <typename IdT, typename RowT>
 __device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t graph_count, RowT* rowinfo, int lane)
 {
+    if (lane == 0) rowinfo[0].set(0, 0, false, 0, 0, 0); // row 0 (virtual source): no predecessors
     for (int32_t r = 1 + lane; r <= graph_count; r += kWave)
     {
         int32_t node = g.sorted_poa[r - 1];
@@ -1242,7 +1257,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
         if (tile_fits && b.stride >= 64 && !(dbg & 32))
         {
             aligned_nodes = traceback_banded_lanes<ScoreT, IdT, ADAPTIVE>(b, g, rowinfo, graph_count, lds_read, read_length,
-                                                                          best_i, alignment_graph, alignment_read, gap_score,
+                                                                          wave_first(best_i), alignment_graph, alignment_read, gap_score,
                                                                           mismatch_score, match_score, rerun, ring_base);
             tb_done = true;
         }

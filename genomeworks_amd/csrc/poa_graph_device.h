@@ -401,57 +401,54 @@ __device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_
     }
     __syncthreads();
     // phase 2: the FIFO loop, executed wave-uniformly (every lane runs the same scalar program, so node words land
-    // in SGPRs). A child whose last in-edge was just consumed is appended and its word kept in registers: along a
-    // chain (the common case) the next iteration needs no queue or node-word read at all, one LDS round trip per node.
+    // in SGPRs). On a lone wavefront a taken branch costs ~25 cycles and an LDS round trip ~55 (tools/microbench.hip),
+    // so the loop body is written branch-light: the first child is handled with selects and unconditional stores
+    // (a dummy node word absorbs the stores of childless nodes), and a child whose last in-edge was just consumed
+    // keeps its word in registers, so along a chain (the common case) an iteration is one LDS round trip.
     {
+        constexpr int32_t kDummy = 3073; // spare word of the 3074-entry region
         int32_t head      = 0;
         int32_t pend_node = -1;
         uint32_t pend_lo = 0, pend_hi = 0;
         while (head < tail)
         {
-            int32_t node;
-            uint32_t lo, hi;
-            if (head == tail - 1 && pend_node >= 0)
-            {
-                node = pend_node; lo = pend_lo; hi = pend_hi;
-            }
-            else
+            int32_t node   = pend_node;
+            uint32_t lo = pend_lo, hi = pend_hi;
+            if (!(head == tail - 1 && pend_node >= 0))
             {
                 node             = wave_first((int32_t)queue[head]);
                 const uint64_t w = wave_first64(ent[node]);
                 lo = (uint32_t)w; hi = (uint32_t)(w >> 32);
             }
             head++;
-            const int32_t oc = (int32_t)(hi & 0xff);
-            if (oc == 0) continue;
-            // the first two children's words are fetched together
-            const int32_t c0 = (int32_t)(lo & 0xffff);
-            const int32_t c1 = oc > 1 ? (int32_t)(lo >> 16) : c0;
-            const uint64_t w0 = ent[c0];
-            const uint64_t w1 = ent[c1];
-            for (int32_t k = 0; k < oc; k++)
+            const int32_t oc  = (int32_t)(hi & 0xff);
+            const int32_t c0  = oc > 0 ? (int32_t)(lo & 0xffff) : kDummy;
+            const uint64_t w0 = wave_first64(ent[c0]);
+            const uint32_t chi0  = (uint32_t)(w0 >> 32);
+            const uint32_t left0 = ((chi0 >> 8) - 1) & 0xff;
+            const bool push0     = oc > 0 && left0 == 0;
+            lane0_store_u8(reinterpret_cast<uint8_t*>(ent + c0) + 5, left0); // a count that reached 0 is never read again
+            lane0_store_u16(queue + tail, (uint32_t)c0);                    // only becomes part of the queue if tail advances
+            tail += push0 ? 1 : 0;
+            pend_node = push0 ? c0 : pend_node;
+            pend_lo   = push0 ? (uint32_t)w0 : pend_lo;
+            pend_hi   = push0 ? (chi0 & 0xff) : pend_hi;
+            for (int32_t k = 1; k < oc; k++) // further children (bubble openings)
             {
-                int32_t child;
-                uint64_t cw;
-                if (k == 0) { child = c0; cw = wave_first64(w0); }
-                else if (k == 1) { child = c1; cw = wave_first64(w1); }
-                else
-                {
-                    child = wave_first((int32_t)g.outgoing_edges[(int64_t)node * kEdges + k]);
-                    cw    = wave_first64(ent[child]);
-                }
+                const int32_t child = k == 1 ? (int32_t)(lo >> 16)
+                                             : wave_first((int32_t)g.outgoing_edges[(int64_t)node * kEdges + k]);
+                const uint64_t cw   = wave_first64(ent[child]);
                 const uint32_t chi  = (uint32_t)(cw >> 32);
                 const uint32_t left = ((chi >> 8) - 1) & 0xff;
+                lane0_store_u8(reinterpret_cast<uint8_t*>(ent + child) + 5, left);
                 if (left == 0)
                 {
-                    if (lane == 0) queue[tail] = (uint16_t)child;
+                    lane0_store_u16(queue + tail, (uint32_t)child);
                     tail++;
                     pend_node = child;
                     pend_lo   = (uint32_t)cw;
-                    pend_hi   = chi & 0xff; // its in-edge count is never read again
+                    pend_hi   = chi & 0xff;
                 }
-                else if (lane == 0)
-                    reinterpret_cast<uint8_t*>(ent + child)[5] = (uint8_t)left;
             }
         }
     }
