@@ -967,6 +967,11 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
     if ((dbg & 4) && general_row_acc) *general_row_acc += general_acc;
 }
 
+} // namespace gwhip
+#include "poa_forward_packed.h"
+namespace gwhip
+{
+
 // ------------------------------------------------------------------------------------------------
 // Banded NW (score-matrix modes): forward pass wave-wide, then sink selection (wave reduction with the
 // reference's first-maximum tie rule) and the lane-0 traceback.
@@ -1055,9 +1060,24 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
 
     constexpr bool kFastOk = std::is_same<RowT, RowInfo<true>>::value && LDS_READ;
     bool fast_done = false;
+    if constexpr (kFastOk && std::is_same<ScoreT, int16_t>::value)
+    {
+        // packed 16-bit pass for the 256-column band (preconditions: poa_forward_packed.h)
+        const bool packed_ok = band_width == 256 && max_column >= band_width && ring_bytes >= kPkSlots * kPkSlotBytes &&
+                               abs(gap_score) <= 30 && abs(match_score) <= 100 && abs(mismatch_score) <= 100 && !(dbg & 256);
+        if (packed_ok)
+        {
+            classify_rows(rowinfo, graph_count, lane, dbg);
+            __syncthreads();
+            banded_forward_packed<IdT>(g, rowinfo, graph_count, lds_read, scores, reinterpret_cast<uint8_t*>(ring_base),
+                                       max_column, gap_score, mismatch_score, match_score, dbg,
+                                       pc.acc ? &pc.acc[kPhOther] : nullptr);
+            fast_done = true;
+        }
+    }
     if constexpr (kFastOk)
     {
-        if (npass == 1 && b.ring_rows >= 2)
+        if (!fast_done && npass == 1 && b.ring_rows >= 2)
         {
             banded_forward_1pass<ScoreT, IdT>(g, rowinfo, graph_count, lds_read, scores, b.ring, b.ring_rows, band_width,
                                               max_column, gap_score, mismatch_score, match_score, dbg,

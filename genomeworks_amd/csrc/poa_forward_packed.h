@@ -1,0 +1,409 @@
+// poa_forward_packed.h -- banded NW forward pass for the 256-column band with int16 scores, written for the
+// execution profile of a lone wavefront on gfx950 (tools/microbench.hip: ~4.5 cycles per issued instruction of
+// any kind, ~25 per taken branch, ~55-70 per LDS round trip). What the pass computes is cudapoa_nw_banded.cuh:
+// 269-408 (restated in oracle/poa_nw.inc); how:
+//
+//   * two score cells per 32-bit register (v_pk_add_i16 / v_pk_max_i16): a lane's four cells are two registers,
+//     which are also exactly the 8 bytes it stores, so nothing is packed or unpacked around memory;
+//   * every row is classified once per read, by all lanes in parallel (classify_rows): class 0 rows have the
+//     previous row as only predecessor and an unmoved band -- the previous row is in registers and one DPP lane
+//     shift aligns the diagonal; class 1 rows (band moved, 2-3 predecessors, predecessor up to 7 rows back) read
+//     every predecessor from an LDS ring; class 2 rows (no predecessor, > 3 predecessors, far predecessors,
+//     band-start transition) take the general 32-bit routine against the HBM matrix. The row loop itself only
+//     tests two bits of the row-table word;
+//   * the LDS ring holds 8 rows of 512 absolute column slots (cell of column x at slot (x - 1) & 511), so a
+//     reader addresses a predecessor row by column alone and never needs that row's band start; each row also
+//     stores sentinel cells behind its band end, which is how a reader recognises a 4-cell chunk that lies
+//     outside the predecessor's band (the reference's chunk predicate, cudapoa_nw_banded.cuh:139-156) without
+//     any band arithmetic, and its left-boundary value at the slot of column band_start;
+//   * the horizontal max-plus recurrence is a prefix maximum of u[t] = v[t] - t*gap (see poa_device.h).
+//
+// Preconditions (checked by the caller, otherwise banded_forward_1pass runs): band_width == 256,
+// max_column >= band_width (no chunk reaches past the read), and score parameters small enough that
+// v - t*gap stays inside int16 (|gap| <= 30). Under the reference's own precondition that no stored score wraps,
+// every value this routine forms fits int16, so packed 16-bit arithmetic is exact.
+#pragma once
+
+namespace gwhip
+{
+
+typedef short pk_i16 __attribute__((ext_vector_type(2)));
+typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(pk_i16, a) + __builtin_bit_cast(pk_i16, b));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(pk_i16, a) - __builtin_bit_cast(pk_i16, b));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk_i16, a), __builtin_bit_cast(pk_i16, b)));
+}
+__device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(pk_u16, a), __builtin_bit_cast(pk_u16, b)));
+}
+__device__ __forceinline__ uint32_t pk_mad_u(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(pk_u16, a) * __builtin_bit_cast(pk_u16, b) + __builtin_bit_cast(pk_u16, c));
+}
+__device__ __forceinline__ uint32_t pk_dup(int32_t v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
+__device__ __forceinline__ uint32_t pk_make(int32_t lo, int32_t hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+__device__ __forceinline__ int32_t pk_lo(uint32_t v) { return (int32_t)(int16_t)(v & 0xffffu); }
+__device__ __forceinline__ int32_t pk_hi(uint32_t v) { return (int32_t)v >> 16; }
+
+constexpr int kPkSlots     = 8;    // ring rows
+constexpr int kPkSlotBytes = 1024; // 512 column slots x int16
+constexpr int kPkMaxDist   = kPkSlots - 1;
+constexpr int kPkGuardCols = 60;   // a reader's band may start at most this far right of a ring predecessor's
+constexpr int kPkSentinel  = -32768;
+constexpr int kClassShift  = 60;   // row class in bits 60..61 of the packed row-table word
+
+// LDS byte address of a pointer into the dynamic shared segment
+__device__ __forceinline__ uint32_t lds_addr(const void* p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_load_u32(uint32_t addr)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(addr);
+}
+__device__ __forceinline__ uint2 lds_load_u64(uint32_t addr)
+{
+    const u32x2 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(addr);
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void lds_store_u64(uint32_t addr, uint32_t lo, uint32_t hi)
+{
+    u32x2 v;
+    v.x = lo; v.y = hi;
+    *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(addr) = v;
+}
+// 8-byte LDS store by lanes 0..16 only (the guard cells + left-boundary quad of a ring row), no branch
+__device__ __forceinline__ void lds_store_u64_lanes17(uint32_t addr, uint32_t lo, uint32_t hi)
+{
+    const uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
+    asm volatile("s_mov_b64 exec, 0x1ffff\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(v) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row classes for banded_forward_packed, all lanes in parallel. Needs the band starts in the table already.
+//   0: one predecessor, the previous row, band not moved
+//   1: 1..3 predecessors, each 1..7 rows back, band starts compatible with the ring (see header)
+//   2: everything else
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void classify_rows(RowInfo<true>* rowinfo, int32_t graph_count, int lane, int32_t dbg = 0)
+{
+    for (int32_t r = 1 + lane; r <= graph_count; r += kWave)
+    {
+        RowInfo<true> ri = rowinfo[r];
+        const int32_t cnt = ri.cnt(), bs = ri.bs();
+        uint64_t cls = 2;
+        if (cnt >= 1 && cnt <= 3)
+        {
+            bool ok = true, first_is_prev_unmoved = false;
+            for (int32_t k = 0; k < cnt; k++)
+            {
+                const int32_t p   = ri.pred(k);
+                const int32_t d   = r - p;
+                const int32_t pbs = rowinfo[p].bs(); // row 0 holds band start 0
+                ok                = ok && d >= 1 && d <= kPkMaxDist && (bs - pbs) <= kPkGuardCols && (bs == 0 || pbs > 0);
+                if (k == 0) first_is_prev_unmoved = (d == 1 && pbs == bs);
+            }
+            if (ok) cls = (cnt == 1 && first_is_prev_unmoved) ? 0 : 1;
+        }
+        // ablations (GWHIP_DEBUG): demote classes to check them against each other
+        if ((dbg & 1024) && cls == 0) cls = 1;
+        if ((dbg & 2048) && cls == 0) cls = 2;
+        if ((dbg & 512) && cls == 1) cls = 2;
+        ri.w       = (ri.w & ~(3ull << kClassShift)) | (cls << kClassShift);
+        rowinfo[r] = ri;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The forward pass. `ring` is kPkSlots * kPkSlotBytes of LDS; `scores` the HBM score matrix (row stride 264, our
+// layout of poa_device.h); lds_read the LDS copy of the read.
+// ------------------------------------------------------------------------------------------------
+template <typename IdT>
+__device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, const RowInfo<true>* rowinfo,
+                                                      int32_t graph_count, const uint8_t* lds_read, int16_t* scores,
+                                                      uint8_t* ring, int32_t max_column, int32_t gap_score,
+                                                      int32_t mismatch_score, int32_t match_score, int32_t dbg,
+                                                      uint64_t* prof_acc)
+{
+    constexpr int32_t band_width = 256;
+    constexpr int32_t stride     = band_width + kRightPad;
+    const int lane               = threadIdx.x & (kWave - 1);
+    const int32_t lane4 = lane * 4, lane8 = lane * 8;
+    const int32_t min_score = Limits<int16_t>::min / 2;
+    const uint32_t MIN2  = pk_dup(min_score);
+    const uint32_t SENT2 = pk_dup(kPkSentinel);
+    const uint32_t GAP2  = pk_dup(gap_score);
+    const uint32_t MAT2  = pk_dup(match_score);
+    const uint32_t DIF2  = pk_dup(mismatch_score - match_score);
+    const uint32_t ONE2  = 0x00010001u;
+    // t * gap for the lane's cells t = 4*lane + k
+    const uint32_t K01 = pk_make((lane4 + 0) * gap_score, (lane4 + 1) * gap_score);
+    const uint32_t K23 = pk_make((lane4 + 2) * gap_score, (lane4 + 3) * gap_score);
+    const uint32_t ring_base = lds_addr(ring);
+    // guard store: lanes 0..15 write sentinel cells for columns band_end + 1 .. + 64, lane 16 the quad that ends in
+    // the left-boundary slot (column band_start); byte offsets relative to the lane's own cell offset
+    const int32_t guard_off = lane < 16 ? 512 : -136;
+    const bool is_lane16    = lane == 16;
+
+    // state carried from row to row
+    uint32_t P01 = pk_make((lane4 + 1) * gap_score, (lane4 + 2) * gap_score); // row 0: H[0][x] = x * gap
+    uint32_t P23 = pk_make((lane4 + 3) * gap_score, (lane4 + 4) * gap_score);
+    int32_t prev_bs = 0, prev_rel0 = 0; // band start and left-boundary value of the row in P
+    int32_t slot    = 0;                // ring slot of that row
+    uint32_t rd4    = *reinterpret_cast<const uint32_t*>(lds_read + lane4); // read characters of columns c+1..c+4
+    int16_t* row_out = scores;
+    bool hbm_dirty   = true;
+    uint64_t prof    = 0;
+
+    auto ring_write = [&](int32_t s, uint32_t a1, uint32_t o01, uint32_t o23, int32_t rel0) {
+        const uint32_t base = ring_base + (uint32_t)s * kPkSlotBytes;
+        lds_store_u64(base + a1, o01, o23);
+        const uint32_t ga   = base + ((a1 + (uint32_t)guard_off) & (kPkSlotBytes - 1));
+        const uint32_t rel0pk = ((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)rel0 << 16);
+        lds_store_u64_lanes17(ga, SENT2, is_lane16 ? rel0pk : SENT2);
+    };
+    // row 0 into slot 0
+    ring_write(0, (uint32_t)lane8, P01, P23, 0);
+
+    // row tail shared by all classes: horizontal scan, then the row goes to HBM, the ring and the P registers
+    auto finish_row = [&](uint32_t s01, uint32_t s23, int32_t fe, int32_t rel0_val, int32_t bs, uint32_t a1) {
+        const uint32_t u01 = pk_sub(s01, K01), u23 = pk_sub(s23, K23);
+        // in-lane prefix maxima: pm01 = (u0, max(u0,u1)), pm23 = (u2, max(u2,u3))
+        const uint32_t pm01 = pk_max(u01, (u01 << 16) | 0x8000u);
+        const uint32_t pm23 = pk_max(u23, (u23 << 16) | 0x8000u);
+        const int32_t m3    = (int32_t)pk_max(pm01, pm23) >> 16; // max(u0..u3)
+        const int32_t incl  = wave_inclusive_max(m3);
+        const int32_t excl  = max(wave_shr1(incl, INT32_MIN), fe + gap_score); // carry-in is element t = -1
+        const uint32_t ex2  = __builtin_amdgcn_perm((uint32_t)excl, (uint32_t)excl, 0x01000100u);
+        const uint32_t m1b  = __builtin_amdgcn_perm(pm01, pm01, 0x03020302u); // max(u0,u1) in both halves
+        P01 = pk_add(pk_max(pm01, ex2), K01);
+        P23 = pk_add(pk_max(pk_max(pm23, m1b), ex2), K23);
+        row_out += stride;
+        slot = (slot + 1) & (kPkSlots - 1);
+        *reinterpret_cast<uint2*>(row_out + lane4 + 1 + kRelShift) = make_uint2(P01, P23);
+        ring_write(slot, a1, P01, P23, rel0_val);
+        if (bs == 0) // only rows whose band starts at column 0 have a real left-boundary value in HBM
+        {
+            if (lane == 0) row_out[kRelShift] = (int16_t)rel0_val;
+        }
+        hbm_dirty = true;
+        prev_bs   = bs;
+        prev_rel0 = rel0_val;
+    };
+    // match / mismatch cost pairs of this row's base against the lane's four read characters
+    auto costs = [&](uint32_t base, uint32_t& c01, uint32_t& c23) {
+        const uint32_t x   = rd4 ^ (base * 0x01010101u);
+        const uint32_t x01 = __builtin_amdgcn_perm(0u, x, 0x0c010c00u); // (byte0, byte1) zero-extended to halves
+        const uint32_t x23 = __builtin_amdgcn_perm(0u, x, 0x0c030c02u);
+        c01 = pk_mad_u(pk_min_u(x01, ONE2), DIF2, MAT2);
+        c23 = pk_mad_u(pk_min_u(x23, ONE2), DIF2, MAT2);
+    };
+    // candidate scores of the four cells from one predecessor row: q01/q23 = its cells of columns c+1..c+4,
+    // s0x = its cell of column c in the HIGH half
+    auto from_pred = [&](uint32_t s0x, uint32_t q01, uint32_t q23, uint32_t c01, uint32_t c23, uint32_t& t01, uint32_t& t23) {
+        const uint32_t d01 = __builtin_amdgcn_alignbit(q01, s0x, 16); // (col c, col c+1)
+        const uint32_t d23 = __builtin_amdgcn_alignbit(q23, q01, 16); // (col c+2, col c+3)
+        t01 = pk_max(pk_add(d01, c01), pk_add(q01, GAP2));
+        t23 = pk_max(pk_add(d23, c23), pk_add(q23, GAP2));
+    };
+
+    RowInfo<true> raw_next = rowinfo[1];
+    int32_t r              = 1;
+    RowInfo<true> ri       = uniform_row(raw_next);
+    raw_next               = rowinfo[min(2, graph_count)];
+    while (r <= graph_count)
+    {
+        const uint32_t cls  = (uint32_t)(ri.w >> kClassShift) & 3u;
+        const int32_t bs    = ri.bs();
+        const uint32_t base = (uint32_t)ri.base();
+        const uint32_t a1   = (uint32_t)(2 * bs + lane8) & (kPkSlotBytes - 1); // ring byte offset of the lane's quad
+        if (cls == 0)
+        {
+            // ---- previous row in registers, band unmoved ----
+            uint32_t c01, c23, s01, s23;
+            costs(base, c01, c23);
+            const uint32_t s0x = (uint32_t)wave_shr1((int32_t)P23, (int32_t)((uint32_t)prev_rel0 << 16));
+            from_pred(s0x, P01, P23, c01, c23, s01, s23);
+            const int32_t fe       = bs == 0 ? max(min_score, prev_rel0) + gap_score : min_score + gap_score;
+            const int32_t rel0_val = bs == 0 ? fe : min_score;
+            finish_row(s01, s23, fe, rel0_val, bs, a1);
+        }
+        else if (cls == 1)
+        {
+            // ---- every predecessor (1..3, at most 7 rows back) from the LDS ring ----
+            const int32_t cnt     = ri.cnt();
+            const int32_t my_slot = (slot + 1) & (kPkSlots - 1);
+            const uint32_t a0     = (a1 - 4) & (kPkSlotBytes - 1); // dword whose high half is the cell of column c
+            rd4                   = *reinterpret_cast<const uint32_t*>(lds_read + bs + lane4);
+            auto slot_base = [&](int32_t k) -> uint32_t {
+                const int32_t d = r - ri.pred(k);
+                return ring_base + (uint32_t)((my_slot - d) & (kPkSlots - 1)) * kPkSlotBytes;
+            };
+            const uint32_t b0 = slot_base(0);
+            const uint32_t b1 = cnt > 1 ? slot_base(1) : b0;
+            const uint32_t b2 = cnt > 2 ? slot_base(2) : b0;
+            // all loads first (one LDS round trip), then the arithmetic
+            const uint32_t x0 = lds_load_u32(b0 + a0);
+            const uint2 q0    = lds_load_u64(b0 + a1);
+            uint32_t x1 = 0, x2 = 0;
+            uint2 q1 = make_uint2(0, 0), q2 = make_uint2(0, 0);
+            if (cnt > 1)
+            {
+                x1 = lds_load_u32(b1 + a0);
+                q1 = lds_load_u64(b1 + a1);
+            }
+            if (cnt > 2)
+            {
+                x2 = lds_load_u32(b2 + a0);
+                q2 = lds_load_u64(b2 + a1);
+            }
+            int32_t fe = min_score + gap_score;
+            if (bs == 0) // left boundary in band: carry-in from the predecessors' column-0 values (:293-326)
+            {
+                int32_t pen = max(min_score, (int32_t)(int16_t)wave_first((int32_t)(lds_load_u32(b0 + kPkSlotBytes - 4) >> 16)));
+                if (cnt > 1) pen = max(pen, (int32_t)(int16_t)wave_first((int32_t)(lds_load_u32(b1 + kPkSlotBytes - 4) >> 16)));
+                if (cnt > 2) pen = max(pen, (int32_t)(int16_t)wave_first((int32_t)(lds_load_u32(b2 + kPkSlotBytes - 4) >> 16)));
+                fe = pen + gap_score;
+            }
+            const int32_t rel0_val = bs == 0 ? fe : min_score;
+            uint32_t c01, c23, s01, s23;
+            costs(base, c01, c23);
+            from_pred(x0, q0.x, q0.y, c01, c23, s01, s23);
+            {
+                const bool outside = (q0.x & 0xffffu) == ((uint32_t)kPkSentinel & 0xffffu); // chunk beyond that row's band
+                s01 = outside ? MIN2 : s01;
+                s23 = outside ? MIN2 : s23;
+            }
+            if (cnt > 1)
+            {
+                uint32_t t01, t23;
+                from_pred(x1, q1.x, q1.y, c01, c23, t01, t23);
+                const bool outside = (q1.x & 0xffffu) == ((uint32_t)kPkSentinel & 0xffffu);
+                s01 = pk_max(s01, outside ? MIN2 : t01);
+                s23 = pk_max(s23, outside ? MIN2 : t23);
+            }
+            if (cnt > 2)
+            {
+                uint32_t t01, t23;
+                from_pred(x2, q2.x, q2.y, c01, c23, t01, t23);
+                const bool outside = (q2.x & 0xffffu) == ((uint32_t)kPkSentinel & 0xffffu);
+                s01 = pk_max(s01, outside ? MIN2 : t01);
+                s23 = pk_max(s23, outside ? MIN2 : t23);
+            }
+            finish_row(s01, s23, fe, rel0_val, bs, a1);
+        }
+        else
+        {
+            // ---- general row: 32-bit arithmetic, previous row from registers, any other row from the HBM matrix ----
+            if (dbg & 4) prof += 1;
+            const int32_t pred_count = ri.cnt();
+            const int32_t c          = bs + lane4;
+            rd4                      = *reinterpret_cast<const uint32_t*>(lds_read + c);
+            const int32_t cp0 = ((rd4 & 0xff) == base) ? match_score : mismatch_score;
+            const int32_t cp1 = (((rd4 >> 8) & 0xff) == base) ? match_score : mismatch_score;
+            const int32_t cp2 = (((rd4 >> 16) & 0xff) == base) ? match_score : mismatch_score;
+            const int32_t cp3 = ((rd4 >> 24) == base) ? match_score : mismatch_score;
+            const int32_t R0 = pk_lo(P01), R1 = pk_hi(P01), R2 = pk_lo(P23), R3 = pk_hi(P23);
+            auto from_regs = [&](int32_t& t0, int32_t& t1, int32_t& t2, int32_t& t3) {
+                const int32_t q    = (bs - prev_bs) >> 2;
+                const int32_t pend = min(prev_bs + band_width - kCellsPerLane, max_column);
+                const int src      = lane + q;
+                // the shuffle must run with every lane active (a lane that is masked off does not supply its value)
+                const int32_t from_left = __shfl(R3, src - 1);
+                const int32_t S0        = (q == 0 && lane == 0) ? prev_rel0 : from_left;
+                const int32_t S1 = __shfl(R0, src), S2 = __shfl(R1, src), S3 = __shfl(R2, src), S4 = __shfl(R3, src);
+                const bool valid = c <= pend;
+                t0 = valid ? max(S0 + cp0, S1 + gap_score) : min_score;
+                t1 = valid ? max(S1 + cp1, S2 + gap_score) : min_score;
+                t2 = valid ? max(S2 + cp2, S3 + gap_score) : min_score;
+                t3 = valid ? max(S3 + cp3, S4 + gap_score) : min_score;
+            };
+            auto from_hbm = [&](int32_t prow, int32_t& t0, int32_t& t1, int32_t& t2, int32_t& t3) {
+                const int32_t pbs  = prow == 0 ? 0 : uniform_row(rowinfo[prow]).bs();
+                const int32_t pend = min(pbs + band_width - kCellsPerLane, max_column);
+                const bool valid   = !(c > pend || c < pbs);
+                if (hbm_dirty) { if (dbg & 4096) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __syncthreads(); hbm_dirty = false; }
+                int32_t S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0;
+                if (valid)
+                {
+                    const int16_t* rowp = scores + (int64_t)prow * stride + (c - pbs) + kRelShift;
+                    S0 = rowp[0];
+                    const Quad<int16_t> qd = *reinterpret_cast<const Quad<int16_t>*>(rowp + 1);
+                    S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
+                }
+                if (pbs > 0 && c == pbs) S0 = min_score; // relative-0 slot of a row whose band starts past column 0
+                t0 = valid ? max(S0 + cp0, S1 + gap_score) : min_score;
+                t1 = valid ? max(S1 + cp1, S2 + gap_score) : min_score;
+                t2 = valid ? max(S2 + cp2, S3 + gap_score) : min_score;
+                t3 = valid ? max(S3 + cp3, S4 + gap_score) : min_score;
+            };
+            auto rel0_of = [&](int32_t prow) -> int32_t {
+                if (prow == r - 1) return prev_rel0;
+                const int32_t pbs = prow == 0 ? 0 : uniform_row(rowinfo[prow]).bs();
+                if (pbs > 0) return min_score;
+                if (hbm_dirty) { if (dbg & 4096) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __syncthreads(); hbm_dirty = false; }
+                return wave_first((int32_t)scores[(int64_t)prow * stride + kRelShift]);
+            };
+            const int32_t node_id = (pred_count > 3) ? (int32_t)g.sorted_poa[r - 1] : 0;
+            auto pred_row = [&](int32_t p) -> int32_t {
+                if (pred_count == 0) return 0;
+                if (p < 3) return ri.pred(p);
+                return wave_first((int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1);
+            };
+            int32_t fe = 0, rel0_val = min_score;
+            if (pred_count == 0)
+            {
+                if (bs == 0) rel0_val = gap_score; // carry-in stays 0 (reference quirk)
+            }
+            else
+            {
+                if (bs > kCellsPerLane && pred_count == 1)
+                    fe = min_score + gap_score;
+                else
+                {
+                    int32_t penalty = min_score;
+                    for (int32_t p = 0; p < pred_count; p++) penalty = max(penalty, rel0_of(pred_row(p)));
+                    fe = penalty + gap_score;
+                }
+                if (bs == 0) rel0_val = fe;
+            }
+            int32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            const int32_t np = max(pred_count, 1);
+            for (int32_t p = 0; p < np; p++)
+            {
+                const int32_t prow = pred_row(p);
+                int32_t t0, t1, t2, t3;
+                if (prow == r - 1 && !(dbg & 8192)) from_regs(t0, t1, t2, t3);
+                else from_hbm(prow, t0, t1, t2, t3);
+                if (p == 0) { s0 = t0; s1 = t1; s2 = t2; s3 = t3; }
+                else { s0 = max(s0, t0); s1 = max(s1, t1); s2 = max(s2, t2); s3 = max(s3, t3); }
+            }
+            uint32_t s01 = pk_make(s0, s1), s23 = pk_make(s2, s3);
+            if ((dbg & 16384) && pred_count == 1 && pred_row(0) == r - 1 && bs == prev_bs)
+            {
+                uint32_t c01, c23;
+                costs(base, c01, c23);
+                const uint32_t s0x = (uint32_t)wave_shr1((int32_t)P23, (int32_t)((uint32_t)prev_rel0 << 16));
+                from_pred(s0x, P01, P23, c01, c23, s01, s23);
+            }
+            finish_row(s01, s23, fe, rel0_val, bs, a1);
+        }
+        r++;
+        ri       = uniform_row(raw_next);
+        raw_next = rowinfo[min(r + 1, graph_count)];
+    }
+    if ((dbg & 4) && prof_acc) *prof_acc += prof;
+}
+
+} // namespace gwhip
