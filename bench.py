@@ -128,6 +128,15 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         gcups = total_cells * args.steps / elapsed / 1e9
         achieved = cells * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC pass of this same workload (rocprofv3 cannot run inside the
+        # timed region; tools/pmc_passes.sh collects FETCH_SIZE / WRITE_SIZE in their own runs)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pmc.get("windows") == args.windows:
+                traffic = pmc["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         out = {
             "metric": "cudapoa consensus GCUPS, 1024-window short-read batch (static band 256, 32 reads <= 1024 bp)",
             "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -140,7 +149,8 @@ def main():
                        "windows_per_gpu": args.windows, "cells_per_gpu": cells, "parallelism": "index-split x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "poa_window_kernel<int16,int16,static_band>",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
                          "kernel_ms": round(k_ms, 3), "output_kernel_ms": round(o_ms, 3),
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL},
             "pcie_inclusive_ms": round(t_pcie * 1e3, 3),
