@@ -33,6 +33,7 @@ constexpr int kRingBytes   = 8448;  // LDS ring of recent score rows: 16 rows of
 constexpr int kRowInfoLds  = 3074;  // rows of the LDS row table (covers max_nodes_per_graph <= 3072)
 constexpr int kRowInfoBytes = kRowInfoLds * 8;
 constexpr int kReadLds     = 2048;  // LDS copy of the current read (+ read-ahead slack)
+constexpr int kCodeTileLds = 4096;  // LDS tile of trace codes for the traceback (64 rows x 64 columns)
 
 struct KernelArgs
 {
@@ -108,6 +109,8 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
     ScoreT* ring = reinterpret_cast<ScoreT*>(smem);
     uint8_t* lds_rowinfo_region = smem + kRingBytes;
     uint8_t* lds_read_buf       = smem + kRingBytes + kRowInfoBytes;
+    uint8_t* lds_code_tile      = LDS_TABLES ? smem + kRingBytes + kRowInfoBytes + kReadLds : nullptr;
+    uint8_t* codes              = a.L.codes ? slab + a.L.codes : nullptr;
     constexpr bool graph_fits_lds = LDS_TABLES;
     using RowT = RowInfo<LDS_TABLES>;
     RowT* rowinfo;
@@ -216,18 +219,18 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
         {
             alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, kRingBytes,
                                                 banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
-                                                c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags);
+                                                c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags, codes, lds_code_tile);
             if (alen == kShiftLeft || alen == kShiftRight)
                 alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, kRingBytes,
                                                     banded_buffer_size, alignment_graph, alignment_read,
                                                     c.alignment_band_width, c.gap_score, c.mismatch_score, c.match_score,
-                                                    alen, cells, pc, a.debug_flags);
+                                                    alen, cells, pc, a.debug_flags, codes, lds_code_tile);
         }
         else if (BM == GWHIP_STATIC_BAND || BM == GWHIP_ADAPTIVE_BAND)
         {
             alen = nw_banded<ScoreT, IdT, RowT, false, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, kRingBytes,
                                                  banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
-                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags);
+                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags, codes, lds_code_tile);
         }
         else
         {
@@ -418,7 +421,7 @@ static bool validate(const gwhip_poa_args* args)
 template <typename ScoreT, typename IdT, typename TraceT, bool MSA, bool LDS_TABLES>
 static hipError_t launch_window_kernel(const KernelArgs& ka, hipStream_t stream)
 {
-    const size_t lds = kRingBytes + (LDS_TABLES ? (size_t)kRowInfoBytes + kReadLds : 0);
+    const size_t lds = kRingBytes + (LDS_TABLES ? (size_t)kRowInfoBytes + kReadLds + kCodeTileLds : 0);
     dim3 grid(ka.total_windows), block(kWave);
 #define GW_LAUNCH(BM)                                                                                              \
     hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES>), grid, block, lds, stream, ka); \

@@ -489,9 +489,11 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
                                                           const uint8_t* read, int32_t read_length, int32_t start_i,
                                                           int32_t* alignment_graph, int32_t* alignment_read,
                                                           int32_t gap_score, int32_t mismatch_score,
-                                                          int32_t match_score, int32_t rerun, ScoreT* tile)
+                                                          int32_t match_score, int32_t rerun, ScoreT* tile,
+                                                          const uint8_t* codes, uint8_t* ctile)
 {
     constexpr int kTileRows = 60, kTileCols = 64, kTileStride = 68, kReanchor = 44, kLead = 40, kHalf = 31;
+    constexpr int kCodeRows = 64, kCodeCols = 64, kCodeReanchor = 60; // LDS tile of trace codes (poa_forward_packed.h)
     constexpr int kStage = 64;
     const int lane      = threadIdx.x & (kWave - 1);
     const int32_t bound = read_length + graph_count + 2;
@@ -545,6 +547,39 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         }
     };
 
+    // ---- trace-code fast path: where the forward pass left a move code the step is a table lookup ----
+    int32_t ctop = -1, ccol = 0; // matrix row in code-tile row 0 and the column its windows are anchored on
+    auto code_lo = [&](int32_t t) -> int32_t { return ((ccol - kLead - t) & ~3) + 1; };
+    auto load_codes = [&](int32_t top, int32_t col) {
+        __syncthreads();
+        ctop = top;
+        ccol = col;
+        const int32_t row = top - lane; // lane = tile row; rows < 1 have no codes
+        int32_t e0 = 0, klo = 1, khi = 0;
+        if (row >= 1)
+        {
+            const int32_t bs = band_start_for_row(row, b.gradient, b.band_width, b.band_shift, b.max_column);
+            e0  = code_lo(lane) - bs + kRelShift; // byte index in the code row, multiple of 4
+            klo = (1 + kRelShift) - e0;           // window bytes that are cells of the band (relative 1 .. band_width)
+            khi = (b.band_width + kRelShift) - e0;
+        }
+        const uint8_t* src = codes + (int64_t)row * b.stride + e0;
+        uint32_t* dst      = reinterpret_cast<uint32_t*>(ctile + lane * kCodeCols);
+        const bool whole   = klo <= 0 && khi >= kCodeCols - 1;
+        if (__ballot(!whole) == 0)
+        {
+#pragma unroll
+            for (int k = 0; k < kCodeCols / 4; k++) dst[k] = reinterpret_cast<const uint32_t*>(src)[k];
+        }
+        else
+        {
+#pragma nounroll
+            for (int k = 0; k < kCodeCols; k++)
+                reinterpret_cast<uint8_t*>(dst)[k] = (k >= klo && k <= khi) ? src[k] : (uint8_t)0;
+        }
+        __syncthreads();
+    };
+
     // lane roles (VGPR constants)
     const int kind        = lane < kHalf ? 0 : (lane < 2 * kHalf ? 1 : (lane == 2 * kHalf ? 2 : 3));
     const int p           = kind == 0 ? lane : lane - kHalf;
@@ -558,6 +593,50 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     bool have = false;
     while (!(i == 0 && j == 0) && loop_count < bound)
     {
+        if (codes != nullptr && i > 0)
+        {
+            {
+                const int32_t t   = ctop - i;
+                const int32_t off = j - code_lo(t);
+                if ((ctop < 0) | (t < 0) | (t >= kCodeReanchor) | (off < 2) | (off >= kCodeCols)) load_codes(i, j);
+            }
+            const int32_t t     = ctop - i;
+            const int32_t off   = j - code_lo(t);
+            const uint32_t code = (uint32_t)wave_first((int32_t)ctile[t * kCodeCols + off]);
+            const uint64_t riw  = wave_first64(rowinfo[i].w);
+            if (code != 0)
+            {
+                bool rerun_break = false;
+                if (ADAPTIVE)
+                {
+                    if (j != 0 && rerun == 0 && b.band_width < kMaxAdaptiveBand)
+                    {
+                        int32_t threshold = max(1, b.max_column / 1024);
+                        if (j > threshold && j < b.max_column - threshold)
+                        {
+                            int32_t bs = band_start_for_row(i, b.gradient, b.band_width, b.band_shift, b.max_column);
+                            if (j <= bs + threshold) { aligned_nodes = kShiftLeft; rerun_break = true; }
+                            else if (j >= (bs + b.band_width - threshold)) { aligned_nodes = kShiftRight; rerun_break = true; }
+                        }
+                    }
+                }
+                if (rerun_break) break;
+                loop_count++;
+                const bool is_vert = code >= 5, is_horiz = code == 1;
+                const uint32_t k   = is_vert ? code - 5 : code - 2;
+                const int32_t pr   = (int32_t)((riw >> (24 + 12 * (k & 3))) & 0xfff);
+                prev_i             = is_horiz ? i : pr;
+                prev_j             = is_vert ? j : j - 1;
+                const uint32_t e = (uint32_t)(uint16_t)(i == prev_i ? -1 : i - 1) | ((uint32_t)(uint16_t)(j == prev_j ? -1 : j - 1) << 16);
+                lane0_store_u32(stage + (aligned_nodes & (kStage - 1)), e);
+                aligned_nodes++;
+                if ((aligned_nodes & (kStage - 1)) == 0) flush_stage(aligned_nodes - kStage, kStage);
+                i    = prev_i;
+                j    = prev_j;
+                have = false;
+                continue;
+            }
+        }
         // keep the current cell and its near predecessors inside the tile
         {
             const int32_t t   = tile_top - i;
@@ -981,7 +1060,8 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                              const uint8_t* lds_read, int32_t read_length, ScoreT* scores, ScoreT* ring_base, int32_t ring_bytes,
                              float max_buffer_size, int32_t* alignment_graph, int32_t* alignment_read,
                              int32_t band_width, int32_t gap_score, int32_t mismatch_score, int32_t match_score,
-                             int32_t rerun, uint64_t& cells, PhaseClock& pc, int32_t dbg = 0)
+                             int32_t rerun, uint64_t& cells, PhaseClock& pc, int32_t dbg = 0, uint8_t* codes = nullptr,
+                             uint8_t* code_tile = nullptr)
 {
     const int lane              = threadIdx.x & (kWave - 1);
     const int32_t min_score     = Limits<ScoreT>::min / 2;
@@ -1059,20 +1139,22 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     auto bs_of = [&](int32_t row) -> int32_t { return row == 0 ? 0 : uniform_row(rowinfo[row]).bs(); };
 
     constexpr bool kFastOk = std::is_same<RowT, RowInfo<true>>::value && LDS_READ;
-    bool fast_done = false;
+    bool fast_done = false, codes_valid = false;
     if constexpr (kFastOk && std::is_same<ScoreT, int16_t>::value)
     {
         // packed 16-bit pass for the 256-column band (preconditions: poa_forward_packed.h)
         const bool packed_ok = band_width == 256 && max_column >= band_width && ring_bytes >= kPkSlots * kPkSlotBytes &&
-                               abs(gap_score) <= 30 && abs(match_score) <= 100 && abs(mismatch_score) <= 100 && !(dbg & 256);
+                               abs(gap_score) <= 30 && abs(match_score) <= 100 && abs(mismatch_score) <= 100 &&
+                               codes != nullptr && !(dbg & 256);
         if (packed_ok)
         {
             classify_rows(rowinfo, graph_count, lane, dbg);
             __syncthreads();
-            banded_forward_packed<IdT>(g, rowinfo, graph_count, lds_read, scores, reinterpret_cast<uint8_t*>(ring_base),
+            banded_forward_packed<IdT>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
                                        max_column, gap_score, mismatch_score, match_score, dbg,
                                        pc.acc ? &pc.acc[kPhOther] : nullptr);
-            fast_done = true;
+            fast_done   = true;
+            codes_valid = true;
         }
     }
     if constexpr (kFastOk)
@@ -1278,7 +1360,8 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
         {
             aligned_nodes = traceback_banded_lanes<ScoreT, IdT, ADAPTIVE>(b, g, rowinfo, graph_count, lds_read, read_length,
                                                                           wave_first(best_i), alignment_graph, alignment_read, gap_score,
-                                                                          mismatch_score, match_score, rerun, ring_base);
+                                                                          mismatch_score, match_score, rerun, ring_base,
+                                                                          (codes_valid && code_tile && !(dbg & 64)) ? codes : nullptr, code_tile);
             tb_done = true;
         }
     }

@@ -126,58 +126,107 @@ __device__ __forceinline__ void classify_rows(RowInfo<true>* rowinfo, int32_t gr
 }
 
 // ------------------------------------------------------------------------------------------------
-// The forward pass. `ring` is kPkSlots * kPkSlotBytes of LDS; `scores` the HBM score matrix (row stride 264, our
-// layout of poa_device.h); lds_read the LDS copy of the read.
+// Trace codes. Besides the score row, classes 0 and 1 store one byte per cell that names the move the reference's
+// traceback (cudapoa_nw_banded.cuh:428-549: diagonal through predecessor 0..n-1, then vertical through
+// predecessor 0..n-1, then horizontal, first equality wins) takes from that cell:
+//   0 undecided here -> the traceback recomputes the step from the score matrix
+//   1 horizontal     2 + k diagonal through predecessor slot k     5 + k vertical through predecessor slot k
+// A code is only written where the forward pass saw exactly the operands the traceback's get_score() would see:
+// the first cell of the band (its horizontal operand is the carry-in, not a stored cell), chunks that lie outside
+// some predecessor's band and all class 2 rows stay 0. Equality of H with a candidate is tested on the stored
+// 16-bit values, which is the comparison the traceback makes.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCodeHoriz = 1, kCodeDiag = 2, kCodeVert = 5;
+
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// keep a loop-invariant in a VGPR (the kernel is SGPR-bound: a uniform constant would otherwise live in an SGPR
+// and be spilled / reloaded with v_readlane inside the row loop)
+__device__ __forceinline__ uint32_t pin_vgpr(uint32_t v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// lane-0 2-byte global store without a divergent branch (wave-uniform caller, all lanes active)
+__device__ __forceinline__ void global_store_u16_lane0(void* p, uint32_t v)
+{
+    const uint32_t zero = 0;
+    asm volatile("s_mov_b64 exec, 1\n\tglobal_store_short %0, %1, %2\n\ts_mov_b64 exec, -1" ::"v"(zero), "v"(v), "s"(p) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// The forward pass. `ring` is kPkSlots * kPkSlotBytes of LDS; `scores` the HBM score matrix and `codes` the HBM
+// trace-code matrix (row stride 264 elements, our layout of poa_device.h); lds_read the LDS copy of the read.
 // ------------------------------------------------------------------------------------------------
 template <typename IdT>
 __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, const RowInfo<true>* rowinfo,
                                                       int32_t graph_count, const uint8_t* lds_read, int16_t* scores,
-                                                      uint8_t* ring, int32_t max_column, int32_t gap_score,
-                                                      int32_t mismatch_score, int32_t match_score, int32_t dbg,
-                                                      uint64_t* prof_acc)
+                                                      uint8_t* codes, uint8_t* ring, int32_t max_column,
+                                                      int32_t gap_score, int32_t mismatch_score, int32_t match_score,
+                                                      int32_t dbg, uint64_t* prof_acc)
 {
     constexpr int32_t band_width = 256;
     constexpr int32_t stride     = band_width + kRightPad;
     const int lane               = threadIdx.x & (kWave - 1);
     const int32_t lane4 = lane * 4, lane8 = lane * 8;
     const int32_t min_score = Limits<int16_t>::min / 2;
-    const uint32_t MIN2  = pk_dup(min_score);
-    const uint32_t SENT2 = pk_dup(kPkSentinel);
-    const uint32_t GAP2  = pk_dup(gap_score);
-    const uint32_t MAT2  = pk_dup(match_score);
-    const uint32_t DIF2  = pk_dup(mismatch_score - match_score);
-    const uint32_t ONE2  = 0x00010001u;
+    const uint32_t MIN2   = pin_vgpr(pk_dup(min_score));
+    const uint32_t SENT2  = pin_vgpr(pk_dup(kPkSentinel));
+    const uint32_t GAP2   = pin_vgpr(pk_dup(gap_score));
+    const uint32_t MAT2   = pin_vgpr(pk_dup(match_score));
+    const uint32_t DIF2   = pin_vgpr(pk_dup(mismatch_score - match_score));
+    const uint32_t ONE2   = pin_vgpr(0x00010001u);
+    const uint32_t TWO2   = pin_vgpr(0x00020002u);
+    const uint32_t THREE2 = pin_vgpr(0x00030003u);
+    const uint32_t FIVE2  = pin_vgpr(0x00050005u);
+    const uint32_t NEG4   = pin_vgpr(0xfffcfffcu);
     // t * gap for the lane's cells t = 4*lane + k
     const uint32_t K01 = pk_make((lane4 + 0) * gap_score, (lane4 + 1) * gap_score);
     const uint32_t K23 = pk_make((lane4 + 2) * gap_score, (lane4 + 3) * gap_score);
     const uint32_t ring_base = lds_addr(ring);
     // guard store: lanes 0..15 write sentinel cells for columns band_end + 1 .. + 64, lane 16 the quad that ends in
     // the left-boundary slot (column band_start); byte offsets relative to the lane's own cell offset
-    const int32_t guard_off = lane < 16 ? 512 : -136;
-    const bool is_lane16    = lane == 16;
+    const uint32_t guard_off  = lane < 16 ? 512u : (uint32_t)-136;
+    const bool is_lane16      = lane == 16;
+    const uint32_t code_keep  = lane == 0 ? 0xffffff00u : 0xffffffffu; // the band's first cell keeps code 0
+    const uint32_t out_off    = (uint32_t)lane8 + 2u * (1 + kRelShift); // byte offset of the lane's quad in an HBM score row
+    const uint32_t code_off   = (uint32_t)lane4 + (1 + kRelShift);      // ... of its four codes in a code row
 
     // state carried from row to row
     uint32_t P01 = pk_make((lane4 + 1) * gap_score, (lane4 + 2) * gap_score); // row 0: H[0][x] = x * gap
     uint32_t P23 = pk_make((lane4 + 3) * gap_score, (lane4 + 4) * gap_score);
     int32_t prev_bs = 0, prev_rel0 = 0; // band start and left-boundary value of the row in P
     int32_t slot    = 0;                // ring slot of that row
-    uint32_t rd4    = *reinterpret_cast<const uint32_t*>(lds_read + lane4); // read characters of columns c+1..c+4
-    int16_t* row_out = scores;
-    bool hbm_dirty   = true;
-    uint64_t prof    = 0;
+    // per-lane values that only change when the band moves: read characters of columns c+1..c+4, ring byte offset
+    // of the lane's quad and of its guard quad
+    uint32_t rd4 = *reinterpret_cast<const uint32_t*>(lds_read + lane4);
+    uint32_t a1  = (uint32_t)lane8;
+    uint32_t ga  = (a1 + guard_off) & (kPkSlotBytes - 1);
+    uint8_t* row_out  = reinterpret_cast<uint8_t*>(scores); // HBM score row of the row in P
+    uint8_t* code_out = codes;
+    bool hbm_dirty    = true;
+    uint64_t prof     = 0;
 
-    auto ring_write = [&](int32_t s, uint32_t a1, uint32_t o01, uint32_t o23, int32_t rel0) {
-        const uint32_t base = ring_base + (uint32_t)s * kPkSlotBytes;
-        lds_store_u64(base + a1, o01, o23);
-        const uint32_t ga   = base + ((a1 + (uint32_t)guard_off) & (kPkSlotBytes - 1));
+    auto ring_write = [&](int32_t s, int32_t rel0) {
+        const uint32_t sbase  = ring_base + (uint32_t)s * kPkSlotBytes;
         const uint32_t rel0pk = ((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)rel0 << 16);
-        lds_store_u64_lanes17(ga, SENT2, is_lane16 ? rel0pk : SENT2);
+        lds_store_u64(sbase + a1, P01, P23);
+        lds_store_u64_lanes17(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
     };
-    // row 0 into slot 0
-    ring_write(0, (uint32_t)lane8, P01, P23, 0);
+    ring_write(0, 0); // row 0 into slot 0
 
-    // row tail shared by all classes: horizontal scan, then the row goes to HBM, the ring and the P registers
-    auto finish_row = [&](uint32_t s01, uint32_t s23, int32_t fe, int32_t rel0_val, int32_t bs, uint32_t a1) {
+    // horizontal max-plus scan of the row's candidates; leaves the finished row in P01/P23
+    auto scan_row = [&](uint32_t s01, uint32_t s23, int32_t fe) {
         const uint32_t u01 = pk_sub(s01, K01), u23 = pk_sub(s23, K23);
         // in-lane prefix maxima: pm01 = (u0, max(u0,u1)), pm23 = (u2, max(u2,u3))
         const uint32_t pm01 = pk_max(u01, (u01 << 16) | 0x8000u);
@@ -189,63 +238,87 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
         const uint32_t m1b  = __builtin_amdgcn_perm(pm01, pm01, 0x03020302u); // max(u0,u1) in both halves
         P01 = pk_add(pk_max(pm01, ex2), K01);
         P23 = pk_add(pk_max(pk_max(pm23, m1b), ex2), K23);
-        row_out += stride;
+    };
+    // the finished row goes to HBM and the ring
+    auto store_row = [&](int32_t bs, int32_t rel0_val) {
+        row_out += stride * 2;
         slot = (slot + 1) & (kPkSlots - 1);
-        *reinterpret_cast<uint2*>(row_out + lane4 + 1 + kRelShift) = make_uint2(P01, P23);
-        ring_write(slot, a1, P01, P23, rel0_val);
+        *reinterpret_cast<uint2*>(row_out + out_off) = make_uint2(P01, P23);
+        ring_write(slot, rel0_val);
         if (bs == 0) // only rows whose band starts at column 0 have a real left-boundary value in HBM
-        {
-            if (lane == 0) row_out[kRelShift] = (int16_t)rel0_val;
-        }
+            global_store_u16_lane0(row_out + 2 * kRelShift, (uint32_t)rel0_val);
         hbm_dirty = true;
         prev_bs   = bs;
         prev_rel0 = rel0_val;
     };
+    auto store_codes = [&](uint32_t code01, uint32_t code23, bool undecided) {
+        code_out += stride;
+        uint32_t c4 = __builtin_amdgcn_perm(code23, code01, 0x06040200u) & code_keep; // low byte of each half
+        c4          = undecided ? 0u : c4;
+        *reinterpret_cast<uint32_t*>(code_out + code_off) = c4;
+    };
+    // 0 where the halves are equal, 1 where they differ
+    auto nz = [&](uint32_t a, uint32_t b) -> uint32_t { return pk_min_u16(pk_sub(a, b), ONE2); };
     // match / mismatch cost pairs of this row's base against the lane's four read characters
     auto costs = [&](uint32_t base, uint32_t& c01, uint32_t& c23) {
         const uint32_t x   = rd4 ^ (base * 0x01010101u);
         const uint32_t x01 = __builtin_amdgcn_perm(0u, x, 0x0c010c00u); // (byte0, byte1) zero-extended to halves
         const uint32_t x23 = __builtin_amdgcn_perm(0u, x, 0x0c030c02u);
-        c01 = pk_mad_u(pk_min_u(x01, ONE2), DIF2, MAT2);
-        c23 = pk_mad_u(pk_min_u(x23, ONE2), DIF2, MAT2);
+        c01 = pk_mad_u16(pk_min_u16(x01, ONE2), DIF2, MAT2);
+        c23 = pk_mad_u16(pk_min_u16(x23, ONE2), DIF2, MAT2);
     };
-    // candidate scores of the four cells from one predecessor row: q01/q23 = its cells of columns c+1..c+4,
-    // s0x = its cell of column c in the HIGH half
-    auto from_pred = [&](uint32_t s0x, uint32_t q01, uint32_t q23, uint32_t c01, uint32_t c23, uint32_t& t01, uint32_t& t23) {
-        const uint32_t d01 = __builtin_amdgcn_alignbit(q01, s0x, 16); // (col c, col c+1)
-        const uint32_t d23 = __builtin_amdgcn_alignbit(q23, q01, 16); // (col c+2, col c+3)
-        t01 = pk_max(pk_add(d01, c01), pk_add(q01, GAP2));
-        t23 = pk_max(pk_add(d23, c23), pk_add(q23, GAP2));
+    // diagonal / vertical candidates of the four cells from one predecessor row: q01/q23 = its cells of columns
+    // c+1..c+4, s0x = its cell of column c in the HIGH half
+    auto from_pred = [&](uint32_t s0x, uint32_t q01, uint32_t q23, uint32_t c01, uint32_t c23, uint32_t& D01, uint32_t& D23,
+                         uint32_t& V01, uint32_t& V23) {
+        D01 = pk_add(__builtin_amdgcn_alignbit(q01, s0x, 16), c01); // from (col c, col c+1)
+        D23 = pk_add(__builtin_amdgcn_alignbit(q23, q01, 16), c23); // from (col c+2, col c+3)
+        V01 = pk_add(q01, GAP2);
+        V23 = pk_add(q23, GAP2);
     };
+    auto class_of = [&](const RowInfo<true>& w) -> uint32_t { return (uint32_t)(w.w >> kClassShift) & 3u; };
 
-    RowInfo<true> raw_next = rowinfo[1];
-    int32_t r              = 1;
-    RowInfo<true> ri       = uniform_row(raw_next);
-    raw_next               = rowinfo[min(2, graph_count)];
+    int32_t r        = 1;
+    RowInfo<true> ri = uniform_row(rowinfo[1]);
+    uint32_t cls     = class_of(ri);
     while (r <= graph_count)
     {
-        const uint32_t cls  = (uint32_t)(ri.w >> kClassShift) & 3u;
-        const int32_t bs    = ri.bs();
-        const uint32_t base = (uint32_t)ri.base();
-        const uint32_t a1   = (uint32_t)(2 * bs + lane8) & (kPkSlotBytes - 1); // ring byte offset of the lane's quad
-        if (cls == 0)
+        // ================= streak of class 0 rows: previous row in registers, band unmoved =================
+        while (cls == 0)
         {
-            // ---- previous row in registers, band unmoved ----
-            uint32_t c01, c23, s01, s23;
-            costs(base, c01, c23);
+            const RowInfo<true> nxt = rowinfo[min(r + 1, graph_count)]; // consumed after the arithmetic
+            const int32_t bs        = ri.bs();
+            uint32_t c01, c23, D01, D23, V01, V23;
+            costs((uint32_t)ri.base(), c01, c23);
             const uint32_t s0x = (uint32_t)wave_shr1((int32_t)P23, (int32_t)((uint32_t)prev_rel0 << 16));
-            from_pred(s0x, P01, P23, c01, c23, s01, s23);
+            from_pred(s0x, P01, P23, c01, c23, D01, D23, V01, V23);
             const int32_t fe       = bs == 0 ? max(min_score, prev_rel0) + gap_score : min_score + gap_score;
             const int32_t rel0_val = bs == 0 ? fe : min_score;
-            finish_row(s01, s23, fe, rel0_val, bs, a1);
+            scan_row(pk_max(D01, V01), pk_max(D23, V23), fe);
+            // code = H == D ? diag : H == V ? vert : horiz  ==  2 + [H != D] * (3 - 4 * [H != V])
+            const uint32_t code01 = pk_mad_u16(nz(P01, D01), pk_mad_u16(nz(P01, V01), NEG4, THREE2), TWO2);
+            const uint32_t code23 = pk_mad_u16(nz(P23, D23), pk_mad_u16(nz(P23, V23), NEG4, THREE2), TWO2);
+            const RowInfo<true> ri_n = uniform_row(nxt); // before this row's LDS stores: no wait behind them
+            store_row(bs, rel0_val);
+            store_codes(code01, code23, false);
+            r++;
+            ri  = ri_n;
+            cls = r <= graph_count ? class_of(ri) : 3u;
         }
-        else if (cls == 1)
+        if (r > graph_count) break;
+
+        const RowInfo<true> nxt = rowinfo[min(r + 1, graph_count)];
+        const int32_t bs        = ri.bs();
+        const uint32_t base     = (uint32_t)ri.base();
+        a1  = (uint32_t)(2 * bs + lane8) & (kPkSlotBytes - 1);
+        ga  = (a1 + guard_off) & (kPkSlotBytes - 1);
+        rd4 = *reinterpret_cast<const uint32_t*>(lds_read + bs + lane4);
+        if (cls == 1)
         {
-            // ---- every predecessor (1..3, at most 7 rows back) from the LDS ring ----
+            // ================= every predecessor (1..3, at most 7 rows back) from the LDS ring =================
             const int32_t cnt     = ri.cnt();
             const int32_t my_slot = (slot + 1) & (kPkSlots - 1);
             const uint32_t a0     = (a1 - 4) & (kPkSlotBytes - 1); // dword whose high half is the cell of column c
-            rd4                   = *reinterpret_cast<const uint32_t*>(lds_read + bs + lane4);
             auto slot_base = [&](int32_t k) -> uint32_t {
                 const int32_t d = r - ri.pred(k);
                 return ring_base + (uint32_t)((my_slot - d) & (kPkSlots - 1)) * kPkSlotBytes;
@@ -277,39 +350,69 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
                 fe = pen + gap_score;
             }
             const int32_t rel0_val = bs == 0 ? fe : min_score;
-            uint32_t c01, c23, s01, s23;
+            const uint32_t sent16  = (uint32_t)kPkSentinel & 0xffffu;
+            uint32_t c01, c23;
             costs(base, c01, c23);
-            from_pred(x0, q0.x, q0.y, c01, c23, s01, s23);
-            {
-                const bool outside = (q0.x & 0xffffu) == ((uint32_t)kPkSentinel & 0xffffu); // chunk beyond that row's band
-                s01 = outside ? MIN2 : s01;
-                s23 = outside ? MIN2 : s23;
-            }
+            // best diagonal / vertical candidate over the predecessors and the first slot that attains it
+            uint32_t D0a, D0b, V0a, V0b;
+            from_pred(x0, q0.x, q0.y, c01, c23, D0a, D0b, V0a, V0b);
+            bool undecided = (q0.x & 0xffffu) == sent16; // chunk beyond that predecessor's band (:139-156)
+            D0a = undecided ? MIN2 : D0a; D0b = undecided ? MIN2 : D0b;
+            V0a = undecided ? MIN2 : V0a; V0b = undecided ? MIN2 : V0b;
+            uint32_t bD01 = D0a, bD23 = D0b, bV01 = V0a, bV23 = V0b;
+            uint32_t kD01 = 0, kD23 = 0, kV01 = 0, kV23 = 0;
             if (cnt > 1)
             {
-                uint32_t t01, t23;
-                from_pred(x1, q1.x, q1.y, c01, c23, t01, t23);
-                const bool outside = (q1.x & 0xffffu) == ((uint32_t)kPkSentinel & 0xffffu);
-                s01 = pk_max(s01, outside ? MIN2 : t01);
-                s23 = pk_max(s23, outside ? MIN2 : t23);
+                uint32_t D1a, D1b, V1a, V1b;
+                from_pred(x1, q1.x, q1.y, c01, c23, D1a, D1b, V1a, V1b);
+                const bool out1 = (q1.x & 0xffffu) == sent16;
+                undecided       = undecided | out1;
+                D1a = out1 ? MIN2 : D1a; D1b = out1 ? MIN2 : D1b;
+                V1a = out1 ? MIN2 : V1a; V1b = out1 ? MIN2 : V1b;
+                bD01 = pk_max(bD01, D1a); bD23 = pk_max(bD23, D1b);
+                bV01 = pk_max(bV01, V1a); bV23 = pk_max(bV23, V1b);
+                if (cnt > 2)
+                {
+                    uint32_t D2a, D2b, V2a, V2b;
+                    from_pred(x2, q2.x, q2.y, c01, c23, D2a, D2b, V2a, V2b);
+                    const bool out2 = (q2.x & 0xffffu) == sent16;
+                    undecided       = undecided | out2;
+                    D2a = out2 ? MIN2 : D2a; D2b = out2 ? MIN2 : D2b;
+                    V2a = out2 ? MIN2 : V2a; V2b = out2 ? MIN2 : V2b;
+                    bD01 = pk_max(bD01, D2a); bD23 = pk_max(bD23, D2b);
+                    bV01 = pk_max(bV01, V2a); bV23 = pk_max(bV23, V2b);
+                    // first slot attaining the maximum: n0 * (1 + n1) with n_k = [slot k misses it]
+                    const uint32_t n0a = nz(bD01, D0a), n0b = nz(bD23, D0b), m0a = nz(bV01, V0a), m0b = nz(bV23, V0b);
+                    kD01 = pk_mad_u16(n0a, nz(bD01, D1a), n0a); kD23 = pk_mad_u16(n0b, nz(bD23, D1b), n0b);
+                    kV01 = pk_mad_u16(m0a, nz(bV01, V1a), m0a); kV23 = pk_mad_u16(m0b, nz(bV23, V1b), m0b);
+                }
+                else
+                {
+                    kD01 = nz(bD01, D0a); kD23 = nz(bD23, D0b);
+                    kV01 = nz(bV01, V0a); kV23 = nz(bV23, V0b);
+                }
             }
-            if (cnt > 2)
-            {
-                uint32_t t01, t23;
-                from_pred(x2, q2.x, q2.y, c01, c23, t01, t23);
-                const bool outside = (q2.x & 0xffffu) == ((uint32_t)kPkSentinel & 0xffffu);
-                s01 = pk_max(s01, outside ? MIN2 : t01);
-                s23 = pk_max(s23, outside ? MIN2 : t23);
-            }
-            finish_row(s01, s23, fe, rel0_val, bs, a1);
+            scan_row(pk_max(bD01, bV01), pk_max(bD23, bV23), fe);
+            // code = H == bestD ? 2 + kD : H == bestV ? 5 + kV : 1
+            auto code_of = [&](uint32_t H, uint32_t bD, uint32_t bV, uint32_t kD, uint32_t kV) -> uint32_t {
+                const uint32_t A  = pk_add(kD, TWO2), B = pk_add(kV, FIVE2);
+                const uint32_t t1 = pk_mad_u16(nz(H, bV), pk_sub(ONE2, B), B);
+                return pk_mad_u16(nz(H, bD), pk_sub(t1, A), A);
+            };
+            const uint32_t code01 = code_of(P01, bD01, bV01, kD01, kV01);
+            const uint32_t code23 = code_of(P23, bD23, bV23, kD23, kV23);
+            const RowInfo<true> ri_n = uniform_row(nxt);
+            store_row(bs, rel0_val);
+            store_codes(code01, code23, undecided);
+            r++;
+            ri = ri_n;
         }
         else
         {
-            // ---- general row: 32-bit arithmetic, previous row from registers, any other row from the HBM matrix ----
+            // ===== general row: 32-bit arithmetic, previous row from registers, any other row from the HBM matrix =====
             if (dbg & 4) prof += 1;
             const int32_t pred_count = ri.cnt();
             const int32_t c          = bs + lane4;
-            rd4                      = *reinterpret_cast<const uint32_t*>(lds_read + c);
             const int32_t cp0 = ((rd4 & 0xff) == base) ? match_score : mismatch_score;
             const int32_t cp1 = (((rd4 >> 8) & 0xff) == base) ? match_score : mismatch_score;
             const int32_t cp2 = (((rd4 >> 16) & 0xff) == base) ? match_score : mismatch_score;
@@ -333,7 +436,7 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
                 const int32_t pbs  = prow == 0 ? 0 : uniform_row(rowinfo[prow]).bs();
                 const int32_t pend = min(pbs + band_width - kCellsPerLane, max_column);
                 const bool valid   = !(c > pend || c < pbs);
-                if (hbm_dirty) { if (dbg & 4096) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __syncthreads(); hbm_dirty = false; }
+                if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
                 int32_t S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0;
                 if (valid)
                 {
@@ -352,7 +455,7 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
                 if (prow == r - 1) return prev_rel0;
                 const int32_t pbs = prow == 0 ? 0 : uniform_row(rowinfo[prow]).bs();
                 if (pbs > 0) return min_score;
-                if (hbm_dirty) { if (dbg & 4096) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __syncthreads(); hbm_dirty = false; }
+                if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
                 return wave_first((int32_t)scores[(int64_t)prow * stride + kRelShift]);
             };
             const int32_t node_id = (pred_count > 3) ? (int32_t)g.sorted_poa[r - 1] : 0;
@@ -389,19 +492,14 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
                 if (p == 0) { s0 = t0; s1 = t1; s2 = t2; s3 = t3; }
                 else { s0 = max(s0, t0); s1 = max(s1, t1); s2 = max(s2, t2); s3 = max(s3, t3); }
             }
-            uint32_t s01 = pk_make(s0, s1), s23 = pk_make(s2, s3);
-            if ((dbg & 16384) && pred_count == 1 && pred_row(0) == r - 1 && bs == prev_bs)
-            {
-                uint32_t c01, c23;
-                costs(base, c01, c23);
-                const uint32_t s0x = (uint32_t)wave_shr1((int32_t)P23, (int32_t)((uint32_t)prev_rel0 << 16));
-                from_pred(s0x, P01, P23, c01, c23, s01, s23);
-            }
-            finish_row(s01, s23, fe, rel0_val, bs, a1);
+            scan_row(pk_make(s0, s1), pk_make(s2, s3), fe);
+            const RowInfo<true> ri_n = uniform_row(nxt);
+            store_row(bs, rel0_val);
+            store_codes(0, 0, true);
+            r++;
+            ri = ri_n;
         }
-        r++;
-        ri       = uniform_row(raw_next);
-        raw_next = rowinfo[min(r + 1, graph_count)];
+        cls = r <= graph_count ? class_of(ri) : 3u;
     }
     if ((dbg & 4) && prof_acc) *prof_acc += prof;
 }
