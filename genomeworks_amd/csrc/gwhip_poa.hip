@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
         status_and_count = wave_first(status_and_count);
         __syncthreads();
         if (status_and_count >= 0 && !c.spoa_accurate && graph_fits_lds)
-            topsort_kahn_lds<IdT>(g, status_and_count, lds_rowinfo_region, smem, lane);
+            topsort_kahn_lds<IdT>(g, status_and_count, lds_rowinfo_region, smem, lane, a.debug_flags, pc.acc ? &pc.acc[kPhOther] : nullptr);
         pc.tick(kPhTopsort);
         if (status_and_count < 0) break;
         node_count = status_and_count;

@@ -316,6 +316,7 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
         if (cls == 1)
         {
             // ================= every predecessor (1..3, at most 7 rows back) from the LDS ring =================
+            if (dbg & 8) prof += 1;
             const int32_t cnt     = ri.cnt();
             const int32_t my_slot = (slot + 1) & (kPkSlots - 1);
             const uint32_t a0     = (a1 - 4) & (kPkSlotBytes - 1); // dword whose high half is the cell of column c
@@ -501,7 +502,7 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
         }
         cls = r <= graph_count ? class_of(ri) : 3u;
     }
-    if ((dbg & 4) && prof_acc) *prof_acc += prof;
+    if ((dbg & 12) && prof_acc) *prof_acc += prof;
 }
 
 } // namespace gwhip

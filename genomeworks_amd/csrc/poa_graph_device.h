@@ -374,7 +374,7 @@ __device__ void topsort_kahn(IdT* sorted_poa, IdT* node_map, int32_t node_count,
 //   queue[] : the FIFO == the sorted order                                                       6 KB (score-ring region)
 template <typename IdT>
 __device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_t node_count, uint8_t* lds,
-                                                 uint8_t* lds_queue, int lane)
+                                                 uint8_t* lds_queue, int lane, int32_t dbg = 0, uint64_t* prof_acc = nullptr)
 {
     // per node one 64-bit LDS word: [0:16) out-edge 0  [16:32) out-edge 1  [32:40) out-degree  [40:48) unvisited in-edges
     uint64_t* ent   = reinterpret_cast<uint64_t*>(lds);
@@ -414,6 +414,7 @@ __device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_
         {
             int32_t node   = pend_node;
             uint32_t lo = pend_lo, hi = pend_hi;
+            if ((dbg & 16) && prof_acc && head == tail - 1 && pend_node >= 0) *prof_acc += 1;
             if (!(head == tail - 1 && pend_node >= 0))
             {
                 node             = wave_first((int32_t)queue[head]);
