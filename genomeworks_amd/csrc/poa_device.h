@@ -757,10 +757,16 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         flush_stage(aligned_nodes & ~(kStage - 1), aligned_nodes & (kStage - 1));
     if (loop_count >= bound) aligned_nodes = kNwLoopFailed;
     __syncthreads();
-    for (int32_t k = lane; k < aligned_nodes; k += kWave)
+    for (int32_t k0 = lane; k0 < aligned_nodes; k0 += 4 * kWave) // 4 independent load chains per lane in flight
     {
-        const int32_t pos = alignment_graph[k];
-        if (pos >= 0) alignment_graph[k] = (int32_t)g.sorted_poa[pos];
+        int32_t pos[4], node[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) pos[u] = (k0 + u * kWave < aligned_nodes) ? alignment_graph[k0 + u * kWave] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; u++) node[u] = (int32_t)g.sorted_poa[max(pos[u], 0)];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (pos[u] >= 0) alignment_graph[k0 + u * kWave] = node[u];
     }
     __syncthreads();
     return aligned_nodes;
@@ -777,12 +783,17 @@ __device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t g
     {
         int32_t node = g.sorted_poa[r - 1];
         RowT ri{};
-        int32_t cnt = g.incoming_edge_count[node];
-        int32_t oc  = g.outgoing_edge_count[node];
-        int32_t pr[3] = {0, 0, 0};
-        for (int32_t p = 0; p < 3; p++)
-            if (p < cnt) pr[p] = (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node * kEdges + p]] + 1;
-        ri.set(g.nodes[node], cnt, oc == 0, pr[0], pr[1], pr[2]);
+        // independent loads are issued together: three dependent HBM round trips per row instead of up to five
+        // (edge slots past the in-degree may hold stale or uninitialised ids; they are range-checked and masked)
+        const int32_t cnt = g.incoming_edge_count[node];
+        const int32_t oc  = g.outgoing_edge_count[node];
+        const int32_t bas = g.nodes[node];
+        const int32_t e0 = g.incoming_edges[(int64_t)node * kEdges + 0], e1 = g.incoming_edges[(int64_t)node * kEdges + 1],
+                      e2 = g.incoming_edges[(int64_t)node * kEdges + 2];
+        const int32_t q0 = g.node_id_to_pos[(uint32_t)e0 < (uint32_t)graph_count ? e0 : 0];
+        const int32_t q1 = g.node_id_to_pos[(uint32_t)e1 < (uint32_t)graph_count ? e1 : 0];
+        const int32_t q2 = g.node_id_to_pos[(uint32_t)e2 < (uint32_t)graph_count ? e2 : 0];
+        ri.set(bas, cnt, oc == 0, cnt > 0 ? q0 + 1 : 0, cnt > 1 ? q1 + 1 : 0, cnt > 2 ? q2 + 1 : 0);
         rowinfo[r] = ri;
     }
 }

@@ -7,10 +7,10 @@
 //     which are also exactly the 8 bytes it stores, so nothing is packed or unpacked around memory;
 //   * every row is classified once per read, by all lanes in parallel (classify_rows): class 0 rows have the
 //     previous row as only predecessor and an unmoved band -- the previous row is in registers and one DPP lane
-//     shift aligns the diagonal; class 1 rows (band moved, 2-3 predecessors, predecessor up to 7 rows back) read
-//     every predecessor from an LDS ring; class 2 rows (no predecessor, > 3 predecessors, far predecessors,
-//     band-start transition) take the general 32-bit routine against the HBM matrix. The row loop itself only
-//     tests two bits of the row-table word;
+//     shift aligns the diagonal; class 1 rows have one predecessor up to 7 rows back (or a moved band) and read it
+//     from an LDS ring; class 2 rows have 2-3 such predecessors; class 3 rows (no predecessor, > 3 predecessors,
+//     far predecessors, band-start transition) take the general 32-bit routine against the HBM matrix. The row
+//     loop itself only tests two bits of the row-table word;
 //   * the LDS ring holds 8 rows of 512 absolute column slots (cell of column x at slot (x - 1) & 511), so a
 //     reader addresses a predecessor row by column alone and never needs that row's band start; each row also
 //     stores sentinel cells behind its band end, which is how a reader recognises a 4-cell chunk that lies
@@ -92,9 +92,10 @@ __device__ __forceinline__ void lds_store_u64_lanes17(uint32_t addr, uint32_t lo
 
 // ------------------------------------------------------------------------------------------------
 // Row classes for banded_forward_packed, all lanes in parallel. Needs the band starts in the table already.
-//   0: one predecessor, the previous row, band not moved
-//   1: 1..3 predecessors, each 1..7 rows back, band starts compatible with the ring (see header)
-//   2: everything else
+//   0: one predecessor, the previous row, band not moved                       (previous row from registers)
+//   1: one predecessor, 1..7 rows back, band starts compatible with the ring     (predecessor from the LDS ring)
+//   2: 2..3 predecessors, each 1..7 rows back, band starts compatible            (predecessors from the LDS ring)
+//   3: everything else                                                           (general routine, HBM matrix)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void classify_rows(RowInfo<true>* rowinfo, int32_t graph_count, int lane, int32_t dbg = 0)
 {
@@ -102,7 +103,7 @@ __device__ __forceinline__ void classify_rows(RowInfo<true>* rowinfo, int32_t gr
     {
         RowInfo<true> ri = rowinfo[r];
         const int32_t cnt = ri.cnt(), bs = ri.bs();
-        uint64_t cls = 2;
+        uint64_t cls = 3;
         if (cnt >= 1 && cnt <= 3)
         {
             bool ok = true, first_is_prev_unmoved = false;
@@ -114,12 +115,13 @@ __device__ __forceinline__ void classify_rows(RowInfo<true>* rowinfo, int32_t gr
                 ok                = ok && d >= 1 && d <= kPkMaxDist && (bs - pbs) <= kPkGuardCols && (bs == 0 || pbs > 0);
                 if (k == 0) first_is_prev_unmoved = (d == 1 && pbs == bs);
             }
-            if (ok) cls = (cnt == 1 && first_is_prev_unmoved) ? 0 : 1;
+            if (ok) cls = cnt > 1 ? 2 : (first_is_prev_unmoved ? 0 : 1);
         }
         // ablations (GWHIP_DEBUG): demote classes to check them against each other
         if ((dbg & 1024) && cls == 0) cls = 1;
-        if ((dbg & 2048) && cls == 0) cls = 2;
-        if ((dbg & 512) && cls == 1) cls = 2;
+        if ((dbg & 2048) && cls == 0) cls = 3;
+        if ((dbg & 512) && (cls == 1 || cls == 2)) cls = 3;
+        if ((dbg & 32768) && cls == 1) cls = 2;
         ri.w       = (ri.w & ~(3ull << kClassShift)) | (cls << kClassShift);
         rowinfo[r] = ri;
     }
@@ -283,27 +285,49 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
     uint32_t cls     = class_of(ri);
     while (r <= graph_count)
     {
-        // ================= streak of class 0 rows: previous row in registers, band unmoved =================
-        while (cls == 0)
+        // ========== streak of single-predecessor rows: class 0 (registers) and class 1 (LDS ring) ==========
+        while (cls <= 1)
         {
             const RowInfo<true> nxt = rowinfo[min(r + 1, graph_count)]; // consumed after the arithmetic
             const int32_t bs        = ri.bs();
+            uint32_t s0x, q01, q23;
+            bool outside = false;
+            int32_t fe   = min_score + gap_score;
+            if (cls == 1)
+            {
+                a1  = (uint32_t)(2 * bs + lane8) & (kPkSlotBytes - 1);
+                ga  = (a1 + guard_off) & (kPkSlotBytes - 1);
+                rd4 = *reinterpret_cast<const uint32_t*>(lds_read + bs + lane4);
+                const int32_t d     = r - ri.pred(0);
+                const uint32_t pb   = ring_base + (uint32_t)((slot + 1 - d) & (kPkSlots - 1)) * kPkSlotBytes;
+                s0x                 = lds_load_u32(pb + ((a1 - 4) & (kPkSlotBytes - 1)));
+                const uint2 q       = lds_load_u64(pb + a1);
+                q01 = q.x; q23 = q.y;
+                outside = (q01 & 0xffffu) == ((uint32_t)kPkSentinel & 0xffffu); // chunk beyond the predecessor's band
+                if (bs == 0)
+                    fe = max(min_score, (int32_t)(int16_t)wave_first((int32_t)(lds_load_u32(pb + kPkSlotBytes - 4) >> 16))) + gap_score;
+            }
+            else
+            {
+                s0x = (uint32_t)wave_shr1((int32_t)P23, (int32_t)((uint32_t)prev_rel0 << 16));
+                q01 = P01; q23 = P23;
+                if (bs == 0) fe = max(min_score, prev_rel0) + gap_score;
+            }
+            const int32_t rel0_val = bs == 0 ? fe : min_score;
             uint32_t c01, c23, D01, D23, V01, V23;
             costs((uint32_t)ri.base(), c01, c23);
-            const uint32_t s0x = (uint32_t)wave_shr1((int32_t)P23, (int32_t)((uint32_t)prev_rel0 << 16));
-            from_pred(s0x, P01, P23, c01, c23, D01, D23, V01, V23);
-            const int32_t fe       = bs == 0 ? max(min_score, prev_rel0) + gap_score : min_score + gap_score;
-            const int32_t rel0_val = bs == 0 ? fe : min_score;
-            scan_row(pk_max(D01, V01), pk_max(D23, V23), fe);
+            from_pred(s0x, q01, q23, c01, c23, D01, D23, V01, V23);
+            const uint32_t s01 = pk_max(D01, V01), s23 = pk_max(D23, V23);
+            scan_row(outside ? MIN2 : s01, outside ? MIN2 : s23, fe);
             // code = H == D ? diag : H == V ? vert : horiz  ==  2 + [H != D] * (3 - 4 * [H != V])
             const uint32_t code01 = pk_mad_u16(nz(P01, D01), pk_mad_u16(nz(P01, V01), NEG4, THREE2), TWO2);
             const uint32_t code23 = pk_mad_u16(nz(P23, D23), pk_mad_u16(nz(P23, V23), NEG4, THREE2), TWO2);
             const RowInfo<true> ri_n = uniform_row(nxt); // before this row's LDS stores: no wait behind them
             store_row(bs, rel0_val);
-            store_codes(code01, code23, false);
+            store_codes(code01, code23, outside);
             r++;
             ri  = ri_n;
-            cls = r <= graph_count ? class_of(ri) : 3u;
+            cls = r <= graph_count ? class_of(ri) : 7u;
         }
         if (r > graph_count) break;
 
@@ -313,9 +337,9 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
         a1  = (uint32_t)(2 * bs + lane8) & (kPkSlotBytes - 1);
         ga  = (a1 + guard_off) & (kPkSlotBytes - 1);
         rd4 = *reinterpret_cast<const uint32_t*>(lds_read + bs + lane4);
-        if (cls == 1)
+        if (cls == 2)
         {
-            // ================= every predecessor (1..3, at most 7 rows back) from the LDS ring =================
+            // ================= every predecessor (2..3, at most 7 rows back) from the LDS ring =================
             if (dbg & 8) prof += 1;
             const int32_t cnt     = ri.cnt();
             const int32_t my_slot = (slot + 1) & (kPkSlots - 1);
@@ -500,7 +524,7 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
             r++;
             ri = ri_n;
         }
-        cls = r <= graph_count ? class_of(ri) : 3u;
+        cls = r <= graph_count ? class_of(ri) : 7u;
     }
     if ((dbg & 12) && prof_acc) *prof_acc += prof;
 }

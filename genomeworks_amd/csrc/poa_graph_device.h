@@ -387,11 +387,12 @@ __device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_
         bool is_src     = false;
         if (n < node_count)
         {
+            // four independent loads, one HBM round trip (slots past the out-degree hold stale ids and are masked)
             const uint32_t ic = g.incoming_edge_count[n];
             const uint32_t oc = g.outgoing_edge_count[n];
-            uint32_t e        = 0;
-            if (oc > 0) e = (uint16_t)g.outgoing_edges[(int64_t)n * kEdges];
-            if (oc > 1) e |= ((uint32_t)(uint16_t)g.outgoing_edges[(int64_t)n * kEdges + 1]) << 16;
+            const uint32_t e0 = (uint16_t)g.outgoing_edges[(int64_t)n * kEdges];
+            const uint32_t e1 = (uint16_t)g.outgoing_edges[(int64_t)n * kEdges + 1];
+            const uint32_t e  = (oc > 0 ? e0 : 0u) | (oc > 1 ? e1 << 16 : 0u);
             ent[n] = (uint64_t)e | ((uint64_t)((oc & 0xff) | ((ic & 0xff) << 8)) << 32);
             is_src = (ic == 0);
         }
