@@ -99,9 +99,26 @@ def build_host(force=False):
     return target
 
 
+def build_cli(force=False):
+    """The `cudapoa` command-line tool (reference: cudapoa/src/main.cpp) -> genomeworks_amd/bin/cudapoa."""
+    bindir = os.path.join(PKG, "bin")
+    os.makedirs(bindir, exist_ok=True)
+    target = os.path.join(bindir, "cudapoa")
+    src = os.path.join(PKG, "host", "cudapoa_main.cpp")
+    sig = _digest(_deps("host", (".cpp", ".h", ".hpp")), HOST_FLAGS)
+    if force or _stale(target, sig):
+        cmd = ["g++"] + [f for f in HOST_FLAGS if f != "-fPIC"] + ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROCM, "include"),
+                          "-o", target, src, "-L", LIB, "-lgenomeworks_amd", "-lgwhip", "-L", os.path.join(ROCM, "lib"),
+                          "-lamdhip64", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+        _run(cmd)
+        _mark(target, sig)
+    return target
+
+
 def build_all(force=False):
     k = build_kernels(force)
     h = build_host(force)
+    build_cli(force)
     return k, h
 
 

@@ -273,3 +273,107 @@ class CudaPoaBatch:
     def reset(self):
         """Reset the batch object. Involves deleting all windows previously assigned to batch object."""
         self._L.gw_poa_reset(self._h)
+
+
+# ---- cudapoa/utils.hpp: batch-shape planning and window-file readers -------------------------------------------
+def _bind_utils(L):
+    if getattr(L, "_gw_poa_utils_bound", False):
+        return L
+    i32, f32 = C.c_int32, C.c_float
+    pi32, pcfg = C.POINTER(i32), C.POINTER(_native.PoaBatchConfig)
+    L.gw_poa_bin_groups.argtypes = [i32, pi32, pi32, pi32, i32, i32, f32, f32, i32, pi32, i32, pi32, pcfg, pi32, pi32]
+    L.gw_poa_get_multi_batch_sizes.argtypes = [i32, pi32, pi32, i32, i32, i32, f32, f32, i32, f32, i32, i32, i32, pi32,
+                                               pcfg, pi32, pi32]
+    L.gw_poa_estimate_max_poas.argtypes = [pcfg, i32, f32, i32, i32, i32]
+    L.gw_windows_parse.restype = C.c_void_p
+    L.gw_windows_parse.argtypes = [C.POINTER(C.c_char_p), i32, i32, i32]
+    L.gw_windows_destroy.argtypes = [C.c_void_p]
+    L.gw_windows_count.argtypes = [C.c_void_p]
+    L.gw_windows_num_sequences.argtypes = [C.c_void_p, i32]
+    L.gw_windows_sequence.restype = C.POINTER(C.c_char)
+    L.gw_windows_sequence.argtypes = [C.c_void_p, i32, i32, pi32]
+    L._gw_poa_utils_bound = True
+    return L
+
+
+def _plan_out(n):
+    return (C.c_int32(0), (_native.PoaBatchConfig * max(n, 1))(), (C.c_int32 * max(n, 1))(), (C.c_int32 * max(n, 1))())
+
+
+def _plan_unpack(nb, cfgs, per_batch, ids):
+    fields = [f[0] for f in _native.PoaBatchConfig._fields_]
+    out_cfgs = [{f: getattr(cfgs[b], f) for f in fields} for b in range(nb.value)]
+    groups, pos = [], 0
+    for b in range(nb.value):
+        groups.append([ids[pos + k] for k in range(per_batch[b])])
+        pos += per_batch[b]
+    return out_cfgs, groups
+
+
+def _i32_array(values):
+    return (C.c_int32 * max(len(values), 1))(*values)
+
+
+def bin_poa_groups(capacity, longest, reads, band_width=256, band_mode="adaptive_band", adaptive_storage_factor=2.0,
+                   graph_length_factor=3.0, max_pred_distance=0, bins_capacity=None):
+    """The binning rule of get_multi_batch_sizes given per-group capacities (no device query).
+    Returns (list of BatchConfig dicts, list of group-index lists)."""
+    L = _bind_utils(_native.host())
+    n = len(capacity)
+    nb, cfgs, per_batch, ids = _plan_out(n)
+    bins = _i32_array(bins_capacity) if bins_capacity is not None else None
+    rc = L.gw_poa_bin_groups(n, _i32_array(capacity), _i32_array(longest), _i32_array(reads), band_width,
+                             _BAND_MODES[band_mode], adaptive_storage_factor, graph_length_factor, max_pred_distance,
+                             bins, len(bins_capacity) if bins_capacity is not None else 0, C.byref(nb), cfgs, per_batch, ids)
+    if rc != 0:
+        raise RuntimeError(L.gw_last_error().decode())
+    return _plan_unpack(nb, cfgs, per_batch, ids)
+
+
+def get_multi_batch_sizes(poa_groups, msa_flag=False, band_width=256, band_mode="adaptive_band",
+                          adaptive_storage_factor=2.0, graph_length_factor=3.0, max_pred_distance=0,
+                          gpu_memory_usage_quota=0.9, mismatch_score=-6, gap_score=-8, match_score=8):
+    """cudapoa::get_multi_batch_sizes (utils.hpp:36-69): poa_groups is a list of windows (lists of sequences).
+    Returns (list of BatchConfig dicts, list of group-index lists). Needs a GPU (free-memory query)."""
+    L = _bind_utils(_native.host())
+    n = len(poa_groups)
+    longest = [max((len(s) for s in g), default=0) for g in poa_groups]
+    reads = [len(g) for g in poa_groups]
+    nb, cfgs, per_batch, ids = _plan_out(n)
+    rc = L.gw_poa_get_multi_batch_sizes(n, _i32_array(longest), _i32_array(reads), int(msa_flag), band_width,
+                                        _BAND_MODES[band_mode], adaptive_storage_factor, graph_length_factor,
+                                        max_pred_distance, gpu_memory_usage_quota, mismatch_score, gap_score, match_score,
+                                        C.byref(nb), cfgs, per_batch, ids)
+    if rc != 0:
+        raise RuntimeError(L.gw_last_error().decode())
+    return _plan_unpack(nb, cfgs, per_batch, ids)
+
+
+def _parse(paths, fasta, total_windows):
+    L = _bind_utils(_native.host())
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    h = L.gw_windows_parse(arr, len(paths), int(fasta), int(total_windows))
+    if not h:
+        raise RuntimeError(L.gw_last_error().decode())
+    try:
+        out = []
+        for w in range(L.gw_windows_count(h)):
+            seqs = []
+            for s in range(L.gw_windows_num_sequences(h, w)):
+                n = C.c_int32(0)
+                p = L.gw_windows_sequence(h, w, s, C.byref(n))
+                seqs.append(C.string_at(p, n.value).decode())
+            out.append(seqs)
+        return out
+    finally:
+        L.gw_windows_destroy(h)
+
+
+def parse_cudapoa_file(filename, total_windows=-1):
+    """cudapoa::parse_cudapoa_file (utils.hpp:112-137): list of windows, each a list of sequences."""
+    return _parse([filename], False, total_windows)
+
+
+def parse_fasta_files(input_paths, total_windows=-1):
+    """cudapoa::parse_fasta_files (utils.hpp:147-162): one window per FASTA file."""
+    return _parse(list(input_paths), True, total_windows)

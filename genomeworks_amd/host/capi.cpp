@@ -2,6 +2,7 @@
 // binding of cudapoa::Batch and cudaaligner::Aligner binds. Exceptions never cross the boundary.
 #include <claraparabricks/genomeworks/cudapoa/batch.hpp>
 #include <claraparabricks/genomeworks/cudapoa/cudapoa.hpp>
+#include <claraparabricks/genomeworks/cudapoa/utils.hpp>
 
 #include <cstring>
 #include <memory>
@@ -375,6 +376,105 @@ int gw_aligner_band_cells(gw_aligner* a, uint64_t* cells)
     *cells = a->impl->total_band_cells();
     return 0;
     GW_CATCH(-1)
+}
+
+
+// ---- cudapoa/utils.hpp: batch-shape planning and window-file readers -----------------------------------------
+
+struct gw_windows
+{
+    std::vector<std::vector<std::string>> windows;
+};
+
+static int emit_plan(const std::vector<poa::BatchConfig>& shapes, const std::vector<std::vector<int32_t>>& groups,
+                     int32_t n_groups, int32_t* n_batches, gw_poa_batch_config* batch_cfgs, int32_t* groups_per_batch,
+                     int32_t* group_ids)
+{
+    *n_batches = static_cast<int32_t>(shapes.size());
+    int32_t pos = 0;
+    for (size_t b = 0; b < shapes.size(); b++)
+    {
+        const poa::BatchConfig& c = shapes[b];
+        batch_cfgs[b] = gw_poa_batch_config{c.max_sequence_size, c.max_consensus_size, c.max_nodes_per_graph,
+                                            c.matrix_sequence_dimension, c.alignment_band_width, c.max_sequences_per_poa,
+                                            static_cast<int32_t>(c.band_mode), c.max_banded_pred_distance};
+        groups_per_batch[b] = static_cast<int32_t>(groups[b].size());
+        for (int32_t id : groups[b])
+        {
+            if (pos >= n_groups) return -1;
+            group_ids[pos++] = id;
+        }
+    }
+    return 0;
+}
+
+int gw_poa_bin_groups(int32_t n_groups, const int32_t* capacity, const int32_t* longest, const int32_t* reads,
+                      int32_t band_width, int32_t band_mode, float adaptive_storage_factor, float graph_length_factor,
+                      int32_t max_pred_distance, const int32_t* bins_capacity, int32_t n_bins, int32_t* n_batches,
+                      gw_poa_batch_config* batch_cfgs, int32_t* groups_per_batch, int32_t* group_ids)
+{
+    GW_TRY
+    std::vector<poa::BatchConfig> shapes;
+    std::vector<std::vector<int32_t>> groups;
+    std::vector<int32_t> bins(bins_capacity ? bins_capacity : nullptr, bins_capacity ? bins_capacity + n_bins : nullptr);
+    poa::bin_poa_groups(shapes, groups, std::vector<int32_t>(capacity, capacity + n_groups),
+                            std::vector<int32_t>(longest, longest + n_groups), std::vector<int32_t>(reads, reads + n_groups),
+                            band_width, static_cast<poa::BandMode>(band_mode), adaptive_storage_factor,
+                            graph_length_factor, max_pred_distance, bins_capacity ? &bins : nullptr);
+    return emit_plan(shapes, groups, n_groups, n_batches, batch_cfgs, groups_per_batch, group_ids);
+    GW_CATCH(-1)
+}
+
+int gw_poa_get_multi_batch_sizes(int32_t n_groups, const int32_t* longest, const int32_t* reads, int32_t msa_flag,
+                                 int32_t band_width, int32_t band_mode, float adaptive_storage_factor,
+                                 float graph_length_factor, int32_t max_pred_distance, float gpu_memory_usage_quota,
+                                 int32_t mismatch_score, int32_t gap_score, int32_t match_score, int32_t* n_batches,
+                                 gw_poa_batch_config* batch_cfgs, int32_t* groups_per_batch, int32_t* group_ids)
+{
+    GW_TRY
+    // groups are described by (longest read, number of reads): only the lengths matter to the planner
+    std::vector<poa::Group> poa_groups(static_cast<size_t>(n_groups));
+    for (int32_t i = 0; i < n_groups; i++)
+        poa_groups[static_cast<size_t>(i)].assign(static_cast<size_t>(reads[i]), poa::Entry{nullptr, nullptr, longest[i]});
+    std::vector<poa::BatchConfig> shapes;
+    std::vector<std::vector<int32_t>> groups;
+    poa::get_multi_batch_sizes(shapes, groups, poa_groups, msa_flag != 0, band_width, static_cast<poa::BandMode>(band_mode),
+                                   adaptive_storage_factor, graph_length_factor, max_pred_distance, nullptr,
+                                   gpu_memory_usage_quota, mismatch_score, gap_score, match_score);
+    return emit_plan(shapes, groups, n_groups, n_batches, batch_cfgs, groups_per_batch, group_ids);
+    GW_CATCH(-1)
+}
+
+int32_t gw_poa_estimate_max_poas(const gw_poa_batch_config* cfg, int32_t msa_flag, float gpu_memory_usage_quota,
+                                 int32_t mismatch_score, int32_t gap_score, int32_t match_score)
+{
+    GW_TRY
+    const poa::BatchConfig c(cfg->max_sequence_size, cfg->max_consensus_size, cfg->max_nodes_per_graph,
+                                 cfg->alignment_band_width, cfg->max_sequences_per_poa, cfg->matrix_sequence_dimension,
+                                 static_cast<poa::BandMode>(cfg->band_mode), cfg->max_banded_pred_distance);
+    return poa::estimate_max_poas(c, msa_flag != 0, gpu_memory_usage_quota, mismatch_score, gap_score, match_score);
+    GW_CATCH(-1)
+}
+
+gw_windows* gw_windows_parse(const char* const* paths, int32_t n_paths, int32_t fasta, int32_t total_windows)
+{
+    GW_TRY
+    std::unique_ptr<gw_windows> w(new gw_windows());
+    if (fasta)
+        poa::parse_fasta_files(w->windows, std::vector<std::string>(paths, paths + n_paths), total_windows);
+    else
+        poa::parse_cudapoa_file(w->windows, paths[0], total_windows);
+    return w.release();
+    GW_CATCH(nullptr)
+}
+void gw_windows_destroy(gw_windows* w) { delete w; }
+int32_t gw_windows_count(const gw_windows* w) { return static_cast<int32_t>(w->windows.size()); }
+int32_t gw_windows_num_sequences(const gw_windows* w, int32_t window) { return static_cast<int32_t>(w->windows.at(static_cast<size_t>(window)).size()); }
+const char* gw_windows_sequence(const gw_windows* w, int32_t window, int32_t seq, int32_t* length)
+{
+    const std::string& s = w->windows.at(static_cast<size_t>(window)).at(static_cast<size_t>(seq));
+    *length              = static_cast<int32_t>(s.size());
+    return s.data();
 }
 
 } // extern "C"

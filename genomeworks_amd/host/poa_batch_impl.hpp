@@ -13,6 +13,12 @@ namespace cudapoa
 
 gwhip_poa_config make_device_config(const BatchConfig& b, int8_t output_mask, int32_t gap, int32_t mismatch, int32_t match);
 
+/// The binning rule of get_multi_batch_sizes on its own (cudapoa_utils.cpp; exposed to the tests through the C API).
+void bin_poa_groups(std::vector<BatchConfig>& list_of_batch_sizes, std::vector<std::vector<int32_t>>& list_of_groups_per_batch,
+                    const std::vector<int32_t>& capacity, const std::vector<int32_t>& longest, const std::vector<int32_t>& reads,
+                    int32_t band_width, BandMode band_mode, float adaptive_storage_factor, float graph_length_factor,
+                    int32_t max_pred_distance, const std::vector<int32_t>* bins_capacity);
+
 class PoaBatch : public Batch
 {
 public:

@@ -132,6 +132,29 @@ int gw_aligner_relaunch(gw_aligner* a);
 /* 32 * band words * target length summed over band attempts and pairs of the last align_all() (device counters) */
 int gw_aligner_band_cells(gw_aligner* a, uint64_t* cells);
 
+/* ---- cudapoa/utils.hpp: batch-shape planning (utils.cu:30-146) and window-file readers (utils.hpp:77-187) ---- */
+/* Binning rule only: capacity[i] / longest[i] / reads[i] describe group i; bins_capacity may be NULL (1,2,4,... x20).
+   Outputs: *n_batches, batch_cfgs[<= n_groups], groups_per_batch[<= n_groups], group_ids[n_groups] (batch by batch). */
+int gw_poa_bin_groups(int32_t n_groups, const int32_t* capacity, const int32_t* longest, const int32_t* reads,
+                      int32_t band_width, int32_t band_mode, float adaptive_storage_factor, float graph_length_factor,
+                      int32_t max_pred_distance, const int32_t* bins_capacity, int32_t n_bins, int32_t* n_batches,
+                      gw_poa_batch_config* batch_cfgs, int32_t* groups_per_batch, int32_t* group_ids);
+/* get_multi_batch_sizes(): capacities from the device's free memory (needs a GPU). */
+int gw_poa_get_multi_batch_sizes(int32_t n_groups, const int32_t* longest, const int32_t* reads, int32_t msa_flag,
+                                 int32_t band_width, int32_t band_mode, float adaptive_storage_factor,
+                                 float graph_length_factor, int32_t max_pred_distance, float gpu_memory_usage_quota,
+                                 int32_t mismatch_score, int32_t gap_score, int32_t match_score, int32_t* n_batches,
+                                 gw_poa_batch_config* batch_cfgs, int32_t* groups_per_batch, int32_t* group_ids);
+int32_t gw_poa_estimate_max_poas(const gw_poa_batch_config* cfg, int32_t msa_flag, float gpu_memory_usage_quota,
+                                 int32_t mismatch_score, int32_t gap_score, int32_t match_score);
+/* parse_cudapoa_file (fasta = 0, first path only) / parse_fasta_files (fasta = 1); NULL on error (gw_last_error). */
+typedef struct gw_windows gw_windows;
+gw_windows* gw_windows_parse(const char* const* paths, int32_t n_paths, int32_t fasta, int32_t total_windows);
+void gw_windows_destroy(gw_windows* w);
+int32_t gw_windows_count(const gw_windows* w);
+int32_t gw_windows_num_sequences(const gw_windows* w, int32_t window);
+const char* gw_windows_sequence(const gw_windows* w, int32_t window, int32_t seq, int32_t* length);
+
 #ifdef __cplusplus
 }
 #endif
