@@ -139,3 +139,35 @@ def test_full_size_batch_properties():
         for i in (0, 511, 1023):
             ref = ws.process(windows[i])
             assert cons[i] == ref["consensus"] and cov[i] == list(ref["coverage"])
+
+
+@pytest.mark.parametrize("scores", [(-3, -4, 5), (-30, -9, 7), (-1, -1, 1), (-8, 0, 8)])
+def test_packed_forward_other_scores_bit_exact(scores):
+    """The packed int16 forward pass / trace codes with score parameters other than the defaults (gap, mismatch, match)."""
+    gap, mismatch, match = scores
+    windows = config3(3, first=2100)
+    b = run_gpu(windows, "static_band", gap_score=gap, mismatch_score=mismatch, match_score=match)
+    cons, cov, status = b.get_consensus()
+    cfg = oracle_cfg("static_band")
+    cfg.gap_score, cfg.mismatch_score, cfg.match_score = gap, mismatch, match
+    O.lib().poa_cfg_select_types(cfg)
+    with O.Workspace(cfg) as ws:
+        for i, w in enumerate(windows):
+            ref = ws.process(w)
+            assert status[i] == ref["status"]
+            if ref["status"] == 0:
+                assert cons[i] == ref["consensus"] and cov[i] == list(ref["coverage"])
+        assert ws.overflow_events() == 0
+
+
+def test_msa_static_band_256_bit_exact():
+    """MSA output on the packed static-band path (merge with per-edge sequence coverage) vs the oracle."""
+    from genomeworks_amd import synthetic
+    windows = [[r.decode() for r in synthetic.generate_window(7300 + w, 400, 10, 20, 10, 10)] for w in range(3)]
+    b = run_gpu(windows, "static_band", max_seq=512, max_seqs=16, output_type="msa")
+    msa, status = b.get_msa()
+    with O.Workspace(oracle_cfg("static_band", 512, 16, output_mask=2)) as ws:
+        for i, w in enumerate(windows):
+            ref = ws.process(w)
+            assert status[i] == ref["status"] == 0
+            assert msa[i] == ref["msa"]
