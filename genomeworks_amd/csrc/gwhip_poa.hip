@@ -334,6 +334,21 @@ __global__ __launch_bounds__(kWave) void poa_consensus_kernel(KernelArgs a)
                                 c.max_consensus_size);
 }
 
+// LDS flavour (16-bit ids, <= 3072 nodes): generate_consensus_lds
+__global__ __launch_bounds__(kWave) void poa_consensus_lds_kernel(KernelArgs a)
+{
+    extern __shared__ __align__(16) uint8_t cons_smem[];
+    const int32_t w    = blockIdx.x;
+    const gwhip_poa_config& c = a.cfg;
+    uint8_t* consensus = a.consensus + (size_t)w * c.max_consensus_size;
+    if (consensus[0] == kKernelError) return;
+    uint8_t* slab          = a.workspace + (size_t)w * a.L.per_window;
+    GraphView<int16_t> g   = carve_graph<int16_t>(slab, a.L);
+    const int32_t n        = a.sequence_lengths[a.window_details[w].seq_len_buffer_offset];
+    generate_consensus_lds<int16_t>(g, n, cons_smem, consensus, a.coverage + (size_t)w * c.max_consensus_size,
+                                    c.max_consensus_size, threadIdx.x & (kWave - 1));
+}
+
 // MSA kernel: lane 0 does the racon topsort + column assignment, then one lane per sequence
 // (loops when num_seqs > 64; the reference launches max_sequences_per_poa threads, cudapoa_kernels.cuh:1025-1026).
 template <typename IdT>
@@ -555,7 +570,10 @@ int gwhip_poa_generate(const gwhip_poa_args* args, gwhip_stream_t stream_)
     }
     else
     {
+        const char* cons_dbg = std::getenv("GWHIP_CONSENSUS_SERIAL"); // debugging: force the HBM-only kernel
         if (args->cfg.size32) hipLaunchKernelGGL(poa_consensus_kernel<int32_t>, grid, block, 0, stream, ka);
+        else if (args->cfg.max_nodes_per_graph <= kConsLdsNodes && !(cons_dbg && cons_dbg[0] == '1'))
+            hipLaunchKernelGGL(poa_consensus_lds_kernel, grid, block, kConsLdsBytes, stream, ka);
         else hipLaunchKernelGGL(poa_consensus_kernel<int16_t>, grid, block, 0, stream, ka);
     }
     e = hipGetLastError();

@@ -657,6 +657,146 @@ __device__ void generate_consensus(const GraphView<IdT>& g, int32_t node_count, 
     consensus[consensus_pos] = '\0';
 }
 
+// ------------------------------------------------------------------------------------------------
+// Heaviest bundle + branch completion + consensus read-out with the working set in LDS (16-bit ids, <= 3072 nodes).
+// Same decisions as generate_consensus / branch_completion above (cudapoa_generate_consensus.cuh:35-283); the
+// serial passes run wave-uniformly on the scalar unit against LDS copies staged by all lanes, so a node costs LDS
+// round trips instead of a chain of HBM round trips, and the consensus / coverage read-out is a parallel map.
+//   rec[n]    3 x u32 : in-edge 0..2 (12 bit each) + in-degree | in-edge 2, weight 0 | weight 1, weight 2
+//   scores[n] i32 with a guard element at index -1; pred[n] i16; the path list aliases rec after the passes
+// ------------------------------------------------------------------------------------------------
+constexpr int kConsLdsNodes = 3072;
+constexpr int kConsLdsBytes = kConsLdsNodes * 12 + (kConsLdsNodes + 4) * 4 + kConsLdsNodes * 2;
+
+template <typename IdT>
+__device__ __forceinline__ void generate_consensus_lds(const GraphView<IdT>& g, int32_t node_count, uint8_t* lds,
+                                                       uint8_t* consensus, uint16_t* coverage,
+                                                       int32_t max_limit_consensus_size, int lane)
+{
+    uint32_t* rec    = reinterpret_cast<uint32_t*>(lds);
+    int32_t* scores  = reinterpret_cast<int32_t*>(lds + kConsLdsNodes * 12) + 1; // index -1 is the guard
+    int16_t* pred    = reinterpret_cast<int16_t*>(lds + kConsLdsNodes * 12 + (kConsLdsNodes + 4) * 4);
+    uint16_t* path   = reinterpret_cast<uint16_t*>(lds); // aliases rec once the passes are done
+
+    for (int32_t n = lane; n < node_count; n += kWave)
+    {
+        const uint32_t cnt = g.incoming_edge_count[n];
+        const uint32_t e0 = (uint16_t)g.incoming_edges[(int64_t)n * kEdges + 0], e1 = (uint16_t)g.incoming_edges[(int64_t)n * kEdges + 1],
+                       e2 = (uint16_t)g.incoming_edges[(int64_t)n * kEdges + 2];
+        const uint32_t w0 = g.incoming_edge_w[(int64_t)n * kEdges + 0], w1 = g.incoming_edge_w[(int64_t)n * kEdges + 1],
+                       w2 = g.incoming_edge_w[(int64_t)n * kEdges + 2];
+        // slots past the in-degree hold stale values: point them at node 0 so their score reads stay in range
+        rec[3 * n + 0] = (cnt > 0 ? e0 & 0xfff : 0u) | ((cnt > 1 ? e1 & 0xfff : 0u) << 12) | (min(cnt, 255u) << 24);
+        rec[3 * n + 1] = (cnt > 2 ? e2 & 0xfff : 0u) | (w0 << 16);
+        rec[3 * n + 2] = w1 | (w2 << 16);
+    }
+    if (lane == 0) scores[-1] = -1;
+    __syncthreads();
+
+    // one pass of the heaviest-bundle recurrence over sorted positions [first_pos, node_count);
+    // skip_cut: edges from nodes whose score was cut to -1 are ignored (branch completion)
+    auto bundle_pass = [&](int32_t first_pos, bool skip_cut, int32_t max_score) -> int32_t {
+        int32_t max_score_id = 0;
+        int32_t chunk_base   = first_pos;
+        int32_t chunk        = (chunk_base + lane < node_count) ? (int32_t)g.sorted_poa[chunk_base + lane] : 0;
+        for (int32_t pos = first_pos; pos < node_count; pos++)
+        {
+            if (pos - chunk_base >= kWave)
+            {
+                chunk_base = pos;
+                chunk      = (chunk_base + lane < node_count) ? (int32_t)g.sorted_poa[chunk_base + lane] : 0;
+            }
+            const int32_t node = __builtin_amdgcn_readlane(chunk, pos - chunk_base);
+            const uint32_t r0 = (uint32_t)wave_first((int32_t)rec[3 * node + 0]);
+            const uint32_t r1 = (uint32_t)wave_first((int32_t)rec[3 * node + 1]);
+            const uint32_t r2 = (uint32_t)wave_first((int32_t)rec[3 * node + 2]);
+            const int32_t cnt = (int32_t)(r0 >> 24);
+            const int32_t b0 = (int32_t)(r0 & 0xfff), b1 = (int32_t)((r0 >> 12) & 0xfff), b2 = (int32_t)(r1 & 0xfff);
+            const int32_t w0 = (int32_t)(r1 >> 16), w1 = (int32_t)(r2 & 0xffff), w2 = (int32_t)(r2 >> 16);
+            const int32_t s0 = wave_first(scores[b0]), s1 = wave_first(scores[b1]), s2 = wave_first(scores[b2]);
+            int32_t best_w = -1, best = -1, best_score = -1; // scores[-1] == -1
+            auto consider = [&](bool present, int32_t begin, int32_t w, int32_t sc) {
+                const bool take = present && !(skip_cut && sc == -1) && (best_w < w || (best_w == w && best_score <= sc));
+                best_w     = take ? w : best_w;
+                best       = take ? begin : best;
+                best_score = take ? sc : best_score;
+            };
+            consider(cnt > 0, b0, w0, s0);
+            consider(cnt > 1, b1, w1, s1);
+            consider(cnt > 2, b2, w2, s2);
+            for (int32_t e = 3; e < cnt; e++) // rare: more than three in-edges, from the HBM lists
+            {
+                const int32_t begin = wave_first((int32_t)g.incoming_edges[(int64_t)node * kEdges + e]);
+                const int32_t w     = wave_first((int32_t)g.incoming_edge_w[(int64_t)node * kEdges + e]);
+                consider(true, begin, w, wave_first(scores[begin]));
+            }
+            const int32_t score = best != -1 ? best_w + best_score : best_w;
+            lane0_store_u16(pred + node, (uint32_t)best);
+            lane0_store_u32(scores + node, (uint32_t)score);
+            const bool better = max_score <= score;
+            max_score         = better ? score : max_score;
+            max_score_id      = better ? node : max_score_id;
+        }
+        return max_score_id;
+    };
+
+    int32_t max_score_id = bundle_pass(0, false, -1);
+    int32_t loop_count   = 0;
+    while (wave_first((int32_t)g.outgoing_edge_count[max_score_id]) != 0 && loop_count < node_count)
+    {
+        // branch completion (:35-97): cut every other way into the successors of the bundle's end, redo the tail
+        const int32_t node_id = max_score_id;
+        const int32_t oc      = wave_first((int32_t)g.outgoing_edge_count[node_id]);
+        for (int32_t oe = 0; oe < oc; oe++)
+        {
+            const int32_t out_node = wave_first((int32_t)g.outgoing_edges[(int64_t)node_id * kEdges + oe]);
+            const int32_t ic       = wave_first((int32_t)g.incoming_edge_count[out_node]);
+            for (int32_t ie = 0; ie < ic; ie++)
+            {
+                const int32_t id = wave_first((int32_t)g.incoming_edges[(int64_t)out_node * kEdges + ie]);
+                if (id != node_id) lane0_store_u32(scores + id, (uint32_t)-1);
+            }
+        }
+        max_score_id = bundle_pass(wave_first((int32_t)g.node_id_to_pos[node_id]) + 1, true, 0);
+        loop_count++;
+    }
+    __syncthreads();
+    if (loop_count >= node_count)
+    {
+        if (lane == 0) { consensus[0] = kKernelError; consensus[1] = kLoopCountExceeded; }
+        return;
+    }
+    // walk the bundle back to its start (serial, LDS), then fill bases and coverage in parallel
+    int32_t count = 0;
+    {
+        int32_t id = max_score_id;
+        for (;;)
+        {
+            lane0_store_u16(path + min(count, 2 * kConsLdsNodes), (uint32_t)id);
+            const int32_t p = wave_first((int32_t)pred[id]);
+            if (p == -1) break;
+            id = p;
+            count++;
+        }
+    }
+    __syncthreads();
+    if (count >= max_limit_consensus_size - 1)
+    {
+        if (lane == 0) { consensus[0] = kKernelError; consensus[1] = kExceededMaximumSequenceSize; }
+        return;
+    }
+    for (int32_t k = lane; k <= count; k += kWave)
+    {
+        const int32_t id = path[k];
+        uint16_t cov     = g.coverage[id];
+        const int32_t na = g.node_alignment_count[id];
+        for (int32_t a = 0; a < na; a++) cov = (uint16_t)(cov + g.coverage[g.node_alignments[(int64_t)id * kAligns + a]]);
+        consensus[k] = g.nodes[id];
+        coverage[k]  = cov;
+    }
+    if (lane == 0) consensus[count + 1] = '\0';
+}
+
 // MSA: column index per node (aligned nodes share a column), then one lane per sequence.
 template <typename IdT>
 __device__ int32_t node_id_to_msa_pos(const GraphView<IdT>& g, int32_t node_count)
