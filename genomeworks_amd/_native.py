@@ -36,7 +36,8 @@ class MyersArgs(C.Structure):
                 ("max_bandwidths", C.c_void_p), ("results", C.c_void_p), ("result_counts", C.c_void_p),
                 ("result_starts", C.c_void_p), ("result_metadata", C.c_void_p), ("results_capacity", C.c_int64),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("total_sequence_length", C.c_int64),
-                ("scheduling_index", C.c_void_p), ("band_cells", C.c_void_p), ("run_counts_out", C.c_void_p)]
+                ("scheduling_index", C.c_void_p), ("band_cells", C.c_void_p), ("run_counts_out", C.c_void_p),
+                ("max_query_length", C.c_int32), ("max_bandwidth_hint", C.c_int32)]
 
 
 class PoaBatchConfig(C.Structure):

@@ -17,7 +17,9 @@
 // second pass packs them behind an exclusive scan of the run counts, so the packed order is the input order.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -41,6 +43,20 @@ struct Band
     __device__ __forceinline__ size_t at(int32_t w, int32_t t) const { return (size_t)t * n_rows + w; }
 };
 
+// Per-lane arrays in LDS, element e of lane l at word e * 64 + l (conflict-free across the lanes of a wave).
+// LDS_STATE kernels keep the previous DP column (pv, mv, score per band word) and the query's pattern table there:
+// the forward pass then never reads the HBM workspace (it only streams the columns out for the backtrace), so a
+// word step costs LDS latency instead of an L2 / HBM round trip on the column it has just written.
+struct LaneArray
+{
+    uint32_t* base; // already offset by the lane
+    __device__ __forceinline__ uint32_t& operator[](int32_t e) const { return base[e * 64]; }
+};
+struct ColumnState
+{
+    LaneArray pv, mv, score;
+};
+
 __device__ __forceinline__ int32_t ceil_div(int32_t a, int32_t b) { return (a + b - 1) / b; }
 
 // bit pattern of query[offset .. offset+32) == x   (myers_gpu.cu:196-208)
@@ -53,7 +69,8 @@ __device__ __forceinline__ uint32_t make_pattern(char x, const char* query, int3
 }
 
 // shifted view on the pattern table (myers_gpu.cu:210-241); index (c >> 1) & 3 => A, C, T, G
-__device__ __forceinline__ uint32_t get_pattern(const uint32_t* patterns, int32_t n_words, int32_t idx, int32_t begin, char x)
+template <typename Table>
+__device__ __forceinline__ uint32_t get_pattern(const Table& patterns, int32_t n_words, int32_t idx, int32_t begin, char x)
 {
     const int32_t ci     = ((unsigned char)x >> 1) & 3;
     const int32_t io     = begin / kWord;
@@ -100,41 +117,62 @@ __device__ __forceinline__ int32_t advance_word(uint32_t hbit, uint32_t eq, uint
 }
 
 // horizontal stripe: columns [t_begin, t_end), fixed rows (myers_gpu.cu:629-674)
-__device__ void horizontal_band(Band& b, const uint32_t* patterns, int32_t n_words_query, const char* target,
+template <bool LDS_STATE, typename Table>
+__device__ void horizontal_band(Band& b, const ColumnState& cs, const Table& patterns, int32_t n_words_query, const char* target,
                                 int32_t t_begin, int32_t t_end, int32_t width, int32_t n_words, int32_t pattern_offset)
 {
+    char tc_next = t_begin < t_end ? target[t_begin - 1] : 0;
     for (int32_t t = t_begin; t < t_end; ++t)
     {
         int32_t h = 1; // worst case for the top border of the band
-        const char tc = target[t - 1];
+        const char tc = tc_next;
+        if (t + 1 < t_end) tc_next = target[t]; // next column's character: its latency overlaps this column
         for (int32_t w = 0; w < n_words; ++w)
         {
-            uint32_t pv = b.pv[b.at(w, t - 1)], mv = b.mv[b.at(w, t - 1)];
+            uint32_t pv, mv;
+            int32_t sc;
+            if (LDS_STATE) { pv = cs.pv[w]; mv = cs.mv[w]; sc = (int32_t)cs.score[w]; }
+            else { pv = b.pv[b.at(w, t - 1)]; mv = b.mv[b.at(w, t - 1)]; sc = b.score[b.at(w, t - 1)]; }
             const uint32_t hbit = 1u << (w == n_words - 1 ? width - (n_words - 1) * kWord - 1 : kWord - 1);
             const uint32_t eq   = get_pattern(patterns, n_words_query, w, pattern_offset, tc);
             h                   = advance_word(hbit, eq, pv, mv, h, nullptr);
-            b.score[b.at(w, t)] = b.score[b.at(w, t - 1)] + h;
+            sc += h;
+            b.score[b.at(w, t)] = sc;
             b.pv[b.at(w, t)]    = pv;
             b.mv[b.at(w, t)]    = mv;
+            if (LDS_STATE) { cs.pv[w] = pv; cs.mv[w] = mv; cs.score[w] = (uint32_t)sc; }
         }
     }
 }
 
 // diagonal part: the band slides one row per column (myers_gpu.cu:676-751)
-__device__ void diagonal_band(Band& b, const uint32_t* patterns, int32_t n_words_query, const char* target, int32_t t_begin,
-                              int32_t t_end, int32_t band_width, int32_t n_words, int32_t pattern_offset)
+template <bool LDS_STATE, typename Table>
+__device__ void diagonal_band(Band& b, const ColumnState& cs, const Table& patterns, int32_t n_words_query, const char* target,
+                              int32_t t_begin, int32_t t_end, int32_t band_width, int32_t n_words, int32_t pattern_offset)
 {
+    char tc_next = t_begin < t_end ? target[t_begin - 1] : 0;
     for (int32_t t = t_begin; t < t_end; ++t)
     {
         int32_t h     = 1;
-        const char tc = target[t - 1];
+        const char tc = tc_next;
+        if (t + 1 < t_end) tc_next = target[t];
+        // word w of the new column needs words w and w + 1 of the previous one; the column state is updated in
+        // place in increasing w, so word w + 1 still holds the previous column when word w is computed
+        uint32_t cur_pv, cur_mv;
+        if (LDS_STATE) { cur_pv = cs.pv[0]; cur_mv = cs.mv[0]; }
+        else { cur_pv = b.pv[b.at(0, t - 1)]; cur_mv = b.mv[b.at(0, t - 1)]; }
         for (int32_t w = 0; w < n_words; ++w)
         {
-            uint32_t pv = b.pv[b.at(w, t - 1)] >> 1, mv = b.mv[b.at(w, t - 1)] >> 1;
+            uint32_t pv = cur_pv >> 1, mv = cur_mv >> 1;
+            int32_t sc;
+            if (LDS_STATE) sc = (int32_t)cs.score[w];
+            else sc = b.score[b.at(w, t - 1)];
             if (w + 1 < n_words)
             {
-                pv |= b.pv[b.at(w + 1, t - 1)] << (kWord - 1);
-                mv |= b.mv[b.at(w + 1, t - 1)] << (kWord - 1);
+                if (LDS_STATE) { cur_pv = cs.pv[w + 1]; cur_mv = cs.mv[w + 1]; }
+                else { cur_pv = b.pv[b.at(w + 1, t - 1)]; cur_mv = b.mv[b.at(w + 1, t - 1)]; }
+                pv |= cur_pv << (kWord - 1);
+                mv |= cur_mv << (kWord - 1);
             }
             const uint32_t eq  = get_pattern(patterns, n_words_query, w, pattern_offset + t - t_begin + 1, tc);
             const uint32_t drb = 1u << (w == n_words - 1 ? band_width - (n_words - 1) * kWord - 2 : kWord - 2);
@@ -147,10 +185,12 @@ __device__ void diagonal_band(Band& b, const uint32_t* patterns, int32_t n_words
             int32_t hy;
             const int32_t hx   = advance_word(drb, eq, pv, mv, h, &hy);
             const int32_t down = ((pv & ddb) ? 1 : 0) - ((mv & ddb) ? 1 : 0);
-            b.score[b.at(w, t)] = b.score[b.at(w, t - 1)] + hx + down;
+            sc += hx + down;
+            b.score[b.at(w, t)] = sc;
             b.pv[b.at(w, t)]    = pv;
             b.mv[b.at(w, t)]    = mv;
-            h                   = hy; // the horizontal delta of the word's last row enters the next word
+            if (LDS_STATE) { cs.pv[w] = pv; cs.mv[w] = mv; cs.score[w] = (uint32_t)sc; }
+            h = hy; // the horizontal delta of the word's last row enters the next word
         }
     }
 }
@@ -256,11 +296,17 @@ struct KernelArgs
     int32_t* run_counts;        // [n] runs per pair, -1: no result
     uint32_t* metadata;         // [n]
     uint64_t* band_cells;       // optional [n]
+    int32_t lds_pattern_words;  // LDS_STATE kernels: per-lane words of the pattern table / of one column-state array
+    int32_t lds_band_words;
 };
 
-// per-alignment body of myers_banded_kernel (myers_gpu.cu:897-1021)
+// per-alignment body of myers_banded_kernel (myers_gpu.cu:897-1021).
+// LDS_STATE: dynamic LDS holds, per lane, the query's pattern table (4 words per query word) followed by the column
+// state (pv, mv, score for a.lds_band_words band words); the launcher only picks it when every pair of the batch fits.
+template <bool LDS_STATE>
 __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
 {
+    extern __shared__ uint32_t myers_lds[];
     const int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= a.n) return;
     const int32_t idx        = a.order[slot];
@@ -303,15 +349,51 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
     b.pv            = base;
     b.mv            = base + max_elems;
     b.score         = reinterpret_cast<int32_t*>(base + 2 * max_elems);
-    uint32_t* patterns = base + 3 * max_elems;
+    uint32_t* hbm_patterns = base + 3 * max_elems;
     b.n_rows        = 0;
+    // pattern table: LDS (per lane) or the pair's HBM workspace
+    const LaneArray lds_patterns{myers_lds + (threadIdx.x & 63)};
+    ColumnState cs{};
+    if (LDS_STATE)
+    {
+        uint32_t* state = myers_lds + (size_t)a.lds_pattern_words * 64 + (threadIdx.x & 63);
+        cs.pv    = LaneArray{state};
+        cs.mv    = LaneArray{state + (size_t)a.lds_band_words * 64};
+        cs.score = LaneArray{state + (size_t)a.lds_band_words * 128};
+    }
     for (int32_t w = 0; w < n_words; ++w)
     {
-        patterns[w * 4 + 0] = make_pattern('A', query, query_size, w * kWord);
-        patterns[w * 4 + 1] = make_pattern('C', query, query_size, w * kWord);
-        patterns[w * 4 + 2] = make_pattern('T', query, query_size, w * kWord);
-        patterns[w * 4 + 3] = make_pattern('G', query, query_size, w * kWord);
+        const uint32_t pa = make_pattern('A', query, query_size, w * kWord), pc = make_pattern('C', query, query_size, w * kWord),
+                       pt = make_pattern('T', query, query_size, w * kWord), pg = make_pattern('G', query, query_size, w * kWord);
+        if (LDS_STATE)
+        {
+            lds_patterns[w * 4 + 0] = pa; lds_patterns[w * 4 + 1] = pc; lds_patterns[w * 4 + 2] = pt; lds_patterns[w * 4 + 3] = pg;
+        }
+        else
+        {
+            hbm_patterns[w * 4 + 0] = pa; hbm_patterns[w * 4 + 1] = pc; hbm_patterns[w * 4 + 2] = pt; hbm_patterns[w * 4 + 3] = pg;
+        }
     }
+    // the two table flavours share the code below through a small dispatch
+    auto run_stripes = [&](auto patterns, int32_t p, int32_t n_words_band, int32_t band_width, int32_t& diagonal_begin,
+                           int32_t& diagonal_end) {
+        if (band_width >= query_size)
+        {
+            diagonal_begin = target_size + 1;
+            diagonal_end   = target_size + 1;
+            horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, 1, target_size + 1, query_size, n_words_band, 0);
+        }
+        else
+        {
+            const int32_t symmetric = (band_width - min(1 + 2 * p + dlen, query_size) == 0) ? 1 : 0;
+            diagonal_begin = query_size < target_size ? target_size - query_size + p + 2 : p + 2 + (1 - symmetric);
+            diagonal_end   = query_size < target_size ? query_size - p + symmetric : query_size - (query_size - target_size) - p + 1;
+            horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, 1, diagonal_begin, band_width, n_words_band, 0);
+            diagonal_band<LDS_STATE>(b, cs, patterns, n_words, target, diagonal_begin, diagonal_end, band_width, n_words_band, 0);
+            horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, diagonal_end, target_size + 1, band_width, n_words_band,
+                                       query_size - band_width);
+        }
+    };
 
     int32_t estimate = max(1, dlen + min(target_size, query_size) / 20);
     int32_t diagonal_begin = -1, diagonal_end = -1, band_width = 0;
@@ -341,25 +423,14 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
         // myers_compute_scores_edit_dist_banded (:753-846)
         for (int32_t w = 0; w < n_words_band; ++w)
         {
+            const int32_t s0    = min((w + 1) * kWord, band_width);
             b.pv[b.at(w, 0)]    = ~0u;
             b.mv[b.at(w, 0)]    = 0u;
-            b.score[b.at(w, 0)] = min((w + 1) * kWord, band_width);
+            b.score[b.at(w, 0)] = s0;
+            if (LDS_STATE) { cs.pv[w] = ~0u; cs.mv[w] = 0u; cs.score[w] = (uint32_t)s0; }
         }
-        if (band_width >= query_size)
-        {
-            diagonal_begin = target_size + 1;
-            diagonal_end   = target_size + 1;
-            horizontal_band(b, patterns, n_words, target, 1, target_size + 1, query_size, n_words_band, 0);
-        }
-        else
-        {
-            const int32_t symmetric = (band_width - min(1 + 2 * p + dlen, query_size) == 0) ? 1 : 0;
-            diagonal_begin = query_size < target_size ? target_size - query_size + p + 2 : p + 2 + (1 - symmetric);
-            diagonal_end   = query_size < target_size ? query_size - p + symmetric : query_size - (query_size - target_size) - p + 1;
-            horizontal_band(b, patterns, n_words, target, 1, diagonal_begin, band_width, n_words_band, 0);
-            diagonal_band(b, patterns, n_words, target, diagonal_begin, diagonal_end, band_width, n_words_band, 0);
-            horizontal_band(b, patterns, n_words, target, diagonal_end, target_size + 1, band_width, n_words_band, query_size - band_width);
-        }
+        if (LDS_STATE) run_stripes(lds_patterns, p, n_words_band, band_width, diagonal_begin, diagonal_end);
+        else run_stripes((const uint32_t*)hbm_patterns, p, n_words_band, band_width, diagonal_begin, diagonal_end);
         const int32_t dist = n_words_band > 0 ? b.score[b.at(n_words_band - 1, target_size)] : target_size;
         if (dist <= estimate || band_width == query_size) break;
         if (band_width == max_bw)
@@ -552,7 +623,27 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
 
     hipLaunchKernelGGL(ws_offsets_kernel, dim3(1), dim3(1024), 0, stream, args->sequence_starts, args->max_bandwidths,
                        const_cast<int64_t*>(ka.ws_offsets), identity, n);
-    hipLaunchKernelGGL(myers_banded_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, ka);
+    // LDS flavour when every pair's pattern table and column state fit one wave's share (<= 1 KiB per lane)
+    bool use_lds = false;
+    if (args->max_query_length > 0 && args->max_bandwidth_hint > 0)
+    {
+        const int32_t qwords = (args->max_query_length + kWord - 1) / kWord;
+        const int32_t bwords = (std::min(args->max_bandwidth_hint + 2, args->max_query_length) + kWord - 1) / kWord + 1;
+        const int32_t per_lane_words = 4 * qwords + 3 * bwords;
+        if (per_lane_words <= 252)
+        {
+            use_lds              = true;
+            ka.lds_pattern_words = 4 * qwords;
+            ka.lds_band_words    = bwords;
+        }
+    }
+    const char* myers_dbg = std::getenv("GWHIP_MYERS_HBM_STATE"); // debugging: force the HBM-state kernel
+    if (myers_dbg && myers_dbg[0] == '1') use_lds = false;
+    if (use_lds)
+        hipLaunchKernelGGL(myers_banded_kernel<true>, dim3((n + 63) / 64), dim3(64),
+                           (size_t)(ka.lds_pattern_words + 3 * ka.lds_band_words) * 64 * sizeof(uint32_t), stream, ka);
+    else
+        hipLaunchKernelGGL(myers_banded_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, stream, ka);
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, ka.run_counts, args->result_starts, n);
     hipLaunchKernelGGL(compact_kernel, dim3(n), dim3(64), 0, stream, ka, args->results, args->result_counts,
                        args->result_starts);

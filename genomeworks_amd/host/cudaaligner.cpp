@@ -221,6 +221,10 @@ void BandedAligner::launch()
     a.total_sequence_length = seq_starts_h_.back();
     a.scheduling_index      = d_order_;
     a.band_cells            = d_cells_;
+    // hints for the LDS-cached kernel variant: longest query and widest band of this batch
+    for (size_t i = 0; i + 2 < seq_starts_h_.size(); i += 2)
+        a.max_query_length = std::max(a.max_query_length, static_cast<int32_t>(seq_starts_h_[i + 1] - seq_starts_h_[i]));
+    for (int32_t bw : max_bandwidths_h_) a.max_bandwidth_hint = std::max(a.max_bandwidth_hint, bw);
     const int rc            = gwhip_myers_banded(&a, stream_);
     if (rc != 0)
     {

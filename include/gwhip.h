@@ -180,6 +180,9 @@ typedef struct gwhip_myers_args
                                         (aligner_global_myers_banded.cpp:306-309); NULL = input order */
     uint64_t* band_cells;            /* optional device uint64[n]: 32*n_words_band*target_len summed over attempts */
     int32_t* run_counts_out;         /* reserved */
+    int32_t max_query_length;        /* optional hints (0 = unknown): longest query and largest max_bandwidth of the batch; */
+    int32_t max_bandwidth_hint;      /* when both are known and small enough, the column state and the query patterns
+                                        of every pair are kept in LDS instead of being re-read from the HBM workspace */
 } gwhip_myers_args;
 
 size_t gwhip_myers_banded_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host,
