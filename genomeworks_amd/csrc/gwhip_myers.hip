@@ -11,7 +11,8 @@
 // the lanes of a wave have similar trip counts.
 //
 // Per pair the kernel keeps pv, mv (uint32) and score (int32) for every (band word, target column) in a
-// column-major workspace because the backtrace needs every column (12 B per 32-cell word-column: the
+// column-major workspace -- interleaved across the 64 pairs of a wavefront, so that the lanes' stores of one
+// (word, column) step form one contiguous 256-byte write -- because the backtrace needs every column (12 B per 32-cell word-column: the
 // algorithmic bytes of SURVEY.md 8(d)). Results are first written into the pair's own slot
 // [sequence_starts[2i], sequence_starts[2i+2]) -- a run-length encoding never exceeds |q|+|t| entries -- and a
 // second pass packs them behind an exclusive scan of the run counts, so the packed order is the input order.
@@ -40,7 +41,8 @@ struct Band
     uint32_t* mv;
     int32_t* score;
     int32_t n_rows; // words in the band
-    __device__ __forceinline__ size_t at(int32_t w, int32_t t) const { return (size_t)t * n_rows + w; }
+    // workspace arrays are interleaved across the 64 lanes of a wave: element k of a lane at word k * 64 (+ lane)
+    __device__ __forceinline__ size_t at(int32_t w, int32_t t) const { return ((size_t)t * n_rows + w) * 64; }
 };
 
 // Per-lane arrays in LDS, element e of lane l at word e * 64 + l (conflict-free across the lanes of a wave).
@@ -58,6 +60,20 @@ struct ColumnState
 };
 
 __device__ __forceinline__ int32_t ceil_div(int32_t a, int32_t b) { return (a + b - 1) / b; }
+
+// workspace need of one pair: `me` words in each of the pv / mv / score arrays (band words of the widest attempt x
+// (target + 1) columns, compute_matrix_size_for_alignment, aligner_global_myers_banded.cpp:47-55) and `pw` words of
+// query patterns
+__host__ __device__ inline void pair_ws_dims(int32_t q, int32_t t, int32_t max_bw, int64_t& me, int32_t& pw)
+{
+    me = 0;
+    pw = 0;
+    if (q == 0 || t == 0) return;
+    const int32_t pmax = (max_bw + 1) / 2;
+    const int32_t bw   = (1 + 2 * pmax) < q ? (1 + 2 * pmax) : q;
+    me                 = (int64_t)((bw + 31) / 32) * ((int64_t)t + 1);
+    pw                 = ((q + 31) / 32) * 4;
+}
 
 // bit pattern of query[offset .. offset+32) == x   (myers_gpu.cu:196-208)
 __device__ __forceinline__ uint32_t make_pattern(char x, const char* query, int32_t query_size, int32_t offset)
@@ -289,7 +305,8 @@ struct KernelArgs
     const int64_t* starts;
     const int32_t* max_bandwidths;
     const int32_t* order;       // scheduling order (longest first)
-    const int64_t* ws_offsets;  // per pair: first uint32 element of its workspace
+    const int64_t* ws_offsets;  // per wave of 64 slots: first uint32 element of its interleaved workspace region
+    int64_t ws_capacity_words;  // words available behind ws (guards against a workspace sized for another order)
     uint32_t* ws;               // [pv | mv | score | patterns] per pair
     int8_t* slot_ops;           // per-pair slots, indexed by sequence offset
     int32_t* slot_counts;
@@ -308,6 +325,20 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
 {
     extern __shared__ uint32_t myers_lds[];
     const int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    // the wave's workspace region is sized by its largest pair: reduce before any lane leaves
+    int64_t me_max = 0;
+    int32_t pw_max = 0;
+    if (slot < a.n)
+    {
+        const int32_t i = a.order[slot];
+        pair_ws_dims((int32_t)(a.starts[2 * i + 1] - a.starts[2 * i]), (int32_t)(a.starts[2 * i + 2] - a.starts[2 * i + 1]),
+                     a.max_bandwidths[i], me_max, pw_max);
+    }
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        me_max = max(me_max, (int64_t)__shfl_xor((long long)me_max, off));
+        pw_max = max(pw_max, __shfl_xor(pw_max, off));
+    }
     if (slot >= a.n) return;
     const int32_t idx        = a.order[slot];
     const char* query        = a.sequences + a.starts[2 * idx];
@@ -344,12 +375,19 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
     const int32_t n_words   = ceil_div(query_size, kWord);
     const int32_t pmax      = (max_bw + 1) / 2;
     const int64_t max_elems = (int64_t)ceil_div(min(1 + 2 * pmax, query_size), kWord) * ((int64_t)target_size + 1);
-    uint32_t* base          = a.ws + a.ws_offsets[idx];
+    const int64_t region    = a.ws_offsets[blockIdx.x];
+    if (region + 64 * (3 * me_max + pw_max) > a.ws_capacity_words) // workspace was sized for a different order
+    {
+        a.run_counts[idx] = -1;
+        a.metadata[idx]   = (uint32_t)idx;
+        return;
+    }
+    uint32_t* base          = a.ws + region + (threadIdx.x & 63);
     Band b;
     b.pv            = base;
-    b.mv            = base + max_elems;
-    b.score         = reinterpret_cast<int32_t*>(base + 2 * max_elems);
-    uint32_t* hbm_patterns = base + 3 * max_elems;
+    b.mv            = base + 64 * me_max;
+    b.score         = reinterpret_cast<int32_t*>(base + 128 * me_max);
+    const LaneArray hbm_patterns{base + 192 * me_max};
     b.n_rows        = 0;
     // pattern table: LDS (per lane) or the pair's HBM workspace
     const LaneArray lds_patterns{myers_lds + (threadIdx.x & 63)};
@@ -430,7 +468,7 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
             if (LDS_STATE) { cs.pv[w] = ~0u; cs.mv[w] = 0u; cs.score[w] = (uint32_t)s0; }
         }
         if (LDS_STATE) run_stripes(lds_patterns, p, n_words_band, band_width, diagonal_begin, diagonal_end);
-        else run_stripes((const uint32_t*)hbm_patterns, p, n_words_band, band_width, diagonal_begin, diagonal_end);
+        else run_stripes(hbm_patterns, p, n_words_band, band_width, diagonal_begin, diagonal_end);
         const int32_t dist = n_words_band > 0 ? b.score[b.at(n_words_band - 1, target_size)] : target_size;
         if (dist <= estimate || band_width == query_size) break;
         if (band_width == max_bw)
@@ -518,32 +556,35 @@ static WsPlan plan_fixed(int32_t n, int64_t total_len)
     return p;
 }
 
-__host__ __device__ inline int64_t pair_ws_elems(int32_t q, int32_t t, int32_t max_bw)
-{
-    if (q == 0 || t == 0) return 0;
-    const int32_t pmax = (max_bw + 1) / 2;
-    const int32_t bw   = (1 + 2 * pmax) < q ? (1 + 2 * pmax) : q;
-    const int64_t me   = (int64_t)((bw + 31) / 32) * ((int64_t)t + 1);
-    const int64_t e    = 3 * me + (int64_t)((q + 31) / 32) * 4;
-    return (e + 3) & ~int64_t(3);
-}
-
-// per-pair workspace sizes, then an in-place exclusive scan by one workgroup
-__global__ __launch_bounds__(1024) void ws_offsets_kernel(const int64_t* starts, const int32_t* max_bws, int64_t* offsets,
-                                                          int32_t* identity, int32_t n)
+// per-wave workspace sizes (64 slots of the processing order each), then an in-place exclusive scan by one workgroup
+__global__ __launch_bounds__(1024) void ws_offsets_kernel(const int64_t* starts, const int32_t* max_bws, const int32_t* order,
+                                                          int64_t* offsets, int32_t* identity, int32_t n)
 {
     __shared__ int64_t part[1024];
     __shared__ int64_t carry;
     if (threadIdx.x == 0) carry = 0;
+    for (int32_t i = threadIdx.x; i < n; i += 1024) identity[i] = i;
+    __threadfence();
     __syncthreads();
-    for (int32_t base = 0; base < n; base += 1024)
+    const int32_t n_waves = (n + 63) / 64;
+    for (int32_t base = 0; base < n_waves; base += 1024)
     {
-        const int32_t i = base + threadIdx.x;
-        int64_t v       = 0;
-        if (i < n)
+        const int32_t wv = base + threadIdx.x;
+        int64_t v        = 0;
+        if (wv < n_waves)
         {
-            v = pair_ws_elems((int32_t)(starts[2 * i + 1] - starts[2 * i]), (int32_t)(starts[2 * i + 2] - starts[2 * i + 1]), max_bws[i]);
-            identity[i] = i;
+            int64_t me_max = 0;
+            int32_t pw_max = 0;
+            for (int32_t s = wv * 64; s < min(n, wv * 64 + 64); s++)
+            {
+                const int32_t i = order[s];
+                int64_t me;
+                int32_t pw;
+                pair_ws_dims((int32_t)(starts[2 * i + 1] - starts[2 * i]), (int32_t)(starts[2 * i + 2] - starts[2 * i + 1]), max_bws[i], me, pw);
+                me_max = max(me_max, me);
+                pw_max = max(pw_max, pw);
+            }
+            v = 64 * (3 * me_max + pw_max);
         }
         part[threadIdx.x] = v;
         __syncthreads();
@@ -554,12 +595,12 @@ __global__ __launch_bounds__(1024) void ws_offsets_kernel(const int64_t* starts,
             part[threadIdx.x] += t;
             __syncthreads();
         }
-        if (i < n) offsets[i] = carry + part[threadIdx.x] - v;
+        if (wv < n_waves) offsets[wv] = carry + part[threadIdx.x] - v;
         __syncthreads();
         if (threadIdx.x == 1023) carry += part[1023];
         __syncthreads();
     }
-    if (threadIdx.x == 0) offsets[n] = carry;
+    if (threadIdx.x == 0) offsets[n_waves] = carry;
 }
 
 static int fail(hipError_t e, const char* what)
@@ -576,17 +617,35 @@ using namespace gwhip::myers;
 
 extern "C" {
 
-size_t gwhip_myers_banded_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host,
-                                          const int32_t* max_bandwidths_host)
+size_t gwhip_myers_banded_workspace_bytes_ordered(int32_t n_alignments, const int64_t* sequence_starts_host,
+                                                  const int32_t* max_bandwidths_host, const int32_t* scheduling_index_host)
 {
     if (n_alignments <= 0) return 256;
     const WsPlan p = plan_fixed(n_alignments, sequence_starts_host[2 * (size_t)n_alignments]);
-    int64_t elems  = 0;
-    for (int32_t i = 0; i < n_alignments; i++)
-        elems += pair_ws_elems((int32_t)(sequence_starts_host[2 * i + 1] - sequence_starts_host[2 * i]),
-                               (int32_t)(sequence_starts_host[2 * i + 2] - sequence_starts_host[2 * i + 1]),
-                               max_bandwidths_host[i]);
-    return p.off_ws + (size_t)elems * 4 + 256;
+    int64_t words  = 0;
+    for (int32_t w0 = 0; w0 < n_alignments; w0 += 64) // one interleaved region per wave of 64 slots
+    {
+        int64_t me_max = 0;
+        int32_t pw_max = 0;
+        for (int32_t s = w0; s < std::min(n_alignments, w0 + 64); s++)
+        {
+            const int32_t i = scheduling_index_host ? scheduling_index_host[s] : s;
+            int64_t me;
+            int32_t pw;
+            pair_ws_dims((int32_t)(sequence_starts_host[2 * i + 1] - sequence_starts_host[2 * i]),
+                         (int32_t)(sequence_starts_host[2 * i + 2] - sequence_starts_host[2 * i + 1]), max_bandwidths_host[i], me, pw);
+            me_max = std::max(me_max, me);
+            pw_max = std::max(pw_max, pw);
+        }
+        words += 64 * (3 * me_max + pw_max);
+    }
+    return p.off_ws + (size_t)words * 4 + 256;
+}
+
+size_t gwhip_myers_banded_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host,
+                                          const int32_t* max_bandwidths_host)
+{
+    return gwhip_myers_banded_workspace_bytes_ordered(n_alignments, sequence_starts_host, max_bandwidths_host, nullptr);
 }
 
 int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
@@ -621,8 +680,9 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
     ka.ws             = reinterpret_cast<uint32_t*>(ws + p.off_ws);
     ka.metadata       = args->result_metadata;
 
+    ka.ws_capacity_words = ((int64_t)args->workspace_bytes - (int64_t)p.off_ws) / 4;
     hipLaunchKernelGGL(ws_offsets_kernel, dim3(1), dim3(1024), 0, stream, args->sequence_starts, args->max_bandwidths,
-                       const_cast<int64_t*>(ka.ws_offsets), identity, n);
+                       ka.order, const_cast<int64_t*>(ka.ws_offsets), identity, n);
     // LDS flavour when every pair's pattern table and column state fit one wave's share (<= 1 KiB per lane)
     bool use_lds = false;
     if (args->max_query_length > 0 && args->max_bandwidth_hint > 0)

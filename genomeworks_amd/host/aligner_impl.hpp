@@ -63,6 +63,7 @@ private:
     std::vector<int32_t> order_h_;
     std::vector<std::shared_ptr<Alignment>> alignments_;
     size_t workspace_bytes_estimate_ = 0;
+    size_t largest_wave_ws_          = 0;
     size_t workspace_bytes_          = 0;
     bool launched_                   = false;
     int64_t total_length_h_          = 0;

@@ -89,6 +89,7 @@ void BandedAligner::reset_data()
     seq_starts_h_.assign(1, 0);
     max_bandwidths_h_.clear();
     workspace_bytes_estimate_ = 0;
+    largest_wave_ws_          = 0;
     launched_                 = false;
 }
 
@@ -138,10 +139,14 @@ StatusType BandedAligner::add_alignment(int32_t max_bandwidth, const char* query
     }
     // device bytes if this pair joins the batch: its matrices + its share of the fixed arrays
     const int64_t starts2[3] = {0, query_length, static_cast<int64_t>(query_length) + target_length};
-    const size_t pair_ws      = gwhip_myers_banded_workspace_bytes(1, starts2, &max_bandwidth);
+    // the workspace interleaves the 64 pairs of a wave and pads them to the largest of the wave: with the pairs
+    // sorted by length that costs at most about one wave of the largest pair on top of the sum
+    const size_t wave_ws      = gwhip_myers_banded_workspace_bytes(1, starts2, &max_bandwidth); // a whole wave of this pair
+    const size_t pair_ws      = wave_ws / 64 + 64;
+    largest_wave_ws_          = std::max(largest_wave_ws_, wave_ws);
     const size_t per_pair_io  = static_cast<size_t>(query_length + target_length) * (1 + 1 + 4) + 64;
-    const size_t new_estimate = workspace_bytes_estimate_ + pair_ws + per_pair_io;
-    if (static_cast<int64_t>(new_estimate) + (1 << 20) >= max_device_memory_)
+    const size_t new_estimate = workspace_bytes_estimate_ + pair_ws + pair_ws / 4 + per_pair_io;
+    if (static_cast<int64_t>(new_estimate + largest_wave_ws_) + (1 << 20) >= max_device_memory_)
     {
         if (n_alignments == 0) throw std::runtime_error("Could not fit alignment into device or host memory.");
         return StatusType::exceeded_max_alignments;
@@ -171,7 +176,7 @@ StatusType BandedAligner::align_all()
         return (seq_starts_h_[2 * a + 2] - seq_starts_h_[2 * a]) > (seq_starts_h_[2 * b + 2] - seq_starts_h_[2 * b]);
     });
 
-    workspace_bytes_ = gwhip_myers_banded_workspace_bytes(n, seq_starts_h_.data(), max_bandwidths_h_.data());
+    workspace_bytes_ = gwhip_myers_banded_workspace_bytes_ordered(n, seq_starts_h_.data(), max_bandwidths_h_.data(), order.data());
     size_t off       = 0;
     auto take        = [&](size_t b) { size_t o = off; off += up256(b); return o; };
     const size_t o_seq = take(static_cast<size_t>(total_len) + 16), o_starts = take((2 * static_cast<size_t>(n) + 1) * 8);

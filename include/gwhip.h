@@ -187,6 +187,10 @@ typedef struct gwhip_myers_args
 
 size_t gwhip_myers_banded_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host,
                                           const int32_t* max_bandwidths_host);
+/* The workspace is laid out per wave of 64 pairs in PROCESSING order (scheduling_index, or input order when NULL):
+   size it with the same order that gwhip_myers_banded will be given (pairs whose wave does not fit report no result). */
+size_t gwhip_myers_banded_workspace_bytes_ordered(int32_t n_alignments, const int64_t* sequence_starts_host,
+                                                  const int32_t* max_bandwidths_host, const int32_t* scheduling_index_host);
 int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream);
 
 /* ---- misc ---- */
