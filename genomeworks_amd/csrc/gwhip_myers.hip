@@ -240,11 +240,38 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
     int32_t myscore          = i > 0 ? b.score[b.at((i - 1) / kWord, j)] : 0;
     int32_t pos = 0, r_count = 0;
     int8_t prev_r = -1;
+    // The three neighbour scores of a step are fetched together (nine independent loads, one memory round trip);
+    // neighbours that the reference derives from a formula instead of the matrix are clamped for the fetch and
+    // replaced afterwards.
+    auto fetch3 = [&](int32_t i0, int32_t j0, int32_t i1, int32_t j1, int32_t i2, int32_t j2, int32_t& s0, int32_t& s1, int32_t& s2) {
+        const int32_t rows = band_width;
+        auto ref = [&](int32_t i, int32_t j, size_t& idx, uint32_t& mask) {
+            i                 = min(max(i, 1), rows);
+            j                 = max(j, 0);
+            const int32_t w   = (i - 1) / kWord;
+            const int32_t bit = (i - 1) % kWord;
+            mask              = bit == 31 ? 0u : ((~1u) << bit);
+            if (w == b.n_rows - 1) mask &= last_mask;
+            idx = b.at(w, j);
+        };
+        size_t x0, x1, x2;
+        uint32_t m0, m1, m2;
+        ref(i0, j0, x0, m0);
+        ref(i1, j1, x1, m1);
+        ref(i2, j2, x2, m2);
+        const int32_t c0 = b.score[x0], c1 = b.score[x1], c2 = b.score[x2];
+        const uint32_t p0 = b.pv[x0], p1 = b.pv[x1], p2 = b.pv[x2];
+        const uint32_t n0 = b.mv[x0], n1 = b.mv[x1], n2 = b.mv[x2];
+        s0 = c0 - __popc(m0 & p0) + __popc(m0 & n0);
+        s1 = c1 - __popc(m1 & p1) + __popc(m1 & n1);
+        s2 = c2 - __popc(m2 & p2) + __popc(m2 & n2);
+    };
     while (j >= diagonal_end)
     {
-        const int32_t above = i <= 1 ? (last_diag + j - diagonal_end) : cell_score(b, i - 1, j, last_mask);
-        const int32_t diag  = i <= 1 ? (last_diag + j - 1 - diagonal_end) : cell_score(b, i - 1, j - 1, last_mask);
-        const int32_t left  = i < 1 ? (last_diag + j - 1 - diagonal_end) : cell_score(b, i, j - 1, last_mask);
+        int32_t above, diag, left;
+        fetch3(i - 1, j, i - 1, j - 1, i, j - 1, above, diag, left);
+        if (i <= 1) { above = last_diag + j - diagonal_end; diag = last_diag + j - 1 - diagonal_end; }
+        if (i < 1) left = last_diag + j - 1 - diagonal_end;
         int8_t r;
         if (left + 1 == myscore) { r = kInsertion; myscore = left; --j; }
         else if (above + 1 == myscore) { r = kDeletion; myscore = above; --i; }
@@ -253,9 +280,11 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
     }
     while (j >= diagonal_begin)
     {
-        const int32_t above = i <= 1 ? out_of_band : cell_score(b, i - 1, j, last_mask);
-        const int32_t diag  = i <= 0 ? j - 1 : cell_score(b, i, j - 1, last_mask);
-        const int32_t left  = i >= band_width ? out_of_band : cell_score(b, i + 1, j - 1, last_mask);
+        int32_t above, diag, left;
+        fetch3(i - 1, j, i, j - 1, i + 1, j - 1, above, diag, left);
+        if (i <= 1) above = out_of_band;
+        if (i <= 0) diag = j - 1;
+        if (i >= band_width) left = out_of_band;
         int8_t r;
         if (left + 1 == myscore) { r = kInsertion; myscore = left; ++i; --j; }
         else if (above + 1 == myscore) { r = kDeletion; myscore = above; --i; }
@@ -264,9 +293,10 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
     }
     while (i > 0 && j > 0)
     {
-        const int32_t above = i == 1 ? j : cell_score(b, i - 1, j, last_mask);
-        const int32_t diag  = i == 1 ? j - 1 : cell_score(b, i - 1, j - 1, last_mask);
-        const int32_t left  = i > band_width ? out_of_band : cell_score(b, i, j - 1, last_mask);
+        int32_t above, diag, left;
+        fetch3(i - 1, j, i - 1, j - 1, i, j - 1, above, diag, left);
+        if (i == 1) { above = j; diag = j - 1; }
+        if (i > band_width) left = out_of_band;
         int8_t r;
         if (left + 1 == myscore) { r = kInsertion; myscore = left; --j; }
         else if (above + 1 == myscore) { r = kDeletion; myscore = above; --i; }
@@ -315,6 +345,7 @@ struct KernelArgs
     uint64_t* band_cells;       // optional [n]
     int32_t lds_pattern_words;  // LDS_STATE kernels: per-lane words of the pattern table / of one column-state array
     int32_t lds_band_words;
+    int32_t debug_skip;         // profiling ablations (GWHIP_MYERS_SKIP): 1 = no backtrace, 2 = no forward stripes, 4 = no pattern build
 };
 
 // per-alignment body of myers_banded_kernel (myers_gpu.cu:897-1021).
@@ -399,10 +430,22 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
         cs.mv    = LaneArray{state + (size_t)a.lds_band_words * 64};
         cs.score = LaneArray{state + (size_t)a.lds_band_words * 128};
     }
-    for (int32_t w = 0; w < n_words; ++w)
+    for (int32_t w = 0; w < ((a.debug_skip & 4) ? 0 : n_words); ++w)
     {
-        const uint32_t pa = make_pattern('A', query, query_size, w * kWord), pc = make_pattern('C', query, query_size, w * kWord),
-                       pt = make_pattern('T', query, query_size, w * kWord), pg = make_pattern('G', query, query_size, w * kWord);
+        // the four patterns of a query word in one sweep over its characters (make_pattern x 4, one load per character)
+        uint32_t pa = 0, pc = 0, pt = 0, pg = 0;
+        {
+            const int32_t nchar = min(query_size - w * kWord, kWord);
+            const char* qw      = query + w * kWord;
+            for (int32_t i = 0; i < nchar; ++i)
+            {
+                const char ch = qw[i];
+                pa |= (uint32_t)(ch == 'A') << i;
+                pc |= (uint32_t)(ch == 'C') << i;
+                pt |= (uint32_t)(ch == 'T') << i;
+                pg |= (uint32_t)(ch == 'G') << i;
+            }
+        }
         if (LDS_STATE)
         {
             lds_patterns[w * 4 + 0] = pa; lds_patterns[w * 4 + 1] = pc; lds_patterns[w * 4 + 2] = pt; lds_patterns[w * 4 + 3] = pg;
@@ -467,7 +510,8 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
             b.score[b.at(w, 0)] = s0;
             if (LDS_STATE) { cs.pv[w] = ~0u; cs.mv[w] = 0u; cs.score[w] = (uint32_t)s0; }
         }
-        if (LDS_STATE) run_stripes(lds_patterns, p, n_words_band, band_width, diagonal_begin, diagonal_end);
+        if (a.debug_skip & 2) {}
+        else if (LDS_STATE) run_stripes(lds_patterns, p, n_words_band, band_width, diagonal_begin, diagonal_end);
         else run_stripes(hbm_patterns, p, n_words_band, band_width, diagonal_begin, diagonal_end);
         const int32_t dist = n_words_band > 0 ? b.score[b.at(n_words_band - 1, target_size)] : target_size;
         if (dist <= estimate || band_width == query_size) break;
@@ -478,7 +522,12 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
         }
         estimate *= 2;
     }
-    if (band_width != 0)
+    if (band_width != 0 && (a.debug_skip & 1))
+    {
+        a.run_counts[idx] = 0;
+        a.metadata[idx]   = (uint32_t)idx;
+    }
+    else if (band_width != 0)
     {
         a.run_counts[idx] = backtrace_banded(path, counts, b, diagonal_begin, diagonal_end, abs(band_width), target_size);
         a.metadata[idx]   = (uint32_t)idx | (band_width > 0 ? (1u << 31) : 0u);
@@ -696,6 +745,10 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
             ka.lds_pattern_words = 4 * qwords;
             ka.lds_band_words    = bwords;
         }
+    }
+    {
+        const char* sk = std::getenv("GWHIP_MYERS_SKIP");
+        ka.debug_skip  = sk ? std::atoi(sk) : 0;
     }
     const char* myers_dbg = std::getenv("GWHIP_MYERS_HBM_STATE"); // debugging: force the HBM-state kernel
     if (myers_dbg && myers_dbg[0] == '1') use_lds = false;
