@@ -171,3 +171,32 @@ def test_msa_static_band_256_bit_exact():
             ref = ws.process(w)
             assert status[i] == ref["status"] == 0
             assert msa[i] == ref["msa"]
+
+
+@pytest.mark.parametrize("band_mode", ["static_band", "adaptive_band"])
+def test_randomized_window_shapes_vs_oracle(band_mode):
+    """Windows of varied length / depth / divergence (incl. N bases and heavy indels) through the band-256 path:
+    consensus, coverage and status must equal the oracle's window by window."""
+    import random
+    from genomeworks_amd import synthetic
+    rng = random.Random(20240917)
+    windows = []
+    for k in range(24):
+        blen = rng.choice([300, 420, 640, 777, 900, 1000])
+        reads = rng.choice([3, 8, 17, 32])
+        mut, ins, dele = rng.choice([(5, 2, 2), (40, 20, 20), (90, 40, 40), (10, 60, 5), (10, 5, 60)])
+        w = [bytearray(r) for r in synthetic.generate_window(9000 + k, blen, reads, mut, ins, dele)]
+        if k % 5 == 0:  # sprinkle non-ACGT characters
+            for r in w:
+                for _ in range(3):
+                    r[rng.randrange(len(r))] = ord("N")
+        windows.append([bytes(r).decode() for r in w if len(r) < 1024])  # reads the batch would reject are left out
+    b = run_gpu(windows, band_mode)
+    cons, cov, status = b.get_consensus()
+    with O.Workspace(oracle_cfg(band_mode)) as ws:
+        for i, w in enumerate(windows):
+            ref = ws.process(w)
+            assert status[i] == ref["status"], (i, status[i], ref["status"])
+            if ref["status"] == 0:
+                assert cons[i] == ref["consensus"], "window %d consensus differs" % i
+                assert cov[i] == list(ref["coverage"]), "window %d coverage differs" % i
