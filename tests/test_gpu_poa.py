@@ -200,3 +200,20 @@ def test_randomized_window_shapes_vs_oracle(band_mode):
             if ref["status"] == 0:
                 assert cons[i] == ref["consensus"], "window %d consensus differs" % i
                 assert cov[i] == list(ref["coverage"]), "window %d coverage differs" % i
+
+
+def test_long_read_adaptive_msa_32bit_path():
+    """BASELINE configs[3] at reduced scale: long reads (7 kbp), adaptive band, MSA output -> 32-bit scores and ids,
+    HBM row table, multi-pass band; bit-exact vs the oracle."""
+    from genomeworks_amd import synthetic
+    windows = [[r.decode() for r in synthetic.generate_window(8800 + w, 7000, 6, 350, 120, 120)] for w in range(2)]
+    b = run_gpu(windows, "adaptive_band", max_seq=8192, max_seqs=8, output_type="msa", nodes=4 * 8192)
+    msa, status = b.get_msa()
+    cfg = oracle_cfg("adaptive_band", 8192, 8, output_mask=2, nodes=4 * 8192)
+    assert cfg.score32 == 1
+    with O.Workspace(cfg) as ws:
+        for i, w in enumerate(windows):
+            ref = ws.process(w)
+            assert status[i] == ref["status"] == 0
+            assert msa[i] == ref["msa"]
+            assert [r.replace("-", "") for r in msa[i]] == w
