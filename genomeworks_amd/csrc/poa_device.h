@@ -490,7 +490,8 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
                                                           int32_t* alignment_graph, int32_t* alignment_read,
                                                           int32_t gap_score, int32_t mismatch_score,
                                                           int32_t match_score, int32_t rerun, ScoreT* tile,
-                                                          const uint8_t* codes, uint8_t* ctile)
+                                                          const uint8_t* codes, uint8_t* ctile, int32_t dbg = 0,
+                                                          uint64_t* prof_acc = nullptr)
 {
     constexpr int kTileRows = 60, kTileCols = 64, kTileStride = 68, kReanchor = 44, kLead = 40, kHalf = 31;
     constexpr int kCodeRows = 64, kCodeCols = 64, kCodeReanchor = 60; // LDS tile of trace codes (poa_forward_packed.h)
@@ -593,20 +594,22 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     bool have = false;
     while (!(i == 0 && j == 0) && loop_count < bound)
     {
-        if (codes != nullptr && i > 0)
+        if (codes != nullptr)
         {
+            // tight loop over consecutive steps whose move code is known
+            bool stop = false;
+            while (i > 0 && loop_count < bound)
             {
                 const int32_t t   = ctop - i;
                 const int32_t off = j - code_lo(t);
-                if ((ctop < 0) | (t < 0) | (t >= kCodeReanchor) | (off < 2) | (off >= kCodeCols)) load_codes(i, j);
-            }
-            const int32_t t     = ctop - i;
-            const int32_t off   = j - code_lo(t);
-            const uint32_t code = (uint32_t)wave_first((int32_t)ctile[t * kCodeCols + off]);
-            const uint64_t riw  = wave_first64(rowinfo[i].w);
-            if (code != 0)
-            {
-                bool rerun_break = false;
+                if ((ctop < 0) | ((uint32_t)t >= (uint32_t)kCodeReanchor) | ((uint32_t)(off - 2) >= (uint32_t)(kCodeCols - 2)))
+                {
+                    load_codes(i, j);
+                    continue;
+                }
+                const uint32_t code = (uint32_t)wave_first((int32_t)ctile[t * kCodeCols + off]);
+                const uint64_t riw  = wave_first64(rowinfo[i].w);
+                if (code == 0) break; // undecided cell: recompute this step below
                 if (ADAPTIVE)
                 {
                     if (j != 0 && rerun == 0 && b.band_width < kMaxAdaptiveBand)
@@ -615,12 +618,11 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
                         if (j > threshold && j < b.max_column - threshold)
                         {
                             int32_t bs = band_start_for_row(i, b.gradient, b.band_width, b.band_shift, b.max_column);
-                            if (j <= bs + threshold) { aligned_nodes = kShiftLeft; rerun_break = true; }
-                            else if (j >= (bs + b.band_width - threshold)) { aligned_nodes = kShiftRight; rerun_break = true; }
+                            if (j <= bs + threshold) { aligned_nodes = kShiftLeft; stop = true; break; }
+                            if (j >= (bs + b.band_width - threshold)) { aligned_nodes = kShiftRight; stop = true; break; }
                         }
                     }
                 }
-                if (rerun_break) break;
                 loop_count++;
                 const bool is_vert = code >= 5, is_horiz = code == 1;
                 const uint32_t k   = is_vert ? code - 5 : code - 2;
@@ -634,8 +636,9 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
                 i    = prev_i;
                 j    = prev_j;
                 have = false;
-                continue;
             }
+            if (stop) break;
+            if ((i == 0 && j == 0) || loop_count >= bound) continue; // the outer condition ends the walk
         }
         // keep the current cell and its near predecessors inside the tile
         {
@@ -755,6 +758,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     }
     if (aligned_nodes > 0 && (aligned_nodes & (kStage - 1)) != 0)
         flush_stage(aligned_nodes & ~(kStage - 1), aligned_nodes & (kStage - 1));
+    if ((dbg & 2) && prof_acc && lane == 0) *prof_acc += (uint64_t)max(aligned_nodes, 0); // profiling: all steps
     if (loop_count >= bound) aligned_nodes = kNwLoopFailed;
     __syncthreads();
     for (int32_t k0 = lane; k0 < aligned_nodes; k0 += 4 * kWave) // 4 independent load chains per lane in flight
@@ -1372,7 +1376,8 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             aligned_nodes = traceback_banded_lanes<ScoreT, IdT, ADAPTIVE>(b, g, rowinfo, graph_count, lds_read, read_length,
                                                                           wave_first(best_i), alignment_graph, alignment_read, gap_score,
                                                                           mismatch_score, match_score, rerun, ring_base,
-                                                                          (codes_valid && code_tile && !(dbg & 64)) ? codes : nullptr, code_tile);
+                                                                          (codes_valid && code_tile && !(dbg & 64)) ? codes : nullptr, code_tile, dbg,
+                                                                          pc.acc ? &pc.acc[kPhOther] : nullptr);
             tb_done = true;
         }
     }

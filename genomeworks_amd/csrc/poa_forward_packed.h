@@ -340,7 +340,6 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
         if (cls == 2)
         {
             // ================= every predecessor (2..3, at most 7 rows back) from the LDS ring =================
-            if (dbg & 8) prof += 1;
             const int32_t cnt     = ri.cnt();
             const int32_t my_slot = (slot + 1) & (kPkSlots - 1);
             const uint32_t a0     = (a1 - 4) & (kPkSlotBytes - 1); // dword whose high half is the cell of column c
@@ -435,7 +434,6 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
         else
         {
             // ===== general row: 32-bit arithmetic, previous row from registers, any other row from the HBM matrix =====
-            if (dbg & 4) prof += 1;
             const int32_t pred_count = ri.cnt();
             const int32_t c          = bs + lane4;
             const int32_t cp0 = ((rd4 & 0xff) == base) ? match_score : mismatch_score;

@@ -415,7 +415,6 @@ __device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_
         {
             int32_t node   = pend_node;
             uint32_t lo = pend_lo, hi = pend_hi;
-            if ((dbg & 16) && prof_acc && head == tail - 1 && pend_node >= 0) *prof_acc += 1;
             if (!(head == tail - 1 && pend_node >= 0))
             {
                 node             = wave_first((int32_t)queue[head]);
