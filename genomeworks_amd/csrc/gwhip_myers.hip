@@ -652,6 +652,301 @@ __global__ __launch_bounds__(1024) void ws_offsets_kernel(const int64_t* starts,
     if (threadIdx.x == 0) offsets[n_waves] = carry;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Default aligner: Hirschberg's divide and conquer on Myers' bit-vector edit distance
+// (replaces hirschberg_myers_gpu, cudaaligner/src/hirschberg_myers_gpu.cu:575-701; constants of
+// aligner_global_hirschberg_myers.cpp:32-33). One lane per pair, like the banded kernel: the reference's warp
+// only carries the words of one query part (<= a few words for most sub-problems) and serialises everything else
+// on lane 0. What decides the output is kept exactly: the LIFO range stack (64 entries, left half pushed first),
+// the leaves (empty side, single query character, full Myers matrix + backtrace for queries shorter than 63 when
+// the matrix fits max_n_words * 64 elements), the query midpoint len / 2 and the target midpoint as the reference's
+// 32 lanes pick it among equal sums (strided first minimum per lane, strict-less shuffle-down tree).
+// Workspace per pair (interleaved across the 64 lanes of a wave, element k at word k * 64 + lane):
+//   stack[256] | fwd[T + 1] | rev[T + 1] | forward patterns[4 Qw] | reverse patterns[4 Qw] | pv[Qw] | mv[Qw] |
+//   leaf pv / mv / score [3 x leaf words]
+// ------------------------------------------------------------------------------------------------
+constexpr int32_t kHbStackEntries = 64;
+constexpr int32_t kHbSwitchToMyers = 63;
+
+struct HirschbergArgs
+{
+    int32_t n;
+    const char* sequences;
+    const int64_t* starts;
+    int32_t max_query_length;
+    int8_t* results;          // per pair: slot at starts[2 i], capacity q + t, states back to front
+    int32_t* result_lengths;  // [n]
+    uint32_t* ws;
+    const int64_t* wave_offsets; // [n_waves + 1] words
+    int64_t ws_capacity_words;
+};
+
+__host__ __device__ inline int64_t hb_leaf_words(int32_t t, int64_t max_elems)
+{
+    const int64_t two_cols = 2 * ((int64_t)t + 1);
+    return two_cols < max_elems ? two_cols : max_elems;
+}
+// words of one lane's workspace for a wave whose longest query has qw words and longest target t characters
+__host__ __device__ inline int64_t hb_lane_words(int32_t qw, int32_t t, int64_t max_elems)
+{
+    return 4 * kHbStackEntries + 2 * ((int64_t)t + 1) + 10 * (int64_t)qw + 3 * hb_leaf_words(t, max_elems);
+}
+
+__global__ __launch_bounds__(1024) void hb_offsets_kernel(const int64_t* starts, int64_t* offsets, int32_t n, int64_t max_elems)
+{
+    __shared__ int64_t part[1024];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int32_t n_waves = (n + 63) / 64;
+    for (int32_t base = 0; base < n_waves; base += 1024)
+    {
+        const int32_t wv = base + threadIdx.x;
+        int64_t v        = 0;
+        if (wv < n_waves)
+        {
+            int32_t qw = 0, tm = 0;
+            for (int32_t i = wv * 64; i < min(n, wv * 64 + 64); i++)
+            {
+                qw = max(qw, ((int32_t)(starts[2 * i + 1] - starts[2 * i]) + kWord - 1) / kWord);
+                tm = max(tm, (int32_t)(starts[2 * i + 2] - starts[2 * i + 1]));
+            }
+            v = 64 * hb_lane_words(qw, tm, max_elems);
+        }
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1)
+        {
+            int64_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (wv < n_waves) offsets[wv] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[n_waves] = carry;
+}
+
+// bit i of the result: reversed_query[offset + i] == x, reversed_query = the query read back to front
+__device__ __forceinline__ uint32_t make_pattern_reverse(char x, const char* query, int32_t query_size, int32_t offset)
+{
+    const int32_t n = min(query_size - offset, kWord);
+    uint32_t r      = 0;
+    for (int32_t i = 0; i < n; ++i) r |= (uint32_t)(query[query_size - 1 - (offset + i)] == x) << i;
+    return r;
+}
+
+__global__ __launch_bounds__(64) void hirschberg_myers_kernel(HirschbergArgs a)
+{
+    const int32_t lane = threadIdx.x & 63;
+    const int32_t idx  = blockIdx.x * 64 + lane;
+    const int64_t max_elems = (int64_t)ceil_div(max(a.max_query_length, 1), kWord) * (kHbSwitchToMyers + 1);
+    // wave-level workspace geometry (all lanes take part)
+    int32_t qw_max = 0, t_max = 0;
+    if (idx < a.n)
+    {
+        qw_max = ceil_div((int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]), kWord);
+        t_max  = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
+    }
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        qw_max = max(qw_max, __shfl_xor(qw_max, off));
+        t_max  = max(t_max, __shfl_xor(t_max, off));
+    }
+    if (idx >= a.n) return;
+    const char* query       = a.sequences + a.starts[2 * idx];
+    const char* target      = a.sequences + a.starts[2 * idx + 1];
+    const int32_t query_size  = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
+    const int32_t target_size = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
+    int8_t* path            = a.results + a.starts[2 * idx];
+    const int64_t region    = a.wave_offsets[blockIdx.x];
+    if (region + 64 * hb_lane_words(qw_max, t_max, max_elems) > a.ws_capacity_words)
+    {
+        a.result_lengths[idx] = 0;
+        return;
+    }
+    uint32_t* base = a.ws + region + lane;
+    const LaneArray stack{base};
+    const LaneArray fwd{stack.base + (size_t)4 * kHbStackEntries * 64};
+    const LaneArray rev{fwd.base + ((size_t)t_max + 1) * 64};
+    const LaneArray pat_f{rev.base + ((size_t)t_max + 1) * 64};
+    const LaneArray pat_r{pat_f.base + (size_t)4 * qw_max * 64};
+    const LaneArray st_pv{pat_r.base + (size_t)4 * qw_max * 64};
+    const LaneArray st_mv{st_pv.base + (size_t)qw_max * 64};
+    const int64_t leaf_words = hb_leaf_words(t_max, max_elems);
+    Band leaf; // full Myers matrices of a leaf (column-major, interleaved)
+    leaf.pv    = st_mv.base + (size_t)qw_max * 64;
+    leaf.mv    = leaf.pv + (size_t)leaf_words * 64;
+    leaf.score = reinterpret_cast<int32_t*>(leaf.mv + (size_t)leaf_words * 64);
+    leaf.n_rows = 0;
+
+    // pattern tables of the whole query, forward and back to front (myers_preprocess, :227-242)
+    const int32_t n_words_query = ceil_div(query_size, kWord);
+    for (int32_t w = 0; w < n_words_query; ++w)
+    {
+        uint32_t pa = 0, pc = 0, pt = 0, pg = 0, ra = 0, rc = 0, rt = 0, rg = 0;
+        const int32_t nchar = min(query_size - w * kWord, kWord);
+        for (int32_t i = 0; i < nchar; ++i)
+        {
+            const char f = query[w * kWord + i], r = query[query_size - 1 - (w * kWord + i)];
+            pa |= (uint32_t)(f == 'A') << i; pc |= (uint32_t)(f == 'C') << i; pt |= (uint32_t)(f == 'T') << i; pg |= (uint32_t)(f == 'G') << i;
+            ra |= (uint32_t)(r == 'A') << i; rc |= (uint32_t)(r == 'C') << i; rt |= (uint32_t)(r == 'T') << i; rg |= (uint32_t)(r == 'G') << i;
+        }
+        pat_f[w * 4 + 0] = pa; pat_f[w * 4 + 1] = pc; pat_f[w * 4 + 2] = pt; pat_f[w * 4 + 3] = pg;
+        pat_r[w * 4 + 0] = ra; pat_r[w * 4 + 1] = rc; pat_r[w * 4 + 2] = rt; pat_r[w * 4 + 3] = rg;
+    }
+
+    // last row of the edit-distance matrix of query[qb, qe) against target[tb, te): out[t], t = 0 .. te - tb
+    // (myers_compute_scores with full_score_matrix == false, :278-381); reverse: both read back to front
+    auto last_row = [&](int32_t qb, int32_t qe, int32_t tb, int32_t te, bool reverse, const LaneArray& out) {
+        const int32_t qn = qe - qb, tn = te - tb;
+        const int32_t nw = ceil_div(qn, kWord);
+        for (int32_t w = 0; w < nw; ++w) { st_pv[w] = ~0u; st_mv[w] = 0u; }
+        const int32_t pattern_offset = reverse ? query_size - qe : qb; // position of the part in the (reversed) query
+        int32_t sc = qn;
+        out[0]     = (uint32_t)sc;
+        const uint32_t last_hbit = 1u << (qn - (nw - 1) * kWord - 1);
+        for (int32_t t = 1; t <= tn; ++t)
+        {
+            const char tc = reverse ? target[te - t] : target[tb + t - 1];
+            int32_t h     = 1; // the implicit first row is 0, 1, 2, ...
+            for (int32_t w = 0; w < nw; ++w)
+            {
+                uint32_t pv = st_pv[w], mv = st_mv[w];
+                const uint32_t hbit = w == nw - 1 ? last_hbit : (1u << (kWord - 1));
+                const uint32_t eq   = reverse ? get_pattern(pat_r, n_words_query, w, pattern_offset, tc)
+                                              : get_pattern(pat_f, n_words_query, w, pattern_offset, tc);
+                h        = advance_word(hbit, eq, pv, mv, h, nullptr);
+                st_pv[w] = pv;
+                st_mv[w] = mv;
+            }
+            sc += h;
+            out[t] = (uint32_t)sc;
+        }
+    };
+    // Note: get_pattern masks nothing beyond the part's end; bits above qn in the last word never reach `hbit`.
+
+    // the explicit stack: entries (qb, qe, tb, te) as offsets
+    int32_t sp = 0;
+    auto push = [&](int32_t qb, int32_t qe, int32_t tb, int32_t te) -> bool {
+        if (sp >= kHbStackEntries) return false;
+        stack[4 * sp + 0] = (uint32_t)qb; stack[4 * sp + 1] = (uint32_t)qe; stack[4 * sp + 2] = (uint32_t)tb; stack[4 * sp + 3] = (uint32_t)te;
+        ++sp;
+        return true;
+    };
+    push(0, query_size, 0, target_size);
+    bool ok     = true;
+    int32_t len = 0;
+    while (ok && sp > 0)
+    {
+        --sp;
+        const int32_t qb = (int32_t)stack[4 * sp + 0], qe = (int32_t)stack[4 * sp + 1];
+        const int32_t tb = (int32_t)stack[4 * sp + 2], te = (int32_t)stack[4 * sp + 3];
+        const int32_t qn = qe - qb, tn = te - tb;
+        if (tn == 0)
+        {
+            for (int32_t k = 0; k < qn; ++k) path[len + k] = kDeletion;
+            len += qn;
+        }
+        else if (qn == 0)
+        {
+            for (int32_t k = 0; k < tn; ++k) path[len + k] = kInsertion;
+            len += tn;
+        }
+        else if (qn == 1)
+        {
+            // hirschberg_myers_single_char_warp (:483-515): right-to-left scan for the first equal character
+            const char qc = query[qb];
+            int32_t p     = len;
+            int32_t t     = te - 1;
+            while (t >= tb)
+            {
+                if (target[t] == qc) { path[p++] = kMatch; --t; break; }
+                path[p++] = kInsertion;
+                --t;
+            }
+            if (path[p - 1] != kMatch) path[p - 1] = kMismatch;
+            while (t >= tb) { path[p++] = kInsertion; --t; }
+            len += tn;
+        }
+        else
+        {
+            const int32_t nw = ceil_div(qn, kWord);
+            if (qn < kHbSwitchToMyers && (int64_t)(tn + 1) * nw <= max_elems)
+            {
+                // leaf: full Myers matrix (hirschberg_myers_compute_path, :383-410) + append_myers_backtrace (:124-181)
+                leaf.n_rows = nw;
+                for (int32_t w = 0; w < nw; ++w)
+                {
+                    leaf.pv[leaf.at(w, 0)]    = ~0u;
+                    leaf.mv[leaf.at(w, 0)]    = 0u;
+                    leaf.score[leaf.at(w, 0)] = min((w + 1) * kWord, qn);
+                }
+                const uint32_t last_hbit = 1u << (qn - (nw - 1) * kWord - 1);
+                for (int32_t t = 1; t <= tn; ++t)
+                {
+                    const char tc = target[tb + t - 1];
+                    int32_t h     = 1;
+                    for (int32_t w = 0; w < nw; ++w)
+                    {
+                        uint32_t pv = leaf.pv[leaf.at(w, t - 1)], mv = leaf.mv[leaf.at(w, t - 1)];
+                        const uint32_t hbit = w == nw - 1 ? last_hbit : (1u << (kWord - 1));
+                        const uint32_t eq   = get_pattern(pat_f, n_words_query, w, qb, tc);
+                        h                   = advance_word(hbit, eq, pv, mv, h, nullptr);
+                        leaf.score[leaf.at(w, t)] = leaf.score[leaf.at(w, t - 1)] + h;
+                        leaf.pv[leaf.at(w, t)]    = pv;
+                        leaf.mv[leaf.at(w, t)]    = mv;
+                    }
+                }
+                const uint32_t last_mask = qn % kWord != 0 ? ((1u << (qn % kWord)) - 1) : ~0u;
+                int32_t i = qn, j = tn;
+                int32_t myscore = leaf.score[leaf.at((i - 1) / kWord, j)];
+                while (i > 0 && j > 0)
+                {
+                    const int32_t above = i == 1 ? j : cell_score(leaf, i - 1, j, last_mask);
+                    const int32_t diag  = i == 1 ? j - 1 : cell_score(leaf, i - 1, j - 1, last_mask);
+                    const int32_t left  = cell_score(leaf, i, j - 1, last_mask);
+                    int8_t r;
+                    if (left + 1 == myscore) { r = kInsertion; myscore = left; --j; }
+                    else if (above + 1 == myscore) { r = kDeletion; myscore = above; --i; }
+                    else { r = diag == myscore ? kMatch : kMismatch; myscore = diag; --i; --j; }
+                    path[len++] = r;
+                }
+                while (i > 0) { path[len++] = kDeletion; --i; }
+                while (j > 0) { path[len++] = kInsertion; --j; }
+                continue;
+            }
+            const int32_t qmid = qb + qn / 2;
+            last_row(qb, qmid, tb, te, false, fwd);
+            last_row(qmid, qe, tb, te, true, rev);
+            // hirschberg_myers_compute_target_mid_warp (:461-481): the 32-lane argmin, emulated by this one lane.
+            // Lane L of the reference sees t = L, L + 32, ...; the tree keeps the lower lane on equal sums.
+            int32_t best_min[32], best_t[32];
+            for (int32_t L = 0; L < 32; ++L)
+            {
+                int32_t cm = INT32_MAX, mp = 0;
+                for (int32_t t = L; t <= tn; t += 32)
+                {
+                    const int32_t sum = (int32_t)fwd[t] + (int32_t)rev[tn - t];
+                    if (sum < cm) { cm = sum; mp = t; }
+                }
+                best_min[L] = cm;
+                best_t[L]   = mp;
+            }
+            for (int32_t step = 16; step > 0; step >>= 1)
+                for (int32_t L = 0; L + step < 32; ++L) // ascending L reads partners that this step has not updated yet
+                    if (best_min[L + step] < best_min[L]) { best_min[L] = best_min[L + step]; best_t[L] = best_t[L + step]; }
+            const int32_t tmid = tb + best_t[0];
+            ok = ok && push(qb, qmid, tb, tmid);
+            ok = ok && push(qmid, qe, tmid, te);
+        }
+    }
+    a.result_lengths[idx] = ok ? len : 0;
+}
+
 static int fail(hipError_t e, const char* what)
 {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -767,6 +1062,63 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
         e = hipMemcpyAsync(args->band_cells, ka.band_cells, (size_t)n * 8, hipMemcpyDeviceToDevice, stream);
         if (e != hipSuccess) return fail(e, "band_cells copy");
     }
+    return 0;
+}
+
+
+size_t gwhip_hirschberg_myers_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host, int32_t max_query_length)
+{
+    if (n_alignments <= 0) return 256;
+    const int64_t max_elems = (int64_t)((std::max(max_query_length, 1) + kWord - 1) / kWord) * (kHbSwitchToMyers + 1);
+    const int32_t n_waves   = (n_alignments + 63) / 64;
+    int64_t words           = 0;
+    for (int32_t wv = 0; wv < n_waves; wv++)
+    {
+        int32_t qw = 0, tm = 0;
+        for (int32_t i = wv * 64; i < std::min(n_alignments, wv * 64 + 64); i++)
+        {
+            qw = std::max(qw, ((int32_t)(sequence_starts_host[2 * i + 1] - sequence_starts_host[2 * i]) + kWord - 1) / kWord);
+            tm = std::max(tm, (int32_t)(sequence_starts_host[2 * i + 2] - sequence_starts_host[2 * i + 1]));
+        }
+        words += 64 * hb_lane_words(qw, tm, max_elems);
+    }
+    return 256 + ((size_t)n_waves + 1) * 8 + 256 + (size_t)words * 4 + 256;
+}
+
+int gwhip_hirschberg_myers(const gwhip_hirschberg_args* args, gwhip_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!args || args->n_alignments < 0 || args->max_query_length < 0)
+    {
+        g_last_error = "gwhip_hirschberg_myers: invalid arguments";
+        return (int)hipErrorInvalidValue;
+    }
+    const int32_t n = args->n_alignments;
+    if (n == 0) return 0;
+    const int32_t n_waves = (n + 63) / 64;
+    uint8_t* ws           = (uint8_t*)args->workspace;
+    const size_t off_ws   = ((((size_t)n_waves + 1) * 8) + 255) / 256 * 256;
+    if (args->workspace_bytes < off_ws + 256)
+    {
+        g_last_error = "gwhip_hirschberg_myers: workspace too small";
+        return (int)hipErrorInvalidValue;
+    }
+    HirschbergArgs ka{};
+    ka.n                 = n;
+    ka.sequences         = args->sequences;
+    ka.starts            = args->sequence_starts;
+    ka.max_query_length  = args->max_query_length;
+    ka.results           = args->results;
+    ka.result_lengths    = args->result_lengths;
+    ka.wave_offsets      = reinterpret_cast<int64_t*>(ws);
+    ka.ws                = reinterpret_cast<uint32_t*>(ws + off_ws);
+    ka.ws_capacity_words = ((int64_t)args->workspace_bytes - (int64_t)off_ws) / 4;
+    const int64_t max_elems = (int64_t)((std::max(args->max_query_length, 1) + kWord - 1) / kWord) * (kHbSwitchToMyers + 1);
+    hipLaunchKernelGGL(hb_offsets_kernel, dim3(1), dim3(1024), 0, stream, args->sequence_starts,
+                       const_cast<int64_t*>(ka.wave_offsets), n, max_elems);
+    hipLaunchKernelGGL(hirschberg_myers_kernel, dim3(n_waves), dim3(64), 0, stream, ka);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(e, "hirschberg kernels launch");
     return 0;
 }
 

@@ -20,6 +20,7 @@
 
 #include "../../include/gwhip.h"
 #include "aligner_impl.hpp"
+#include "hirschberg_aligner.hpp"
 #include "alignment_impl.hpp"
 
 namespace claraparabricks
@@ -339,12 +340,8 @@ std::unique_ptr<Aligner> create_aligner(int32_t max_query_length, int32_t max_ta
     throw_on_negative(max_query_length, "max_query_length must be non-negative.");
     throw_on_negative(max_target_length, "max_target_length must be non-negative.");
     throw_on_negative(max_alignments, "max_alignments must be non-negative.");
-    // The reference's default is Hirschberg + Myers (linear memory, optimal). We run the unbanded Myers kernel
-    // (band >= query length => full matrix), which is optimal as well; see DESIGN.md for the parity status.
-    int32_t bw = std::max(max_query_length, 1);
-    if (bw % kWordSize == 1) bw += 1;
-    return std::make_unique<BandedAligner>(-1, bw, allocator, stream, device_id, true, max_query_length,
-                                           max_target_length, max_alignments);
+    // the reference's default: Hirschberg + Myers (aligner.cpp:39-43)
+    return std::make_unique<HirschbergAligner>(max_query_length, max_target_length, max_alignments, allocator, stream, device_id);
 }
 
 std::unique_ptr<Aligner> create_aligner(int32_t max_query_length, int32_t max_target_length, int32_t max_alignments,

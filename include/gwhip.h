@@ -193,6 +193,24 @@ size_t gwhip_myers_banded_workspace_bytes_ordered(int32_t n_alignments, const in
                                                   const int32_t* max_bandwidths_host, const int32_t* scheduling_index_host);
 int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream);
 
+/* ---- cudaaligner: default aligner, Hirschberg + Myers (hirschberg_myers_gpu.cuh:45, hirschberg_myers_gpu.cu:684-701) ---- */
+typedef struct gwhip_hirschberg_args
+{
+    int32_t n_alignments;
+    const char* sequences;          /* concatenated: q0 t0 q1 t1 ... */
+    const int64_t* sequence_starts; /* [2n+1] */
+    int32_t max_query_length;       /* the aligner's constructor argument: bounds the matrix of the full-Myers leaves
+                                       (aligner_global_hirschberg_myers.cpp:37-44), i.e. it is part of the result */
+    int8_t* results;                /* alignment i: AlignmentState bytes, BACK TO FRONT (the host reverses,
+                                       aligner_global.cpp:180), in the slot [sequence_starts[2i], sequence_starts[2i+2]) */
+    int32_t* result_lengths;        /* [n]; 0 = no result (range stack overflow) or two empty sequences */
+    void* workspace;
+    size_t workspace_bytes;
+} gwhip_hirschberg_args;
+
+size_t gwhip_hirschberg_myers_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host, int32_t max_query_length);
+int gwhip_hirschberg_myers(const gwhip_hirschberg_args* args, gwhip_stream_t stream);
+
 /* ---- misc ---- */
 /* Copies the last error text of the calling thread (NUL terminated) and returns its length. */
 int gwhip_last_error_string(char* buf, size_t len);

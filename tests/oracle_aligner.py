@@ -78,3 +78,28 @@ def cigar(runs, extended):
     if last is not None:
         out.append("%d%s" % (acc, last))
     return "".join(out)
+
+
+def hirschberg(query, target, max_query_length=None):
+    """The default aligner (Hirschberg + Myers restatement, oracle/hirschberg_oracle.c):
+    dict(status, states (forward order), cigar, cigar_extended, edit_distance)."""
+    L = lib()
+    L.hirschberg_oracle_align.restype = C.c_int32
+    L.hirschberg_oracle_align.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p,
+                                          C.POINTER(C.c_int32)]
+    q = query.encode() if isinstance(query, str) else bytes(query)
+    t = target.encode() if isinstance(target, str) else bytes(target)
+    if max_query_length is None:
+        max_query_length = max(len(q), len(t)) + 1
+    path = np.zeros(len(q) + len(t) + 8, np.int8)
+    n = C.c_int32(0)
+    rc = L.hirschberg_oracle_align(q, len(q), t, len(t), max_query_length, path.ctypes.data, C.byref(n))
+    states = [int(x) for x in path[:n.value]][::-1]  # the host reverses (aligner_global.cpp:180)
+    runs = []
+    for s in states:
+        if runs and runs[-1][0] == s:
+            runs[-1] = (s, runs[-1][1] + 1)
+        else:
+            runs.append((s, 1))
+    return dict(status=rc, states=states, cigar=cigar(runs, False), cigar_extended=cigar(runs, True),
+                edit_distance=sum(1 for s in states if s != 0))

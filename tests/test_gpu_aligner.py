@@ -92,3 +92,42 @@ def test_config2_sample_and_cell_counts():
         ref_cells += ref["cells"]
         assert r.cigar_extended == ref["cigar_extended"] and r.is_optimal
     assert cells == ref_cells
+
+
+@pytest.mark.parametrize("max_len", [700, 70])
+def test_default_aligner_bit_exact_vs_hirschberg_oracle(max_len):
+    """create_aligner(max_query, max_target, n): Hirschberg + Myers. Every alignment state equals the oracle's, for
+    lengths on both sides of the full-Myers leaf threshold (63) and of the word size; the constructor's
+    max_query_length takes part (it bounds the leaf matrix), hence the two values."""
+    import random
+    from genomeworks_amd import cudaaligner
+    rng = random.Random(99)
+    pairs = []
+    for k in range(160):
+        n = rng.choice([1, 2, 3, 17, 31, 32, 33, 61, 62, 63, 64, 65, 96, 127, 128, 129, 300, 690])
+        n = min(n, max_len - 2)
+        q = "".join(rng.choice("ACGT") for _ in range(n))
+        if k % 3 == 0:
+            t = "".join(rng.choice("ACGT") for _ in range(rng.randint(0, min(max_len - 2, n + n // 2 + 2))))
+        else:
+            t = list(q)
+            for _ in range(max(1, n // 7)):
+                op, p = rng.random(), rng.randrange(max(1, len(t)))
+                if op < 0.4 and t:
+                    t[p] = rng.choice("ACGT")
+                elif op < 0.7 and len(t) < max_len - 2:
+                    t.insert(p, rng.choice("ACGT"))
+                elif t:
+                    del t[p]
+            t = "".join(t)
+        pairs.append((q, t))
+    al = cudaaligner.CudaAlignerBatch(max_len, max_len, len(pairs), max_device_memory_allocator_caching_size=4 << 30)
+    for q, t in pairs:
+        assert al.add_alignment(q, t) == 0
+    al.align_all()
+    res = al.get_alignments()
+    for r, (q, t) in zip(res, pairs):
+        ref = A.hirschberg(q, t, max_len)
+        assert r.status == 0
+        assert list(r.alignment) == ref["states"], (q, t)
+        assert r.cigar == ref["cigar"]

@@ -123,3 +123,62 @@ def test_monotone_over_bandwidths():
     assert final["optimal"]
     if R is not None:
         assert final["edit_distance"] == R.ref_nw_edit_distance(t.encode(), len(t), q.encode(), len(q))
+
+
+# ---- default aligner (Hirschberg + Myers) restatement, oracle/hirschberg_oracle.c ----
+HIRSCHBERG_KNOWN = [  # cudaaligner/tests/Test_AlignerGlobal.cpp:79-108,145-146 (HirschbergMyers uses the same table)
+    ("AAAA", "TTAT", "4M"), ("ATAAAAAAAA", "AAAAAAAAA", "1M1D8M"), ("AAAAAAAAA", "ATAAAAAAAA", "1M1I8M"),
+    ("ACTGA", "GCTAG", "3M1D1M1I"), ("ACTG", "ACTG", "4M"), ("A", "T", "1M"),
+    ("", "GACTCTCCCCCTCCCCTTTAAATATATAAAAATGGGGTGTAGCTAG", "46I"), ("GACTCTCCCCCTCCCCTTTAAATATATAAAAATGGGGTGTAGCTAG", "", "46D"),
+    ("", "", "")]
+
+
+@pytest.mark.parametrize("q,t,cigar", HIRSCHBERG_KNOWN)
+def test_hirschberg_known_cigars(q, t, cigar):
+    assert A.hirschberg(q, t)["cigar"] == cigar
+
+
+def _mutate(rng, q, n_edits):
+    t = list(q)
+    for _ in range(n_edits):
+        op, p = rng.random(), rng.randrange(max(1, len(t)))
+        if op < 0.4 and t:
+            t[p] = rng.choice("ACGT")
+        elif op < 0.7:
+            t.insert(p, rng.choice("ACGT"))
+        elif t:
+            del t[p]
+    return "".join(t)
+
+
+def test_hirschberg_paths_are_valid_and_optimal():
+    import random
+    rng = random.Random(11)
+    ref = A.ref()
+    for k in range(200):
+        n = rng.choice([2, 5, 31, 32, 33, 62, 63, 64, 65, 127, 200, 400])
+        q = "".join(rng.choice("ACGT") for _ in range(n))
+        t = _mutate(rng, q, max(1, n // 8)) if k % 2 else "".join(rng.choice("ACGT") for _ in range(max(0, n + rng.randint(-n // 3, n // 3))))
+        r = A.hirschberg(q, t, max(len(q), len(t)) + 1)
+        qi = ti = 0
+        for s in r["states"]:
+            if s in (0, 1):
+                assert (q[qi] == t[ti]) == (s == 0)
+                qi += 1
+                ti += 1
+            elif s == 2:
+                ti += 1
+            else:
+                qi += 1
+        assert (qi, ti) == (len(q), len(t))
+        if ref is not None and q and t:
+            assert r["edit_distance"] == ref.ref_nw_edit_distance(q.encode(), len(q), t.encode(), len(t))
+
+
+def test_hirschberg_range_stack_is_bounded():
+    # 64 entries suffice for any realistic input: a 60 kbp pair recurses ~10 levels deep with at most depth + 1 live ranges
+    import random
+    rng = random.Random(5)
+    q = "".join(rng.choice("ACGT") for _ in range(3000))
+    r = A.hirschberg(q, _mutate(rng, q, 150), 4096)
+    assert r["status"] == 0 and len(r["states"]) >= 3000
