@@ -679,6 +679,7 @@ struct HirschbergArgs
     uint32_t* ws;
     const int64_t* wave_offsets; // [n_waves + 1] words
     int64_t ws_capacity_words;
+    int32_t lds_state_words;     // LDS_STATE kernels: words per lane of one column-state array
 };
 
 __host__ __device__ inline int64_t hb_leaf_words(int32_t t, int64_t max_elems)
@@ -739,8 +740,11 @@ __device__ __forceinline__ uint32_t make_pattern_reverse(char x, const char* que
     return r;
 }
 
+// LDS_STATE: the pv / mv words of the running column (2 x lds_state_words per lane) live in dynamic LDS.
+template <bool LDS_STATE>
 __global__ __launch_bounds__(64) void hirschberg_myers_kernel(HirschbergArgs a)
 {
+    extern __shared__ uint32_t hb_lds[];
     const int32_t lane = threadIdx.x & 63;
     const int32_t idx  = blockIdx.x * 64 + lane;
     const int64_t max_elems = (int64_t)ceil_div(max(a.max_query_length, 1), kWord) * (kHbSwitchToMyers + 1);
@@ -774,11 +778,14 @@ __global__ __launch_bounds__(64) void hirschberg_myers_kernel(HirschbergArgs a)
     const LaneArray rev{fwd.base + ((size_t)t_max + 1) * 64};
     const LaneArray pat_f{rev.base + ((size_t)t_max + 1) * 64};
     const LaneArray pat_r{pat_f.base + (size_t)4 * qw_max * 64};
-    const LaneArray st_pv{pat_r.base + (size_t)4 * qw_max * 64};
-    const LaneArray st_mv{st_pv.base + (size_t)qw_max * 64};
+    const LaneArray hbm_pv{pat_r.base + (size_t)4 * qw_max * 64};
+    const LaneArray hbm_mv{hbm_pv.base + (size_t)qw_max * 64};
+    const LaneArray st_pv = LDS_STATE ? LaneArray{hb_lds + lane} : hbm_pv;
+    const LaneArray st_mv = LDS_STATE ? LaneArray{hb_lds + (size_t)a.lds_state_words * 64 + lane} : hbm_mv;
+    const LaneArray part_pat{hb_lds + (size_t)a.lds_state_words * 128 + lane}; // LDS_STATE only: 4 words per part word
     const int64_t leaf_words = hb_leaf_words(t_max, max_elems);
     Band leaf; // full Myers matrices of a leaf (column-major, interleaved)
-    leaf.pv    = st_mv.base + (size_t)qw_max * 64;
+    leaf.pv    = hbm_mv.base + (size_t)qw_max * 64;
     leaf.mv    = leaf.pv + (size_t)leaf_words * 64;
     leaf.score = reinterpret_cast<int32_t*>(leaf.mv + (size_t)leaf_words * 64);
     leaf.n_rows = 0;
@@ -806,19 +813,30 @@ __global__ __launch_bounds__(64) void hirschberg_myers_kernel(HirschbergArgs a)
         const int32_t nw = ceil_div(qn, kWord);
         for (int32_t w = 0; w < nw; ++w) { st_pv[w] = ~0u; st_mv[w] = 0u; }
         const int32_t pattern_offset = reverse ? query_size - qe : qb; // position of the part in the (reversed) query
+        if (LDS_STATE) // the part's (shifted) pattern words once, into LDS: the column loop then touches no HBM table
+            for (int32_t w = 0; w < nw; ++w)
+            {
+                const char acgt[4] = {'A', 'C', 'T', 'G'};
+                for (int32_t ci = 0; ci < 4; ++ci)
+                    part_pat[w * 4 + ci] = reverse ? get_pattern(pat_r, n_words_query, w, pattern_offset, acgt[ci])
+                                                   : get_pattern(pat_f, n_words_query, w, pattern_offset, acgt[ci]);
+            }
         int32_t sc = qn;
         out[0]     = (uint32_t)sc;
         const uint32_t last_hbit = 1u << (qn - (nw - 1) * kWord - 1);
+        char tc_next = reverse ? target[te - 1] : target[tb];
         for (int32_t t = 1; t <= tn; ++t)
         {
-            const char tc = reverse ? target[te - t] : target[tb + t - 1];
+            const char tc = tc_next;
+            if (t < tn) tc_next = reverse ? target[te - t - 1] : target[tb + t]; // next column's character, overlapped
             int32_t h     = 1; // the implicit first row is 0, 1, 2, ...
             for (int32_t w = 0; w < nw; ++w)
             {
                 uint32_t pv = st_pv[w], mv = st_mv[w];
                 const uint32_t hbit = w == nw - 1 ? last_hbit : (1u << (kWord - 1));
-                const uint32_t eq   = reverse ? get_pattern(pat_r, n_words_query, w, pattern_offset, tc)
-                                              : get_pattern(pat_f, n_words_query, w, pattern_offset, tc);
+                const uint32_t eq   = LDS_STATE ? part_pat[w * 4 + (((unsigned char)tc >> 1) & 3)]
+                                      : reverse  ? get_pattern(pat_r, n_words_query, w, pattern_offset, tc)
+                                                 : get_pattern(pat_f, n_words_query, w, pattern_offset, tc);
                 h        = advance_word(hbit, eq, pv, mv, h, nullptr);
                 st_pv[w] = pv;
                 st_mv[w] = mv;
@@ -1116,7 +1134,14 @@ int gwhip_hirschberg_myers(const gwhip_hirschberg_args* args, gwhip_stream_t str
     const int64_t max_elems = (int64_t)((std::max(args->max_query_length, 1) + kWord - 1) / kWord) * (kHbSwitchToMyers + 1);
     hipLaunchKernelGGL(hb_offsets_kernel, dim3(1), dim3(1024), 0, stream, args->sequence_starts,
                        const_cast<int64_t*>(ka.wave_offsets), n, max_elems);
-    hipLaunchKernelGGL(hirschberg_myers_kernel, dim3(n_waves), dim3(64), 0, stream, ka);
+    const int32_t qwords = (std::max(args->max_query_length, 1) + kWord - 1) / kWord;
+    if ((size_t)qwords * 6 * 64 * sizeof(uint32_t) <= 60 * 1024)
+    {
+        ka.lds_state_words = qwords;
+        hipLaunchKernelGGL(hirschberg_myers_kernel<true>, dim3(n_waves), dim3(64), (size_t)qwords * 6 * 64 * sizeof(uint32_t), stream, ka);
+    }
+    else
+        hipLaunchKernelGGL(hirschberg_myers_kernel<false>, dim3(n_waves), dim3(64), 0, stream, ka);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(e, "hirschberg kernels launch");
     return 0;
