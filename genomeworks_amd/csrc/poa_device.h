@@ -1163,7 +1163,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                                codes != nullptr && !(dbg & 256);
         if (packed_ok)
         {
-            classify_rows(rowinfo, graph_count, lane, dbg);
+            classify_rows(rowinfo, graph_count, lane, dbg, pc.acc ? &pc.acc[kPhOther] : nullptr);
             __syncthreads();
             banded_forward_packed<IdT>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
                                        max_column, gap_score, mismatch_score, match_score, dbg,

@@ -97,8 +97,10 @@ __device__ __forceinline__ void lds_store_u64_lanes17(uint32_t addr, uint32_t lo
 //   2: 2..3 predecessors, each 1..7 rows back, band starts compatible            (predecessors from the LDS ring)
 //   3: everything else                                                           (general routine, HBM matrix)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void classify_rows(RowInfo<true>* rowinfo, int32_t graph_count, int lane, int32_t dbg = 0)
+__device__ __forceinline__ void classify_rows(RowInfo<true>* rowinfo, int32_t graph_count, int lane, int32_t dbg = 0,
+                                              uint64_t* prof_acc = nullptr)
 {
+    int32_t prof_count = 0; // profiling (GWHIP_DEBUG bits 2-3 = class to count: 1, 2 or 3)
     for (int32_t r = 1 + lane; r <= graph_count; r += kWave)
     {
         RowInfo<true> ri = rowinfo[r];
@@ -124,6 +126,12 @@ __device__ __forceinline__ void classify_rows(RowInfo<true>* rowinfo, int32_t gr
         if ((dbg & 32768) && cls == 1) cls = 2;
         ri.w       = (ri.w & ~(3ull << kClassShift)) | (cls << kClassShift);
         rowinfo[r] = ri;
+        if ((dbg & 12) && cls == (uint64_t)((dbg >> 2) & 3)) prof_count++;
+    }
+    if ((dbg & 12) && prof_acc)
+    {
+        for (int off = 32; off > 0; off >>= 1) prof_count += __shfl_xor(prof_count, off);
+        *prof_acc += (uint64_t)prof_count;
     }
 }
 
@@ -524,7 +532,6 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
         }
         cls = r <= graph_count ? class_of(ri) : 7u;
     }
-    if ((dbg & 12) && prof_acc) *prof_acc += prof;
 }
 
 } // namespace gwhip
