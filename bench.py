@@ -156,7 +156,7 @@ def main():
             "pcie_inclusive_ms": round(t_pcie * 1e3, 3),
             "pcie_inclusive_gcups": round(cells / t_pcie / 1e9, 3),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(windows)
         print(json.dumps(out))
     if dist is not None:
