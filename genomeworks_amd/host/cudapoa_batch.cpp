@@ -13,6 +13,7 @@
 #include <claraparabricks/genomeworks/logging/logging.hpp>
 
 #include <algorithm>
+#include <thread>
 #include <atomic>
 #include <climits>
 #include <cstring>
@@ -513,25 +514,46 @@ StatusType PoaBatch::get_consensus(std::vector<std::string>& consensus, std::vec
         GW_CU_CHECK_ERR(hipMemcpyAsync(h_coverage_, d_coverage_, n * sizeof(uint16_t), hipMemcpyDeviceToHost, stream_));
     }
     GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
-    for (int32_t poa = 0; poa < poa_count_; poa++)
+    // un-reverse into the caller's vectors; the windows are independent, so large batches are split over a few host
+    // threads (the results are appended behind whatever the caller's vectors already hold, as in the reference)
+    const size_t base_c = consensus.size(), base_v = coverage.size(), base_s = output_status.size();
+    const size_t count  = static_cast<size_t>(poa_count_);
+    consensus.resize(base_c + count);
+    coverage.resize(base_v + count);
+    output_status.resize(base_s + count, StatusType::success);
+    auto unpack = [&](size_t first, size_t last) {
+        for (size_t poa = first; poa < last; poa++)
+        {
+            const char* c = reinterpret_cast<const char*>(&h_consensus_[poa * batch_size_.max_consensus_size]);
+            if (static_cast<uint8_t>(c[0]) == kKernelError)
+            {
+                output_status[base_s + poa] = static_cast<StatusType>(c[1]); // logged below, in window order
+                continue;
+            }
+            std::string& s = consensus[base_c + poa];
+            s.assign(c);
+            std::reverse(s.begin(), s.end());
+            const uint16_t* cv = &h_coverage_[poa * batch_size_.max_consensus_size];
+            coverage[base_v + poa].assign(std::make_reverse_iterator(cv + s.size()), std::make_reverse_iterator(cv));
+        }
+    };
+    const size_t n_threads = count >= 256 ? 4 : 1;
+    if (n_threads == 1)
+        unpack(0, count);
+    else
     {
-        const char* c = reinterpret_cast<const char*>(&h_consensus_[static_cast<size_t>(poa) * batch_size_.max_consensus_size]);
-        if (static_cast<uint8_t>(c[0]) == kKernelError)
-        {
-            log_kernel_error(static_cast<StatusType>(c[1]), output_status);
-            consensus.emplace_back(std::string());
-            coverage.emplace_back(std::vector<uint16_t>());
-        }
-        else
-        {
-            output_status.emplace_back(StatusType::success);
-            consensus.emplace_back(std::string(c));
-            std::reverse(consensus.back().begin(), consensus.back().end());
-            const uint16_t* cv = &h_coverage_[static_cast<size_t>(poa) * batch_size_.max_consensus_size];
-            coverage.emplace_back(std::vector<uint16_t>(cv, cv + get_size(consensus.back())));
-            std::reverse(coverage.back().begin(), coverage.back().end());
-        }
+        std::vector<std::thread> workers;
+        const size_t chunk = (count + n_threads - 1) / n_threads;
+        for (size_t t = 1; t < n_threads; t++) workers.emplace_back(unpack, std::min(count, t * chunk), std::min(count, (t + 1) * chunk));
+        unpack(0, std::min(count, chunk));
+        for (std::thread& w : workers) w.join();
     }
+    for (size_t poa = 0; poa < count; poa++)
+        if (output_status[base_s + poa] != StatusType::success)
+        {
+            std::vector<StatusType> sink; // log_kernel_error appends the code; the status slot is already filled
+            log_kernel_error(output_status[base_s + poa], sink);
+        }
     return StatusType::success;
 }
 
