@@ -261,7 +261,8 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
                                                       (uint16_t)s, (uint32_t)c.max_sequences_per_poa,
                                                       c.max_nodes_per_graph, reinterpret_cast<int16_t*>(smem),
                                                       reinterpret_cast<int16_t*>(smem) + 2048,
-                                                      reinterpret_cast<uint32_t*>(lds_rowinfo_region), lane);
+                                                      reinterpret_cast<uint32_t*>(lds_rowinfo_region), lane, a.debug_flags,
+                                                      pc.acc ? &pc.acc[kPhOther] : nullptr);
             if (par_rc == 0)
             {
                 if (lane == 0) seq_lens[0] = new_count; // :506

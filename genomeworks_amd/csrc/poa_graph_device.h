@@ -156,9 +156,20 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
                                                           const int8_t* base_weights, int32_t read_length,
                                                           IdT* sequence_begin_nodes_ids, uint16_t s,
                                                           uint32_t max_sequences_per_poa, int32_t max_nodes,
-                                                          int16_t* gnode, int16_t* curr, uint32_t* onpath, int lane)
+                                                          int16_t* gnode, int16_t* curr, uint32_t* onpath, int lane,
+                                                          int32_t dbg = 0, uint64_t* prof_acc = nullptr)
 {
     const int32_t L = read_length;
+    const int32_t prof_sel = (dbg >> 16) & 7; // profiling (GWHIP_DEBUG bits 16-18): 1 = load, 2 = classify, 3 = create, 4 = edges
+    uint64_t prof_t = prof_sel ? clock64() : 0;
+    auto prof_mark = [&](int32_t which) {
+        if (prof_sel)
+        {
+            const uint64_t now = clock64();
+            if (prof_sel == which && prof_acc) *prof_acc += now - prof_t;
+            prof_t = now;
+        }
+    };
     for (int32_t i = lane; i < (node_count + 31) / 32; i += kWave) onpath[i] = 0;
     for (int32_t i = lane; i < L; i += kWave) gnode[i] = -1;
     __syncthreads();
@@ -179,6 +190,7 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
     // The map over read positions needs a complete alignment (every read position exactly once); a degenerate
     // traceback result (reference quirk: a walk that finds no predecessor at its first step) goes the serial way.
     if (covered != L) return -1;
+    prof_mark(1);
 
     // ---- A + B: classify, detect conflicts, number new nodes in rp order ----
     int32_t running   = 0;
@@ -222,6 +234,7 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
     for (int off = 32; off > 0; off >>= 1) rp_nodeerr = min(rp_nodeerr, __shfl_xor(rp_nodeerr, off));
     __syncthreads();
 
+    prof_mark(2);
     const int32_t first_new = node_count;
     auto in_count_of  = [&](int32_t n) -> int32_t { return n >= first_new ? 0 : (int32_t)g.incoming_edge_count[n]; };
     auto out_count_of = [&](int32_t n) -> int32_t { return n >= first_new ? 0 : (int32_t)g.outgoing_edge_count[n]; };
@@ -273,6 +286,7 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
         g.node_alignment_count[cur] = (uint16_t)na_new;
     }
     __syncthreads();
+    prof_mark(3);
 
     // ---- D: edges and coverage ----
     int32_t rp_edgeerr = INT32_MAX;
@@ -285,12 +299,32 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
             const uint16_t w   = (uint16_t)((uint16_t)base_weights[rp - 1] + base_weights[rp]);
             const int32_t ic   = in_count_of(cur);
             bool exists        = false;
-            for (int32_t e = 0; e < ic; e++)
             {
-                if (g.incoming_edges[(int64_t)cur * kEdges + e] == head)
+                // the first four in-edge slots and their weights are fetched together with the count (independent loads,
+                // one HBM round trip; slots past the in-degree hold stale values and are masked); longer lists loop on
+                constexpr int kBatch = 4;
+                int32_t be[kBatch];
+                uint16_t bw[kBatch];
+#pragma unroll
+                for (int e = 0; e < kBatch; e++)
                 {
-                    exists = true;
-                    g.incoming_edge_w[(int64_t)cur * kEdges + e] += w;
+                    be[e] = g.incoming_edges[(int64_t)cur * kEdges + e];
+                    bw[e] = g.incoming_edge_w[(int64_t)cur * kEdges + e];
+                }
+#pragma unroll
+                for (int e = 0; e < kBatch; e++)
+                    if (e < ic && be[e] == head)
+                    {
+                        exists = true;
+                        g.incoming_edge_w[(int64_t)cur * kEdges + e] = (uint16_t)(bw[e] + w);
+                    }
+                for (int32_t e = kBatch; e < ic; e++)
+                {
+                    if (g.incoming_edges[(int64_t)cur * kEdges + e] == head)
+                    {
+                        exists = true;
+                        g.incoming_edge_w[(int64_t)cur * kEdges + e] += w;
+                    }
                 }
             }
             if (!exists)
@@ -329,6 +363,7 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
     }
     for (int off = 32; off > 0; off >>= 1) rp_edgeerr = min(rp_edgeerr, __shfl_xor(rp_edgeerr, off));
     __syncthreads();
+    prof_mark(4);
     if (rp_edgeerr != INT32_MAX) return (int32_t)kEdgeCountExceeded;
     new_node_count = node_count + running;
     return 0;
