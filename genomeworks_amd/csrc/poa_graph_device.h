@@ -178,9 +178,9 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
     {
         const int32_t k  = base + lane;
         const int32_t rp = k < alen ? ar[k] : -1;
+        const int32_t gn = k < alen ? ag[k] : -1; // independent of rp: both loads are in flight together
         if (rp >= 0)
         {
-            const int32_t gn = ag[k];
             gnode[rp]        = (int16_t)gn;
             if (gn >= 0) atomicOr(&onpath[gn >> 5], 1u << (gn & 31));
         }
@@ -293,11 +293,13 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
     for (int32_t rp = lane; rp < L; rp += kWave)
     {
         const int32_t cur = curr[rp];
+        const uint16_t cov = g.coverage[cur]; // zeroed in pass C for new nodes
         if (rp > 0)
         {
             const int32_t head = curr[rp - 1];
             const uint16_t w   = (uint16_t)((uint16_t)base_weights[rp - 1] + base_weights[rp]);
             const int32_t ic   = in_count_of(cur);
+            const int32_t oc_head = out_count_of(head); // heads are distinct across rp, nobody else bumps it
             bool exists        = false;
             {
                 // the first four in-edge slots and their weights are fetched together with the count (independent loads,
@@ -332,7 +334,7 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
                 g.incoming_edges[(int64_t)cur * kEdges + ic]  = (IdT)head;
                 g.incoming_edge_w[(int64_t)cur * kEdges + ic] = w;
                 g.incoming_edge_count[cur]                    = (uint16_t)(ic + 1);
-                const int32_t oc                              = out_count_of(head);
+                const int32_t oc                              = oc_head;
                 g.outgoing_edges[(int64_t)head * kEdges + oc] = (IdT)cur;
                 if (MSA)
                 {
@@ -359,7 +361,7 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
         }
         else if (MSA)
             *sequence_begin_nodes_ids = (IdT)cur;
-        g.coverage[cur]++;
+        g.coverage[cur] = (uint16_t)(cov + 1);
     }
     for (int off = 32; off > 0; off >>= 1) rp_edgeerr = min(rp_edgeerr, __shfl_xor(rp_edgeerr, off));
     __syncthreads();
