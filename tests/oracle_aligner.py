@@ -41,6 +41,8 @@ def ref():
             f.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32]
         _R.ref_needleman_wunsch_cpu.restype = C.c_int32
         _R.ref_needleman_wunsch_cpu.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32]
+        _R.ref_ukkonen_cpu.restype = C.c_int32
+        _R.ref_ukkonen_cpu.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
     return _R
 
 
@@ -103,3 +105,49 @@ def hirschberg(query, target, max_query_length=None):
             runs.append((s, 1))
     return dict(status=rc, states=states, cigar=cigar(runs, False), cigar_extended=cigar(runs, True),
                 edit_distance=sum(1 for s in states if s != 0))
+
+
+def _states_result(states, rc=0):
+    runs = []
+    for s in states:
+        if runs and runs[-1][0] == s:
+            runs[-1] = (s, runs[-1][1] + 1)
+        else:
+            runs.append((s, 1))
+    return dict(status=rc, states=states, cigar=cigar(runs, False), cigar_extended=cigar(runs, True),
+                edit_distance=sum(1 for s in states if s != 0))
+
+
+def _global(fn_name, query, target, *extra):
+    L = lib()
+    fn = getattr(L, fn_name)
+    fn.restype = C.c_int32
+    q = query.encode() if isinstance(query, str) else bytes(query)
+    t = target.encode() if isinstance(target, str) else bytes(target)
+    path = np.zeros(len(q) + len(t) + 8, np.int8)
+    n = C.c_int32(0)
+    rc = fn(C.c_char_p(q), C.c_int32(len(q)), C.c_char_p(t), C.c_int32(len(t)), *[C.c_int32(x) for x in extra],
+            C.c_void_p(path.ctypes.data), C.byref(n))
+    return _states_result([int(x) for x in path[:n.value]][::-1], rc)  # the host reverses (aligner_global.cpp:180)
+
+
+def ukkonen(query, target, p=100):
+    """AlignerGlobalUkkonen restatement (oracle/global_oracle.c), band parameter p (the class fixes p = 100)."""
+    return _global("ukkonen_oracle_align", query, target, p)
+
+
+def myers_full(query, target):
+    """AlignerGlobalMyers restatement (oracle/global_oracle.c)."""
+    return _global("myers_full_oracle_align", query, target)
+
+
+def ref_ukkonen_cpu(query, target, p):
+    """The reference's own ukkonen_cpu() (target, query, p) -> states in forward order, or None without oracle/_ref."""
+    R = ref()
+    if R is None:
+        return None
+    q = query.encode() if isinstance(query, str) else bytes(query)
+    t = target.encode() if isinstance(target, str) else bytes(target)
+    out = np.zeros(len(q) + len(t) + 8, np.int8)
+    n = R.ref_ukkonen_cpu(t, len(t), q, len(q), p, out.ctypes.data, len(out))
+    return [int(x) for x in out[:n]]

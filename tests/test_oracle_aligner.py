@@ -182,3 +182,77 @@ def test_hirschberg_range_stack_is_bounded():
     q = "".join(rng.choice("ACGT") for _ in range(3000))
     r = A.hirschberg(q, _mutate(rng, q, 150), 4096)
     assert r["status"] == 0 and len(r["states"]) >= 3000
+
+
+# ---- AlignerGlobalUkkonen / AlignerGlobalMyers restatements (oracle/global_oracle.c) ----
+# Test_AlignerGlobal.cpp:79-108 runs this table for the Ukkonen and the Myers class too (:138-139); the empty-sequence
+# cases (:145-153) only for Myers ("Ukkonen cannot handle these cases")
+GLOBAL_KNOWN = [
+    ("AAAA", "TTAT", "4M", 3),
+    ("ATAAAAAAAA", "AAAAAAAAA", "1M1D8M", 1),
+    ("AAAAAAAAA", "ATAAAAAAAA", "1M1I8M", 1),
+    ("ACTGA", "GCTAG", "3M1D1M1I", 3),
+    ("ACTG", "ACTG", "4M", 0),
+    ("A", "T", "1M", 1),
+]
+EMPTY_KNOWN = [
+    ("", "GACTCTCCCCCTCCCCTTTAAATATATAAAAATGGGGTGTAGCTAG", "46I", 46),
+    ("GACTCTCCCCCTCCCCTTTAAATATATAAAAATGGGGTGTAGCTAG", "", "46D", 46),
+    ("", "", "", 0),
+]
+
+
+@pytest.mark.parametrize("q,t,cigar,dist", GLOBAL_KNOWN)
+def test_ukkonen_known_cigars(q, t, cigar, dist):
+    r = A.ukkonen(q, t, 100)
+    assert (r["status"], r["cigar"], r["edit_distance"]) == (0, cigar, dist)
+
+
+@pytest.mark.parametrize("q,t,cigar,dist", GLOBAL_KNOWN + EMPTY_KNOWN)
+def test_myers_full_known_cigars(q, t, cigar, dist):
+    r = A.myers_full(q, t)
+    assert (r["status"], r["cigar"], r["edit_distance"]) == (0, cigar, dist)
+
+
+def _pairs(seed, n, lo, hi, div=5):
+    rng = random.Random(seed)
+    for _ in range(n):
+        L = rng.randrange(lo, hi)
+        q = "".join(rng.choice("ACGT") for _ in range(L))
+        t = _mutate(rng, q, rng.randrange(0, max(2, L // div)))
+        if t:
+            yield q, t
+
+
+@pytest.mark.parametrize("p,lo,hi", [(0, 1, 300), (1, 1, 300), (3, 1, 300), (10, 30, 200), (30, 80, 300), (100, 150, 500)])
+def test_ukkonen_matches_reference_cpu_ukkonen(p, lo, hi):
+    """Against the reference's own ukkonen_cpu() (oracle/_ref): the function Test_NeedlemanWunschImplementation.cpp:286-293
+    compares the GPU path with. Small p makes most paths run along the band edges (clipped, non-optimal results).
+    ukkonen_cpu wants target >= query; the class swaps the roles (and insertion <-> deletion) otherwise."""
+    if A.ref() is None:
+        pytest.skip("oracle/_ref not built")
+    swap = {0: 0, 1: 1, 2: 3, 3: 2}
+    clipped = 0
+    for q, t in _pairs(100 + p, 120, lo, hi):
+        mine = A.ukkonen(q, t, p)["states"]
+        if len(t) >= len(q):
+            ref = A.ref_ukkonen_cpu(q, t, p)
+        else:
+            ref = [swap[x] for x in A.ref_ukkonen_cpu(t, q, p)]
+        assert mine == ref
+        clipped += sum(1 for s in mine if s != 0) != A.ref().ref_nw_edit_distance(t.encode(), len(t), q.encode(), len(q))
+    if p <= 1:
+        assert clipped > 10  # the band-clipped regime is really exercised
+
+
+def test_myers_full_is_optimal_and_equals_wide_banded_myers():
+    """The full-matrix class and the banded class share the backtrace rule; with a band that covers the whole matrix
+    the banded oracle (pinned separately above) must give the identical path."""
+    for q, t in _pairs(77, 150, 1, 400):
+        r = A.myers_full(q, t)
+        b = A.align(q, t, 1 << 20)
+        states = [o for o, c in b["runs"] for _ in range(c)]
+        assert r["states"] == states
+        if A.ref() is not None:
+            assert r["edit_distance"] == A.ref().ref_nw_edit_distance(t.encode(), len(t), q.encode(), len(q))
+        assert sum(1 for s in r["states"] if s != 2) == len(q) and sum(1 for s in r["states"] if s != 3) == len(t)
