@@ -35,6 +35,8 @@ def _bind(L):
     L.gw_aligner_create_banded.argtypes = [i32, vp, i32, C.c_int64]
     L.gw_aligner_create.restype = vp
     L.gw_aligner_create.argtypes = [i32, i32, i32, vp, i32, C.c_int64]
+    L.gw_aligner_create_algorithm.restype = vp
+    L.gw_aligner_create_algorithm.argtypes = [C.c_char_p, i32, i32, i32, vp, i32, C.c_int64]
     L.gw_aligner_destroy.argtypes = [vp]
     L.gw_aligner_add_alignment.argtypes = [vp, C.c_char_p, i32, C.c_char_p, i32, C.c_int, C.c_int]
     for n in ("gw_aligner_align_all", "gw_aligner_sync_alignments", "gw_aligner_num_alignments", "gw_aligner_reset",
@@ -80,7 +82,10 @@ class CudaAlignerBatch:
     """Python API for GPU-accelerated global pairwise alignment (pygenomeworks CudaAlignerBatch)."""
 
     def __init__(self, max_query_length=None, max_target_length=None, max_alignments=None, alignment_type="global",
-                 stream=None, device_id=0, max_device_memory_allocator_caching_size=-1, max_bandwidth=None):
+                 stream=None, device_id=0, max_device_memory_allocator_caching_size=-1, max_bandwidth=None,
+                 algorithm=None):
+        """algorithm (not in pygenomeworks): one of the reference's non-public aligner classes that its C++ tests and
+        benchmarks construct directly -- "hirschberg_myers" (the default), "ukkonen", "myers"."""
         self._L = _bind(_native.host())
         if alignment_type != "global":
             raise RuntimeError("Unknown alignment_type provided. Must be global.")
@@ -91,6 +96,10 @@ class CudaAlignerBatch:
         if max_bandwidth is not None:
             self._h = self._L.gw_aligner_create_banded(int(max_bandwidth), st, device_id,
                                                        int(max_device_memory_allocator_caching_size))
+        elif algorithm is not None:
+            self._h = self._L.gw_aligner_create_algorithm(algorithm.encode(), int(max_query_length), int(max_target_length),
+                                                          int(max_alignments), st, device_id,
+                                                          int(max_device_memory_allocator_caching_size))
         else:
             self._h = self._L.gw_aligner_create(int(max_query_length), int(max_target_length), int(max_alignments), st,
                                                 device_id, int(max_device_memory_allocator_caching_size))

@@ -13,6 +13,9 @@
 #include "host_common.hpp"
 #include "poa_batch_impl.hpp"
 #include "aligner_impl.hpp"
+#include "aligner_global.hpp"
+#include <claraparabricks/genomeworks/utils/cudautils.hpp>
+#include <stdexcept>
 #include <claraparabricks/genomeworks/cudaaligner/aligner.hpp>
 #include <claraparabricks/genomeworks/cudaaligner/alignment.hpp>
 
@@ -290,6 +293,34 @@ gw_aligner* gw_aligner_create(int32_t max_query_length, int32_t max_target_lengt
     h->aligner = aln::create_aligner(max_query_length, max_target_length, max_alignments, aln::AlignmentType::global_alignment,
                                      static_cast<cudaStream_t>(stream), device_id, max_device_memory);
     h->impl    = dynamic_cast<aln::BandedAligner*>(h->aligner.get());
+    return h.release();
+    GW_CATCH(nullptr)
+}
+
+gw_aligner* gw_aligner_create_algorithm(const char* algorithm, int32_t max_query_length, int32_t max_target_length,
+                                        int32_t max_alignments, void* stream, int32_t device_id, int64_t max_device_memory)
+{
+    GW_TRY
+    const std::string algo = algorithm ? algorithm : "default";
+    if (algo == "default")
+        return gw_aligner_create(max_query_length, max_target_length, max_alignments, stream, device_id, max_device_memory);
+    gw::scoped_device_switch device(device_id);
+    if (max_device_memory < -1) throw std::invalid_argument("max_device_memory has to be -1 (all available memory) or >= 0.");
+    if (max_device_memory == -1) max_device_memory = gw::cudautils::find_largest_contiguous_device_memory_section();
+    gw::DefaultDeviceAllocator allocator(static_cast<size_t>(max_device_memory), static_cast<cudaStream_t>(stream));
+    auto h = std::make_unique<gw_aligner>();
+    if (algo == "hirschberg_myers")
+        h->aligner = std::make_unique<aln::AlignerGlobalHirschbergMyers>(max_query_length, max_target_length, max_alignments, allocator,
+                                                                          static_cast<cudaStream_t>(stream), device_id);
+    else if (algo == "ukkonen")
+        h->aligner = std::make_unique<aln::AlignerGlobalUkkonen>(max_query_length, max_target_length, max_alignments, allocator,
+                                                                  static_cast<cudaStream_t>(stream), device_id);
+    else if (algo == "myers")
+        h->aligner = std::make_unique<aln::AlignerGlobalMyers>(max_query_length, max_target_length, max_alignments, allocator,
+                                                                static_cast<cudaStream_t>(stream), device_id);
+    else
+        throw std::invalid_argument("unknown aligner algorithm '" + algo + "' (default, hirschberg_myers, ukkonen, myers)");
+    h->impl = dynamic_cast<aln::BandedAligner*>(h->aligner.get());
     return h.release();
     GW_CATCH(nullptr)
 }

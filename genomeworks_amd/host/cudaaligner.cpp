@@ -20,7 +20,7 @@
 
 #include "../../include/gwhip.h"
 #include "aligner_impl.hpp"
-#include "hirschberg_aligner.hpp"
+#include "aligner_global.hpp"
 #include "alignment_impl.hpp"
 
 namespace claraparabricks

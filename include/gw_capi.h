@@ -115,6 +115,10 @@ int gw_poa_profile_phases(gw_poa_batch* b, double* out6);
 gw_aligner* gw_aligner_create_banded(int32_t max_bandwidth, void* stream, int32_t device_id, int64_t max_device_memory);
 gw_aligner* gw_aligner_create(int32_t max_query_length, int32_t max_target_length, int32_t max_alignments,
                               void* stream, int32_t device_id, int64_t max_device_memory);
+/* The reference's non-public aligner classes (cudaaligner/src/aligner_global_{hirschberg_myers,ukkonen,myers}.hpp), which
+   its tests and benchmarks construct directly: algorithm = "default" | "hirschberg_myers" | "ukkonen" | "myers". */
+gw_aligner* gw_aligner_create_algorithm(const char* algorithm, int32_t max_query_length, int32_t max_target_length,
+                                        int32_t max_alignments, void* stream, int32_t device_id, int64_t max_device_memory);
 void gw_aligner_destroy(gw_aligner* a);
 int gw_aligner_add_alignment(gw_aligner* a, const char* query, int32_t query_length, const char* target,
                              int32_t target_length, int reverse_complement_query, int reverse_complement_target);

@@ -211,6 +211,26 @@ typedef struct gwhip_hirschberg_args
 size_t gwhip_hirschberg_myers_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host, int32_t max_query_length);
 int gwhip_hirschberg_myers(const gwhip_hirschberg_args* args, gwhip_stream_t stream);
 
+/* ---- cudaaligner: AlignerGlobalUkkonen (ukkonen_gpu.cuh:43-50, ukkonen_gpu.cu:313-327) ---- */
+typedef struct gwhip_ukkonen_args
+{
+    int32_t n_alignments;
+    const char* sequences;          /* concatenated: q0 t0 q1 t1 ... */
+    const int64_t* sequence_starts; /* [2n+1] */
+    int32_t ukkonen_p;              /* band parameter; AlignerGlobalUkkonen fixes 100 (aligner_global_ukkonen.cpp:35) */
+    int32_t max_length_difference;  /* max |query - target| over the batch, computed by the host exactly as the
+                                       reference does before its launch (aligner_global_ukkonen.cpp:66-72) */
+    int32_t max_sequence_length;    /* max(query, target) over the batch (the reference's max_target_query_length) */
+    int8_t* results;                /* alignment i: AlignmentState bytes, BACK TO FRONT (the host reverses,
+                                       aligner_global.cpp:180), in the slot [sequence_starts[2i], sequence_starts[2i+2]) */
+    int32_t* result_lengths;        /* [n] */
+    void* workspace;                /* 256-byte aligned; holds the int16 band storage of every pair */
+    size_t workspace_bytes;
+} gwhip_ukkonen_args;
+
+size_t gwhip_ukkonen_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host, int32_t ukkonen_p);
+int gwhip_ukkonen(const gwhip_ukkonen_args* args, gwhip_stream_t stream);
+
 /* ---- misc ---- */
 /* Copies the last error text of the calling thread (NUL terminated) and returns its length. */
 int gwhip_last_error_string(char* buf, size_t len);

@@ -131,3 +131,94 @@ def test_default_aligner_bit_exact_vs_hirschberg_oracle(max_len):
         assert r.status == 0
         assert list(r.alignment) == ref["states"], (q, t)
         assert r.cigar == ref["cigar"]
+
+
+# ---- the non-default classes: AlignerGlobalUkkonen / AlignerGlobalMyers ----
+def _run_algorithm(algorithm, pairs, max_len):
+    from genomeworks_amd import cudaaligner
+    al = cudaaligner.CudaAlignerBatch(max_len, max_len, len(pairs), algorithm=algorithm,
+                                      max_device_memory_allocator_caching_size=6 << 30)
+    for q, t in pairs:
+        assert al.add_alignment(q, t) == 0, (len(q), len(t))
+    al.align_all()
+    return al.get_alignments()
+
+
+@pytest.mark.parametrize("algorithm", ["ukkonen", "myers", "hirschberg_myers"])
+def test_algorithm_classes_known_cigars(algorithm):
+    # Test_AlignerGlobal.cpp:79-153: one table for every class; the empty-sequence cases not for Ukkonen
+    from test_oracle_aligner import GLOBAL_KNOWN, EMPTY_KNOWN
+    table = GLOBAL_KNOWN + ([] if algorithm == "ukkonen" else EMPTY_KNOWN)
+    res = _run_algorithm(algorithm, [(q, t) for q, t, _, _ in table] * 4, 500)  # :110-124 repeats the table in one batch
+    for r, (q, t, cigar, dist) in zip(res, table * 4):
+        assert r.status == 0 and r.is_optimal
+        assert (r.cigar, r.edit_distance) == (cigar, dist)
+
+
+def _global_pairs(seed, n, max_len, max_diff):
+    rng = random.Random(seed)
+    pairs = []
+    while len(pairs) < n:
+        L = rng.choice([1, 2, 5, 31, 32, 33, 64, 65, 100, 199, 200, 201, 333, 640, max_len - 1])
+        L = min(L, max_len - 1)
+        q = "".join(rng.choice("ACGT") for _ in range(L))
+        t = _mutate(rng, q, rng.randrange(0, max(2, L // 4)))[:max_len]
+        if rng.random() < 0.3:
+            q, t = t, q  # query longer than target: the Ukkonen class swaps roles and gap states
+        if q and t and abs(len(q) - len(t)) <= max_diff:
+            pairs.append((q, t))
+    return pairs
+
+
+def test_ukkonen_class_bit_exact_vs_oracle():
+    """Every alignment state equals the restatement of ukkonen_gpu.cu (p = 100): in-band optimal paths, both
+    orientations, bands wider than one wavefront pass (bw up to 100 + 35 slots per anti-diagonal)."""
+    max_len = 700
+    pairs = _global_pairs(7, 150, max_len, int(max_len * 0.1))
+    res = _run_algorithm("ukkonen", pairs, max_len)
+    for r, (q, t) in zip(res, pairs):
+        ref = A.ukkonen(q, t, 100)
+        assert r.status == 0 and r.is_optimal
+        assert list(r.alignment) == ref["states"], (len(q), len(t))
+        assert r.cigar == ref["cigar"]
+
+
+def test_ukkonen_class_band_clipped_paths():
+    """Pairs whose optimal path leaves the p = 100 band (a 150-base block moved from the front to the back): the class
+    returns the band-restricted path, identical to the oracle's, including steps along the band edges."""
+    rng = random.Random(3)
+    pairs = []
+    for _ in range(12):
+        core = "".join(rng.choice("ACGT") for _ in range(rng.randrange(700, 900)))
+        block = "".join(rng.choice("ACGT") for _ in range(rng.randrange(130, 180)))
+        pairs.append((block + core, core + block))
+        pairs.append((core + block, block + core[:len(core) - 20]))
+    res = _run_algorithm("ukkonen", pairs, 1100)
+    clipped = 0
+    for r, (q, t) in zip(res, pairs):
+        ref = A.ukkonen(q, t, 100)
+        assert list(r.alignment) == ref["states"]
+        clipped += ref["edit_distance"] != A.myers_full(q, t)["edit_distance"]
+    assert clipped >= len(pairs) // 2
+
+
+def test_ukkonen_class_rejects_large_length_difference():
+    from genomeworks_amd import cudaaligner
+    al = cudaaligner.CudaAlignerBatch(100, 100, 4, algorithm="ukkonen", max_device_memory_allocator_caching_size=1 << 30)
+    # aligner_global_ukkonen.cpp:53-59: |q - t| > int(max_target_length * 0.1f)
+    assert al.add_alignment("A" * 50, "A" * 61) == cudaaligner.exceeded_max_alignment_difference
+    assert al.add_alignment("A" * 50, "A" * 60) == 0
+    assert al.add_alignment("A" * 101, "A" * 100) == cudaaligner.exceeded_max_length
+    al.align_all()
+    assert al.get_alignments()[0].cigar == A.ukkonen("A" * 50, "A" * 60)["cigar"]
+
+
+def test_myers_class_bit_exact_vs_oracle():
+    max_len = 700
+    pairs = _global_pairs(11, 150, max_len, max_len) + [("", "ACGT"), ("ACGT", ""), ("", "")]
+    res = _run_algorithm("myers", pairs, max_len)
+    for r, (q, t) in zip(res, pairs):
+        ref = A.myers_full(q, t)
+        assert r.status == 0 and r.is_optimal
+        assert list(r.alignment) == ref["states"], (len(q), len(t))
+        assert r.cigar == ref["cigar"]
