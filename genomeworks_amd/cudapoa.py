@@ -226,16 +226,24 @@ class CudaPoaBatch:
             status.append(self._L.gw_poa_output_status(self._h, i))
         return (cons, cov, status)
 
-    def get_msa(self):
-        """Returns (msa[group][sequence], per-group status)."""
+    def get_msa_native(self):
+        """D2H + host unpack inside the library (Batch::get_msa), without marshalling the rows to Python.
+        Returns the group count; collect_msa(count) fetches the rows afterwards."""
         n = C.c_int32(0)
         err = self._L.gw_poa_get_msa(self._h, C.byref(n))
         if err == output_type_unavailable:
             raise RuntimeError("Output type not requested during batch initialization")
         if err < 0:
             raise RuntimeError(self._L.gw_last_error().decode())
+        return n.value
+
+    def get_msa(self):
+        """Returns (msa[group][sequence], per-group status)."""
+        return self.collect_msa(self.get_msa_native())
+
+    def collect_msa(self, count):
         msa, status = [], []
-        for i in range(n.value):
+        for i in range(count):
             rows = []
             for r in range(self._L.gw_poa_msa_rows(self._h, i)):
                 ln = C.c_int32(0)

@@ -217,3 +217,29 @@ def test_long_read_adaptive_msa_32bit_path():
             assert status[i] == ref["status"] == 0
             assert msa[i] == ref["msa"]
             assert [r.replace("-", "") for r in msa[i]] == w
+
+
+def test_group_with_every_read_rejected_keeps_its_output_slot():
+    """Reference quirk (cudapoa_batch.cuh:122-150): add_poa_group opens the POA before it tries the reads, so a group
+    whose reads are all rejected returns empty_poa_group but stays in the batch with zero reads and owns an output
+    entry; callers that skip it (cudapoa/src/main.cpp:312-318 does) must still count that slot. The neighbours are
+    unaffected and bit-exact."""
+    from genomeworks_amd import cudapoa, synthetic
+    good = [[r.decode() for r in synthetic.generate_window(4100 + w, 300, 6, 15, 6, 6)] for w in range(2)]
+    too_long = ["ACGT" * 200, "TTGCA" * 150]  # both longer than max_sequence_size = 512
+    b = cudapoa.CudaPoaBatch(8, 512, 1 << 30, output_type="consensus", band_mode="static_band", max_nodes_per_graph=1536)
+    assert b.add_poa_group(good[0])[0] == 0
+    st, seq_st = b.add_poa_group(too_long)
+    assert st == cudapoa.empty_poa_group
+    assert seq_st == [cudapoa.exceeded_maximum_sequence_size] * 2
+    assert b.add_poa_group(good[1])[0] == 0
+    assert b.total_poas == 3
+    b.generate_poa()
+    cons, cov, status = b.get_consensus()
+    assert len(cons) == len(status) == 3
+    cfg = oracle_cfg("static_band", 512, 8, nodes=1536)
+    with O.Workspace(cfg) as ws:
+        for slot, w in ((0, good[0]), (2, good[1])):
+            ref = ws.process(w)
+            assert status[slot] == 0 and cons[slot] == ref["consensus"]
+            assert list(cov[slot]) == list(ref["coverage"])
