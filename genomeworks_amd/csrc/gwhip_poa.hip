@@ -34,6 +34,12 @@ constexpr int kRowInfoLds  = 3074;  // rows of the LDS row table (covers max_nod
 constexpr int kRowInfoBytes = kRowInfoLds * 8;
 constexpr int kReadLds     = 2048;  // LDS copy of the current read (+ read-ahead slack)
 constexpr int kCodeTileLds = 4096;  // LDS tile of trace codes for the traceback (64 rows x 64 columns)
+// Graphs that do not fit the LDS tables (long reads: HBM row table, 32-bit cells, bands up to 1536 columns) spend their
+// LDS on the forward pass instead: a ring of the most recent score rows wide enough for 5 rows of the widest band,
+// the band starts of those rows, and a sliding window of the read. 4 blocks per CU still fit (4 x 35 KB).
+constexpr int kWideRingBytes = 5 * (1536 + 8) * 4; // 30880
+constexpr int kBsRingBytes   = 2048; // band starts of the ring rows (64 x 4 B) + 64 staged rows of the HBM row table (64 x 24 B)
+constexpr int kReadWinBytes  = 4096;
 
 struct KernelArgs
 {
@@ -110,6 +116,9 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
     uint8_t* lds_rowinfo_region = smem + kRingBytes;
     uint8_t* lds_read_buf       = smem + kRingBytes + kRowInfoBytes;
     uint8_t* lds_code_tile      = LDS_TABLES ? smem + kRingBytes + kRowInfoBytes + kReadLds : nullptr;
+    constexpr int32_t ring_bytes = LDS_TABLES ? kRingBytes : kWideRingBytes;
+    int32_t* lds_bs_ring        = LDS_TABLES ? nullptr : reinterpret_cast<int32_t*>(smem + kWideRingBytes);
+    uint8_t* lds_read_window    = LDS_TABLES ? nullptr : smem + kWideRingBytes + kBsRingBytes;
     uint8_t* codes              = a.L.codes ? slab + a.L.codes : nullptr;
     constexpr bool graph_fits_lds = LDS_TABLES;
     using RowT = RowInfo<LDS_TABLES>;
@@ -217,20 +226,20 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
         }
         else if (BM == GWHIP_ADAPTIVE_BAND && c.alignment_band_width < kMaxAdaptiveBand)
         {
-            alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, kRingBytes,
+            alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                 banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
-                                                c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags, codes, lds_code_tile);
+                                                c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring);
             if (alen == kShiftLeft || alen == kShiftRight)
-                alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, kRingBytes,
+                alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                     banded_buffer_size, alignment_graph, alignment_read,
                                                     c.alignment_band_width, c.gap_score, c.mismatch_score, c.match_score,
-                                                    alen, cells, pc, a.debug_flags, codes, lds_code_tile);
+                                                    alen, cells, pc, a.debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring);
         }
         else if (BM == GWHIP_STATIC_BAND || BM == GWHIP_ADAPTIVE_BAND)
         {
-            alen = nw_banded<ScoreT, IdT, RowT, false, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, kRingBytes,
+            alen = nw_banded<ScoreT, IdT, RowT, false, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                  banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
-                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags, codes, lds_code_tile);
+                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring);
         }
         else
         {
@@ -253,6 +262,30 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
         pc.tick(kPhTraceback);
         int32_t status_and_count = 0;
         int32_t par_rc           = -1; // -1: use the serial merge
+        if constexpr (!LDS_TABLES && !TB && BM != GWHIP_FULL_BAND)
+        {
+            // graphs beyond the LDS tables (long reads): same lane-parallel merge, its scratch in the score matrix
+            // (dead until the next read's forward pass); 2 x read length + node bitset always fit in it
+            int32_t new_count   = 0;
+            int32_t* scratch    = reinterpret_cast<int32_t*>(scores);
+            const int32_t lpad  = (seq_len + 63) & ~63;
+            par_rc = add_alignment_parallel<IdT, MSA, int32_t>(new_count, g, node_count, alen, alignment_graph, alignment_read,
+                                                               sequence, base_weights, seq_len, MSA ? g.seq_begin + s : nullptr,
+                                                               (uint16_t)s, (uint32_t)c.max_sequences_per_poa,
+                                                               c.max_nodes_per_graph, scratch, scratch + lpad,
+                                                               reinterpret_cast<uint32_t*>(scratch + 2 * lpad), lane,
+                                                               a.debug_flags, pc.acc ? &pc.acc[kPhOther] : nullptr);
+            if (par_rc == 0)
+            {
+                if (lane == 0) seq_lens[0] = new_count; // :506
+                status_and_count = new_count;
+            }
+            else if (par_rc > 0)
+            {
+                if (lane == 0) { consensus[0] = kKernelError; consensus[1] = (uint8_t)par_rc; }
+                status_and_count = -1;
+            }
+        }
         if constexpr (LDS_TABLES)
         {
             int32_t new_count = 0;
@@ -437,7 +470,8 @@ static bool validate(const gwhip_poa_args* args)
 template <typename ScoreT, typename IdT, typename TraceT, bool MSA, bool LDS_TABLES>
 static hipError_t launch_window_kernel(const KernelArgs& ka, hipStream_t stream)
 {
-    const size_t lds = kRingBytes + (LDS_TABLES ? (size_t)kRowInfoBytes + kReadLds + kCodeTileLds : 0);
+    const size_t lds = LDS_TABLES ? (size_t)kRingBytes + kRowInfoBytes + kReadLds + kCodeTileLds
+                                  : (size_t)kWideRingBytes + kBsRingBytes + kReadWinBytes;
     dim3 grid(ka.total_windows), block(kWave);
 #define GW_LAUNCH(BM)                                                                                              \
     hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES>), grid, block, lds, stream, ka); \

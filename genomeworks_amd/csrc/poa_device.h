@@ -61,7 +61,9 @@ template <> struct alignas(8) RowInfo<false>
     __device__ __forceinline__ int32_t cnt() const { return cnt_sink_ & 0x7f; }
     __device__ __forceinline__ bool sink() const { return (cnt_sink_ & 0x80) != 0; }
     __device__ __forceinline__ int32_t bs() const { return bs_; }
-    __device__ __forceinline__ int32_t pred(int k) const { return pred_[k]; }
+    // selects, not pred_[k]: a runtime index would put the struct in scratch memory, and a scratch load in the row
+    // loop waits for every outstanding score store
+    __device__ __forceinline__ int32_t pred(int k) const { return k == 0 ? pred_[0] : (k == 1 ? pred_[1] : pred_[2]); }
     __device__ __forceinline__ void set(int32_t base, int32_t cnt, bool sink, int32_t p0, int32_t p1, int32_t p2)
     {
         base_ = (uint8_t)base; cnt_sink_ = (uint8_t)((cnt & 0x7f) | (sink ? 0x80 : 0)); pad_ = 0; bs_ = 0;
@@ -1076,7 +1078,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                              float max_buffer_size, int32_t* alignment_graph, int32_t* alignment_read,
                              int32_t band_width, int32_t gap_score, int32_t mismatch_score, int32_t match_score,
                              int32_t rerun, uint64_t& cells, PhaseClock& pc, int32_t dbg = 0, uint8_t* codes = nullptr,
-                             uint8_t* code_tile = nullptr)
+                             uint8_t* code_tile = nullptr, uint8_t* read_window = nullptr, int32_t* bs_ring = nullptr)
 {
     const int lane              = threadIdx.x & (kWave - 1);
     const int32_t min_score     = Limits<ScoreT>::min / 2;
@@ -1121,6 +1123,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     b.ring       = ring_base;
     b.ring_rows  = ring_bytes / (int32_t)(b.stride * sizeof(ScoreT));
     if (b.ring_rows < 2) b.ring_rows = 0;
+    if (bs_ring != nullptr) b.ring_rows = min(b.ring_rows, 64); // entries of bs_ring
     const int32_t stride = b.stride;
     const int32_t npass  = (band_width + 255) / 256;
     const bool reg_path  = (npass == 1); // previous row carried in registers
@@ -1151,7 +1154,30 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     bool hbm_dirty = true; // stores since the last workgroup sync (needed before reading the HBM matrix)
     __syncthreads();
     hbm_dirty = false;
-    auto bs_of = [&](int32_t row) -> int32_t { return row == 0 ? 0 : uniform_row(rowinfo[row]).bs(); };
+    // rows still in the LDS ring have their band start there too (bs_ring): with the row table in HBM a load of it
+    // in the middle of a row would wait for the previous row's score stores (loads and stores return in order)
+    auto bs_of = [&](int32_t row, int32_t r) -> int32_t {
+        if (row == 0) return 0;
+        if (bs_ring && b.ring_rows && r - row < b.ring_rows) return bs_ring[row % b.ring_rows];
+        return uniform_row(rowinfo[row]).bs();
+    };
+    // sliding LDS window over the read (graphs whose tables live in HBM): columns [staged_end - 4096, staged_end)
+    constexpr int32_t kWin = 4096, kWinStep = 1024;
+    int32_t staged_end = 0;
+    auto stage_read = [&](int32_t need_end) { // wave-uniform
+        while (staged_end < need_end)
+        {
+            for (int32_t i = lane * 4; i < kWinStep; i += kWave * 4)
+            {
+                const int32_t col = staged_end + i;
+                // positions past the read are never consumed (the input buffer keeps zero slack behind every read)
+                const uint32_t v = col < read_length + 8 ? *reinterpret_cast<const uint32_t*>(read + col) : 0u;
+                *reinterpret_cast<uint32_t*>(read_window + (col & (kWin - 1))) = v;
+            }
+            staged_end += kWinStep;
+        }
+        __syncthreads();
+    };
 
     constexpr bool kFastOk = std::is_same<RowT, RowInfo<true>>::value && LDS_READ;
     bool fast_done = false, codes_valid = false;
@@ -1182,23 +1208,45 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             fast_done = true;
         }
     }
-    RowT ri_next = uniform_row(rowinfo[1]);
-    for (int32_t r = 1; r <= graph_count && !fast_done; r++)
-    {
-        const RowT ri            = ri_next;
-        if (r < graph_count) ri_next = uniform_row(rowinfo[r + 1]); // prefetch: hides the LDS latency of the table
+    // Row table through LDS when it lives in HBM: 64 rows at a time, so the row loop itself issues no global load
+    // (one would wait for the previous row's score stores: loads and stores return in order).
+    RowT* ri_stage       = nullptr;
+    int32_t ri_stage_end = 0;
+    if constexpr (!std::is_same<RowT, RowInfo<true>>::value)
+        if (bs_ring != nullptr) ri_stage = reinterpret_cast<RowT*>(bs_ring + 64);
+    auto fetch_ri = [&](int32_t row) -> RowT {
+        if (ri_stage == nullptr) return uniform_row(rowinfo[row]);
+        if (row >= ri_stage_end) // wave-uniform
+        {
+            __syncthreads();
+            if (row + lane <= graph_count) ri_stage[(row + lane) & 63] = rowinfo[row + lane];
+            ri_stage_end = row + 64;
+            __syncthreads();
+        }
+        return ri_stage[row & 63];
+    };
+    // One row. FAST: every predecessor row is still in the LDS ring (and there are at most three), so this
+    // instantiation contains LDS traffic and score stores only -- no load that would drain the store queue.
+    auto row_body = [&](auto fast_tag, const int32_t r, const int32_t slot_r, const RowT& ri) {
+        constexpr bool FAST      = decltype(fast_tag)::value;
         const int32_t pred_count = ri.cnt();
         const int32_t bs         = ri.bs();
-        const int32_t node_id    = (pred_count > 3) ? (int32_t)g.sorted_poa[r - 1] : 0;
+        const int32_t node_id    = (!FAST && pred_count > 3) ? (int32_t)g.sorted_poa[r - 1] : 0;
         auto pred_row = [&](int32_t p) -> int32_t {
             if (pred_count == 0) return 0;
-            if (p < 3) return ri.pred(p);
+            if (FAST || p < 3) return ri.pred(p);
             return (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
+        };
+        // ring slot of an earlier row that is still in the ring
+        auto slot_of = [&](int32_t row) -> int32_t {
+            if (!FAST) return row % b.ring_rows;
+            const int32_t sl = slot_r - (r - row);
+            return sl < 0 ? sl + b.ring_rows : sl;
         };
         // relative-0 slot of an arbitrary earlier row (get_score(row, -1): reads rel 0 unconditionally)
         auto rel0_of = [&](int32_t row) -> int32_t {
             if (reg_path && row == r - 1) return prev_rel0;
-            if (b.ring_rows && r - row < b.ring_rows) return b.ring[(row % b.ring_rows) * stride + kRelShift];
+            if (FAST || (b.ring_rows && r - row < b.ring_rows)) return b.ring[slot_of(row) * stride + kRelShift];
             if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
             return scores[(int64_t)row * stride + kRelShift];
         };
@@ -1224,6 +1272,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             if (bs == 0) rel0_val = (ScoreT)fe;
         }
 
+        if (read_window != nullptr && bs + npass * 256 + 4 > staged_end) stage_read(bs + npass * 256 + 4);
         int32_t carry = fe;
         int32_t N0 = 0, N1 = 0, N2 = 0, N3 = 0; // this row's cells of the (single) register pass
         for (int32_t pass = 0; pass < npass; pass++)
@@ -1234,7 +1283,8 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             // They come from the LDS copy when the read was staged: a global load here would make every row
             // wait for the previous row's score store (loads and stores share the in-order vmcnt counter).
             const uint32_t rd4   = LDS_READ ? *reinterpret_cast<const uint32_t*>(lds_read + c)
-                                            : *reinterpret_cast<const uint32_t*>(read + c);
+                                   : read_window != nullptr ? *reinterpret_cast<const uint32_t*>(read_window + (c & (kWin - 1)))
+                                                            : *reinterpret_cast<const uint32_t*>(read + c);
             const int32_t cp0    = ((rd4 & 0xff) == (uint32_t)ri.base()) ? match_score : mismatch_score;
             const int32_t cp1    = (((rd4 >> 8) & 0xff) == (uint32_t)ri.base()) ? match_score : mismatch_score;
             const int32_t cp2    = (((rd4 >> 16) & 0xff) == (uint32_t)ri.base()) ? match_score : mismatch_score;
@@ -1244,7 +1294,8 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             for (int32_t p = 0; p < np; p++)
             {
                 const int32_t prow = (p == 0) ? pred_idx0 : pred_row(p);
-                const int32_t pbs  = (reg_path && prow == r - 1) ? prev_bs : bs_of(prow);
+                const int32_t pbs  = (reg_path && prow == r - 1) ? prev_bs
+                                     : FAST ? (prow == 0 ? 0 : bs_ring[slot_of(prow)]) : bs_of(prow, r);
                 const int32_t pend = min(pbs + band_width - kCellsPerLane, max_column);
                 const bool valid   = !(c > pend || c < pbs);
                 int32_t S0, S1, S2, S3, S4; // predecessor row columns c .. c+4
@@ -1270,7 +1321,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                 }
                 else
                 {
-                    const bool in_ring = b.ring_rows && r - prow < b.ring_rows;
+                    const bool in_ring = FAST || (b.ring_rows && r - prow < b.ring_rows);
                     if (!in_ring && hbm_dirty) { __syncthreads(); hbm_dirty = false; }
                     S0 = S1 = S2 = S3 = S4 = 0;
                     if (valid)
@@ -1278,7 +1329,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                         const int32_t rel = c - pbs; // multiple of 4
                         if (in_ring) // LDS ring: ds_read ops only
                         {
-                            const ScoreT* rowp = b.ring + (prow % b.ring_rows) * stride;
+                            const ScoreT* rowp = b.ring + slot_of(prow) * stride;
                             S0 = rowp[rel + kRelShift];
                             Quad<ScoreT> qd = *reinterpret_cast<const Quad<ScoreT>*>(rowp + rel + kRelShift + 1);
                             S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
@@ -1329,13 +1380,14 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                 const int32_t rel = pass * 256 + 4 * lane + 1;
                 if (!(dbg & 1)) *reinterpret_cast<Quad<ScoreT>*>(scores + (int64_t)r * stride + rel + kRelShift) = out;
                 if (b.ring_rows && !(dbg & 2))
-                    *reinterpret_cast<Quad<ScoreT>*>(b.ring + (r % b.ring_rows) * stride + rel + kRelShift) = out;
+                    *reinterpret_cast<Quad<ScoreT>*>(b.ring + slot_r * stride + rel + kRelShift) = out;
             }
         }
         if (lane == 0)
         {
             if (!(dbg & 1)) scores[(int64_t)r * stride + kRelShift] = (ScoreT)rel0_val;
-            if (b.ring_rows && !(dbg & 2)) b.ring[(r % b.ring_rows) * stride + kRelShift] = (ScoreT)rel0_val;
+            if (b.ring_rows && !(dbg & 2)) b.ring[slot_r * stride + kRelShift] = (ScoreT)rel0_val;
+            if (bs_ring && b.ring_rows) bs_ring[slot_r] = bs;
         }
         hbm_dirty = true;
         if (reg_path)
@@ -1343,6 +1395,28 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             P0 = N0; P1 = N1; P2 = N2; P3 = N3;
             prev_bs   = bs;
             prev_rel0 = rel0_val;
+        }
+    };
+    if (!fast_done)
+    {
+        RowT ri_next   = fetch_ri(1);
+        int32_t slot_r = b.ring_rows ? 1 % b.ring_rows : 0; // r % ring_rows, kept incrementally
+        for (int32_t r = 1; r <= graph_count; r++)
+        {
+            const RowT ri = ri_next;
+            if (r < graph_count) ri_next = fetch_ri(r + 1); // prefetch: hides the LDS latency of the table
+            bool all_in_ring = ri_stage != nullptr && b.ring_rows >= 2 && ri.cnt() <= 3;
+            if (all_in_ring)
+            {
+                const int32_t np = max(ri.cnt(), 1);
+                for (int32_t p = 0; p < np; p++) all_in_ring = all_in_ring && (r - (ri.cnt() ? ri.pred(p) : 0) < b.ring_rows);
+            }
+            if ((dbg & (1 << 20)) && pc.acc) pc.acc[kPhOther] += all_in_ring ? 1 : (1 << 20); // profiling: rows per path
+            if (wave_first((int32_t)all_in_ring))
+                row_body(std::true_type{}, r, slot_r, ri);
+            else
+                row_body(std::false_type{}, r, slot_r, ri);
+            slot_r = (b.ring_rows && slot_r + 1 == b.ring_rows) ? 0 : slot_r + 1;
         }
     }
     __syncthreads(); // score matrix complete and visible to lane 0's traceback

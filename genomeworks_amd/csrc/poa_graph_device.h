@@ -147,16 +147,17 @@ __device__ uint8_t add_alignment_to_graph(int32_t& new_node_count, const GraphVi
 // (they never are in a well-formed POA); phase A verifies exactly that and returns -1, before anything was
 // modified, so the caller can fall back to the serial routine. Error precedence (first failing rp, node
 // overflow before edge overflow inside one rp) is reproduced.
-// LDS scratch: gnode[L], curr[L] (int16) and a node bitset `onpath`.
+// Scratch: gnode[L], curr[L] (NodeT) and a node bitset `onpath` -- in LDS when the graph fits there (16-bit ids),
+// otherwise in the window's score matrix, which is dead between the traceback and the next forward pass.
 // ------------------------------------------------------------------------------------------------
-template <typename IdT, bool MSA>
+template <typename IdT, bool MSA, typename NodeT = int16_t>
 __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_count, const GraphView<IdT>& g,
                                                           int32_t node_count, int32_t alen, const int32_t* ag,
                                                           const int32_t* ar, const uint8_t* read,
                                                           const int8_t* base_weights, int32_t read_length,
                                                           IdT* sequence_begin_nodes_ids, uint16_t s,
                                                           uint32_t max_sequences_per_poa, int32_t max_nodes,
-                                                          int16_t* gnode, int16_t* curr, uint32_t* onpath, int lane,
+                                                          NodeT* gnode, NodeT* curr, uint32_t* onpath, int lane,
                                                           int32_t dbg = 0, uint64_t* prof_acc = nullptr)
 {
     const int32_t L = read_length;
@@ -181,7 +182,7 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
         const int32_t gn = k < alen ? ag[k] : -1; // independent of rp: both loads are in flight together
         if (rp >= 0)
         {
-            gnode[rp]        = (int16_t)gn;
+            gnode[rp]        = (NodeT)gn;
             if (gn >= 0) atomicOr(&onpath[gn >> 5], 1u << (gn & 31));
         }
         covered += __popcll(__ballot(rp >= 0));
@@ -227,7 +228,7 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
             cur = node_count + running + __popcll(m & ((1ull << lane) - 1));
             if (cur + 1 >= max_nodes) rp_nodeerr = min(rp_nodeerr, rp);
         }
-        if (rp < L) curr[rp] = (int16_t)cur;
+        if (rp < L) curr[rp] = (NodeT)cur;
         running += __popcll(m);
     }
     if (__any(conflict)) return -1;
