@@ -143,6 +143,31 @@ template <> __device__ __forceinline__ RowInfo<true> uniform_row(RowInfo<true> r
     r.w = wave_first64(r.w);
     return r;
 }
+// Load through an explicit LDS pointer. Where an LDS branch and an HBM branch do the same loads the optimiser would
+// otherwise merge them behind one flat pointer (flat loads wait on both memory counters).
+template <typename T> __device__ __forceinline__ T lds_ld(const T* p)
+{
+    return *(const __attribute__((address_space(3))) T*)p;
+}
+template <typename ScoreT> __device__ __forceinline__ Quad<ScoreT> lds_ld_quad(const ScoreT* p)
+{
+    const __attribute__((address_space(3))) ScoreT* q = (const __attribute__((address_space(3))) ScoreT*)p;
+    Quad<ScoreT> r;
+    r.v[0] = q[0]; r.v[1] = q[1]; r.v[2] = q[2]; r.v[3] = q[3];
+    return r;
+}
+
+// every lane loaded the same record: moving it to scalar registers lets the row loop branch and index on the scalar unit
+template <> __device__ __forceinline__ RowInfo<false> uniform_row(RowInfo<false> r)
+{
+    static_assert(sizeof(RowInfo<false>) == 24, "six dwords");
+    int32_t w[6];
+    __builtin_memcpy(w, &r, sizeof(r));
+#pragma unroll
+    for (int k = 0; k < 6; k++) w[k] = wave_first(w[k]);
+    __builtin_memcpy(&r, w, sizeof(r));
+    return r;
+}
 
 // Single-lane LDS stores without a branch: the compiler turns `if (lane == 0) *p = v;` into an exec-mask save,
 // a skip branch and a restore; inside wave-uniform code (all 64 lanes active) narrowing exec around the store is
@@ -1223,7 +1248,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             ri_stage_end = row + 64;
             __syncthreads();
         }
-        return ri_stage[row & 63];
+        return uniform_row(ri_stage[row & 63]);
     };
     // One row. FAST: every predecessor row is still in the LDS ring (and there are at most three), so this
     // instantiation contains LDS traffic and score stores only -- no load that would drain the store queue.
@@ -1246,7 +1271,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
         // relative-0 slot of an arbitrary earlier row (get_score(row, -1): reads rel 0 unconditionally)
         auto rel0_of = [&](int32_t row) -> int32_t {
             if (reg_path && row == r - 1) return prev_rel0;
-            if (FAST || (b.ring_rows && r - row < b.ring_rows)) return b.ring[slot_of(row) * stride + kRelShift];
+            if (FAST || (b.ring_rows && r - row < b.ring_rows)) return lds_ld(b.ring + slot_of(row) * stride + kRelShift);
             if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
             return scores[(int64_t)row * stride + kRelShift];
         };
@@ -1330,8 +1355,8 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                         if (in_ring) // LDS ring: ds_read ops only
                         {
                             const ScoreT* rowp = b.ring + slot_of(prow) * stride;
-                            S0 = rowp[rel + kRelShift];
-                            Quad<ScoreT> qd = *reinterpret_cast<const Quad<ScoreT>*>(rowp + rel + kRelShift + 1);
+                            S0 = lds_ld(rowp + rel + kRelShift);
+                            Quad<ScoreT> qd = lds_ld_quad(rowp + rel + kRelShift + 1);
                             S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
                         }
                         else // HBM score matrix
