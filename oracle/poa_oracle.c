@@ -353,6 +353,31 @@ static void topsort_kahn(int32_t* sorted_poa, int32_t* sorted_poa_node_map, int3
     }
 }
 
+#include <stdio.h>
+#include "topsort_incr_model.inc"
+static int32_t* tsm_sorted = NULL;
+static int32_t* tsm_map    = NULL;
+static uint16_t* tsm_meta  = NULL;
+static int32_t tsm_cap = 0, tsm_nold = 0;
+static void tsm_begin_window(int32_t max_nodes, int32_t len0)
+{
+    if (max_nodes > tsm_cap)
+    {
+        free(tsm_sorted); free(tsm_map); free(tsm_meta);
+        tsm_sorted = (int32_t*)malloc(sizeof(int32_t) * (size_t)max_nodes);
+        tsm_map    = (int32_t*)malloc(sizeof(int32_t) * (size_t)max_nodes);
+        tsm_meta   = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)max_nodes);
+        tsm_cap    = max_nodes;
+    }
+    for (int32_t n = 0; n < len0; n++) /* backbone chain: queue length 1 everywhere */
+    {
+        tsm_sorted[n] = n;
+        tsm_map[n]    = n;
+        tsm_meta[n]   = (uint16_t)(1 | ((n < len0 - 1 ? 1 : 0) << 4) | ((n > 0 ? 1 : 0) << 10));
+    }
+    tsm_nold = len0;
+}
+
 /* raconTopologicalSortDeviceUtil: cudapoa_topsort.cuh:103-197 */
 static void topsort_racon(int32_t* sorted_poa, int32_t* sorted_poa_node_map, int32_t node_count,
                           const uint16_t* incoming_edge_count, const int32_t* incoming_edges,
@@ -624,6 +649,7 @@ int32_t poa_process_window(poa_workspace* ws, const uint8_t* seqs, const int8_t*
         }
     }
     consensus[0] = 0;
+    if (tsm_enabled && !c->spoa_accurate && c->max_nodes_per_graph <= 4095) tsm_begin_window(c->max_nodes_per_graph, seq_lens[0]);
 
     float banded_buffer_size = (float)c->max_nodes_per_graph * (float)c->matrix_sequence_dimension; /* :149-162 */
     int32_t scores_width     = 0; /* full band: window_details.scores_width, cudapoa_batch.cuh:502-507 */
@@ -735,8 +761,18 @@ int32_t poa_process_window(poa_workspace* ws, const uint8_t* seqs, const int8_t*
                           g->node_alignment_count, g->node_alignments, g->node_marks, g->check_aligned_nodes,
                           g->nodes_to_visit, (int32_t)(uint16_t)c->max_nodes_per_graph /* (uint16_t) cast :519 */);
         else
+        {
             topsort_kahn(g->sorted_poa, g->node_id_to_pos, new_node_count, g->incoming_edge_count, g->outgoing_edges,
                          g->outgoing_edge_count, g->local_incoming_edge_count);
+            if (tsm_enabled && c->max_nodes_per_graph <= 4095) /* model of the kernel's incremental order, see the .inc */
+            {
+                topsort_incr_model(tsm_sorted, tsm_map, tsm_nold, new_node_count, g->incoming_edge_count,
+                                   g->outgoing_edges, g->outgoing_edge_count, tsm_meta);
+                tsm_nold = new_node_count;
+                for (int32_t n = 0; n < new_node_count; n++)
+                    if (tsm_sorted[n] != g->sorted_poa[n] || tsm_map[n] != g->node_id_to_pos[n]) { tsm_stats[TSM_MISMATCH]++; break; }
+            }
+        }
     }
 
     /* output kernels: cudapoa_kernels.cuh:1023-1075 -- msa bit set => ONLY the MSA kernel runs */

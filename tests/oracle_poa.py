@@ -37,6 +37,8 @@ def lib():
         L.poa_cfg_init.argtypes = [C.POINTER(PoaCfg), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         L.poa_cfg_select_types.argtypes = [C.POINTER(PoaCfg)]
+        L.poa_topsort_model_enable.argtypes = [C.c_int, C.c_int]
+        L.poa_topsort_model_stats.argtypes = [C.c_void_p]
         L.poa_run_nw_full.restype = C.c_int32
         L.poa_run_nw_banded.restype = C.c_int32
         L.poa_run_add_alignment.restype = C.c_int32
@@ -160,3 +162,27 @@ class Workspace:
                 rows.append(bytes(row[:int(np.argmax(row == 0))]).decode())
             out["msa"] = rows
         return out
+
+
+TOPSORT_MODEL_STATS = ("reads", "nodes", "real_steps", "blocks", "block_nodes", "sync_checks", "sync_hits", "mismatch",
+                       "empty_blocks")
+
+
+class topsort_model:
+    """Context manager: run the scalar model of the kernel's incremental Kahn order (oracle/topsort_incr_model.inc)
+    next to the plain topologicalSortDeviceUtil restatement inside poa_process_window and count disagreements."""
+
+    def __init__(self, lane_order=0):
+        self.lane_order = lane_order
+
+    def __enter__(self):
+        lib().poa_topsort_model_enable(1, self.lane_order)
+        return self
+
+    def stats(self):
+        st = (C.c_int64 * len(TOPSORT_MODEL_STATS))()
+        lib().poa_topsort_model_stats(st)
+        return dict(zip(TOPSORT_MODEL_STATS, list(st)))
+
+    def __exit__(self, *a):
+        lib().poa_topsort_model_enable(0, 0)
