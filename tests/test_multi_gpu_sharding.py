@@ -21,6 +21,26 @@ def test_shard_range_partitions_exactly():
         shard_range(10, 2, 2)
 
 
+def test_balanced_partition_is_exact_deterministic_and_balanced():
+    import random
+    from genomeworks_amd.multi_gpu import balanced_partition, poa_window_cost, pair_cost
+    rng = random.Random(3)
+    costs = [rng.choice([1, 5, 40, 300]) * rng.randrange(1, 50) for _ in range(997)]
+    for world in (1, 2, 3, 8):
+        parts = balanced_partition(costs, world)
+        assert sorted(i for p in parts for i in p) == list(range(len(costs)))  # every unit exactly once
+        assert all(p == sorted(p) for p in parts)
+        assert parts == balanced_partition(list(costs), world)                # same on every rank
+        loads = [sum(costs[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(costs)                          # LPT bound
+    assert balanced_partition([], 4) == [[], [], [], []]
+    assert poa_window_cost(["ACGT" * 10] * 3) == 2 * 40 * 256 and poa_window_cost(["ACGT"]) == 0
+    assert poa_window_cost(["ACGT" * 10, "ACG"], band_width=0) == 40 * 3
+    assert pair_cost("ACGT", "AC") == 6
+    with pytest.raises(ValueError):
+        balanced_partition([1], 0)
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -36,8 +56,11 @@ def _worker(rank, world, port, q):
         return [u[::-1] + ":%d" % (lo + k) for k, u in enumerate(chunk)]
 
     res = run_sharded(units, process)
+    # cost-balanced split of the same units: results still land by global index
+    costs = [(i * 7919) % 13 + 1 for i in range(len(units))]
+    res_b = run_sharded(units, lambda chunk, idx: [u[::-1] + ":%d" % i for u, i in zip(chunk, idx)], costs=costs)
     dist.barrier()
-    q.put((rank, seen, res))
+    q.put((rank, seen, (res, res_b)))
     dist.destroy_process_group()
 
 
@@ -55,5 +78,6 @@ def test_two_rank_gloo_gather_is_order_independent():
     got.sort()
     (r0, seen0, res0), (r1, seen1, res1) = got
     assert seen0 == [(0, 19)] and seen1 == [(19, 18)]
-    assert res1 is None
-    assert res0 == [("w%04d" % i)[::-1] + ":%d" % i for i in range(37)]  # same as a single-rank run
+    assert res1 == (None, None)
+    want = [("w%04d" % i)[::-1] + ":%d" % i for i in range(37)]  # same as a single-rank run
+    assert res0[0] == want and res0[1] == want
