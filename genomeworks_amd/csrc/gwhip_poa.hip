@@ -34,6 +34,7 @@ constexpr int kRowInfoLds  = 3074;  // rows of the LDS row table (covers max_nod
 constexpr int kRowInfoBytes = kRowInfoLds * 8;
 constexpr int kReadLds     = 2048;  // LDS copy of the current read (+ read-ahead slack)
 constexpr int kCodeTileLds = 4096;  // LDS tile of trace codes for the traceback (64 rows x 64 columns)
+static_assert(kReadLds + kCodeTileLds >= 3072 * 2, "the incremental topsort keeps the previous order (uint16 x 3072) in the read + code-tile regions");
 // Graphs that do not fit the LDS tables (long reads: HBM row table, 32-bit cells, bands up to 1536 columns) spend their
 // LDS on the forward pass instead: a ring of the most recent score rows wide enough for 5 rows of the widest band,
 // the band starts of those rows, and a sliding window of the read. 4 blocks per CU still fit (4 x 35 KB).
@@ -147,6 +148,8 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
         g.node_alignment_count[i] = 0;
         g.coverage[i]             = 1;
         g.outgoing_edge_count[i]  = (i == len0 - 1) ? 0 : 1;
+        // per-node record of the incremental topsort: queue length 1 | out-degree << 4 | in-degree << 10
+        g.local_cnt[i] = (uint16_t)(1 | ((i == len0 - 1 ? 0 : 1) << 4) | ((i == 0 ? 0 : 1) << 10));
         if (i < len0 - 1)
         {
             g.outgoing_edges[(int64_t)i * kEdges] = (IdT)(i + 1);
@@ -339,7 +342,15 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
         status_and_count = wave_first(status_and_count);
         __syncthreads();
         if (status_and_count >= 0 && !c.spoa_accurate && graph_fits_lds)
-            topsort_kahn_lds<IdT>(g, status_and_count, lds_rowinfo_region, smem, lane, a.debug_flags, pc.acc ? &pc.acc[kPhOther] : nullptr);
+        {
+            if constexpr (LDS_TABLES)
+            {
+                if (!(a.debug_flags & (1 << 21))) // GWHIP_DEBUG bit 21: full re-sort after every read (A/B switch)
+                    topsort_kahn_incr_lds<IdT>(g, node_count, status_and_count, lds_rowinfo_region, smem, lds_read_buf, lane);
+                else
+                    topsort_kahn_lds<IdT>(g, status_and_count, lds_rowinfo_region, smem, lane, a.debug_flags, pc.acc ? &pc.acc[kPhOther] : nullptr);
+            }
+        }
         pc.tick(kPhTopsort);
         if (status_and_count < 0) break;
         node_count = status_and_count;

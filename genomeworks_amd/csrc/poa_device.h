@@ -529,9 +529,14 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     int32_t i = start_i, j = read_length, prev_i = 0, prev_j = 0;
     int32_t tile_top = -1, tile_col = 0; // matrix row in tile row 0 and the column the windows are anchored on
     uint32_t* stage  = reinterpret_cast<uint32_t*>(tile + kTileRows * kTileStride);
+    // profiling (GWHIP_DEBUG bits 22-24, outside the table-lookup loop): 2 cycles in load_codes, 3 its calls,
+    // 4 cycles in recomputed steps (incl. their tile loads), 5 their number, 6 cycles of the post-pass, 7 load_tile calls
+    const int32_t psel = prof_acc ? (dbg >> 22) & 7 : 0;
+    uint64_t pacc      = 0;
 
     auto window_lo = [&](int32_t t) -> int32_t { return ((tile_col - kLead - t) & ~3) + 1; };
     auto load_tile = [&](int32_t top, int32_t col) {
+        if (psel == 7) pacc++;
         __syncthreads();
         tile_top = top;
         tile_col = col;
@@ -579,6 +584,8 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     int32_t ctop = -1, ccol = 0; // matrix row in code-tile row 0 and the column its windows are anchored on
     auto code_lo = [&](int32_t t) -> int32_t { return ((ccol - kLead - t) & ~3) + 1; };
     auto load_codes = [&](int32_t top, int32_t col) {
+        const uint64_t t_lc = psel == 2 ? clock64() : 0;
+        if (psel == 3) pacc++;
         __syncthreads();
         ctop = top;
         ccol = col;
@@ -606,6 +613,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
                 reinterpret_cast<uint8_t*>(dst)[k] = (k >= klo && k <= khi) ? src[k] : (uint8_t)0;
         }
         __syncthreads();
+        if (psel == 2) pacc += clock64() - t_lc;
     };
 
     // lane roles (VGPR constants)
@@ -667,6 +675,8 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
             if (stop) break;
             if ((i == 0 && j == 0) || loop_count >= bound) continue; // the outer condition ends the walk
         }
+        const uint64_t t_rc = psel == 4 ? clock64() : 0;
+        if (psel == 5) pacc++;
         // keep the current cell and its near predecessors inside the tile
         {
             const int32_t t   = tile_top - i;
@@ -782,7 +792,9 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         ri_hi     = next_hi;
         rch       = next_rch;
         have      = found;
+        if (psel == 4) pacc += clock64() - t_rc;
     }
+    const uint64_t t_pp = psel == 6 ? clock64() : 0;
     if (aligned_nodes > 0 && (aligned_nodes & (kStage - 1)) != 0)
         flush_stage(aligned_nodes & ~(kStage - 1), aligned_nodes & (kStage - 1));
     if ((dbg & 2) && prof_acc && lane == 0) *prof_acc += (uint64_t)max(aligned_nodes, 0); // profiling: all steps
@@ -800,6 +812,8 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
             if (pos[u] >= 0) alignment_graph[k0 + u * kWave] = node[u];
     }
     __syncthreads();
+    if (psel == 6) pacc += clock64() - t_pp;
+    if (psel && lane == 0) *prof_acc += pacc;
     return aligned_nodes;
 }
 
@@ -1448,6 +1462,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     pc.tick(kPhForward);
 
     // ---- sink selection (:410-426): first row with the strictly greatest H(row, L) among sink rows ----
+    const uint64_t t_sink = (pc.acc && ((dbg >> 22) & 7) == 1) ? clock64() : 0;
     int32_t best = min_score, best_i = 0;
     for (int32_t idx = 1 + lane; idx <= graph_count; idx += kWave)
     {
@@ -1464,6 +1479,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
         if (ob > best || (ob == best && oi != 0 && (best_i == 0 || oi < best_i))) { best = ob; best_i = oi; }
     }
 
+    if (pc.acc && ((dbg >> 22) & 7) == 1) pc.acc[kPhOther] += clock64() - t_sink;
     int32_t aligned_nodes = 0;
     const bool tile_fits = (int32_t)(64 * 64 * sizeof(ScoreT) + 64 * sizeof(int32_t)) <= ring_bytes; // also covers the 60 x 68 + 64-word layout
     constexpr bool kLanesOk = std::is_same<RowT, RowInfo<true>>::value && LDS_READ;

@@ -501,6 +501,186 @@ __device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Incremental Kahn order. The reference re-sorts the whole graph after every read (cudapoa_kernels.cuh:516-531),
+// but one read changes the graph in a few places only, and Kahn's FIFO order is a deterministic replay: if, when
+// position p of the PREVIOUS order sigma is about to be popped, (1) the old nodes output so far are exactly
+// sigma[0..p) and (2) the queue holds exactly what the previous run's queue held at that moment, then popping a
+// node without a new out-edge whose children have no new in-edge does what the previous run did. Such steps are
+// taken up to 64 at a time (one lane per step; in-edge counters decremented with LDS atomics; order copied from
+// sigma), every other step is an ordinary Kahn step, and the state is in sync again as soon as (1) and (2) hold.
+// Output identical to topsort_kahn; the algorithm is modelled and checked against the plain restatement on CPU
+// (oracle/topsort_incr_model.inc, tests/test_oracle_poa.py).
+//   per node, carried from read to read in GraphView::local_cnt (uint16): queue length when the node was popped
+//   (4 bits, 15 = "15 or more": never a sync point) | out-degree << 4 | in-degree << 10;
+//   node word lo: out-edge 0 [0:12)  out-edge 1 [12:24)  out-degree [24:32)
+//             hi: unvisited in-edges [0:8)  new in-edge / new node [8]  new out-edge / new node [9]
+//                 previous position [10:22)  previous queue length [22:26)  in-degree [26:32)
+//   LDS: ent (row-table region), queue (score-ring region), previous order (read + trace-code-tile regions, 6 KB).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ti_din(uint32_t h) { return (h >> 8) & 1u; }
+__device__ __forceinline__ uint32_t ti_dout(uint32_t h) { return (h >> 9) & 1u; }
+__device__ __forceinline__ int32_t ti_pos(uint32_t h) { return (int32_t)((h >> 10) & 0xfffu); }
+__device__ __forceinline__ int32_t ti_qlen(uint32_t h) { return (int32_t)((h >> 22) & 15u); }
+__device__ __forceinline__ uint32_t lds_dec_u32(uint32_t* p) // returns the old value
+{
+    return __hip_atomic_fetch_sub(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <typename IdT>
+__device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, int32_t n_old, int32_t node_count,
+                                                      uint8_t* lds, uint8_t* lds_queue, uint8_t* lds_old, int lane)
+{
+    constexpr int32_t kDummy = 3073; // spare word of the 3074-entry region
+    constexpr int32_t kQClip = 15;
+    uint64_t* ent   = reinterpret_cast<uint64_t*>(lds);
+    uint32_t* ent32 = reinterpret_cast<uint32_t*>(lds);
+    uint16_t* queue = reinterpret_cast<uint16_t*>(lds_queue);
+    uint16_t* sold  = reinterpret_cast<uint16_t*>(lds_old);
+    auto hi_of = [&](int32_t n) -> uint32_t { return ent32[2 * n + 1]; };
+    // phase 1 (all lanes): node words with change flags, previous order into LDS, sources in ascending node id
+    int32_t tail = 0;
+    for (int32_t base = 0; base < node_count; base += kWave)
+    {
+        const int32_t n = base + lane;
+        bool is_src     = false;
+        if (n < node_count)
+        {
+            const bool is_new = n >= n_old;
+            const int32_t nn  = is_new ? 0 : n;
+            // seven independent loads, one HBM round trip
+            const uint32_t ic = g.incoming_edge_count[n];
+            const uint32_t oc = g.outgoing_edge_count[n];
+            const uint32_t e0 = (uint32_t)g.outgoing_edges[(int64_t)n * kEdges] & 0xfffu;
+            const uint32_t e1 = (uint32_t)g.outgoing_edges[(int64_t)n * kEdges + 1] & 0xfffu;
+            const uint32_t m  = g.local_cnt[nn];
+            const uint32_t po = (uint32_t)g.node_id_to_pos[nn] & 0xfffu;
+            const uint32_t so = (uint32_t)g.sorted_poa[nn] & 0xfffu;
+            if (!is_new) sold[n] = (uint16_t)so;
+            const uint32_t din  = (is_new || ((m >> 10) & 63u) != ic) ? 1u : 0u;
+            const uint32_t dout = (is_new || ((m >> 4) & 63u) != oc) ? 1u : 0u;
+            const uint32_t lo   = (oc > 0 ? e0 : 0u) | (oc > 1 ? e1 << 12 : 0u) | ((oc & 0xffu) << 24);
+            const uint32_t hi   = (ic & 0xffu) | (din << 8) | (dout << 9) | (is_new ? 0u : (po << 10) | ((m & 15u) << 22)) | (ic << 26);
+            ent[n] = (uint64_t)lo | ((uint64_t)hi << 32);
+            is_src = (ic == 0);
+        }
+        const unsigned long long m = __ballot(is_src);
+        if (is_src) queue[tail + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)n;
+        tail += __popcll(m);
+    }
+    __syncthreads();
+    // phase 2: wave-uniform control; k = new nodes output so far, M = highest previous position output so far
+    int32_t head = 0, k = 0, M = -1;
+    while (head < tail)
+    {
+        const int32_t u   = wave_first((int32_t)queue[head]) & 0xfff;
+        const uint64_t w  = wave_first64(ent[u]);
+        const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+        const int32_t oc  = (int32_t)(lo >> 24);
+        const int32_t c0  = oc > 0 ? (int32_t)(lo & 0xfffu) : kDummy;
+        const int32_t c1  = oc > 1 ? (int32_t)((lo >> 12) & 0xfffu) : kDummy;
+        const uint32_t h0 = (uint32_t)wave_first((int32_t)hi_of(c0));
+        const uint32_t h1 = (uint32_t)wave_first((int32_t)hi_of(c1));
+        const int32_t len = tail - head;
+        const int32_t p = ti_pos(hi), qo = ti_qlen(hi);
+        const bool is_new = u >= n_old;
+        // a real step is needed when the node has a new out-edge or a child has a new in-edge
+        const bool need_real = is_new | (ti_dout(hi) != 0) | (oc > 2) | ((oc > 0) & (ti_din(h0) != 0)) | ((oc > 1) & (ti_din(h1) != 0));
+        bool block = !need_real && (head - k == p) && (M == p - 1) && (len == qo) && (qo < kQClip);
+        if (block && len > 1) // the queue must be the previous run's queue at p, element by element
+        {
+            const int32_t qi  = lane < len ? (int32_t)(queue[head + lane] & 0xfff) : u;
+            const uint32_t qh = hi_of(qi);
+            const bool ok     = lane >= len || (qi < n_old && ti_pos(qh) == p + lane);
+            block             = __ballot(!ok) == 0;
+        }
+        if (block)
+        {
+            // lane l replays the pop of position p + l of the previous order
+            const int32_t posl = p + lane;
+            const bool valid   = posl < n_old;
+            const int32_t node = valid ? (int32_t)sold[posl] : u;
+            const uint64_t wn  = ent[node];
+            const uint32_t nlo = (uint32_t)wn, nhi = (uint32_t)(wn >> 32);
+            const int32_t noc  = (int32_t)(nlo >> 24);
+            const int32_t ch0  = noc > 0 ? (int32_t)(nlo & 0xfffu) : node;
+            const int32_t ch1  = noc > 1 ? (int32_t)((nlo >> 12) & 0xfffu) : node;
+            const uint32_t g0 = hi_of(ch0), g1 = hi_of(ch1);
+            bool bad = !valid | (ti_dout(nhi) != 0) | ((lane > 0) & (ti_din(nhi) != 0)) | ((noc > 0) & (ti_din(g0) != 0)) |
+                       ((noc > 1) & (ti_din(g1) != 0));
+            if (!bad)
+                for (int32_t e = 2; e < noc; e++) // rare: more than two out-edges
+                {
+                    const int32_t c = (int32_t)g.outgoing_edges[(int64_t)node * kEdges + e] & 0xfff;
+                    bad |= ti_din(hi_of(c)) != 0;
+                }
+            const unsigned long long mb = __ballot(bad);
+            const int32_t b = mb ? __ffsll(mb) - 1 : kWave; // >= 1: lane 0 passed the test above
+            int32_t cnt     = 0;
+            if (lane < b)
+            {
+                if (noc > 0) cnt += (lds_dec_u32(ent32 + 2 * ch0 + 1) & 0xffu) == 1u;
+                if (noc > 1) cnt += (lds_dec_u32(ent32 + 2 * ch1 + 1) & 0xffu) == 1u;
+                for (int32_t e = 2; e < noc; e++)
+                {
+                    const int32_t c = (int32_t)g.outgoing_edges[(int64_t)node * kEdges + e] & 0xfff;
+                    cnt += (lds_dec_u32(ent32 + 2 * c + 1) & 0xffu) == 1u;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+            const int32_t npush = wave_first(cnt);
+            // pushed entries continue the previous order; slots popped inside this same block are written by the
+            // popping lane (with their queue length), the others here: disjoint slots
+            for (int32_t j = lane; j < npush; j += kWave)
+                if (tail + j >= head + b) queue[tail + j] = sold[p + len + j];
+            if (lane < b) queue[head + lane] = (uint16_t)((uint32_t)node | ((uint32_t)ti_qlen(nhi) << 12));
+            head += b;
+            tail += npush;
+            M = p + b - 1;
+            __syncthreads();
+            continue;
+        }
+        // ordinary Kahn step
+        lane0_store_u16(queue + head, (uint32_t)u | ((uint32_t)min(len, kQClip) << 12));
+        head++;
+        k += is_new ? 1 : 0;
+        M = is_new ? M : max(M, p);
+        {
+            const uint32_t left0 = ((h0 & 0xffu) - 1u) & 0xffu;
+            const bool push0     = oc > 0 && left0 == 0;
+            lane0_store_u8(reinterpret_cast<uint8_t*>(ent + c0) + 4, left0); // the dummy word absorbs it when oc == 0
+            lane0_store_u16(queue + tail, (uint32_t)c0);                    // only part of the queue if tail advances
+            tail += push0 ? 1 : 0;
+        }
+        if (oc > 1)
+        {
+            const uint32_t left1 = ((h1 & 0xffu) - 1u) & 0xffu;
+            lane0_store_u8(reinterpret_cast<uint8_t*>(ent + c1) + 4, left1);
+            lane0_store_u16(queue + tail, (uint32_t)c1);
+            tail += left1 == 0 ? 1 : 0;
+            for (int32_t e = 2; e < oc; e++)
+            {
+                const int32_t child = wave_first((int32_t)g.outgoing_edges[(int64_t)u * kEdges + e]) & 0xfff;
+                const uint32_t left = (((uint32_t)wave_first((int32_t)hi_of(child)) & 0xffu) - 1u) & 0xffu;
+                lane0_store_u8(reinterpret_cast<uint8_t*>(ent + child) + 4, left);
+                lane0_store_u16(queue + tail, (uint32_t)child);
+                tail += left == 0 ? 1 : 0;
+            }
+        }
+    }
+    __syncthreads();
+    // phase 3 (all lanes): publish order, inverse map and the per-node record for the next read
+    for (int32_t i = lane; i < node_count; i += kWave)
+    {
+        const uint32_t e    = queue[i];
+        const int32_t node  = (int32_t)(e & 0xfffu);
+        const uint64_t wn   = ent[node];
+        g.sorted_poa[i]        = (IdT)node;
+        g.node_id_to_pos[node] = (IdT)i;
+        g.local_cnt[node]      = (uint16_t)((e >> 12) | (((uint32_t)wn >> 24) << 4) | ((uint32_t)(wn >> 58) << 10));
+    }
+}
+
 // racon/spoa DFS order (aligned nodes adjacent)
 template <typename IdT>
 __device__ void topsort_racon(const GraphView<IdT>& g, int32_t node_count, int32_t max_nodes_per_graph)

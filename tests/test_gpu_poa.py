@@ -243,3 +243,32 @@ def test_group_with_every_read_rejected_keeps_its_output_slot():
             ref = ws.process(w)
             assert status[slot] == 0 and cons[slot] == ref["consensus"]
             assert list(cov[slot]) == list(ref["coverage"])
+
+
+def test_incremental_topsort_equals_full_resort(monkeypatch):
+    """A/B inside the kernel: the incremental Kahn order (default) and the full re-sort after every read
+    (GWHIP_DEBUG bit 21, the reference's schedule) must give identical consensus, coverage, status and cell counts
+    on the config-3 windows and on windows of varied shape."""
+    import random
+    from genomeworks_amd import synthetic
+    rng = random.Random(5)
+    windows = config3(192)
+    for k in range(64):
+        blen = rng.choice([40, 130, 300, 640, 900, 1000])
+        reads = rng.choice([2, 3, 8, 17, 32])
+        mut, ins, dele = rng.choice([(0, 0, 0), (5, 2, 2), (40, 20, 20), (90, 40, 40), (10, 60, 5), (10, 5, 60)])
+        w = [r.decode() for r in synthetic.generate_window(7000 + k, blen, reads, mut, ins, dele)]
+        if k % 4 == 0:
+            w = [("GATTACA"[: rng.randrange(8)] + r)[rng.randrange(5):] for r in w]
+        windows.append([r for r in w if 0 < len(r) < 1024])
+    out = {}
+    for name, flag in (("incremental", None), ("full", str(1 << 21))):
+        if flag is None:
+            monkeypatch.delenv("GWHIP_DEBUG", raising=False)
+        else:
+            monkeypatch.setenv("GWHIP_DEBUG", flag)
+        for mode in ("static_band", "adaptive_band"):
+            b = run_gpu(windows, mode)
+            out[name, mode] = (b.get_consensus(), b.total_cells())
+    for mode in ("static_band", "adaptive_band"):
+        assert out["incremental", mode] == out["full", mode], mode
