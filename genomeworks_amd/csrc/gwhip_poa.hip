@@ -346,7 +346,8 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
             if constexpr (LDS_TABLES)
             {
                 if (!(a.debug_flags & (1 << 21))) // GWHIP_DEBUG bit 21: full re-sort after every read (A/B switch)
-                    topsort_kahn_incr_lds<IdT>(g, node_count, status_and_count, lds_rowinfo_region, smem, lds_read_buf, lane);
+                    topsort_kahn_incr_lds<IdT>(g, node_count, status_and_count, lds_rowinfo_region, smem, lds_read_buf, lane,
+                                               a.debug_flags, pc.acc ? &pc.acc[kPhOther] : nullptr);
                 else
                     topsort_kahn_lds<IdT>(g, status_and_count, lds_rowinfo_region, smem, lane, a.debug_flags, pc.acc ? &pc.acc[kPhOther] : nullptr);
             }

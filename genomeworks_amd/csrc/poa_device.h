@@ -583,34 +583,41 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     // ---- trace-code fast path: where the forward pass left a move code the step is a table lookup ----
     int32_t ctop = -1, ccol = 0; // matrix row in code-tile row 0 and the column its windows are anchored on
     auto code_lo = [&](int32_t t) -> int32_t { return ((ccol - kLead - t) & ~3) + 1; };
+    // Loader: 4 lanes per tile row (16 bytes each), 16 rows per pass -- a pass touches 16 code rows (lane-per-row
+    // loads touch 64 different cache lines per instruction and took ~6 000 cycles per tile); band starts come from the
+    // LDS row table. Bytes that are not cells of the band (window reaching past a band edge, rows < 1) become code 0.
+    struct __attribute__((packed, aligned(4))) CodeSeg { uint32_t d[4]; };
     auto load_codes = [&](int32_t top, int32_t col) {
         const uint64_t t_lc = psel == 2 ? clock64() : 0;
         if (psel == 3) pacc++;
         __syncthreads();
         ctop = top;
         ccol = col;
-        const int32_t row = top - lane; // lane = tile row; rows < 1 have no codes
-        int32_t e0 = 0, klo = 1, khi = 0;
-        if (row >= 1)
-        {
-            const int32_t bs = band_start_for_row(row, b.gradient, b.band_width, b.band_shift, b.max_column);
-            e0  = code_lo(lane) - bs + kRelShift; // byte index in the code row, multiple of 4
-            klo = (1 + kRelShift) - e0;           // window bytes that are cells of the band (relative 1 .. band_width)
-            khi = (b.band_width + kRelShift) - e0;
-        }
-        const uint8_t* src = codes + (int64_t)row * b.stride + e0;
-        uint32_t* dst      = reinterpret_cast<uint32_t*>(ctile + lane * kCodeCols);
-        const bool whole   = klo <= 0 && khi >= kCodeCols - 1;
-        if (__ballot(!whole) == 0)
-        {
+        const int seg = lane & 3;
 #pragma unroll
-            for (int k = 0; k < kCodeCols / 4; k++) dst[k] = reinterpret_cast<const uint32_t*>(src)[k];
-        }
-        else
+        for (int pass = 0; pass < kCodeRows / 16; pass++)
         {
-#pragma nounroll
-            for (int k = 0; k < kCodeCols; k++)
-                reinterpret_cast<uint8_t*>(dst)[k] = (k >= klo && k <= khi) ? src[k] : (uint8_t)0;
+            const int32_t t    = pass * 16 + (lane >> 2);
+            const int32_t row  = top - t;
+            const int32_t rowc = max(row, 1);
+            const int32_t bs   = rowinfo[rowc].bs();
+            const int32_t e0   = code_lo(t) - bs + kRelShift; // byte index in the code row, multiple of 4
+            const int32_t klo  = row >= 1 ? (1 + kRelShift) - e0 : 1; // window bytes that are cells of the band
+            const int32_t khi  = row >= 1 ? (b.band_width + kRelShift) - e0 : 0;
+            CodeSeg v = *reinterpret_cast<const CodeSeg*>(codes + (int64_t)rowc * b.stride + e0 + seg * 16);
+            if (__ballot(!(klo <= 0 && khi >= kCodeCols - 1)) != 0)
+            {
+#pragma unroll
+                for (int d = 0; d < 4; d++)
+                {
+                    const int32_t k0 = seg * 16 + d * 4;
+                    const int32_t lo = min(max(klo - k0, 0), 4), hi = min(max(khi - k0 + 1, 0), 4);
+                    const uint32_t mhi = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
+                    const uint32_t mlo = lo >= 4 ? 0xffffffffu : ((1u << (8 * lo)) - 1u);
+                    v.d[d] &= hi > lo ? (mhi & ~mlo) : 0u;
+                }
+            }
+            *reinterpret_cast<uint4*>(ctile + t * kCodeCols + seg * 16) = make_uint4(v.d[0], v.d[1], v.d[2], v.d[3]);
         }
         __syncthreads();
         if (psel == 2) pacc += clock64() - t_lc;
@@ -620,8 +627,12 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     const int kind        = lane < kHalf ? 0 : (lane < 2 * kHalf ? 1 : (lane == 2 * kHalf ? 2 : 3));
     const int p           = kind == 0 ? lane : lane - kHalf;
     const int psh         = 24 + 12 * min(p, 2);
-    const bool is_diag    = kind == 0, is_vert = kind == 1, is_horiz = kind == 2;
-    const int32_t col_dec = is_vert ? 0 : 1; // candidate column = j - col_dec
+    const bool is_diag    = kind == 0, is_vert = kind == 1, is_horiz = kind == 2, is_self = kind == 3;
+    const int32_t col_dec = (is_vert | is_self) ? 0 : 1; // candidate column = j - col_dec
+    // With trace codes the recomputed steps are isolated (about 2 % of the steps, scattered along the path): a
+    // 60-row score tile per such step cost ~8 700 cycles. They read their few operands straight from the HBM matrix
+    // instead, all in one round trip: the candidates and, on lane 63, H(i, j) itself.
+    const bool use_tile = codes == nullptr;
     // Wave-uniform walk state, kept in SGPRs (every update goes through readfirstlane / readlane so that the
     // loop control stays scalar): position, H(i, j), the row-table word of row i and the read character j - 1.
     int32_t scores_ij = 0;
@@ -678,6 +689,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         const uint64_t t_rc = psel == 4 ? clock64() : 0;
         if (psel == 5) pacc++;
         // keep the current cell and its near predecessors inside the tile
+        if (use_tile)
         {
             const int32_t t   = tile_top - i;
             const int32_t off = j - window_lo(t);
@@ -685,9 +697,10 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
             if (reload && i > 0) load_tile(i, j);
         }
         loop_count++;
+        const bool need_self = !have && !use_tile; // H(i, j) arrives with the candidates
         if (!have)
         {
-            scores_ij        = wave_first(get_score(b, i, j));
+            if (use_tile) scores_ij = wave_first(get_score(b, i, j));
             const uint64_t w = i != 0 ? wave_first64(rowinfo[i].w) : 0;
             ri_lo = (uint32_t)w; ri_hi = (uint32_t)(w >> 32);
             rch   = j > 0 ? (uint32_t)wave_first((int32_t)read[j - 1]) : 0u;
@@ -717,7 +730,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
             const bool en = (is_diag & (i != 0) & (j != 0) & (p < np)) | (is_vert & (i != 0) & (p < np)) | is_horiz;
             const uint64_t riw = (uint64_t)ri_lo | ((uint64_t)ri_hi << 32);
             int32_t crow       = pred_count != 0 ? (int32_t)((riw >> psh) & 0xfff) : 0;
-            crow               = is_horiz ? i : crow;
+            crow               = (is_horiz | is_self) ? i : crow;
             if (pred_count > 3) // predecessor slots beyond the three packed ones live in the HBM edge list
             {
                 if (en && !is_horiz && p >= 3)
@@ -730,16 +743,18 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
             const int32_t cost = is_diag ? match_cost : gap_score;
             const int32_t t    = tile_top - crow;
             const int32_t off  = ccol - window_lo(t);
-            const bool in_tile = ((uint32_t)t < (uint32_t)kTileRows) & ((uint32_t)off < (uint32_t)kTileCols);
+            const bool in_tile = use_tile & ((uint32_t)t < (uint32_t)kTileRows) & ((uint32_t)off < (uint32_t)kTileCols);
             // three independent LDS reads, one round trip: the candidate cell, and what the next step needs if this
             // candidate wins (its row-table word -- row 0 holds 0 -- and the read character left of its column)
             int32_t val        = tile[in_tile ? t * kTileStride + off : 0];
             const uint64_t cw  = rowinfo[crow].w;
             const uint32_t cch = read[max(ccol - 1, 0)];
-            if (__ballot(en & !in_tile) != 0) // far predecessor / band edge: the HBM copy
+            const bool from_hbm = (en | (is_self & need_self)) & !in_tile;
+            if (__ballot(from_hbm) != 0) // no tile / far predecessor / band edge: the HBM copy
             {
-                if (en & !in_tile) val = get_score(b, crow, ccol);
+                if (from_hbm) val = get_score(b, crow, ccol);
             }
+            if (need_self) scores_ij = __builtin_amdgcn_readlane(val, kWave - 1);
             const bool hit   = en & (scores_ij == val + cost);
             const uint64_t m = __ballot(hit);
             found            = m != 0;
@@ -755,6 +770,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         }
         else // more predecessors than candidate lanes: the reference's sequential order, wave-uniform
         {
+            if (need_self) scores_ij = wave_first(get_score(b, i, j));
             const int32_t node_id = g.sorted_poa[i - 1];
             RowInfo<true> ri;
             ri.w = (uint64_t)ri_lo | ((uint64_t)ri_hi << 32);

@@ -529,8 +529,14 @@ __device__ __forceinline__ uint32_t lds_dec_u32(uint32_t* p) // returns the old 
 
 template <typename IdT>
 __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, int32_t n_old, int32_t node_count,
-                                                      uint8_t* lds, uint8_t* lds_queue, uint8_t* lds_old, int lane)
+                                                      uint8_t* lds, uint8_t* lds_queue, uint8_t* lds_old, int lane,
+                                                      int32_t dbg = 0, uint64_t* prof_acc = nullptr)
 {
+    // profiling (GWHIP_DEBUG bits 25-27): cycles of 1 phase 1, 2 replayed blocks, 3 ordinary steps, 4 phase 3;
+    // 5 number of blocks, 6 number of ordinary steps
+    const int32_t tsel = prof_acc ? (dbg >> 25) & 7 : 0;
+    uint64_t tacc      = 0;
+    const uint64_t t_p1 = tsel == 1 ? clock64() : 0;
     constexpr int32_t kDummy = 3073; // spare word of the 3074-entry region
     constexpr int32_t kQClip = 15;
     uint64_t* ent   = reinterpret_cast<uint64_t*>(lds);
@@ -569,10 +575,12 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
         tail += __popcll(m);
     }
     __syncthreads();
+    if (tsel == 1) tacc += clock64() - t_p1;
     // phase 2: wave-uniform control; k = new nodes output so far, M = highest previous position output so far
     int32_t head = 0, k = 0, M = -1;
     while (head < tail)
     {
+        const uint64_t t_it = (tsel == 2 || tsel == 3) ? clock64() : 0;
         const int32_t u   = wave_first((int32_t)queue[head]) & 0xfff;
         const uint64_t w  = wave_first64(ent[u]);
         const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
@@ -608,27 +616,37 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
             const uint32_t g0 = hi_of(ch0), g1 = hi_of(ch1);
             bool bad = !valid | (ti_dout(nhi) != 0) | ((lane > 0) & (ti_din(nhi) != 0)) | ((noc > 0) & (ti_din(g0) != 0)) |
                        ((noc > 1) & (ti_din(g1) != 0));
-            if (!bad)
-                for (int32_t e = 2; e < noc; e++) // rare: more than two out-edges
-                {
-                    const int32_t c = (int32_t)g.outgoing_edges[(int64_t)node * kEdges + e] & 0xfff;
-                    bad |= ti_din(hi_of(c)) != 0;
-                }
+            const bool many = valid && noc > 2; // rare: more than two out-edges (the rest of the list is in HBM)
+            const bool any_many = __ballot(many) != 0;
+            if (any_many)
+            {
+                if (many && !bad)
+                    for (int32_t e = 2; e < noc; e++)
+                    {
+                        const int32_t c = (int32_t)g.outgoing_edges[(int64_t)node * kEdges + e] & 0xfff;
+                        bad |= ti_din(hi_of(c)) != 0;
+                    }
+            }
             const unsigned long long mb = __ballot(bad);
             const int32_t b = mb ? __ffsll(mb) - 1 : kWave; // >= 1: lane 0 passed the test above
-            int32_t cnt     = 0;
-            if (lane < b)
+            // both decrements in flight together; a child whose counter reaches 0 was pushed by the previous run here
+            const bool do0 = lane < b && noc > 0, do1 = lane < b && noc > 1;
+            uint32_t r0 = 0, r1 = 0;
+            if (do0) r0 = lds_dec_u32(ent32 + 2 * ch0 + 1);
+            if (do1) r1 = lds_dec_u32(ent32 + 2 * ch1 + 1);
+            int32_t npush = __popcll(__ballot(do0 && (r0 & 0xffu) == 1u)) + __popcll(__ballot(do1 && (r1 & 0xffu) == 1u));
+            if (any_many)
             {
-                if (noc > 0) cnt += (lds_dec_u32(ent32 + 2 * ch0 + 1) & 0xffu) == 1u;
-                if (noc > 1) cnt += (lds_dec_u32(ent32 + 2 * ch1 + 1) & 0xffu) == 1u;
-                for (int32_t e = 2; e < noc; e++)
-                {
-                    const int32_t c = (int32_t)g.outgoing_edges[(int64_t)node * kEdges + e] & 0xfff;
-                    cnt += (lds_dec_u32(ent32 + 2 * c + 1) & 0xffu) == 1u;
-                }
+                int32_t cnt = 0;
+                if (many && lane < b)
+                    for (int32_t e = 2; e < noc; e++)
+                    {
+                        const int32_t c = (int32_t)g.outgoing_edges[(int64_t)node * kEdges + e] & 0xfff;
+                        cnt += (lds_dec_u32(ent32 + 2 * c + 1) & 0xffu) == 1u;
+                    }
+                for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+                npush += wave_first(cnt);
             }
-            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-            const int32_t npush = wave_first(cnt);
             // pushed entries continue the previous order; slots popped inside this same block are written by the
             // popping lane (with their queue length), the others here: disjoint slots
             for (int32_t j = lane; j < npush; j += kWave)
@@ -637,7 +655,9 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
             head += b;
             tail += npush;
             M = p + b - 1;
-            __syncthreads();
+            asm volatile("" ::: "memory"); // LDS executes one wavefront's operations in order: no wait, no barrier
+            if (tsel == 2) tacc += clock64() - t_it;
+            if (tsel == 5) tacc++;
             continue;
         }
         // ordinary Kahn step
@@ -667,8 +687,11 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
                 tail += left == 0 ? 1 : 0;
             }
         }
+        if (tsel == 3) tacc += clock64() - t_it;
+        if (tsel == 6) tacc++;
     }
     __syncthreads();
+    const uint64_t t_p3 = tsel == 4 ? clock64() : 0;
     // phase 3 (all lanes): publish order, inverse map and the per-node record for the next read
     for (int32_t i = lane; i < node_count; i += kWave)
     {
@@ -679,6 +702,12 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
         g.node_id_to_pos[node] = (IdT)i;
         g.local_cnt[node]      = (uint16_t)((e >> 12) | (((uint32_t)wn >> 24) << 4) | ((uint32_t)(wn >> 58) << 10));
     }
+    if (tsel == 4)
+    {
+        __syncthreads();
+        tacc += clock64() - t_p3;
+    }
+    if (tsel && lane == 0) *prof_acc += tacc;
 }
 
 // racon/spoa DFS order (aligned nodes adjacent)
