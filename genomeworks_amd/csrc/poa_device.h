@@ -531,12 +531,13 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     uint32_t* stage  = reinterpret_cast<uint32_t*>(tile + kTileRows * kTileStride);
     // profiling (GWHIP_DEBUG bits 22-24, outside the table-lookup loop): 2 cycles in load_codes, 3 its calls,
     // 4 cycles in recomputed steps (incl. their tile loads), 5 their number, 6 cycles of the post-pass, 7 load_tile calls
+    // (counts are scaled by 1000 to stand out of the "other" accumulator they arrive in)
     const int32_t psel = prof_acc ? (dbg >> 22) & 7 : 0;
     uint64_t pacc      = 0;
 
     auto window_lo = [&](int32_t t) -> int32_t { return ((tile_col - kLead - t) & ~3) + 1; };
     auto load_tile = [&](int32_t top, int32_t col) {
-        if (psel == 7) pacc++;
+        if (psel == 7) pacc += 1000;
         __syncthreads();
         tile_top = top;
         tile_col = col;
@@ -589,7 +590,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     struct __attribute__((packed, aligned(4))) CodeSeg { uint32_t d[4]; };
     auto load_codes = [&](int32_t top, int32_t col) {
         const uint64_t t_lc = psel == 2 ? clock64() : 0;
-        if (psel == 3) pacc++;
+        if (psel == 3) pacc += 1000;
         __syncthreads();
         ctop = top;
         ccol = col;
@@ -687,7 +688,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
             if ((i == 0 && j == 0) || loop_count >= bound) continue; // the outer condition ends the walk
         }
         const uint64_t t_rc = psel == 4 ? clock64() : 0;
-        if (psel == 5) pacc++;
+        if (psel == 5) pacc += 1000;
         // keep the current cell and its near predecessors inside the tile
         if (use_tile)
         {
@@ -840,22 +841,43 @@ template <typename IdT, typename RowT>
 __device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t graph_count, RowT* rowinfo, int lane)
 {
     if (lane == 0) rowinfo[0].set(0, 0, false, 0, 0, 0); // row 0 (virtual source): no predecessors
-    for (int32_t r = 1 + lane; r <= graph_count; r += kWave)
+    // Four 64-row chunks per iteration: a chunk is three dependent HBM round trips (row -> node -> its first three
+    // in-edges -> their rows), and the chunks of one iteration share them (18 round trips per read instead of 66).
+    // Edge slots past the in-degree may hold stale or uninitialised ids; they are range-checked and masked.
+    constexpr int kU = 4;
+    for (int32_t r0 = 1 + lane; r0 <= graph_count; r0 += kU * kWave)
     {
-        int32_t node = g.sorted_poa[r - 1];
-        RowT ri{};
-        // independent loads are issued together: three dependent HBM round trips per row instead of up to five
-        // (edge slots past the in-degree may hold stale or uninitialised ids; they are range-checked and masked)
-        const int32_t cnt = g.incoming_edge_count[node];
-        const int32_t oc  = g.outgoing_edge_count[node];
-        const int32_t bas = g.nodes[node];
-        const int32_t e0 = g.incoming_edges[(int64_t)node * kEdges + 0], e1 = g.incoming_edges[(int64_t)node * kEdges + 1],
-                      e2 = g.incoming_edges[(int64_t)node * kEdges + 2];
-        const int32_t q0 = g.node_id_to_pos[(uint32_t)e0 < (uint32_t)graph_count ? e0 : 0];
-        const int32_t q1 = g.node_id_to_pos[(uint32_t)e1 < (uint32_t)graph_count ? e1 : 0];
-        const int32_t q2 = g.node_id_to_pos[(uint32_t)e2 < (uint32_t)graph_count ? e2 : 0];
-        ri.set(bas, cnt, oc == 0, cnt > 0 ? q0 + 1 : 0, cnt > 1 ? q1 + 1 : 0, cnt > 2 ? q2 + 1 : 0);
-        rowinfo[r] = ri;
+        int32_t node[kU], cnt[kU], oc[kU], bas[kU], e0[kU], e1[kU], e2[kU], q0[kU], q1[kU], q2[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) node[u] = g.sorted_poa[min(r0 + u * kWave, graph_count) - 1];
+#pragma unroll
+        for (int u = 0; u < kU; u++)
+        {
+            cnt[u] = g.incoming_edge_count[node[u]];
+            oc[u]  = g.outgoing_edge_count[node[u]];
+            bas[u] = g.nodes[node[u]];
+            e0[u]  = g.incoming_edges[(int64_t)node[u] * kEdges + 0];
+            e1[u]  = g.incoming_edges[(int64_t)node[u] * kEdges + 1];
+            e2[u]  = g.incoming_edges[(int64_t)node[u] * kEdges + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; u++)
+        {
+            q0[u] = g.node_id_to_pos[(uint32_t)e0[u] < (uint32_t)graph_count ? e0[u] : 0];
+            q1[u] = g.node_id_to_pos[(uint32_t)e1[u] < (uint32_t)graph_count ? e1[u] : 0];
+            q2[u] = g.node_id_to_pos[(uint32_t)e2[u] < (uint32_t)graph_count ? e2[u] : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; u++)
+        {
+            const int32_t r = r0 + u * kWave;
+            if (r <= graph_count)
+            {
+                RowT ri{};
+                ri.set(bas[u], cnt[u], oc[u] == 0, cnt[u] > 0 ? q0[u] + 1 : 0, cnt[u] > 1 ? q1[u] + 1 : 0, cnt[u] > 2 ? q2[u] + 1 : 0);
+                rowinfo[r] = ri;
+            }
+        }
     }
 }
 

@@ -513,15 +513,19 @@ __device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_
 // (oracle/topsort_incr_model.inc, tests/test_oracle_poa.py).
 //   per node, carried from read to read in GraphView::local_cnt (uint16): queue length when the node was popped
 //   (4 bits, 15 = "15 or more": never a sync point) | out-degree << 4 | in-degree << 10;
-//   node word lo: out-edge 0 [0:12)  out-edge 1 [12:24)  out-degree [24:32)
-//             hi: unvisited in-edges [0:8)  new in-edge / new node [8]  new out-edge / new node [9]
-//                 previous position [10:22)  previous queue length [22:26)  in-degree [26:32)
+//   node word lo: out-edge 0 [0:12)  out-edge 1 [12:24)  min(out-degree, 4) [24:27)  previous queue length [27:31)
+//             hi: unvisited in-edges [0:6)  new in-edge / new node [6]  new out-edge / new node [7]
+//                 previous position [8:20)  out-edge 2 [20:32)
+//   (three out-edges in the word; a node with more takes an ordinary step that reads the rest from HBM)
 //   LDS: ent (row-table region), queue (score-ring region), previous order (read + trace-code-tile regions, 6 KB).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t ti_din(uint32_t h) { return (h >> 8) & 1u; }
-__device__ __forceinline__ uint32_t ti_dout(uint32_t h) { return (h >> 9) & 1u; }
-__device__ __forceinline__ int32_t ti_pos(uint32_t h) { return (int32_t)((h >> 10) & 0xfffu); }
-__device__ __forceinline__ int32_t ti_qlen(uint32_t h) { return (int32_t)((h >> 22) & 15u); }
+__device__ __forceinline__ uint32_t ti_inleft(uint32_t h) { return h & 0x3fu; }
+__device__ __forceinline__ uint32_t ti_din(uint32_t h) { return (h >> 6) & 1u; }
+__device__ __forceinline__ uint32_t ti_dout(uint32_t h) { return (h >> 7) & 1u; }
+__device__ __forceinline__ int32_t ti_pos(uint32_t h) { return (int32_t)((h >> 8) & 0xfffu); }
+__device__ __forceinline__ int32_t ti_e2(uint32_t h) { return (int32_t)(h >> 20); }
+__device__ __forceinline__ int32_t ti_ocq(uint32_t l) { return (int32_t)((l >> 24) & 7u); }
+__device__ __forceinline__ int32_t ti_qlen(uint32_t l) { return (int32_t)((l >> 27) & 15u); }
 __device__ __forceinline__ uint32_t lds_dec_u32(uint32_t* p) // returns the old value
 {
     return __hip_atomic_fetch_sub(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -533,7 +537,7 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
                                                       int32_t dbg = 0, uint64_t* prof_acc = nullptr)
 {
     // profiling (GWHIP_DEBUG bits 25-27): cycles of 1 phase 1, 2 replayed blocks, 3 ordinary steps, 4 phase 3;
-    // 5 number of blocks, 6 number of ordinary steps
+    // 5 number of blocks x 1000, 6 number of ordinary steps x 1000
     const int32_t tsel = prof_acc ? (dbg >> 25) & 7 : 0;
     uint64_t tacc      = 0;
     const uint64_t t_p1 = tsel == 1 ? clock64() : 0;
@@ -544,35 +548,49 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
     uint16_t* queue = reinterpret_cast<uint16_t*>(lds_queue);
     uint16_t* sold  = reinterpret_cast<uint16_t*>(lds_old);
     auto hi_of = [&](int32_t n) -> uint32_t { return ent32[2 * n + 1]; };
-    // phase 1 (all lanes): node words with change flags, previous order into LDS, sources in ascending node id
+    // phase 1 (all lanes): node words with change flags, previous order into LDS, sources in ascending node id.
+    // Four 64-node chunks per iteration share one HBM round trip (eight independent loads per node; edge slots
+    // past the out-degree hold stale ids: masked).
     int32_t tail = 0;
-    for (int32_t base = 0; base < node_count; base += kWave)
+    constexpr int kU = 4;
+    for (int32_t base = 0; base < node_count; base += kU * kWave)
     {
-        const int32_t n = base + lane;
-        bool is_src     = false;
-        if (n < node_count)
+        uint32_t ic[kU], oc[kU], e0[kU], e1[kU], e2[kU], m[kU], po[kU], so[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++)
         {
-            const bool is_new = n >= n_old;
-            const int32_t nn  = is_new ? 0 : n;
-            // seven independent loads, one HBM round trip
-            const uint32_t ic = g.incoming_edge_count[n];
-            const uint32_t oc = g.outgoing_edge_count[n];
-            const uint32_t e0 = (uint32_t)g.outgoing_edges[(int64_t)n * kEdges] & 0xfffu;
-            const uint32_t e1 = (uint32_t)g.outgoing_edges[(int64_t)n * kEdges + 1] & 0xfffu;
-            const uint32_t m  = g.local_cnt[nn];
-            const uint32_t po = (uint32_t)g.node_id_to_pos[nn] & 0xfffu;
-            const uint32_t so = (uint32_t)g.sorted_poa[nn] & 0xfffu;
-            if (!is_new) sold[n] = (uint16_t)so;
-            const uint32_t din  = (is_new || ((m >> 10) & 63u) != ic) ? 1u : 0u;
-            const uint32_t dout = (is_new || ((m >> 4) & 63u) != oc) ? 1u : 0u;
-            const uint32_t lo   = (oc > 0 ? e0 : 0u) | (oc > 1 ? e1 << 12 : 0u) | ((oc & 0xffu) << 24);
-            const uint32_t hi   = (ic & 0xffu) | (din << 8) | (dout << 9) | (is_new ? 0u : (po << 10) | ((m & 15u) << 22)) | (ic << 26);
-            ent[n] = (uint64_t)lo | ((uint64_t)hi << 32);
-            is_src = (ic == 0);
+            const int32_t n  = min(base + u * kWave + lane, node_count - 1);
+            const int32_t nn = n >= n_old ? 0 : n;
+            ic[u] = g.incoming_edge_count[n];
+            oc[u] = g.outgoing_edge_count[n];
+            e0[u] = (uint32_t)g.outgoing_edges[(int64_t)n * kEdges] & 0xfffu;
+            e1[u] = (uint32_t)g.outgoing_edges[(int64_t)n * kEdges + 1] & 0xfffu;
+            e2[u] = (uint32_t)g.outgoing_edges[(int64_t)n * kEdges + 2] & 0xfffu;
+            m[u]  = g.local_cnt[nn];
+            po[u] = (uint32_t)g.node_id_to_pos[nn] & 0xfffu;
+            so[u] = (uint32_t)g.sorted_poa[nn] & 0xfffu;
         }
-        const unsigned long long m = __ballot(is_src);
-        if (is_src) queue[tail + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)n;
-        tail += __popcll(m);
+#pragma unroll
+        for (int u = 0; u < kU; u++)
+        {
+            const int32_t n = base + u * kWave + lane;
+            bool is_src     = false;
+            if (n < node_count)
+            {
+                const bool is_new = n >= n_old;
+                if (!is_new) sold[n] = (uint16_t)so[u];
+                const uint32_t din  = (is_new || ((m[u] >> 10) & 63u) != ic[u]) ? 1u : 0u;
+                const uint32_t dout = (is_new || ((m[u] >> 4) & 63u) != oc[u]) ? 1u : 0u;
+                const uint32_t lo   = (oc[u] > 0 ? e0[u] : 0u) | (oc[u] > 1 ? e1[u] << 12 : 0u) | (min(oc[u], 4u) << 24) |
+                                    (is_new ? 0u : (m[u] & 15u) << 27);
+                const uint32_t hi = (ic[u] & 0x3fu) | (din << 6) | (dout << 7) | (is_new ? 0u : po[u] << 8) | (oc[u] > 2 ? e2[u] << 20 : 0u);
+                ent[n] = (uint64_t)lo | ((uint64_t)hi << 32);
+                is_src = (ic[u] == 0);
+            }
+            const unsigned long long ms = __ballot(is_src);
+            if (is_src) queue[tail + __popcll(ms & ((1ull << lane) - 1))] = (uint16_t)n;
+            tail += __popcll(ms);
+        }
     }
     __syncthreads();
     if (tsel == 1) tacc += clock64() - t_p1;
@@ -584,16 +602,19 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
         const int32_t u   = wave_first((int32_t)queue[head]) & 0xfff;
         const uint64_t w  = wave_first64(ent[u]);
         const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-        const int32_t oc  = (int32_t)(lo >> 24);
-        const int32_t c0  = oc > 0 ? (int32_t)(lo & 0xfffu) : kDummy;
-        const int32_t c1  = oc > 1 ? (int32_t)((lo >> 12) & 0xfffu) : kDummy;
+        const int32_t ocq = ti_ocq(lo);
+        const int32_t c0  = ocq > 0 ? (int32_t)(lo & 0xfffu) : kDummy;
+        const int32_t c1  = ocq > 1 ? (int32_t)((lo >> 12) & 0xfffu) : kDummy;
+        const int32_t c2  = ocq > 2 ? ti_e2(hi) : kDummy;
         const uint32_t h0 = (uint32_t)wave_first((int32_t)hi_of(c0));
         const uint32_t h1 = (uint32_t)wave_first((int32_t)hi_of(c1));
+        const uint32_t h2 = (uint32_t)wave_first((int32_t)hi_of(c2));
         const int32_t len = tail - head;
-        const int32_t p = ti_pos(hi), qo = ti_qlen(hi);
+        const int32_t p = ti_pos(hi), qo = ti_qlen(lo);
         const bool is_new = u >= n_old;
-        // a real step is needed when the node has a new out-edge or a child has a new in-edge
-        const bool need_real = is_new | (ti_dout(hi) != 0) | (oc > 2) | ((oc > 0) & (ti_din(h0) != 0)) | ((oc > 1) & (ti_din(h1) != 0));
+        // an ordinary step is needed when the node has a new out-edge or a child has a new in-edge
+        const bool need_real = is_new | (ti_dout(hi) != 0) | (ocq > 3) | ((ocq > 0) & (ti_din(h0) != 0)) |
+                               ((ocq > 1) & (ti_din(h1) != 0)) | ((ocq > 2) & (ti_din(h2) != 0));
         bool block = !need_real && (head - k == p) && (M == p - 1) && (len == qo) && (qo < kQClip);
         if (block && len > 1) // the queue must be the previous run's queue at p, element by element
         {
@@ -610,54 +631,35 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
             const int32_t node = valid ? (int32_t)sold[posl] : u;
             const uint64_t wn  = ent[node];
             const uint32_t nlo = (uint32_t)wn, nhi = (uint32_t)(wn >> 32);
-            const int32_t noc  = (int32_t)(nlo >> 24);
+            const int32_t noc  = ti_ocq(nlo);
             const int32_t ch0  = noc > 0 ? (int32_t)(nlo & 0xfffu) : node;
             const int32_t ch1  = noc > 1 ? (int32_t)((nlo >> 12) & 0xfffu) : node;
-            const uint32_t g0 = hi_of(ch0), g1 = hi_of(ch1);
-            bool bad = !valid | (ti_dout(nhi) != 0) | ((lane > 0) & (ti_din(nhi) != 0)) | ((noc > 0) & (ti_din(g0) != 0)) |
-                       ((noc > 1) & (ti_din(g1) != 0));
-            const bool many = valid && noc > 2; // rare: more than two out-edges (the rest of the list is in HBM)
-            const bool any_many = __ballot(many) != 0;
-            if (any_many)
-            {
-                if (many && !bad)
-                    for (int32_t e = 2; e < noc; e++)
-                    {
-                        const int32_t c = (int32_t)g.outgoing_edges[(int64_t)node * kEdges + e] & 0xfff;
-                        bad |= ti_din(hi_of(c)) != 0;
-                    }
-            }
+            const int32_t ch2  = noc > 2 ? ti_e2(nhi) : node;
+            const uint32_t g0 = hi_of(ch0), g1 = hi_of(ch1), g2 = hi_of(ch2);
+            // more than three out-edges: the lane ends the block (its own step is an ordinary one)
+            const bool bad = !valid | (ti_dout(nhi) != 0) | ((lane > 0) & (ti_din(nhi) != 0)) | (noc > 3) |
+                             ((noc > 0) & (ti_din(g0) != 0)) | ((noc > 1) & (ti_din(g1) != 0)) | ((noc > 2) & (ti_din(g2) != 0));
             const unsigned long long mb = __ballot(bad);
             const int32_t b = mb ? __ffsll(mb) - 1 : kWave; // >= 1: lane 0 passed the test above
-            // both decrements in flight together; a child whose counter reaches 0 was pushed by the previous run here
-            const bool do0 = lane < b && noc > 0, do1 = lane < b && noc > 1;
-            uint32_t r0 = 0, r1 = 0;
+            // all decrements in flight together; a child whose counter reaches 0 was pushed by the previous run here
+            const bool do0 = lane < b && noc > 0, do1 = lane < b && noc > 1, do2 = lane < b && noc > 2;
+            uint32_t r0 = 0, r1 = 0, r2 = 0;
             if (do0) r0 = lds_dec_u32(ent32 + 2 * ch0 + 1);
             if (do1) r1 = lds_dec_u32(ent32 + 2 * ch1 + 1);
-            int32_t npush = __popcll(__ballot(do0 && (r0 & 0xffu) == 1u)) + __popcll(__ballot(do1 && (r1 & 0xffu) == 1u));
-            if (any_many)
-            {
-                int32_t cnt = 0;
-                if (many && lane < b)
-                    for (int32_t e = 2; e < noc; e++)
-                    {
-                        const int32_t c = (int32_t)g.outgoing_edges[(int64_t)node * kEdges + e] & 0xfff;
-                        cnt += (lds_dec_u32(ent32 + 2 * c + 1) & 0xffu) == 1u;
-                    }
-                for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-                npush += wave_first(cnt);
-            }
+            if (do2) r2 = lds_dec_u32(ent32 + 2 * ch2 + 1);
+            const int32_t npush = __popcll(__ballot(do0 && ti_inleft(r0) == 1u)) + __popcll(__ballot(do1 && ti_inleft(r1) == 1u)) +
+                                  __popcll(__ballot(do2 && ti_inleft(r2) == 1u));
             // pushed entries continue the previous order; slots popped inside this same block are written by the
             // popping lane (with their queue length), the others here: disjoint slots
             for (int32_t j = lane; j < npush; j += kWave)
                 if (tail + j >= head + b) queue[tail + j] = sold[p + len + j];
-            if (lane < b) queue[head + lane] = (uint16_t)((uint32_t)node | ((uint32_t)ti_qlen(nhi) << 12));
+            if (lane < b) queue[head + lane] = (uint16_t)((uint32_t)node | ((uint32_t)ti_qlen(nlo) << 12));
             head += b;
             tail += npush;
             M = p + b - 1;
             asm volatile("" ::: "memory"); // LDS executes one wavefront's operations in order: no wait, no barrier
             if (tsel == 2) tacc += clock64() - t_it;
-            if (tsel == 5) tacc++;
+            if (tsel == 5) tacc += 1000;
             continue;
         }
         // ordinary Kahn step
@@ -666,29 +668,40 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
         k += is_new ? 1 : 0;
         M = is_new ? M : max(M, p);
         {
-            const uint32_t left0 = ((h0 & 0xffu) - 1u) & 0xffu;
-            const bool push0     = oc > 0 && left0 == 0;
-            lane0_store_u8(reinterpret_cast<uint8_t*>(ent + c0) + 4, left0); // the dummy word absorbs it when oc == 0
-            lane0_store_u16(queue + tail, (uint32_t)c0);                    // only part of the queue if tail advances
-            tail += push0 ? 1 : 0;
+            const uint32_t left0 = (ti_inleft(h0) - 1u) & 0x3fu;
+            lane0_store_u8(reinterpret_cast<uint8_t*>(ent + c0) + 4, (h0 & 0xc0u) | left0); // the dummy word absorbs it when ocq == 0
+            lane0_store_u16(queue + tail, (uint32_t)c0);                                   // only part of the queue if tail advances
+            tail += (ocq > 0 && left0 == 0) ? 1 : 0;
         }
-        if (oc > 1)
+        if (ocq > 1)
         {
-            const uint32_t left1 = ((h1 & 0xffu) - 1u) & 0xffu;
-            lane0_store_u8(reinterpret_cast<uint8_t*>(ent + c1) + 4, left1);
+            const uint32_t left1 = (ti_inleft(h1) - 1u) & 0x3fu;
+            lane0_store_u8(reinterpret_cast<uint8_t*>(ent + c1) + 4, (h1 & 0xc0u) | left1);
             lane0_store_u16(queue + tail, (uint32_t)c1);
             tail += left1 == 0 ? 1 : 0;
-            for (int32_t e = 2; e < oc; e++)
+            if (ocq > 2)
             {
-                const int32_t child = wave_first((int32_t)g.outgoing_edges[(int64_t)u * kEdges + e]) & 0xfff;
-                const uint32_t left = (((uint32_t)wave_first((int32_t)hi_of(child)) & 0xffu) - 1u) & 0xffu;
-                lane0_store_u8(reinterpret_cast<uint8_t*>(ent + child) + 4, left);
-                lane0_store_u16(queue + tail, (uint32_t)child);
-                tail += left == 0 ? 1 : 0;
+                const uint32_t left2 = (ti_inleft(h2) - 1u) & 0x3fu;
+                lane0_store_u8(reinterpret_cast<uint8_t*>(ent + c2) + 4, (h2 & 0xc0u) | left2);
+                lane0_store_u16(queue + tail, (uint32_t)c2);
+                tail += left2 == 0 ? 1 : 0;
+                if (ocq > 3) // rare: the rest of the list from HBM
+                {
+                    const int32_t oc = wave_first((int32_t)g.outgoing_edge_count[u]);
+                    for (int32_t e = 3; e < oc; e++)
+                    {
+                        const int32_t child = wave_first((int32_t)g.outgoing_edges[(int64_t)u * kEdges + e]) & 0xfff;
+                        const uint32_t hc   = (uint32_t)wave_first((int32_t)hi_of(child));
+                        const uint32_t left = (ti_inleft(hc) - 1u) & 0x3fu;
+                        lane0_store_u8(reinterpret_cast<uint8_t*>(ent + child) + 4, (hc & 0xc0u) | left);
+                        lane0_store_u16(queue + tail, (uint32_t)child);
+                        tail += left == 0 ? 1 : 0;
+                    }
+                }
             }
         }
         if (tsel == 3) tacc += clock64() - t_it;
-        if (tsel == 6) tacc++;
+        if (tsel == 6) tacc += 1000;
     }
     __syncthreads();
     const uint64_t t_p3 = tsel == 4 ? clock64() : 0;
@@ -697,10 +710,10 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
     {
         const uint32_t e    = queue[i];
         const int32_t node  = (int32_t)(e & 0xfffu);
-        const uint64_t wn   = ent[node];
+        const uint32_t oc = g.outgoing_edge_count[node], ic = g.incoming_edge_count[node];
         g.sorted_poa[i]        = (IdT)node;
         g.node_id_to_pos[node] = (IdT)i;
-        g.local_cnt[node]      = (uint16_t)((e >> 12) | (((uint32_t)wn >> 24) << 4) | ((uint32_t)(wn >> 58) << 10));
+        g.local_cnt[node]      = (uint16_t)((e >> 12) | (oc << 4) | (ic << 10));
     }
     if (tsel == 4)
     {

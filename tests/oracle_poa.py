@@ -165,7 +165,7 @@ class Workspace:
 
 
 TOPSORT_MODEL_STATS = ("reads", "nodes", "real_steps", "blocks", "block_nodes", "sync_checks", "sync_hits", "mismatch",
-                       "empty_blocks")
+                       "empty_blocks", "wide_nodes", "wide_steps")
 
 
 class topsort_model:
