@@ -530,14 +530,13 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     int32_t tile_top = -1, tile_col = 0; // matrix row in tile row 0 and the column the windows are anchored on
     uint32_t* stage  = reinterpret_cast<uint32_t*>(tile + kTileRows * kTileStride);
     // profiling (GWHIP_DEBUG bits 22-24, outside the table-lookup loop): 2 cycles in load_codes, 3 its calls,
-    // 4 cycles in recomputed steps (incl. their tile loads), 5 their number, 6 cycles of the post-pass, 7 load_tile calls
+    // 4 cycles in recomputed steps (incl. their tile loads), 5 their number, 6 cycles of the post-pass, 7 code tiles taken from the look-ahead
     // (counts are scaled by 1000 to stand out of the "other" accumulator they arrive in)
     const int32_t psel = prof_acc ? (dbg >> 22) & 7 : 0;
     uint64_t pacc      = 0;
 
     auto window_lo = [&](int32_t t) -> int32_t { return ((tile_col - kLead - t) & ~3) + 1; };
     auto load_tile = [&](int32_t top, int32_t col) {
-        if (psel == 7) pacc += 1000;
         __syncthreads();
         tile_top = top;
         tile_col = col;
@@ -583,29 +582,39 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
 
     // ---- trace-code fast path: where the forward pass left a move code the step is a table lookup ----
     int32_t ctop = -1, ccol = 0; // matrix row in code-tile row 0 and the column its windows are anchored on
-    auto code_lo = [&](int32_t t) -> int32_t { return ((ccol - kLead - t) & ~3) + 1; };
-    // Loader: 4 lanes per tile row (16 bytes each), 16 rows per pass -- a pass touches 16 code rows (lane-per-row
-    // loads touch 64 different cache lines per instruction and took ~6 000 cycles per tile); band starts come from the
-    // LDS row table. Bytes that are not cells of the band (window reaching past a band edge, rows < 1) become code 0.
+    auto lo_of   = [&](int32_t col, int32_t t) -> int32_t { return ((col - kLead - t) & ~3) + 1; };
+    auto code_lo = [&](int32_t t) -> int32_t { return lo_of(ccol, t); };
+    // Loader: 4 lanes per tile row (16 bytes each), 16 rows per pass; band starts come from the LDS row table. Bytes
+    // that are not cells of the band (window reaching past a band edge, rows < 1) become code 0.
+    // A tile load is one cold HBM round trip (~5 000 cycles with 1024 windows in flight) and the walk needs one every
+    // ~40 steps, so the NEXT tile is requested as soon as the current one is in place -- 56 rows further up, at the
+    // column the band's slope predicts -- and waits in registers; when the walk leaves the current tile inside the
+    // predicted one, that one is committed to LDS without a wait. A wrong prediction costs an ordinary load.
     struct __attribute__((packed, aligned(4))) CodeSeg { uint32_t d[4]; };
-    auto load_codes = [&](int32_t top, int32_t col) {
-        const uint64_t t_lc = psel == 2 ? clock64() : 0;
-        if (psel == 3) pacc += 1000;
+    constexpr int kPasses = kCodeRows / 16, kAhead = 56;
+    const int seg = lane & 3;
+    auto issue_codes = [&](int32_t top, int32_t col, CodeSeg (&v)[kPasses]) {
+#pragma unroll
+        for (int pass = 0; pass < kPasses; pass++)
+        {
+            const int32_t t    = pass * 16 + (lane >> 2);
+            const int32_t rowc = max(top - t, 1);
+            const int32_t e0   = lo_of(col, t) - rowinfo[rowc].bs() + kRelShift; // byte index in the code row, multiple of 4
+            v[pass] = *reinterpret_cast<const CodeSeg*>(codes + (int64_t)rowc * b.stride + e0 + seg * 16);
+        }
+    };
+    auto commit_codes = [&](int32_t top, int32_t col, CodeSeg (&v)[kPasses]) {
         __syncthreads();
         ctop = top;
         ccol = col;
-        const int seg = lane & 3;
 #pragma unroll
-        for (int pass = 0; pass < kCodeRows / 16; pass++)
+        for (int pass = 0; pass < kPasses; pass++)
         {
             const int32_t t    = pass * 16 + (lane >> 2);
             const int32_t row  = top - t;
-            const int32_t rowc = max(row, 1);
-            const int32_t bs   = rowinfo[rowc].bs();
-            const int32_t e0   = code_lo(t) - bs + kRelShift; // byte index in the code row, multiple of 4
+            const int32_t e0   = lo_of(col, t) - rowinfo[max(row, 1)].bs() + kRelShift;
             const int32_t klo  = row >= 1 ? (1 + kRelShift) - e0 : 1; // window bytes that are cells of the band
             const int32_t khi  = row >= 1 ? (b.band_width + kRelShift) - e0 : 0;
-            CodeSeg v = *reinterpret_cast<const CodeSeg*>(codes + (int64_t)rowc * b.stride + e0 + seg * 16);
             if (__ballot(!(klo <= 0 && khi >= kCodeCols - 1)) != 0)
             {
 #pragma unroll
@@ -615,12 +624,44 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
                     const int32_t lo = min(max(klo - k0, 0), 4), hi = min(max(khi - k0 + 1, 0), 4);
                     const uint32_t mhi = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
                     const uint32_t mlo = lo >= 4 ? 0xffffffffu : ((1u << (8 * lo)) - 1u);
-                    v.d[d] &= hi > lo ? (mhi & ~mlo) : 0u;
+                    v[pass].d[d] &= hi > lo ? (mhi & ~mlo) : 0u;
                 }
             }
-            *reinterpret_cast<uint4*>(ctile + t * kCodeCols + seg * 16) = make_uint4(v.d[0], v.d[1], v.d[2], v.d[3]);
+            *reinterpret_cast<uint4*>(ctile + t * kCodeCols + seg * 16) = make_uint4(v[pass].d[0], v[pass].d[1], v[pass].d[2], v[pass].d[3]);
         }
         __syncthreads();
+    };
+    CodeSeg ahead[kPasses] = {};
+    int32_t atop = -1, acol = 0; // anchor of the tile in `ahead` (atop < 0: none)
+    // columns the path moves per row, and where inside a 64-column window it should enter so that the drift between
+    // the window's slope (1 column per row) and the path's stays inside the window
+    const int32_t ahead_cols = (int32_t)(b.gradient * (float)kAhead);
+    const int32_t ahead_bias = min(max((int32_t)((1.0f - b.gradient) * 32.0f), -12), 12);
+    auto load_codes = [&](int32_t top, int32_t col) {
+        const uint64_t t_lc = psel == 2 ? clock64() : 0;
+        if (psel == 3) pacc += 1000;
+        bool hit = false;
+        if (atop >= 0)
+        {
+            const int32_t t   = atop - top;
+            const int32_t off = col - lo_of(acol, t);
+            hit = ((uint32_t)t < (uint32_t)kCodeReanchor) & ((uint32_t)(off - 2) < (uint32_t)(kCodeCols - 2));
+        }
+        if (hit)
+        {
+            if (psel == 7) pacc += 1000;
+            commit_codes(atop, acol, ahead);
+        }
+        else
+        {
+            CodeSeg now[kPasses];
+            issue_codes(top, col, now);
+            commit_codes(top, col, now);
+        }
+        atop = ctop - kAhead;
+        acol = ccol - ahead_cols + ahead_bias;
+        if (atop >= 1) issue_codes(atop, acol, ahead);
+        else atop = -1;
         if (psel == 2) pacc += clock64() - t_lc;
     };
 

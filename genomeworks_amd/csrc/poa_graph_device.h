@@ -516,8 +516,11 @@ __device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_
 //   node word lo: out-edge 0 [0:12)  out-edge 1 [12:24)  min(out-degree, 4) [24:27)  previous queue length [27:31)
 //             hi: unvisited in-edges [0:6)  new in-edge / new node [6]  new out-edge / new node [7]
 //                 previous position [8:20)  out-edge 2 [20:32)
-//   (three out-edges in the word; a node with more takes an ordinary step that reads the rest from HBM)
-//   LDS: ent (row-table region), queue (score-ring region), previous order (read + trace-code-tile regions, 6 KB).
+//   (three out-edges in the word; out-edges 3..5 of the few nodes that have more sit in a 256-slot direct-mapped LDS
+//   table keyed by node id: {node [0:12), valid [12], out-degree [13:19), edge 3 [20:32), edge 4 [32:44), edge 5 [44:56)};
+//   a node that lost its slot or has more than six out-edges reads the rest of its list from HBM in an ordinary step)
+//   LDS: ent (row-table region), queue + wide-node table (score-ring region), previous order (read + trace-code-tile
+//   regions, 6 KB).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t ti_inleft(uint32_t h) { return h & 0x3fu; }
 __device__ __forceinline__ uint32_t ti_din(uint32_t h) { return (h >> 6) & 1u; }
@@ -547,7 +550,14 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
     uint32_t* ent32 = reinterpret_cast<uint32_t*>(lds);
     uint16_t* queue = reinterpret_cast<uint16_t*>(lds_queue);
     uint16_t* sold  = reinterpret_cast<uint16_t*>(lds_old);
+    uint64_t* wide  = reinterpret_cast<uint64_t*>(lds_queue + 6144 + 16); // 256 slots behind the 3072-entry queue (+ its spill slot)
     auto hi_of = [&](int32_t n) -> uint32_t { return ent32[2 * n + 1]; };
+    auto wide_hit = [&](uint64_t we, int32_t n) -> bool {
+        return (int32_t)(we & 0xfffu) == n && ((we >> 12) & 1u) != 0 && ((we >> 13) & 63u) <= 6u;
+    };
+#pragma unroll
+    for (int q = 0; q < 4; q++) wide[q * kWave + lane] = 0; // entries of the previous read are stale
+    __syncthreads();
     // phase 1 (all lanes): node words with change flags, previous order into LDS, sources in ascending node id.
     // Four 64-node chunks per iteration share one HBM round trip (eight independent loads per node; edge slots
     // past the out-degree hold stale ids: masked).
@@ -555,7 +565,7 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
     constexpr int kU = 4;
     for (int32_t base = 0; base < node_count; base += kU * kWave)
     {
-        uint32_t ic[kU], oc[kU], e0[kU], e1[kU], e2[kU], m[kU], po[kU], so[kU];
+        uint32_t ic[kU], oc[kU], e0[kU], e1[kU], e2[kU], e3[kU], e4[kU], e5[kU], m[kU], po[kU], so[kU];
 #pragma unroll
         for (int u = 0; u < kU; u++)
         {
@@ -566,6 +576,9 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
             e0[u] = (uint32_t)g.outgoing_edges[(int64_t)n * kEdges] & 0xfffu;
             e1[u] = (uint32_t)g.outgoing_edges[(int64_t)n * kEdges + 1] & 0xfffu;
             e2[u] = (uint32_t)g.outgoing_edges[(int64_t)n * kEdges + 2] & 0xfffu;
+            e3[u] = (uint32_t)g.outgoing_edges[(int64_t)n * kEdges + 3] & 0xfffu;
+            e4[u] = (uint32_t)g.outgoing_edges[(int64_t)n * kEdges + 4] & 0xfffu;
+            e5[u] = (uint32_t)g.outgoing_edges[(int64_t)n * kEdges + 5] & 0xfffu;
             m[u]  = g.local_cnt[nn];
             po[u] = (uint32_t)g.node_id_to_pos[nn] & 0xfffu;
             so[u] = (uint32_t)g.sorted_poa[nn] & 0xfffu;
@@ -585,6 +598,9 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
                                     (is_new ? 0u : (m[u] & 15u) << 27);
                 const uint32_t hi = (ic[u] & 0x3fu) | (din << 6) | (dout << 7) | (is_new ? 0u : po[u] << 8) | (oc[u] > 2 ? e2[u] << 20 : 0u);
                 ent[n] = (uint64_t)lo | ((uint64_t)hi << 32);
+                if (oc[u] > 3) // last writer of a slot wins; the others fall back to the HBM list
+                    wide[n & 255] = (uint64_t)((uint32_t)n | (1u << 12) | (oc[u] << 13) | (e3[u] << 20)) | ((uint64_t)e4[u] << 32) |
+                                    ((uint64_t)e5[u] << 44);
                 is_src = (ic[u] == 0);
             }
             const unsigned long long ms = __ballot(is_src);
@@ -613,8 +629,28 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
         const int32_t p = ti_pos(hi), qo = ti_qlen(lo);
         const bool is_new = u >= n_old;
         // an ordinary step is needed when the node has a new out-edge or a child has a new in-edge
-        const bool need_real = is_new | (ti_dout(hi) != 0) | (ocq > 3) | ((ocq > 0) & (ti_din(h0) != 0)) |
-                               ((ocq > 1) & (ti_din(h1) != 0)) | ((ocq > 2) & (ti_din(h2) != 0));
+        bool need_real = is_new | (ti_dout(hi) != 0) | ((ocq > 0) & (ti_din(h0) != 0)) | ((ocq > 1) & (ti_din(h1) != 0)) |
+                         ((ocq > 2) & (ti_din(h2) != 0));
+        // more than three out-edges (about 1.6 % of the nodes): edges 3..5 from the wide-node table
+        uint64_t uw = 0;
+        bool uw_ok  = false;
+        int32_t uoc = ocq;
+        if (ocq > 3)
+        {
+            uw    = wave_first64(wide[u & 255]);
+            uw_ok = wide_hit(uw, u);
+            uoc   = uw_ok ? (int32_t)((uw >> 13) & 63u) : 4;
+            if (uw_ok)
+            {
+                const int32_t x3 = (int32_t)((uw >> 20) & 0xfffu), x4 = uoc > 4 ? (int32_t)((uw >> 32) & 0xfffu) : x3,
+                              x5 = uoc > 5 ? (int32_t)((uw >> 44) & 0xfffu) : x3;
+                const uint32_t d = ti_din((uint32_t)wave_first((int32_t)hi_of(x3))) | ti_din((uint32_t)wave_first((int32_t)hi_of(x4))) |
+                                   ti_din((uint32_t)wave_first((int32_t)hi_of(x5)));
+                need_real |= d != 0;
+            }
+            else
+                need_real = true;
+        }
         bool block = !need_real && (head - k == p) && (M == p - 1) && (len == qo) && (qo < kQClip);
         if (block && len > 1) // the queue must be the previous run's queue at p, element by element
         {
@@ -636,9 +672,31 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
             const int32_t ch1  = noc > 1 ? (int32_t)((nlo >> 12) & 0xfffu) : node;
             const int32_t ch2  = noc > 2 ? ti_e2(nhi) : node;
             const uint32_t g0 = hi_of(ch0), g1 = hi_of(ch1), g2 = hi_of(ch2);
-            // more than three out-edges: the lane ends the block (its own step is an ordinary one)
-            const bool bad = !valid | (ti_dout(nhi) != 0) | ((lane > 0) & (ti_din(nhi) != 0)) | (noc > 3) |
-                             ((noc > 0) & (ti_din(g0) != 0)) | ((noc > 1) & (ti_din(g1) != 0)) | ((noc > 2) & (ti_din(g2) != 0));
+            bool bad = !valid | (ti_dout(nhi) != 0) | ((lane > 0) & (ti_din(nhi) != 0)) | ((noc > 0) & (ti_din(g0) != 0)) |
+                       ((noc > 1) & (ti_din(g1) != 0)) | ((noc > 2) & (ti_din(g2) != 0));
+            // more than three out-edges: edges 3..5 from the wide-node table; a lane whose node is not there ends
+            // the block (its own step is an ordinary one)
+            const bool is_wide   = valid && noc > 3;
+            const bool any_wide  = __ballot(is_wide) != 0;
+            int32_t woc = 0, ch3 = node, ch4 = node, ch5 = node;
+            if (any_wide)
+            {
+                const uint64_t we = wide[node & 255];
+                if (is_wide)
+                {
+                    if (wide_hit(we, node))
+                    {
+                        woc = (int32_t)((we >> 13) & 63u);
+                        ch3 = (int32_t)((we >> 20) & 0xfffu);
+                        ch4 = woc > 4 ? (int32_t)((we >> 32) & 0xfffu) : node;
+                        ch5 = woc > 5 ? (int32_t)((we >> 44) & 0xfffu) : node;
+                    }
+                    else
+                        bad = true;
+                }
+                const uint32_t g3 = hi_of(ch3), g4 = hi_of(ch4), g5 = hi_of(ch5);
+                bad |= ((woc > 3) & (ti_din(g3) != 0)) | ((woc > 4) & (ti_din(g4) != 0)) | ((woc > 5) & (ti_din(g5) != 0));
+            }
             const unsigned long long mb = __ballot(bad);
             const int32_t b = mb ? __ffsll(mb) - 1 : kWave; // >= 1: lane 0 passed the test above
             // all decrements in flight together; a child whose counter reaches 0 was pushed by the previous run here
@@ -647,8 +705,18 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
             if (do0) r0 = lds_dec_u32(ent32 + 2 * ch0 + 1);
             if (do1) r1 = lds_dec_u32(ent32 + 2 * ch1 + 1);
             if (do2) r2 = lds_dec_u32(ent32 + 2 * ch2 + 1);
-            const int32_t npush = __popcll(__ballot(do0 && ti_inleft(r0) == 1u)) + __popcll(__ballot(do1 && ti_inleft(r1) == 1u)) +
-                                  __popcll(__ballot(do2 && ti_inleft(r2) == 1u));
+            int32_t npush = __popcll(__ballot(do0 && ti_inleft(r0) == 1u)) + __popcll(__ballot(do1 && ti_inleft(r1) == 1u)) +
+                            __popcll(__ballot(do2 && ti_inleft(r2) == 1u));
+            if (any_wide)
+            {
+                const bool do3 = lane < b && woc > 3, do4 = lane < b && woc > 4, do5 = lane < b && woc > 5;
+                uint32_t r3 = 0, r4 = 0, r5 = 0;
+                if (do3) r3 = lds_dec_u32(ent32 + 2 * ch3 + 1);
+                if (do4) r4 = lds_dec_u32(ent32 + 2 * ch4 + 1);
+                if (do5) r5 = lds_dec_u32(ent32 + 2 * ch5 + 1);
+                npush += __popcll(__ballot(do3 && ti_inleft(r3) == 1u)) + __popcll(__ballot(do4 && ti_inleft(r4) == 1u)) +
+                         __popcll(__ballot(do5 && ti_inleft(r5) == 1u));
+            }
             // pushed entries continue the previous order; slots popped inside this same block are written by the
             // popping lane (with their queue length), the others here: disjoint slots
             for (int32_t j = lane; j < npush; j += kWave)
@@ -685,12 +753,13 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
                 lane0_store_u8(reinterpret_cast<uint8_t*>(ent + c2) + 4, (h2 & 0xc0u) | left2);
                 lane0_store_u16(queue + tail, (uint32_t)c2);
                 tail += left2 == 0 ? 1 : 0;
-                if (ocq > 3) // rare: the rest of the list from HBM
+                if (ocq > 3) // the rest of the list: the wide-node table, or (rare) HBM
                 {
-                    const int32_t oc = wave_first((int32_t)g.outgoing_edge_count[u]);
+                    const int32_t oc = uw_ok ? uoc : wave_first((int32_t)g.outgoing_edge_count[u]);
                     for (int32_t e = 3; e < oc; e++)
                     {
-                        const int32_t child = wave_first((int32_t)g.outgoing_edges[(int64_t)u * kEdges + e]) & 0xfff;
+                        const int32_t child = uw_ok ? (int32_t)((uw >> (20 + 12 * (e - 3))) & 0xfffu)
+                                                    : wave_first((int32_t)g.outgoing_edges[(int64_t)u * kEdges + e]) & 0xfff;
                         const uint32_t hc   = (uint32_t)wave_first((int32_t)hi_of(child));
                         const uint32_t left = (ti_inleft(hc) - 1u) & 0x3fu;
                         lane0_store_u8(reinterpret_cast<uint8_t*>(ent + child) + 4, (hc & 0xc0u) | left);
