@@ -193,7 +193,9 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
             break;
         }
         pc.tick(kPhOther);
-        build_rowinfo<IdT, RowT>(g, node_count, rowinfo, lane);
+        // rows with 4..6 predecessors keep predecessors 3..5 in an LDS side table (the trace-code tile region is free
+        // until the traceback)
+        build_rowinfo<IdT, RowT>(g, node_count, rowinfo, lane, LDS_TABLES ? reinterpret_cast<uint64_t*>(lds_code_tile) : nullptr);
         // stage the read (plus the never-consumed read-ahead) in LDS when it fits
         constexpr bool LDS_READ = LDS_TABLES && BM != GWHIP_FULL_BAND && !TB;
         const uint8_t* lds_read = lds_read_buf;

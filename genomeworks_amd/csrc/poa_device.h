@@ -879,8 +879,18 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
 // Per-read row table: all lanes gather (base, predecessor rows, sink flag) for rows 1..N.
 // ------------------------------------------------------------------------------------------------
 template <typename IdT, typename RowT>
-__device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t graph_count, RowT* rowinfo, int lane)
+__device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t graph_count, RowT* rowinfo, int lane,
+                                              uint64_t* xpred = nullptr)
 {
+    // xpred (optional, LDS, 256 slots keyed by row & 255): predecessor rows 3..5 of the rows that have more than the
+    // three the row table holds: {row [0:12), valid [12], count [13:19), pred 3 [20:32), pred 4 [32:44), pred 5 [44:56)}.
+    // The last writer of a slot wins; a reader checks the row id (poa_forward_packed.h: classify_rows).
+    if (xpred != nullptr)
+    {
+#pragma unroll
+        for (int q = 0; q < 4; q++) xpred[q * kWave + lane] = 0;
+        __syncthreads();
+    }
     if (lane == 0) rowinfo[0].set(0, 0, false, 0, 0, 0); // row 0 (virtual source): no predecessors
     // Four 64-row chunks per iteration: a chunk is three dependent HBM round trips (row -> node -> its first three
     // in-edges -> their rows), and the chunks of one iteration share them (18 round trips per read instead of 66).
@@ -889,6 +899,7 @@ __device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t g
     for (int32_t r0 = 1 + lane; r0 <= graph_count; r0 += kU * kWave)
     {
         int32_t node[kU], cnt[kU], oc[kU], bas[kU], e0[kU], e1[kU], e2[kU], q0[kU], q1[kU], q2[kU];
+        int32_t e3[kU], e4[kU], e5[kU], q3[kU], q4[kU], q5[kU];
 #pragma unroll
         for (int u = 0; u < kU; u++) node[u] = g.sorted_poa[min(r0 + u * kWave, graph_count) - 1];
 #pragma unroll
@@ -900,6 +911,12 @@ __device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t g
             e0[u]  = g.incoming_edges[(int64_t)node[u] * kEdges + 0];
             e1[u]  = g.incoming_edges[(int64_t)node[u] * kEdges + 1];
             e2[u]  = g.incoming_edges[(int64_t)node[u] * kEdges + 2];
+            if (xpred != nullptr) // wave-uniform
+            {
+                e3[u] = g.incoming_edges[(int64_t)node[u] * kEdges + 3];
+                e4[u] = g.incoming_edges[(int64_t)node[u] * kEdges + 4];
+                e5[u] = g.incoming_edges[(int64_t)node[u] * kEdges + 5];
+            }
         }
 #pragma unroll
         for (int u = 0; u < kU; u++)
@@ -907,6 +924,12 @@ __device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t g
             q0[u] = g.node_id_to_pos[(uint32_t)e0[u] < (uint32_t)graph_count ? e0[u] : 0];
             q1[u] = g.node_id_to_pos[(uint32_t)e1[u] < (uint32_t)graph_count ? e1[u] : 0];
             q2[u] = g.node_id_to_pos[(uint32_t)e2[u] < (uint32_t)graph_count ? e2[u] : 0];
+            if (xpred != nullptr)
+            {
+                q3[u] = g.node_id_to_pos[(uint32_t)e3[u] < (uint32_t)graph_count ? e3[u] : 0];
+                q4[u] = g.node_id_to_pos[(uint32_t)e4[u] < (uint32_t)graph_count ? e4[u] : 0];
+                q5[u] = g.node_id_to_pos[(uint32_t)e5[u] < (uint32_t)graph_count ? e5[u] : 0];
+            }
         }
 #pragma unroll
         for (int u = 0; u < kU; u++)
@@ -917,6 +940,9 @@ __device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t g
                 RowT ri{};
                 ri.set(bas[u], cnt[u], oc[u] == 0, cnt[u] > 0 ? q0[u] + 1 : 0, cnt[u] > 1 ? q1[u] + 1 : 0, cnt[u] > 2 ? q2[u] + 1 : 0);
                 rowinfo[r] = ri;
+                if (xpred != nullptr && cnt[u] > 3)
+                    xpred[r & 255] = (uint64_t)((uint32_t)r | (1u << 12) | ((uint32_t)(cnt[u] & 63) << 13) | ((uint32_t)((q3[u] + 1) & 0xfff) << 20)) |
+                                     ((uint64_t)((q4[u] + 1) & 0xfff) << 32) | ((uint64_t)((q5[u] + 1) & 0xfff) << 44);
             }
         }
     }
@@ -1307,10 +1333,10 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                                codes != nullptr && !(dbg & 256);
         if (packed_ok)
         {
-            classify_rows(rowinfo, graph_count, lane, dbg, pc.acc ? &pc.acc[kPhOther] : nullptr);
+            classify_rows(rowinfo, graph_count, lane, reinterpret_cast<const uint64_t*>(code_tile), dbg, pc.acc ? &pc.acc[kPhOther] : nullptr);
             __syncthreads();
             banded_forward_packed<IdT>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
-                                       max_column, gap_score, mismatch_score, match_score, dbg,
+                                       reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score, dbg,
                                        pc.acc ? &pc.acc[kPhOther] : nullptr);
             fast_done   = true;
             codes_valid = true;

@@ -97,8 +97,14 @@ __device__ __forceinline__ void lds_store_u64_lanes17(uint32_t addr, uint32_t lo
 //   2: 2..3 predecessors, each 1..7 rows back, band starts compatible            (predecessors from the LDS ring)
 //   3: everything else                                                           (general routine, HBM matrix)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void classify_rows(RowInfo<true>* rowinfo, int32_t graph_count, int lane, int32_t dbg = 0,
-                                              uint64_t* prof_acc = nullptr)
+__device__ __forceinline__ bool xpred_hit(uint64_t e, int32_t row, int32_t cnt)
+{
+    return (int32_t)(e & 0xfffu) == row && ((e >> 12) & 1u) != 0 && (int32_t)((e >> 13) & 63u) == cnt;
+}
+__device__ __forceinline__ int32_t xpred_row(uint64_t e, int32_t k) { return (int32_t)((e >> (20 + 12 * (k - 3))) & 0xfffu); } // k = 3..5
+
+__device__ __forceinline__ void classify_rows(RowInfo<true>* rowinfo, int32_t graph_count, int lane, const uint64_t* xpred,
+                                              int32_t dbg = 0, uint64_t* prof_acc = nullptr)
 {
     int32_t prof_count = 0; // profiling (GWHIP_DEBUG bits 2-3 = class to count: 1, 2 or 3)
     for (int32_t r = 1 + lane; r <= graph_count; r += kWave)
@@ -106,19 +112,30 @@ __device__ __forceinline__ void classify_rows(RowInfo<true>* rowinfo, int32_t gr
         RowInfo<true> ri = rowinfo[r];
         const int32_t cnt = ri.cnt(), bs = ri.bs();
         uint64_t cls = 3;
-        if (cnt >= 1 && cnt <= 3)
+        // profiling (GWHIP_DEBUG bits 12, 14, 19 = reason selector): rows that are class 3 because of
+        // 1 no predecessor, 2 more than three, 3 a predecessor more than 7 rows back, 4 band guard, 5 band-start transition
+        const int32_t rsel = ((dbg >> 12) & 1) | (((dbg >> 14) & 1) << 1) | (((dbg >> 19) & 1) << 2);
+        // 4..6 predecessors: rows 3..5 from the side table build_rowinfo left (a row that lost its slot stays class 3)
+        const uint64_t xe  = (cnt > 3 && cnt <= 6 && xpred != nullptr) ? xpred[r & 255] : 0ull;
+        const bool many_ok = cnt > 3 && cnt <= 6 && xpred_hit(xe, r, cnt) && !(dbg & (1 << 30));
+        int32_t reason     = cnt == 0 ? 1 : ((cnt > 3 && !many_ok) ? 2 : 0);
+        if (cnt >= 1 && (cnt <= 3 || many_ok))
         {
             bool ok = true, first_is_prev_unmoved = false;
             for (int32_t k = 0; k < cnt; k++)
             {
-                const int32_t p   = ri.pred(k);
+                const int32_t p   = k < 3 ? ri.pred(k) : xpred_row(xe, k);
                 const int32_t d   = r - p;
                 const int32_t pbs = rowinfo[p].bs(); // row 0 holds band start 0
                 ok                = ok && d >= 1 && d <= kPkMaxDist && (bs - pbs) <= kPkGuardCols && (bs == 0 || pbs > 0);
                 if (k == 0) first_is_prev_unmoved = (d == 1 && pbs == bs);
+                if (reason == 0 && !(d >= 1 && d <= kPkMaxDist)) reason = 3;
+                if (reason == 0 && !((bs - pbs) <= kPkGuardCols)) reason = 4;
+                if (reason == 0 && !(bs == 0 || pbs > 0)) reason = 5;
             }
             if (ok) cls = cnt > 1 ? 2 : (first_is_prev_unmoved ? 0 : 1);
         }
+        if (rsel && reason == rsel) prof_count += 1000;
         // ablations (GWHIP_DEBUG): demote classes to check them against each other
         if ((dbg & 1024) && cls == 0) cls = 1;
         if ((dbg & 2048) && cls == 0) cls = 3;
@@ -128,7 +145,7 @@ __device__ __forceinline__ void classify_rows(RowInfo<true>* rowinfo, int32_t gr
         rowinfo[r] = ri;
         if ((dbg & 12) && cls == (uint64_t)((dbg >> 2) & 3)) prof_count++;
     }
-    if ((dbg & 12) && prof_acc)
+    if (((dbg & 12) || (dbg & ((1 << 12) | (1 << 14) | (1 << 19)))) && prof_acc)
     {
         for (int off = 32; off > 0; off >>= 1) prof_count += __shfl_xor(prof_count, off);
         *prof_acc += (uint64_t)prof_count;
@@ -181,7 +198,7 @@ __device__ __forceinline__ void global_store_u16_lane0(void* p, uint32_t v)
 template <typename IdT>
 __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, const RowInfo<true>* rowinfo,
                                                       int32_t graph_count, const uint8_t* lds_read, int16_t* scores,
-                                                      uint8_t* codes, uint8_t* ring, int32_t max_column,
+                                                      uint8_t* codes, uint8_t* ring, const uint64_t* xpred, int32_t max_column,
                                                       int32_t gap_score, int32_t mismatch_score, int32_t match_score,
                                                       int32_t dbg, uint64_t* prof_acc)
 {
@@ -288,6 +305,9 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
     };
     auto class_of = [&](const RowInfo<true>& w) -> uint32_t { return (uint32_t)(w.w >> kClassShift) & 3u; };
 
+    // profiling (GWHIP_DEBUG bits 28-29): 1 cycles in class 3 rows, 2 their number x 1000, 3 cycles in class 2 rows
+    const int32_t fsel = prof_acc ? (dbg >> 28) & 3 : 0;
+    uint64_t facc      = 0;
     int32_t r        = 1;
     RowInfo<true> ri = uniform_row(rowinfo[1]);
     uint32_t cls     = class_of(ri);
@@ -339,6 +359,8 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
         }
         if (r > graph_count) break;
 
+        const uint64_t t_row = fsel ? clock64() : 0;
+        const uint32_t cls_now = cls;
         const RowInfo<true> nxt = rowinfo[min(r + 1, graph_count)];
         const int32_t bs        = ri.bs();
         const uint32_t base     = (uint32_t)ri.base();
@@ -348,7 +370,8 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
         if (cls == 2)
         {
             // ================= every predecessor (2..3, at most 7 rows back) from the LDS ring =================
-            const int32_t cnt     = ri.cnt();
+            const int32_t cnt_all = ri.cnt();         // 2..6; predecessors 3..5 are in the side table
+            const int32_t cnt     = min(cnt_all, 3);
             const int32_t my_slot = (slot + 1) & (kPkSlots - 1);
             const uint32_t a0     = (a1 - 4) & (kPkSlotBytes - 1); // dword whose high half is the cell of column c
             auto slot_base = [&](int32_t k) -> uint32_t {
@@ -381,7 +404,7 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
                 if (cnt > 2) pen = max(pen, (int32_t)(int16_t)wave_first((int32_t)(lds_load_u32(b2 + kPkSlotBytes - 4) >> 16)));
                 fe = pen + gap_score;
             }
-            const int32_t rel0_val = bs == 0 ? fe : min_score;
+            int32_t rel0_val = bs == 0 ? fe : min_score;
             const uint32_t sent16  = (uint32_t)kPkSentinel & 0xffffu;
             uint32_t c01, c23;
             costs(base, c01, c23);
@@ -424,15 +447,48 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
                     kV01 = nz(bV01, V0a); kV23 = nz(bV23, V0b);
                 }
             }
+            // move codes if the best candidate is attained by one of the first three predecessors: 2 + kD / 5 + kV
+            uint32_t A01 = pk_add(kD01, TWO2), A23 = pk_add(kD23, TWO2), B01 = pk_add(kV01, FIVE2), B23 = pk_add(kV23, FIVE2);
+            if (cnt_all > 3)
+            {
+                // predecessors 3..5 (rows from the side table, cells from the ring): they raise the maxima; where only
+                // they attain a maximum the first attaining slot is >= 3, which a code cannot name -> that code is 0
+                const uint64_t xe = wave_first64(xpred[r & 255]);
+                uint32_t xD01 = MIN2, xD23 = MIN2, xV01 = MIN2, xV23 = MIN2;
+                int32_t pen_x = min_score;
+                for (int32_t k = 3; k < cnt_all; k++)
+                {
+                    const int32_t d   = r - xpred_row(xe, k);
+                    const uint32_t bk = ring_base + (uint32_t)((my_slot - d) & (kPkSlots - 1)) * kPkSlotBytes;
+                    const uint32_t xk = lds_load_u32(bk + a0);
+                    const uint2 qk    = lds_load_u64(bk + a1);
+                    uint32_t Da, Db, Va, Vb;
+                    from_pred(xk, qk.x, qk.y, c01, c23, Da, Db, Va, Vb);
+                    const bool outk = (qk.x & 0xffffu) == sent16;
+                    undecided       = undecided | outk;
+                    xD01 = pk_max(xD01, outk ? MIN2 : Da); xD23 = pk_max(xD23, outk ? MIN2 : Db);
+                    xV01 = pk_max(xV01, outk ? MIN2 : Va); xV23 = pk_max(xV23, outk ? MIN2 : Vb);
+                    if (bs == 0) pen_x = max(pen_x, (int32_t)(int16_t)wave_first((int32_t)(lds_load_u32(bk + kPkSlotBytes - 4) >> 16)));
+                }
+                if (bs == 0)
+                {
+                    fe       = max(fe - gap_score, pen_x) + gap_score;
+                    rel0_val = fe;
+                }
+                const uint32_t fD01 = pk_max(bD01, xD01), fD23 = pk_max(bD23, xD23), fV01 = pk_max(bV01, xV01), fV23 = pk_max(bV23, xV23);
+                // A *= [max of the first three == overall max]
+                A01 = pk_mad_u16(nz(bD01, fD01), pk_sub(0u, A01), A01); A23 = pk_mad_u16(nz(bD23, fD23), pk_sub(0u, A23), A23);
+                B01 = pk_mad_u16(nz(bV01, fV01), pk_sub(0u, B01), B01); B23 = pk_mad_u16(nz(bV23, fV23), pk_sub(0u, B23), B23);
+                bD01 = fD01; bD23 = fD23; bV01 = fV01; bV23 = fV23;
+            }
             scan_row(pk_max(bD01, bV01), pk_max(bD23, bV23), fe);
-            // code = H == bestD ? 2 + kD : H == bestV ? 5 + kV : 1
-            auto code_of = [&](uint32_t H, uint32_t bD, uint32_t bV, uint32_t kD, uint32_t kV) -> uint32_t {
-                const uint32_t A  = pk_add(kD, TWO2), B = pk_add(kV, FIVE2);
+            // code = H == bestD ? A : H == bestV ? B : 1
+            auto code_of = [&](uint32_t H, uint32_t bD, uint32_t bV, uint32_t A, uint32_t B) -> uint32_t {
                 const uint32_t t1 = pk_mad_u16(nz(H, bV), pk_sub(ONE2, B), B);
                 return pk_mad_u16(nz(H, bD), pk_sub(t1, A), A);
             };
-            const uint32_t code01 = code_of(P01, bD01, bV01, kD01, kV01);
-            const uint32_t code23 = code_of(P23, bD23, bV23, kD23, kV23);
+            const uint32_t code01 = code_of(P01, bD01, bV01, A01, B01);
+            const uint32_t code23 = code_of(P23, bD23, bV23, A23, B23);
             const RowInfo<true> ri_n = uniform_row(nxt);
             store_row(bs, rel0_val);
             store_codes(code01, code23, undecided);
@@ -531,7 +587,11 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
             ri = ri_n;
         }
         cls = r <= graph_count ? class_of(ri) : 7u;
+        if (fsel == 1 && cls_now == 3) facc += clock64() - t_row;
+        if (fsel == 2 && cls_now == 3) facc += 1000;
+        if (fsel == 3 && cls_now == 2) facc += clock64() - t_row;
     }
+    if (fsel && lane == 0) *prof_acc += facc;
 }
 
 } // namespace gwhip

@@ -13,3 +13,7 @@ for sel in 1 2 3 4 5 6; do
   v=$(GWHIP_DEBUG=$((sel << 25)) python tools/profile_phases.py $N 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print(d['ticks_per_window']['other'], d['ticks_per_window']['topsort'], d['kernel_ms'])")
   echo "topsort sel=$sel other/topsort/kernel_ms: $v" | tee -a $OUT
 done
+for sel in 1 2 3; do
+  v=$(GWHIP_DEBUG=$((sel << 28)) python tools/profile_phases.py $N 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print(d['ticks_per_window']['other'], d['ticks_per_window']['nw_forward'], d['kernel_ms'])")
+  echo "forward sel=$sel other/forward/kernel_ms: $v" | tee -a $OUT
+done
