@@ -571,17 +571,26 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         }
         __syncthreads();
     };
+    // stage[k] = cell (row | column << 16) step k LEFT; the entry the reference records for a step -- graph position or
+    // -1 when the row did not change, read position or -1 when the column did not change -- follows from two
+    // consecutive cells, so the walk stores one word per step and the lanes format 64 steps at a time. The cell
+    // after the last staged step is the walk's current cell (i, j).
     auto flush_stage = [&](int32_t first, int32_t count) {
         if (lane < count)
         {
-            const uint32_t e              = stage[lane];
-            alignment_graph[first + lane] = (int32_t)(int16_t)(e & 0xffff); // sorted position; node ids are filled in below
-            alignment_read[first + lane]  = (int32_t)(int16_t)(e >> 16);
+            const uint32_t cur = stage[lane];
+            const uint32_t nxt = lane + 1 < count ? stage[lane + 1] : ((uint32_t)i | ((uint32_t)j << 16));
+            const int32_t ci = (int32_t)(cur & 0xffff), cj = (int32_t)(cur >> 16);
+            const int32_t ni = (int32_t)(nxt & 0xffff), nj = (int32_t)(nxt >> 16);
+            alignment_graph[first + lane] = ci == ni ? -1 : ci - 1; // sorted position; node ids are filled in below
+            alignment_read[first + lane]  = cj == nj ? -1 : cj - 1;
         }
     };
 
     // ---- trace-code fast path: where the forward pass left a move code the step is a table lookup ----
-    int32_t ctop = -1, ccol = 0; // matrix row in code-tile row 0 and the column its windows are anchored on
+    // matrix row in code-tile row 0 (far below any row while no tile is loaded, so that the range test of the walk
+    // fails without a separate flag) and the column its windows are anchored on
+    int32_t ctop = -(1 << 20), ccol = 0, ccol_lead = 0;
     auto lo_of   = [&](int32_t col, int32_t t) -> int32_t { return ((col - kLead - t) & ~3) + 1; };
     auto code_lo = [&](int32_t t) -> int32_t { return lo_of(ccol, t); };
     // Loader: 4 lanes per tile row (16 bytes each), 16 rows per pass; band starts come from the LDS row table. Bytes
@@ -607,6 +616,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         __syncthreads();
         ctop = top;
         ccol = col;
+        ccol_lead = col - kLead;
 #pragma unroll
         for (int pass = 0; pass < kPasses; pass++)
         {
@@ -680,22 +690,25 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     int32_t scores_ij = 0;
     uint32_t ri_lo = 0, ri_hi = 0, rch = 0;
     bool have = false;
-    while (!(i == 0 && j == 0) && loop_count < bound)
+    // (every step appends one entry, so the reference's loop counter is aligned_nodes)
+    while (!(i == 0 && j == 0) && aligned_nodes < bound)
     {
         if (codes != nullptr)
         {
             // tight loop over consecutive steps whose move code is known
             bool stop = false;
-            while (i > 0 && loop_count < bound)
+            // shift of the predecessor slot a code names inside the row-table word (codes 2..4 diagonal, 5..7 vertical)
+            constexpr uint64_t kShiftLut = 0x3024183024181818ull;
+            while (i > 0 && aligned_nodes < bound)
             {
-                const int32_t t   = ctop - i;
-                const int32_t off = j - code_lo(t);
-                if ((ctop < 0) | ((uint32_t)t >= (uint32_t)kCodeReanchor) | ((uint32_t)(off - 2) >= (uint32_t)(kCodeCols - 2)))
+                const int32_t t  = ctop - i;
+                const int32_t lo = (ccol_lead - t) & ~3; // code_lo(t) - 1
+                if (((uint32_t)t >= (uint32_t)kCodeReanchor) | ((uint32_t)(j - lo - 3) >= (uint32_t)(kCodeCols - 2)))
                 {
                     load_codes(i, j);
                     continue;
                 }
-                const uint32_t code = (uint32_t)wave_first((int32_t)ctile[t * kCodeCols + off]);
+                const uint32_t code = (uint32_t)wave_first((int32_t)ctile[t * kCodeCols + (j - lo - 1)]);
                 const uint64_t riw  = wave_first64(rowinfo[i].w);
                 if (code == 0) break; // undecided cell: recompute this step below
                 if (ADAPTIVE)
@@ -711,22 +724,17 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
                         }
                     }
                 }
-                loop_count++;
-                const bool is_vert = code >= 5, is_horiz = code == 1;
-                const uint32_t k   = is_vert ? code - 5 : code - 2;
-                const int32_t pr   = (int32_t)((riw >> (24 + 12 * (k & 3))) & 0xfff);
-                prev_i             = is_horiz ? i : pr;
-                prev_j             = is_vert ? j : j - 1;
-                const uint32_t e = (uint32_t)(uint16_t)(i == prev_i ? -1 : i - 1) | ((uint32_t)(uint16_t)(j == prev_j ? -1 : j - 1) << 16);
-                lane0_store_u32(stage + (aligned_nodes & (kStage - 1)), e);
+                lane0_store_u32(stage + (aligned_nodes & (kStage - 1)), (uint32_t)i | ((uint32_t)j << 16));
                 aligned_nodes++;
+                const uint32_t sh = (uint32_t)(kShiftLut >> (code * 8)) & 0xffu;
+                const int32_t pr  = (int32_t)((riw >> sh) & 0xfff);
+                i                 = code == 1 ? i : pr;
+                j                 = code >= 5 ? j : j - 1;
                 if ((aligned_nodes & (kStage - 1)) == 0) flush_stage(aligned_nodes - kStage, kStage);
-                i    = prev_i;
-                j    = prev_j;
                 have = false;
             }
             if (stop) break;
-            if ((i == 0 && j == 0) || loop_count >= bound) continue; // the outer condition ends the walk
+            if ((i == 0 && j == 0) || aligned_nodes >= bound) continue; // the outer condition ends the walk
         }
         const uint64_t t_rc = psel == 4 ? clock64() : 0;
         if (psel == 5) pacc += 1000;
@@ -738,7 +746,6 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
             const bool reload = (tile_top < 0) | (t < 0) | (t >= kReanchor) | (off < 2) | (off >= kTileCols);
             if (reload && i > 0) load_tile(i, j);
         }
-        loop_count++;
         const bool need_self = !have && !use_tile; // H(i, j) arrives with the candidates
         if (!have)
         {
@@ -837,14 +844,11 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         }
         prev_i = next_i;
         prev_j = next_j;
-        {
-            const uint32_t e = (uint32_t)(uint16_t)(i == prev_i ? -1 : i - 1) | ((uint32_t)(uint16_t)(j == prev_j ? -1 : j - 1) << 16);
-            lane0_store_u32(stage + (aligned_nodes & (kStage - 1)), e);
-        }
+        lane0_store_u32(stage + (aligned_nodes & (kStage - 1)), (uint32_t)i | ((uint32_t)j << 16));
         aligned_nodes++;
-        if ((aligned_nodes & (kStage - 1)) == 0) flush_stage(aligned_nodes - kStage, kStage);
         i         = prev_i;
         j         = prev_j;
+        if ((aligned_nodes & (kStage - 1)) == 0) flush_stage(aligned_nodes - kStage, kStage);
         scores_ij = next_score;
         ri_lo     = next_lo;
         ri_hi     = next_hi;
@@ -856,7 +860,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     if (aligned_nodes > 0 && (aligned_nodes & (kStage - 1)) != 0)
         flush_stage(aligned_nodes & ~(kStage - 1), aligned_nodes & (kStage - 1));
     if ((dbg & 2) && prof_acc && lane == 0) *prof_acc += (uint64_t)max(aligned_nodes, 0); // profiling: all steps
-    if (loop_count >= bound) aligned_nodes = kNwLoopFailed;
+    if (aligned_nodes >= bound) aligned_nodes = kNwLoopFailed;
     __syncthreads();
     for (int32_t k0 = lane; k0 < aligned_nodes; k0 += 4 * kWave) // 4 independent load chains per lane in flight
     {
@@ -899,7 +903,7 @@ __device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t g
     for (int32_t r0 = 1 + lane; r0 <= graph_count; r0 += kU * kWave)
     {
         int32_t node[kU], cnt[kU], oc[kU], bas[kU], e0[kU], e1[kU], e2[kU], q0[kU], q1[kU], q2[kU];
-        int32_t e3[kU], e4[kU], e5[kU], q3[kU], q4[kU], q5[kU];
+        int32_t e3[kU], e4[kU], e5[kU], q3[kU] = {}, q4[kU] = {}, q5[kU] = {};
 #pragma unroll
         for (int u = 0; u < kU; u++) node[u] = g.sorted_poa[min(r0 + u * kWave, graph_count) - 1];
 #pragma unroll
@@ -911,12 +915,6 @@ __device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t g
             e0[u]  = g.incoming_edges[(int64_t)node[u] * kEdges + 0];
             e1[u]  = g.incoming_edges[(int64_t)node[u] * kEdges + 1];
             e2[u]  = g.incoming_edges[(int64_t)node[u] * kEdges + 2];
-            if (xpred != nullptr) // wave-uniform
-            {
-                e3[u] = g.incoming_edges[(int64_t)node[u] * kEdges + 3];
-                e4[u] = g.incoming_edges[(int64_t)node[u] * kEdges + 4];
-                e5[u] = g.incoming_edges[(int64_t)node[u] * kEdges + 5];
-            }
         }
 #pragma unroll
         for (int u = 0; u < kU; u++)
@@ -924,11 +922,33 @@ __device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t g
             q0[u] = g.node_id_to_pos[(uint32_t)e0[u] < (uint32_t)graph_count ? e0[u] : 0];
             q1[u] = g.node_id_to_pos[(uint32_t)e1[u] < (uint32_t)graph_count ? e1[u] : 0];
             q2[u] = g.node_id_to_pos[(uint32_t)e2[u] < (uint32_t)graph_count ? e2[u] : 0];
-            if (xpred != nullptr)
+            // in-edges 3..5 of the few rows that have them ride along with this round trip (only those lanes load)
+            e3[u] = e4[u] = e5[u] = 0;
+            if (xpred != nullptr && cnt[u] > 3)
             {
-                q3[u] = g.node_id_to_pos[(uint32_t)e3[u] < (uint32_t)graph_count ? e3[u] : 0];
-                q4[u] = g.node_id_to_pos[(uint32_t)e4[u] < (uint32_t)graph_count ? e4[u] : 0];
-                q5[u] = g.node_id_to_pos[(uint32_t)e5[u] < (uint32_t)graph_count ? e5[u] : 0];
+                e3[u] = g.incoming_edges[(int64_t)node[u] * kEdges + 3];
+                e4[u] = g.incoming_edges[(int64_t)node[u] * kEdges + 4];
+                e5[u] = g.incoming_edges[(int64_t)node[u] * kEdges + 5];
+            }
+        }
+        if (xpred != nullptr)
+        {
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < kU; u++) any |= cnt[u] > 3;
+            if (__ballot(any) != 0)
+            {
+#pragma unroll
+                for (int u = 0; u < kU; u++)
+                {
+                    q3[u] = q4[u] = q5[u] = 0;
+                    if (cnt[u] > 3)
+                    {
+                        q3[u] = g.node_id_to_pos[(uint32_t)e3[u] < (uint32_t)graph_count ? e3[u] : 0];
+                        q4[u] = g.node_id_to_pos[(uint32_t)e4[u] < (uint32_t)graph_count ? e4[u] : 0];
+                        q5[u] = g.node_id_to_pos[(uint32_t)e5[u] < (uint32_t)graph_count ? e5[u] : 0];
+                    }
+                }
             }
         }
 #pragma unroll
