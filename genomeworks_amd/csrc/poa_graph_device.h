@@ -290,79 +290,94 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
     prof_mark(3);
 
     // ---- D: edges and coverage ----
+    // Read positions are independent here (a node is the current node of one position and the head of one
+    // position), so four 64-position chunks go through each HBM round trip together: first every load of the four
+    // chunks (coverage, in-degree, head's out-degree, the first four in-edge slots with their weights -- slots past
+    // the in-degree hold stale values and are masked), then their stores.
     int32_t rp_edgeerr = INT32_MAX;
-    for (int32_t rp = lane; rp < L; rp += kWave)
+    constexpr int kUD = 4, kBatch = 4;
+    for (int32_t rp0 = lane; rp0 < L; rp0 += kUD * kWave)
     {
-        const int32_t cur = curr[rp];
-        const uint16_t cov = g.coverage[cur]; // zeroed in pass C for new nodes
-        if (rp > 0)
+        int32_t cur[kUD], head[kUD], ic[kUD], oc_head[kUD], be[kUD][kBatch];
+        uint16_t cov[kUD], w[kUD], bw[kUD][kBatch];
+#pragma unroll
+        for (int u = 0; u < kUD; u++)
         {
-            const int32_t head = curr[rp - 1];
-            const uint16_t w   = (uint16_t)((uint16_t)base_weights[rp - 1] + base_weights[rp]);
-            const int32_t ic   = in_count_of(cur);
-            const int32_t oc_head = out_count_of(head); // heads are distinct across rp, nobody else bumps it
-            bool exists        = false;
-            {
-                // the first four in-edge slots and their weights are fetched together with the count (independent loads,
-                // one HBM round trip; slots past the in-degree hold stale values and are masked); longer lists loop on
-                constexpr int kBatch = 4;
-                int32_t be[kBatch];
-                uint16_t bw[kBatch];
+            const int32_t rp = min(rp0 + u * kWave, L - 1); // clamped lanes load valid addresses and store nothing
+            cur[u]  = curr[rp];
+            head[u] = rp > 0 ? (int32_t)curr[rp - 1] : cur[u];
+            w[u]    = rp > 0 ? (uint16_t)((uint16_t)base_weights[rp - 1] + base_weights[rp]) : (uint16_t)0;
+        }
 #pragma unroll
-                for (int e = 0; e < kBatch; e++)
-                {
-                    be[e] = g.incoming_edges[(int64_t)cur * kEdges + e];
-                    bw[e] = g.incoming_edge_w[(int64_t)cur * kEdges + e];
-                }
+        for (int u = 0; u < kUD; u++)
+        {
+            cov[u]     = g.coverage[cur[u]]; // zeroed in pass C for new nodes
+            ic[u]      = in_count_of(cur[u]);
+            oc_head[u] = out_count_of(head[u]); // heads are distinct across rp, nobody else bumps it
 #pragma unroll
-                for (int e = 0; e < kBatch; e++)
-                    if (e < ic && be[e] == head)
-                    {
-                        exists = true;
-                        g.incoming_edge_w[(int64_t)cur * kEdges + e] = (uint16_t)(bw[e] + w);
-                    }
-                for (int32_t e = kBatch; e < ic; e++)
-                {
-                    if (g.incoming_edges[(int64_t)cur * kEdges + e] == head)
-                    {
-                        exists = true;
-                        g.incoming_edge_w[(int64_t)cur * kEdges + e] += w;
-                    }
-                }
-            }
-            if (!exists)
+            for (int e = 0; e < kBatch; e++)
             {
-                g.incoming_edges[(int64_t)cur * kEdges + ic]  = (IdT)head;
-                g.incoming_edge_w[(int64_t)cur * kEdges + ic] = w;
-                g.incoming_edge_count[cur]                    = (uint16_t)(ic + 1);
-                const int32_t oc                              = oc_head;
-                g.outgoing_edges[(int64_t)head * kEdges + oc] = (IdT)cur;
-                if (MSA)
-                {
-                    g.out_cov_cnt[(int64_t)head * kEdges + oc]                          = 1;
-                    g.out_cov[((int64_t)head * kEdges + oc) * max_sequences_per_poa]    = s;
-                }
-                g.outgoing_edge_count[head] = (uint16_t)(oc + 1);
-                if (oc + 1 >= kEdges || ic + 1 >= kEdges) rp_edgeerr = min(rp_edgeerr, rp);
-            }
-            else if (MSA)
-            {
-                const int32_t oc = out_count_of(head);
-                for (int32_t e = 0; e < oc; e++)
-                {
-                    if (g.outgoing_edges[(int64_t)head * kEdges + e] == cur)
-                    {
-                        const uint16_t cc = g.out_cov_cnt[(int64_t)head * kEdges + e];
-                        g.out_cov[((int64_t)head * kEdges + e) * max_sequences_per_poa + cc] = s;
-                        g.out_cov_cnt[(int64_t)head * kEdges + e]                            = cc + 1;
-                        break;
-                    }
-                }
+                be[u][e] = g.incoming_edges[(int64_t)cur[u] * kEdges + e];
+                bw[u][e] = g.incoming_edge_w[(int64_t)cur[u] * kEdges + e];
             }
         }
-        else if (MSA)
-            *sequence_begin_nodes_ids = (IdT)cur;
-        g.coverage[cur] = (uint16_t)(cov + 1);
+#pragma unroll
+        for (int u = 0; u < kUD; u++)
+        {
+            const int32_t rp = rp0 + u * kWave;
+            if (rp >= L) continue;
+            if (rp > 0)
+            {
+                bool exists = false;
+#pragma unroll
+                for (int e = 0; e < kBatch; e++)
+                    if (e < ic[u] && be[u][e] == head[u])
+                    {
+                        exists = true;
+                        g.incoming_edge_w[(int64_t)cur[u] * kEdges + e] = (uint16_t)(bw[u][e] + w[u]);
+                    }
+                for (int32_t e = kBatch; e < ic[u]; e++) // longer in-edge lists loop on
+                {
+                    if (g.incoming_edges[(int64_t)cur[u] * kEdges + e] == head[u])
+                    {
+                        exists = true;
+                        g.incoming_edge_w[(int64_t)cur[u] * kEdges + e] += w[u];
+                    }
+                }
+                if (!exists)
+                {
+                    g.incoming_edges[(int64_t)cur[u] * kEdges + ic[u]]  = (IdT)head[u];
+                    g.incoming_edge_w[(int64_t)cur[u] * kEdges + ic[u]] = w[u];
+                    g.incoming_edge_count[cur[u]]                       = (uint16_t)(ic[u] + 1);
+                    const int32_t oc                                    = oc_head[u];
+                    g.outgoing_edges[(int64_t)head[u] * kEdges + oc]    = (IdT)cur[u];
+                    if (MSA)
+                    {
+                        g.out_cov_cnt[(int64_t)head[u] * kEdges + oc]                       = 1;
+                        g.out_cov[((int64_t)head[u] * kEdges + oc) * max_sequences_per_poa] = s;
+                    }
+                    g.outgoing_edge_count[head[u]] = (uint16_t)(oc + 1);
+                    if (oc + 1 >= kEdges || ic[u] + 1 >= kEdges) rp_edgeerr = min(rp_edgeerr, rp);
+                }
+                else if (MSA)
+                {
+                    const int32_t oc = oc_head[u];
+                    for (int32_t e = 0; e < oc; e++)
+                    {
+                        if (g.outgoing_edges[(int64_t)head[u] * kEdges + e] == cur[u])
+                        {
+                            const uint16_t cc = g.out_cov_cnt[(int64_t)head[u] * kEdges + e];
+                            g.out_cov[((int64_t)head[u] * kEdges + e) * max_sequences_per_poa + cc] = s;
+                            g.out_cov_cnt[(int64_t)head[u] * kEdges + e]                            = cc + 1;
+                            break;
+                        }
+                    }
+                }
+            }
+            else if (MSA)
+                *sequence_begin_nodes_ids = (IdT)cur[u];
+            g.coverage[cur[u]] = (uint16_t)(cov[u] + 1);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) rp_edgeerr = min(rp_edgeerr, __shfl_xor(rp_edgeerr, off));
     __syncthreads();
