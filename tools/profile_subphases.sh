@@ -17,3 +17,7 @@ for sel in 1 2 3; do
   v=$(GWHIP_DEBUG=$((sel << 28)) python tools/profile_phases.py $N 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print(d['ticks_per_window']['other'], d['ticks_per_window']['nw_forward'], d['kernel_ms'])")
   echo "forward sel=$sel other/forward/kernel_ms: $v" | tee -a $OUT
 done
+for sel in 1 2 3 4; do
+  v=$(GWHIP_DEBUG=$((sel << 16)) python tools/profile_phases.py $N 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print(d['ticks_per_window']['other'], d['ticks_per_window']['graph_merge'], d['kernel_ms'])")
+  echo "merge sel=$sel (1 load, 2 classify, 3 create, 4 edges) other/merge/kernel_ms: $v" | tee -a $OUT
+done
