@@ -18,7 +18,7 @@ HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
 KERNEL_SRCS = ["csrc/gwhip_poa.hip", "csrc/gwhip_poa_hooks.hip", "csrc/gwhip_myers.hip", "csrc/gwhip_ukkonen.hip"]
 HOST_SRCS = ["host/capi.cpp", "host/cudapoa_batch.cpp", "host/cudapoa_utils.cpp", "host/cudaaligner.cpp", "host/aligner_global.cpp", "host/device_pool.cpp",
-             "host/alignment_impl.cpp", "host/runtime.cpp", "host/logging.cpp"]
+             "host/alignment_impl.cpp", "host/runtime.cpp", "host/logging.cpp", "host/overlap_alignment.cpp"]
 
 # no fast-math, no FMA contraction: band placement is IEEE fp32
 KERNEL_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
@@ -100,18 +100,21 @@ def build_host(force=False):
 
 
 def build_cli(force=False):
-    """The `cudapoa` command-line tool (reference: cudapoa/src/main.cpp) -> genomeworks_amd/bin/cudapoa."""
+    """The command-line tools -> genomeworks_amd/bin/: `cudapoa` (reference: cudapoa/src/main.cpp) and
+    `align_overlaps` (the alignment stage of cudamapper, cudamapper/src/main.cu:54-187)."""
     bindir = os.path.join(PKG, "bin")
     os.makedirs(bindir, exist_ok=True)
-    target = os.path.join(bindir, "cudapoa")
-    src = os.path.join(PKG, "host", "cudapoa_main.cpp")
     sig = _digest(_deps("host", (".cpp", ".h", ".hpp")), HOST_FLAGS)
-    if force or _stale(target, sig):
-        cmd = ["g++"] + [f for f in HOST_FLAGS if f != "-fPIC"] + ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROCM, "include"),
-                          "-o", target, src, "-L", LIB, "-lgenomeworks_amd", "-lgwhip", "-L", os.path.join(ROCM, "lib"),
-                          "-lamdhip64", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
-        _run(cmd)
-        _mark(target, sig)
+    target = None
+    for tool, main_src in (("align_overlaps", "align_overlaps_main.cpp"), ("cudapoa", "cudapoa_main.cpp")):
+        target = os.path.join(bindir, tool)
+        src = os.path.join(PKG, "host", main_src)
+        if force or _stale(target, sig):
+            cmd = ["g++"] + [f for f in HOST_FLAGS if f != "-fPIC"] + ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROCM, "include"),
+                              "-o", target, src, "-L", LIB, "-lgenomeworks_amd", "-lgwhip", "-L", os.path.join(ROCM, "lib"),
+                              "-lamdhip64", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+            _run(cmd)
+            _mark(target, sig)
     return target
 
 

@@ -245,10 +245,11 @@ def test_group_with_every_read_rejected_keeps_its_output_slot():
             assert list(cov[slot]) == list(ref["coverage"])
 
 
-def test_incremental_topsort_equals_full_resort(monkeypatch):
-    """A/B inside the kernel: the incremental Kahn order (default) and the full re-sort after every read
-    (GWHIP_DEBUG bit 21, the reference's schedule) must give identical consensus, coverage, status and cell counts
-    on the config-3 windows and on windows of varied shape."""
+def test_kernel_shortcuts_equal_the_plain_schedule(monkeypatch):
+    """A/B inside the kernel: the incremental Kahn order (default) vs the full re-sort after every read
+    (GWHIP_DEBUG bit 21, the reference's schedule), and rows with 4..6 predecessors in the LDS-ring class (default) vs
+    the general routine (bit 30), must give identical consensus, coverage, status and cell counts on the config-3
+    windows and on windows of varied shape."""
     import random
     from genomeworks_amd import synthetic
     rng = random.Random(5)
@@ -262,7 +263,8 @@ def test_incremental_topsort_equals_full_resort(monkeypatch):
             w = [("GATTACA"[: rng.randrange(8)] + r)[rng.randrange(5):] for r in w]
         windows.append([r for r in w if 0 < len(r) < 1024])
     out = {}
-    for name, flag in (("incremental", None), ("full", str(1 << 21))):
+    for name, flag in (("incremental", None), ("full", str(1 << 21)), ("general_rows", str(1 << 30)),
+                       ("plain", str((1 << 21) | (1 << 30)))):
         if flag is None:
             monkeypatch.delenv("GWHIP_DEBUG", raising=False)
         else:
@@ -271,4 +273,5 @@ def test_incremental_topsort_equals_full_resort(monkeypatch):
             b = run_gpu(windows, mode)
             out[name, mode] = (b.get_consensus(), b.total_cells())
     for mode in ("static_band", "adaptive_band"):
-        assert out["incremental", mode] == out["full", mode], mode
+        for name in ("full", "general_rows", "plain"):
+            assert out["incremental", mode] == out[name, mode], (name, mode)
