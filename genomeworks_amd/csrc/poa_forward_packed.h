@@ -8,9 +8,10 @@
 //   * every row is classified once per read, by all lanes in parallel (classify_rows): class 0 rows have the
 //     previous row as only predecessor and an unmoved band -- the previous row is in registers and one DPP lane
 //     shift aligns the diagonal; class 1 rows have one predecessor up to 7 rows back (or a moved band) and read it
-//     from an LDS ring; class 2 rows have 2-3 such predecessors; class 3 rows (no predecessor, > 3 predecessors,
-//     far predecessors, band-start transition) take the general 32-bit routine against the HBM matrix. The row
-//     loop itself only tests two bits of the row-table word;
+//     from an LDS ring; class 2 rows have 2-6 such predecessors (rows 3..5 of them in the LDS side table that
+//     build_rowinfo fills); class 3 rows (no predecessor, > 6 predecessors, far predecessors, band-start
+//     transition) take the general 32-bit routine against the HBM matrix. The row loop itself only tests two bits
+//     of the row-table word;
 //   * the LDS ring holds 8 rows of 512 absolute column slots (cell of column x at slot (x - 1) & 511), so a
 //     reader addresses a predecessor row by column alone and never needs that row's band start; each row also
 //     stores sentinel cells behind its band end, which is how a reader recognises a 4-cell chunk that lies
@@ -94,7 +95,7 @@ __device__ __forceinline__ void lds_store_u64_lanes17(uint32_t addr, uint32_t lo
 // Row classes for banded_forward_packed, all lanes in parallel. Needs the band starts in the table already.
 //   0: one predecessor, the previous row, band not moved                       (previous row from registers)
 //   1: one predecessor, 1..7 rows back, band starts compatible with the ring     (predecessor from the LDS ring)
-//   2: 2..3 predecessors, each 1..7 rows back, band starts compatible            (predecessors from the LDS ring)
+//   2: 2..6 predecessors, each 1..7 rows back, band starts compatible            (predecessors from the LDS ring)
 //   3: everything else                                                           (general routine, HBM matrix)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool xpred_hit(uint64_t e, int32_t row, int32_t cnt)
@@ -153,15 +154,16 @@ __device__ __forceinline__ void classify_rows(RowInfo<true>* rowinfo, int32_t gr
 }
 
 // ------------------------------------------------------------------------------------------------
-// Trace codes. Besides the score row, classes 0 and 1 store one byte per cell that names the move the reference's
+// Trace codes. Besides the score row, classes 0, 1 and 2 store one byte per cell that names the move the reference's
 // traceback (cudapoa_nw_banded.cuh:428-549: diagonal through predecessor 0..n-1, then vertical through
 // predecessor 0..n-1, then horizontal, first equality wins) takes from that cell:
 //   0 undecided here -> the traceback recomputes the step from the score matrix
 //   1 horizontal     2 + k diagonal through predecessor slot k     5 + k vertical through predecessor slot k
 // A code is only written where the forward pass saw exactly the operands the traceback's get_score() would see:
 // the first cell of the band (its horizontal operand is the carry-in, not a stored cell), chunks that lie outside
-// some predecessor's band and all class 2 rows stay 0. Equality of H with a candidate is tested on the stored
-// 16-bit values, which is the comparison the traceback makes.
+// some predecessor's band, cells whose maximum is only attained by predecessor slot 3 or later (a code names slots
+// 0..2) and all class 3 rows stay 0. Equality of H with a candidate is tested on the stored 16-bit values, which is
+// the comparison the traceback makes.
 // ------------------------------------------------------------------------------------------------
 constexpr int kCodeHoriz = 1, kCodeDiag = 2, kCodeVert = 5;
 
