@@ -59,6 +59,7 @@ struct KernelArgs
     uint64_t* cells;
     uint64_t* phase_cycles; // optional [windows][kPhCount]
     int32_t debug_flags;    // profiling ablations (GWHIP_DEBUG env var); 0 in production
+    int32_t cons_lds_nodes; // node capacity of the consensus kernel's LDS tables (poa_graph_device.h)
 };
 
 template <typename IdT>
@@ -393,8 +394,12 @@ __global__ __launch_bounds__(kWave) void poa_consensus_lds_kernel(KernelArgs a)
     uint8_t* slab          = a.workspace + (size_t)w * a.L.per_window;
     GraphView<int16_t> g   = carve_graph<int16_t>(slab, a.L);
     const int32_t n        = a.sequence_lengths[a.window_details[w].seq_len_buffer_offset];
-    generate_consensus_lds<int16_t>(g, n, cons_smem, consensus, a.coverage + (size_t)w * c.max_consensus_size,
-                                    c.max_consensus_size, threadIdx.x & (kWave - 1));
+    if (n <= a.cons_lds_nodes)
+        generate_consensus_lds<int16_t>(g, n, cons_smem, a.cons_lds_nodes, consensus, a.coverage + (size_t)w * c.max_consensus_size,
+                                        c.max_consensus_size, threadIdx.x & (kWave - 1));
+    else if (threadIdx.x == 0) // a graph beyond the LDS tables of this launch: the serial HBM routine
+        generate_consensus<int16_t>(g, n, g.cons_pred, g.cons_scores, consensus, a.coverage + (size_t)w * c.max_consensus_size,
+                                    c.max_consensus_size);
 }
 
 // MSA kernel: lane 0 does the racon topsort + column assignment, then one lane per sequence
@@ -622,7 +627,19 @@ int gwhip_poa_generate(const gwhip_poa_args* args, gwhip_stream_t stream_)
         const char* cons_dbg = std::getenv("GWHIP_CONSENSUS_SERIAL"); // debugging: force the HBM-only kernel
         if (args->cfg.size32) hipLaunchKernelGGL(poa_consensus_kernel<int32_t>, grid, block, 0, stream, ka);
         else if (args->cfg.max_nodes_per_graph <= kConsLdsNodes && !(cons_dbg && cons_dbg[0] == '1'))
-            hipLaunchKernelGGL(poa_consensus_lds_kernel, grid, block, kConsLdsBytes, stream, ka);
+        {
+            // 55 KB of LDS for the largest graph lets two blocks share a CU; with more windows than that holds at once
+            // the tables are sized for 2176 nodes (39 KB, four blocks per CU) and larger graphs take the HBM routine
+            int cus = 0, dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            const int32_t cap = (args->cfg.max_nodes_per_graph > kConsLdsNodesSmall && args->total_windows > 2 * cus &&
+                                 !(cons_dbg && cons_dbg[0] == '2'))
+                                    ? kConsLdsNodesSmall
+                                    : std::min<int32_t>(args->cfg.max_nodes_per_graph, kConsLdsNodes);
+            ka.cons_lds_nodes = cap;
+            hipLaunchKernelGGL(poa_consensus_lds_kernel, grid, block, cons_lds_bytes(cap), stream, ka);
+        }
         else hipLaunchKernelGGL(poa_consensus_kernel<int16_t>, grid, block, 0, stream, ka);
     }
     e = hipGetLastError();

@@ -1008,17 +1008,22 @@ __device__ void generate_consensus(const GraphView<IdT>& g, int32_t node_count, 
 //   rec[n]    3 x u32 : in-edge 0..2 (12 bit each) + in-degree | in-edge 2, weight 0 | weight 1, weight 2
 //   scores[n] i32 with a guard element at index -1; pred[n] i16; the path list aliases rec after the passes
 // ------------------------------------------------------------------------------------------------
-constexpr int kConsLdsNodes = 3072;
-constexpr int kConsLdsBytes = kConsLdsNodes * 12 + (kConsLdsNodes + 4) * 4 + kConsLdsNodes * 2;
+// The tables are laid out for `cap` nodes, chosen at launch: 18 B per node, so the full 3072-node graph needs 55 KB
+// (two blocks per CU), while 2176 nodes fit the 39 KB that let four blocks share a CU -- which is what a batch of
+// more than 512 windows needs to run in one round. A window whose graph is larger than `cap` takes the HBM routine.
+constexpr int kConsLdsNodes      = 3072;
+constexpr int kConsLdsNodesSmall = 2176;
+__host__ __device__ constexpr int cons_lds_bytes(int cap) { return cap * 12 + (cap + 4) * 4 + cap * 2; }
+constexpr int kConsLdsBytes = cons_lds_bytes(kConsLdsNodes);
 
 template <typename IdT>
-__device__ __forceinline__ void generate_consensus_lds(const GraphView<IdT>& g, int32_t node_count, uint8_t* lds,
+__device__ __forceinline__ void generate_consensus_lds(const GraphView<IdT>& g, int32_t node_count, uint8_t* lds, int32_t cap,
                                                        uint8_t* consensus, uint16_t* coverage,
                                                        int32_t max_limit_consensus_size, int lane)
 {
     uint32_t* rec    = reinterpret_cast<uint32_t*>(lds);
-    int32_t* scores  = reinterpret_cast<int32_t*>(lds + kConsLdsNodes * 12) + 1; // index -1 is the guard
-    int16_t* pred    = reinterpret_cast<int16_t*>(lds + kConsLdsNodes * 12 + (kConsLdsNodes + 4) * 4);
+    int32_t* scores  = reinterpret_cast<int32_t*>(lds + cap * 12) + 1; // index -1 is the guard
+    int16_t* pred    = reinterpret_cast<int16_t*>(lds + cap * 12 + (cap + 4) * 4);
     uint16_t* path   = reinterpret_cast<uint16_t*>(lds); // aliases rec once the passes are done
 
     for (int32_t n = lane; n < node_count; n += kWave)
@@ -1115,7 +1120,7 @@ __device__ __forceinline__ void generate_consensus_lds(const GraphView<IdT>& g, 
         int32_t id = max_score_id;
         for (;;)
         {
-            lane0_store_u16(path + min(count, 2 * kConsLdsNodes), (uint32_t)id);
+            lane0_store_u16(path + min(count, 2 * cap), (uint32_t)id);
             const int32_t p = wave_first((int32_t)pred[id]);
             if (p == -1) break;
             id = p;

@@ -275,3 +275,29 @@ def test_kernel_shortcuts_equal_the_plain_schedule(monkeypatch):
     for mode in ("static_band", "adaptive_band"):
         for name in ("full", "general_rows", "plain"):
             assert out["incremental", mode] == out[name, mode], (name, mode)
+
+
+def test_consensus_kernel_with_small_lds_tables_and_oversized_graphs():
+    """More than 512 windows: the consensus kernel sizes its LDS tables for 2176 nodes (four blocks per CU) and a
+    window whose graph is larger takes the HBM routine inside the same launch. Results must equal those of the same
+    windows in a small batch (full-size tables) and the oracle's."""
+    from genomeworks_amd import synthetic
+    small = [[r.decode() for r in synthetic.generate_window(4000 + k, 90, 3, 4, 2, 2)] for k in range(520)]
+    big = [[r.decode() for r in synthetic.generate_window(4600 + k, 980, 14, 400, 100, 100)] for k in range(6)]  # ~2450 nodes
+    big = [[r for r in w if len(r) < 1024] for w in big]
+    windows = small[:300] + big + small[300:]
+    b = run_gpu(windows, "static_band", max_seqs=14)
+    cons, cov, status = b.get_consensus()
+    sub = run_gpu(big + small[:4], "static_band", max_seqs=14)
+    c2, v2, s2 = sub.get_consensus()
+    assert cons[300:306] == c2[:6] and cov[300:306] == v2[:6] and status[300:306] == s2[:6]
+    assert cons[:4] == c2[6:10]
+    n_big = 0
+    with O.Workspace(oracle_cfg("static_band", max_seqs=14)) as ws:
+        for i in range(300, 306):
+            ref = ws.process(windows[i])
+            assert status[i] == ref["status"]
+            if ref["status"] == 0:
+                assert cons[i] == ref["consensus"] and cov[i] == list(ref["coverage"])
+                n_big += ref["node_count"] > 2176
+    assert n_big >= 3, n_big  # the HBM routine really ran
