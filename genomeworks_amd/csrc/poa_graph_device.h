@@ -175,17 +175,26 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
     for (int32_t i = lane; i < L; i += kWave) gnode[i] = -1;
     __syncthreads();
     int32_t covered = 0;
-    for (int32_t base = 0; base < alen; base += kWave)
+    for (int32_t base = 0; base < alen; base += 4 * kWave) // four chunks per HBM round trip
     {
-        const int32_t k  = base + lane;
-        const int32_t rp = k < alen ? ar[k] : -1;
-        const int32_t gn = k < alen ? ag[k] : -1; // independent of rp: both loads are in flight together
-        if (rp >= 0)
+        int32_t rp[4], gn[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
         {
-            gnode[rp]        = (NodeT)gn;
-            if (gn >= 0) atomicOr(&onpath[gn >> 5], 1u << (gn & 31));
+            const int32_t k = base + u * kWave + lane;
+            rp[u] = k < alen ? ar[k] : -1;
+            gn[u] = k < alen ? ag[k] : -1; // independent of rp: all loads are in flight together
         }
-        covered += __popcll(__ballot(rp >= 0));
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            if (rp[u] >= 0)
+            {
+                gnode[rp[u]] = (NodeT)gn[u];
+                if (gn[u] >= 0) atomicOr(&onpath[gn[u] >> 5], 1u << (gn[u] & 31));
+            }
+            covered += __popcll(__ballot(rp[u] >= 0));
+        }
     }
     __syncthreads();
     // The map over read positions needs a complete alignment (every read position exactly once); a degenerate
@@ -197,39 +206,64 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
     int32_t running   = 0;
     bool conflict     = false;
     int32_t rp_nodeerr = INT32_MAX;
-    for (int32_t base = 0; base < L; base += kWave)
+    // Four 64-position chunks per iteration share the HBM round trips: read base and graph node -> the node's base,
+    // its aligned-node count and first aligned node -> that node's base. Longer aligned-node lists (rare) loop on.
+    // New node ids are numbered chunk by chunk, in read-position order.
+    for (int32_t base = 0; base < L; base += 4 * kWave)
     {
-        const int32_t rp = base + lane;
-        bool is_new      = false;
-        int32_t cur      = -1;
-        if (rp < L)
+        int32_t gn[4], nb[4], na[4], a0[4], nb0[4];
+        uint8_t rb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
         {
-            const int32_t gn      = gnode[rp];
-            const uint8_t rbase   = read[rp];
-            if (gn < 0)
-                is_new = true;
-            else if (g.nodes[gn] == rbase)
-                cur = gn;
-            else
+            const int32_t rp = base + u * kWave + lane;
+            gn[u] = rp < L ? (int32_t)gnode[rp] : -1;
+            rb[u] = rp < L ? read[rp] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const int32_t gi = max(gn[u], 0);
+            nb[u] = g.nodes[gi];
+            na[u] = g.node_alignment_count[gi];
+            a0[u] = g.node_alignments[(int64_t)gi * kAligns];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            nb0[u] = g.nodes[(gn[u] >= 0 && na[u] > 0 && (uint32_t)a0[u] < (uint32_t)node_count) ? a0[u] : 0];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const int32_t rp = base + u * kWave + lane;
+            bool is_new      = false;
+            int32_t cur      = -1;
+            if (rp < L)
             {
-                const int32_t na = g.node_alignment_count[gn];
-                for (int32_t n = 0; n < na; n++)
+                if (gn[u] < 0)
+                    is_new = true;
+                else if (nb[u] == (int32_t)rb[u])
+                    cur = gn[u];
+                else
                 {
-                    const int32_t aid = g.node_alignments[(int64_t)gn * kAligns + n];
-                    if ((onpath[aid >> 5] >> (aid & 31)) & 1u) conflict = true;
-                    if (cur < 0 && g.nodes[aid] == rbase) cur = aid;
+                    for (int32_t n = 0; n < na[u]; n++)
+                    {
+                        const int32_t aid = n == 0 ? a0[u] : (int32_t)g.node_alignments[(int64_t)gn[u] * kAligns + n];
+                        if ((onpath[aid >> 5] >> (aid & 31)) & 1u) conflict = true;
+                        const int32_t ab = n == 0 ? nb0[u] : (int32_t)g.nodes[aid];
+                        if (cur < 0 && ab == (int32_t)rb[u]) cur = aid;
+                    }
+                    if (cur < 0) is_new = true;
                 }
-                if (cur < 0) is_new = true;
             }
+            const unsigned long long m = __ballot(is_new);
+            if (is_new)
+            {
+                cur = node_count + running + __popcll(m & ((1ull << lane) - 1));
+                if (cur + 1 >= max_nodes) rp_nodeerr = min(rp_nodeerr, rp);
+            }
+            if (rp < L) curr[rp] = (NodeT)cur;
+            running += __popcll(m);
         }
-        const unsigned long long m = __ballot(is_new);
-        if (is_new)
-        {
-            cur = node_count + running + __popcll(m & ((1ull << lane) - 1));
-            if (cur + 1 >= max_nodes) rp_nodeerr = min(rp_nodeerr, rp);
-        }
-        if (rp < L) curr[rp] = (NodeT)cur;
-        running += __popcll(m);
     }
     if (__any(conflict)) return -1;
     for (int off = 32; off > 0; off >>= 1) rp_nodeerr = min(rp_nodeerr, __shfl_xor(rp_nodeerr, off));
@@ -790,14 +824,29 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
     __syncthreads();
     const uint64_t t_p3 = tsel == 4 ? clock64() : 0;
     // phase 3 (all lanes): publish order, inverse map and the per-node record for the next read
-    for (int32_t i = lane; i < node_count; i += kWave)
+    for (int32_t i0 = lane; i0 < node_count; i0 += 4 * kWave) // four chunks per HBM round trip
     {
-        const uint32_t e    = queue[i];
-        const int32_t node  = (int32_t)(e & 0xfffu);
-        const uint32_t oc = g.outgoing_edge_count[node], ic = g.incoming_edge_count[node];
-        g.sorted_poa[i]        = (IdT)node;
-        g.node_id_to_pos[node] = (IdT)i;
-        g.local_cnt[node]      = (uint16_t)((e >> 12) | (oc << 4) | (ic << 10));
+        uint32_t e[4], oc[4], ic[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            e[u] = queue[min(i0 + u * kWave, node_count - 1)];
+            const int32_t node = (int32_t)(e[u] & 0xfffu);
+            oc[u] = g.outgoing_edge_count[node];
+            ic[u] = g.incoming_edge_count[node];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const int32_t i = i0 + u * kWave;
+            if (i < node_count)
+            {
+                const int32_t node     = (int32_t)(e[u] & 0xfffu);
+                g.sorted_poa[i]        = (IdT)node;
+                g.node_id_to_pos[node] = (IdT)i;
+                g.local_cnt[node]      = (uint16_t)((e[u] >> 12) | (oc[u] << 4) | (ic[u] << 10));
+            }
+        }
     }
     if (tsel == 4)
     {
