@@ -301,3 +301,51 @@ def test_consensus_kernel_with_small_lds_tables_and_oversized_graphs():
                 assert cons[i] == ref["consensus"] and cov[i] == list(ref["coverage"])
                 n_big += ref["node_count"] > 2176
     assert n_big >= 3, n_big  # the HBM routine really ran
+
+
+def test_high_degree_graphs_vs_oracle():
+    """Windows built to leave the common case of the LDS fast paths: many reads that each carry a DIFFERENT base or
+    insertion at the same backbone positions (nodes with more than six in- and out-edges: the side tables of the
+    forward pass and of the topological sort fall back to the HBM lists), long parallel branches (wide Kahn queues,
+    beyond the 4-bit queue-length field), reads that start and end at different offsets (several sources and sinks)."""
+    import random
+    rng = random.Random(99)
+    windows = []
+    for k in range(10):
+        backbone = "".join(rng.choice("ACGT") for _ in range(rng.choice([200, 400, 700])))
+        reads = [backbone]
+        hot = sorted(rng.sample(range(20, len(backbone) - 20), 6))
+        for r in range(rng.choice([12, 24, 31])):
+            s = list(backbone)
+            for h in hot:
+                kind = rng.randrange(4)
+                if kind == 0:
+                    s[h] = rng.choice("ACGT")                                             # many alternative bases
+                elif kind == 1:
+                    s[h] = s[h] + "".join(rng.choice("ACGT") for _ in range(rng.randrange(1, 12)))  # distinct insertions
+                elif kind == 2:
+                    for d in range(rng.randrange(1, 9)):                                  # deletions of different lengths
+                        s[h + d] = ""
+            t = "".join(s)
+            a, b = rng.randrange(0, 8), rng.randrange(0, 8)
+            reads.append(t[a:len(t) - b] if k % 2 else t)
+        windows.append(reads)
+    for mode in ("static_band", "adaptive_band"):
+        b = run_gpu(windows, mode)
+        cons, cov, status = b.get_consensus()
+        with O.Workspace(oracle_cfg(mode)) as ws:
+            for i, w in enumerate(windows):
+                ref = ws.process(w)
+                assert status[i] == ref["status"], (mode, i, status[i], ref["status"])
+                if ref["status"] == 0:
+                    assert cons[i] == ref["consensus"] and cov[i] == list(ref["coverage"]), (mode, i)
+            assert ws.overflow_events() == 0
+    # MSA on the same graphs (racon order in the output kernel) through the same build kernel
+    b = run_gpu(windows, "static_band", output_type="msa")
+    msa, status = b.get_msa()
+    with O.Workspace(oracle_cfg("static_band", output_mask=2)) as ws:
+        for i, w in enumerate(windows):
+            ref = ws.process(w)
+            assert status[i] == ref["status"]
+            if ref["status"] == 0:
+                assert msa[i] == ref["msa"], i

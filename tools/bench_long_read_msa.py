@@ -95,6 +95,9 @@ def main():
             n_out = batch.get_msa_native()  # D2H + row unpack in the library = Batch::get_msa
             dt = time.perf_counter() - t0
             msa, status = batch.collect_msa(n_out)  # Python marshalling, not part of the reference's timed region
+            lens = [max(len(r) for r in windows[g]) for g in taken if g is not None]
+            print("[rank %d]   launch %d: %d windows, longest read %d..%d, %.1f ms" % (rank, launches, len(lens), min(lens), max(lens), dt * 1e3),
+                  file=sys.stderr, flush=True)
             if args.kernel_time:
                 k_ms, o_ms = batch.relaunch_timed()
                 kernel_ms += k_ms + o_ms
