@@ -645,11 +645,17 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     int32_t atop = -1, acol = 0; // anchor of the tile in `ahead` (atop < 0: none)
     // columns the path moves per row, and where inside a 64-column window it should enter so that the drift between
     // the window's slope (1 column per row) and the path's stays inside the window
-    const int32_t ahead_cols = (int32_t)(b.gradient * (float)kAhead);
     const int32_t ahead_bias = min(max((int32_t)((1.0f - b.gradient) * 32.0f), -12), 12);
+    // columns per row in 1/256: the band's slope until the walk has covered a stretch, then the walk's own slope
+    // between two tile changes
+    int32_t slope_q8 = (int32_t)(b.gradient * 256.0f);
+    int32_t last_i = -1, last_j = 0;
     auto load_codes = [&](int32_t top, int32_t col) {
         const uint64_t t_lc = psel == 2 ? clock64() : 0;
         if (psel == 3) pacc += 1000;
+        if (last_i - top >= 24) slope_q8 = ((last_j - col) << 8) / (last_i - top);
+        last_i = top;
+        last_j = col;
         bool hit = false;
         if (atop >= 0)
         {
@@ -669,7 +675,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
             commit_codes(top, col, now);
         }
         atop = ctop - kAhead;
-        acol = ccol - ahead_cols + ahead_bias;
+        acol = col - ((slope_q8 * (top - atop)) >> 8) + ahead_bias; // where the walk should be when it reaches row atop
         if (atop >= 1) issue_codes(atop, acol, ahead);
         else atop = -1;
         if (psel == 2) pacc += clock64() - t_lc;
