@@ -307,7 +307,9 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
     };
     auto class_of = [&](const RowInfo<true>& w) -> uint32_t { return (uint32_t)(w.w >> kClassShift) & 3u; };
 
-    // profiling (GWHIP_DEBUG bits 28-29): 1 cycles in class 3 rows, 2 their number x 1000, 3 cycles in class 2 rows
+    // profiling (GWHIP_DEBUG bits 28-29): 1 cycles in class 3 rows, 2 their number x 1000 -- tested inside the (rare)
+    // class 3 branch only; 3 cycles in class 2 rows needs a build with -DGWHIP_PROFILE_CLASS2 (a test per class 2 row
+    // costs ~1 % of the kernel)
     const int32_t fsel = prof_acc ? (dbg >> 28) & 3 : 0;
     uint64_t facc      = 0;
     int32_t r        = 1;
@@ -361,8 +363,10 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
         }
         if (r > graph_count) break;
 
-        const uint64_t t_row = fsel ? clock64() : 0;
+#ifdef GWHIP_PROFILE_CLASS2
+        const uint64_t t_row2 = (fsel == 3 && cls == 2) ? clock64() : 0;
         const uint32_t cls_now = cls;
+#endif
         const RowInfo<true> nxt = rowinfo[min(r + 1, graph_count)];
         const int32_t bs        = ri.bs();
         const uint32_t base     = (uint32_t)ri.base();
@@ -500,6 +504,8 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
         else
         {
             // ===== general row: 32-bit arithmetic, previous row from registers, any other row from the HBM matrix =====
+            const uint64_t t_row3 = fsel == 1 ? clock64() : 0;
+            if (fsel == 2) facc += 1000;
             const int32_t pred_count = ri.cnt();
             const int32_t c          = bs + lane4;
             const int32_t cp0 = ((rd4 & 0xff) == base) ? match_score : mismatch_score;
@@ -587,11 +593,12 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
             store_codes(0, 0, true);
             r++;
             ri = ri_n;
+            if (fsel == 1) facc += clock64() - t_row3;
         }
         cls = r <= graph_count ? class_of(ri) : 7u;
-        if (fsel == 1 && cls_now == 3) facc += clock64() - t_row;
-        if (fsel == 2 && cls_now == 3) facc += 1000;
-        if (fsel == 3 && cls_now == 2) facc += clock64() - t_row;
+#ifdef GWHIP_PROFILE_CLASS2
+        if (fsel == 3 && cls_now == 2) facc += clock64() - t_row2;
+#endif
     }
     if (fsel && lane == 0) *prof_acc += facc;
 }
