@@ -646,16 +646,13 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     // columns the path moves per row, and where inside a 64-column window it should enter so that the drift between
     // the window's slope (1 column per row) and the path's stays inside the window
     const int32_t ahead_bias = min(max((int32_t)((1.0f - b.gradient) * 32.0f), -12), 12);
-    // columns per row in 1/256: the band's slope until the walk has covered a stretch, then the walk's own slope
-    // between two tile changes
-    int32_t slope_q8 = (int32_t)(b.gradient * 256.0f);
-    int32_t last_i = -1, last_j = 0;
+    // columns per row in 1/256: the band's slope. (The walk's own slope between two tile changes predicts better --
+    // 94 % instead of 72 % of the tiles are taken without a wait -- but its integer division per tile costs more than
+    // the extra hits save: 17.21 M vs 17.11 M cycles per window, measured on one box.)
+    const int32_t slope_q8 = (int32_t)(b.gradient * 256.0f);
     auto load_codes = [&](int32_t top, int32_t col) {
         const uint64_t t_lc = psel == 2 ? clock64() : 0;
         if (psel == 3) pacc += 1000;
-        if (last_i - top >= 24) slope_q8 = ((last_j - col) << 8) / (last_i - top);
-        last_i = top;
-        last_j = col;
         bool hit = false;
         if (atop >= 0)
         {
