@@ -1,7 +1,8 @@
 #!/bin/bash
 # Sub-phase profile of the graph-build kernel on the config-3 batch (needs a GPU): one run per selector, the
 # selected quantity arrives in the "other" accumulator (minus the ~0.09 M cycles "other" always holds).
-# traceback selectors: GWHIP_DEBUG bits 22-24, topsort selectors: bits 25-27 (see the kernels).
+# traceback selectors: GWHIP_DEBUG bits 22-24, topsort: bits 25-27, forward: bits 28-29 (class 3 rows; the class 2
+# timer, selector 3, only exists in a build with -DGWHIP_PROFILE_CLASS2), merge passes: bits 16-18 (see the kernels).
 OUT=${1:-gpurun_out/subphases.txt}
 N=${2:-1024}
 : > $OUT
