@@ -435,10 +435,11 @@ __global__ __launch_bounds__(kWave) void poa_msa_kernel(KernelArgs a)
 }
 
 template <typename IdT>
-__global__ void poa_export_graph_kernel(KernelArgs a, uint8_t* nodes, int32_t* in_edges, uint16_t* in_w, uint16_t* in_cnt,
-                                        int32_t* out_edges, uint16_t* out_cnt)
+__global__ void poa_export_graph_kernel(KernelArgs a, int32_t first_window, uint8_t* nodes, int32_t* in_edges, uint16_t* in_w,
+                                        uint16_t* in_cnt, int32_t* out_edges, uint16_t* out_cnt)
 {
-    const int32_t w  = blockIdx.x;
+    const int32_t w  = first_window + blockIdx.x; // window in the batch
+    const size_t o   = blockIdx.x;                // its slot in the output arrays
     const int32_t mn = a.cfg.max_nodes_per_graph;
     uint8_t* slab    = a.workspace + (size_t)w * a.L.per_window;
     GraphView<IdT> g = carve_graph<IdT>(slab, a.L);
@@ -446,20 +447,20 @@ __global__ void poa_export_graph_kernel(KernelArgs a, uint8_t* nodes, int32_t* i
     if (a.consensus[(size_t)w * a.cfg.max_consensus_size] == kKernelError) return;
     for (int32_t i = threadIdx.x; i < n && i < mn; i += blockDim.x)
     {
-        nodes[(size_t)w * mn + i] = g.nodes[i];
-        uint16_t ic               = g.incoming_edge_count[i];
-        in_cnt[(size_t)w * mn + i] = ic;
+        nodes[o * mn + i]  = g.nodes[i];
+        uint16_t ic        = g.incoming_edge_count[i];
+        in_cnt[o * mn + i] = ic;
         for (int32_t e = 0; e < ic && e < kEdges; e++)
         {
-            in_edges[((size_t)w * mn + i) * kEdges + e] = g.incoming_edges[(int64_t)i * kEdges + e];
-            in_w[((size_t)w * mn + i) * kEdges + e]     = g.incoming_edge_w[(int64_t)i * kEdges + e];
+            in_edges[(o * mn + i) * kEdges + e] = g.incoming_edges[(int64_t)i * kEdges + e];
+            in_w[(o * mn + i) * kEdges + e]     = g.incoming_edge_w[(int64_t)i * kEdges + e];
         }
         if (out_edges && out_cnt)
         {
-            uint16_t oc                 = g.outgoing_edge_count[i];
-            out_cnt[(size_t)w * mn + i] = oc;
+            uint16_t oc         = g.outgoing_edge_count[i];
+            out_cnt[o * mn + i] = oc;
             for (int32_t e = 0; e < oc && e < kEdges; e++)
-                out_edges[((size_t)w * mn + i) * kEdges + e] = g.outgoing_edges[(int64_t)i * kEdges + e];
+                out_edges[(o * mn + i) * kEdges + e] = g.outgoing_edges[(int64_t)i * kEdges + e];
         }
     }
 }
@@ -600,10 +601,10 @@ int gwhip_poa_generate(const gwhip_poa_args* args, gwhip_stream_t stream_)
     if (!args || !validate(args)) return fail_msg((int)hipErrorInvalidValue, "gwhip_poa_generate: invalid arguments");
     if (args->total_windows == 0) return 0;
     KernelArgs ka = make_kernel_args(args);
-    size_t need   = gwhip_poa_workspace_bytes(&args->cfg, args->total_windows, 0);
-    (void)need;
     if (!args->workspace || ((uintptr_t)args->workspace & 255) != 0)
         return fail_msg((int)hipErrorInvalidValue, "gwhip_poa_generate: workspace must be 256-byte aligned");
+    if (args->workspace_bytes < gwhip_poa_workspace_bytes(&args->cfg, args->total_windows, 0))
+        return fail_msg((int)hipErrorInvalidValue, "gwhip_poa_generate: workspace_bytes is smaller than gwhip_poa_workspace_bytes(cfg, total_windows, 0)");
     hipError_t e;
     const bool msa = (args->cfg.output_mask & 2) != 0;
     if (args->cfg.score32)
@@ -647,24 +648,36 @@ int gwhip_poa_generate(const gwhip_poa_args* args, gwhip_stream_t stream_)
     return 0;
 }
 
-int gwhip_poa_export_graphs(const gwhip_poa_args* args, uint8_t* nodes, int32_t* incoming_edges,
-                            uint16_t* incoming_edge_weights, uint16_t* incoming_edge_count, int32_t* outgoing_edges,
-                            uint16_t* outgoing_edge_count, gwhip_stream_t stream_)
+int gwhip_poa_export_graphs_range(const gwhip_poa_args* args, int32_t first_window, int32_t n_windows, uint8_t* nodes,
+                                  int32_t* incoming_edges, uint16_t* incoming_edge_weights, uint16_t* incoming_edge_count,
+                                  int32_t* outgoing_edges, uint16_t* outgoing_edge_count, gwhip_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!args || !validate(args)) return fail_msg((int)hipErrorInvalidValue, "gwhip_poa_export_graphs: invalid arguments");
-    if (args->total_windows == 0) return 0;
+    if (!args || !validate(args) || first_window < 0 || n_windows < 0 || first_window + n_windows > args->total_windows)
+        return fail_msg((int)hipErrorInvalidValue, "gwhip_poa_export_graphs: invalid arguments");
+    if (n_windows == 0) return 0;
+    if (args->workspace_bytes < gwhip_poa_workspace_bytes(&args->cfg, args->total_windows, 0))
+        return fail_msg((int)hipErrorInvalidValue, "gwhip_poa_export_graphs: workspace_bytes is smaller than gwhip_poa_workspace_bytes(cfg, total_windows, 0)");
     KernelArgs ka = make_kernel_args(args);
-    dim3 grid(args->total_windows), block(256);
+    dim3 grid(n_windows), block(256);
     if (args->cfg.size32)
-        hipLaunchKernelGGL(poa_export_graph_kernel<int32_t>, grid, block, 0, stream, ka, nodes, incoming_edges,
+        hipLaunchKernelGGL(poa_export_graph_kernel<int32_t>, grid, block, 0, stream, ka, first_window, nodes, incoming_edges,
                            incoming_edge_weights, incoming_edge_count, outgoing_edges, outgoing_edge_count);
     else
-        hipLaunchKernelGGL(poa_export_graph_kernel<int16_t>, grid, block, 0, stream, ka, nodes, incoming_edges,
+        hipLaunchKernelGGL(poa_export_graph_kernel<int16_t>, grid, block, 0, stream, ka, first_window, nodes, incoming_edges,
                            incoming_edge_weights, incoming_edge_count, outgoing_edges, outgoing_edge_count);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(e, "poa_export_graph_kernel launch");
     return 0;
+}
+
+int gwhip_poa_export_graphs(const gwhip_poa_args* args, uint8_t* nodes, int32_t* incoming_edges,
+                            uint16_t* incoming_edge_weights, uint16_t* incoming_edge_count, int32_t* outgoing_edges,
+                            uint16_t* outgoing_edge_count, gwhip_stream_t stream)
+{
+    if (!args) return fail_msg((int)hipErrorInvalidValue, "gwhip_poa_export_graphs: invalid arguments");
+    return gwhip_poa_export_graphs_range(args, 0, args->total_windows, nodes, incoming_edges, incoming_edge_weights,
+                                         incoming_edge_count, outgoing_edges, outgoing_edge_count, stream);
 }
 
 int gwhip_last_error_string(char* buf, size_t len)

@@ -48,6 +48,10 @@ def _bind(L):
     L.gw_alignment_cigar.argtypes = [vp, i32, i32, C.POINTER(i32)]
     L.gw_alignment_states.argtypes = [vp, i32, vp, i32]
     L.gw_aligner_band_cells.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.gw_aligner_get_runs.restype = C.c_int64
+    L.gw_aligner_get_runs.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp]
+    L.gw_aligner_device_alignments.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_int64)]
+    L.gw_aligner_copy_device_alignments.argtypes = [vp, vp, vp, vp, vp]
     L._gw_aln_bound = True
     return L
 
@@ -149,6 +153,41 @@ class CudaAlignerBatch:
         if st != 0:
             raise RuntimeError("sync_alignments failed")
         return self._L.gw_aligner_num_alignments(self._h)
+
+    def get_runs(self):
+        """sync_alignments() + every alignment as a run-length CIGAR in forward order, without per-alignment Python
+        objects: dict(offsets[n + 1], ops, counts, status[n], optimal[n]) of numpy arrays."""
+        n = self.sync()
+        total = self._L.gw_aligner_get_runs(self._h, None, None, None, 0, None, None)
+        if total < 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        offsets = np.zeros(n + 1, np.int64)
+        ops = np.zeros(max(total, 1), np.int8)
+        counts = np.zeros(max(total, 1), np.int32)
+        status = np.zeros(max(n, 1), np.int32)
+        optimal = np.zeros(max(n, 1), np.int32)
+        self._L.gw_aligner_get_runs(self._h, offsets.ctypes.data, ops.ctypes.data, counts.ctypes.data, total,
+                                    status.ctypes.data, optimal.ctypes.data)
+        return dict(offsets=offsets, ops=ops[:total], counts=counts[:total], status=status[:n], optimal=optimal[:n])
+
+    def get_alignments_device(self):
+        """Aligner::get_alignments_device() read back for inspection (stream synchronised first): dict of numpy arrays
+        cigar_operations, cigar_runlengths (each alignment back to front), cigar_offsets[n + 1], metadata[n] (bit 31
+        is_optimal, bits 26-0 index as added), or None for aligners without a device-resident form."""
+        n, total = C.c_int32(0), C.c_int64(0)
+        rc = self._L.gw_aligner_device_alignments(self._h, C.byref(n), C.byref(total))
+        if rc < 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        if rc != 0:
+            return None
+        ops = np.zeros(max(total.value, 1), np.int8)
+        runs = np.zeros(max(total.value, 1), np.int32)
+        offs = np.zeros(n.value + 1, np.int32)
+        meta = np.zeros(max(n.value, 1), np.uint32)
+        if self._L.gw_aligner_copy_device_alignments(self._h, ops.ctypes.data, runs.ctypes.data, offs.ctypes.data, meta.ctypes.data) != 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        return dict(cigar_operations=ops[:total.value], cigar_runlengths=runs[:total.value], cigar_offsets=offs,
+                    metadata=meta[:n.value], total_length=total.value, n_alignments=n.value)
 
     def get_alignments(self):
         """sync_alignments() + list of CudaAlignment in the order the pairs were added."""

@@ -241,6 +241,15 @@ class CudaPoaBatch:
         """Returns (msa[group][sequence], per-group status)."""
         return self.collect_msa(self.get_msa_native())
 
+    def collect_msa_one(self, i):
+        """(rows, status) of group i after get_msa_native()."""
+        rows = []
+        for r in range(self._L.gw_poa_msa_rows(self._h, i)):
+            ln = C.c_int32(0)
+            p = self._L.gw_poa_msa_row(self._h, i, r, C.byref(ln))
+            rows.append(C.string_at(p, ln.value).decode("utf-8"))
+        return rows, self._L.gw_poa_output_status(self._h, i)
+
     def collect_msa(self, count):
         msa, status = [], []
         for i in range(count):
@@ -293,6 +302,8 @@ def _bind_utils(L):
     L.gw_poa_get_multi_batch_sizes.argtypes = [i32, pi32, pi32, i32, i32, i32, f32, f32, i32, f32, i32, i32, i32, pi32,
                                                pcfg, pi32, pi32]
     L.gw_poa_estimate_max_poas.argtypes = [pcfg, i32, f32, i32, i32, i32]
+    L.gw_poa_window_device_bytes.restype = C.c_int64
+    L.gw_poa_window_device_bytes.argtypes = [pcfg, i32, i32, i32, i32]
     L.gw_windows_parse.restype = C.c_void_p
     L.gw_windows_parse.argtypes = [C.POINTER(C.c_char_p), i32, i32, i32]
     L.gw_windows_destroy.argtypes = [C.c_void_p]
@@ -336,6 +347,30 @@ def bin_poa_groups(capacity, longest, reads, band_width=256, band_mode="adaptive
     if rc != 0:
         raise RuntimeError(L.gw_last_error().decode())
     return _plan_unpack(nb, cfgs, per_batch, ids)
+
+
+def plan_multi_batch_sizes(poa_groups, memory_budget_bytes, msa_flag=False, band_width=256, band_mode="adaptive_band",
+                           adaptive_storage_factor=2.0, graph_length_factor=3.0, max_pred_distance=0, mismatch_score=-6,
+                           gap_score=-8, match_score=8):
+    """get_multi_batch_sizes for a stated device-memory budget instead of the free memory of the current device: the
+    same per-group capacities (budget // bytes per window of the group's own shape) and the same binning rule, but
+    reproducible on any box and without a GPU (the goldens of the long-read config are planned this way).
+    Returns (list of BatchConfig dicts, list of group-index lists)."""
+    L = _bind_utils(_bind(_native.host()))
+    longest = [max((len(s) for s in g), default=0) for g in poa_groups]
+    reads = [len(g) for g in poa_groups]
+    capacity = []
+    for ln, nr in zip(longest, reads):
+        cfg = _native.PoaBatchConfig()
+        if L.gw_poa_batch_config_default(C.byref(cfg), ln, nr, band_width, _BAND_MODES[band_mode], adaptive_storage_factor,
+                                         graph_length_factor, max_pred_distance) != 0:
+            raise ValueError(L.gw_last_error().decode())
+        per_window = L.gw_poa_window_device_bytes(C.byref(cfg), int(msa_flag), mismatch_score, gap_score, match_score)
+        if per_window <= 0:
+            raise RuntimeError(L.gw_last_error().decode())
+        capacity.append(int(min(memory_budget_bytes // per_window, 2 ** 31 - 1)))
+    return bin_poa_groups(capacity, longest, reads, band_width, band_mode, adaptive_storage_factor, graph_length_factor,
+                          max_pred_distance)
 
 
 def get_multi_batch_sizes(poa_groups, msa_flag=False, band_width=256, band_mode="adaptive_band",

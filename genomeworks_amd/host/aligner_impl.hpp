@@ -42,6 +42,7 @@ public:
 
     // benchmark helpers (not part of the reference interface)
     void relaunch_resident();     ///< run the kernels again on the inputs already resident in HBM
+    bool expands_results() const { return expand_results_; }
     uint64_t total_band_cells();  ///< 32 * band words * target length, summed over band attempts and pairs
 
 private:
@@ -57,7 +58,7 @@ private:
     bool expand_results_;
     int32_t max_query_length_, max_target_length_, max_alignments_;
 
-    std::vector<char> seq_h_, seq_kept_;
+    std::vector<char> seq_h_;
     std::vector<int64_t> seq_starts_h_{0};
     std::vector<int32_t> max_bandwidths_h_;
     std::vector<int32_t> order_h_;
@@ -68,6 +69,9 @@ private:
     bool launched_                   = false;
     int64_t total_length_h_          = 0;
     int32_t n_last_                  = 0;
+    char* head_                      = nullptr; ///< pinned: result_starts[n + 1] | metadata[n] of the last launch
+    size_t head_cap_                 = 0;
+    int32_t n_head_                  = 0;
 
     char* device_block_        = nullptr;
     size_t device_block_bytes_ = 0;

@@ -7,6 +7,7 @@
 #include <claraparabricks/genomeworks/utils/signed_integer_utils.hpp>
 
 #include <algorithm>
+#include <mutex>
 #include <stdexcept>
 
 namespace claraparabricks
@@ -56,6 +57,37 @@ std::string build_cigar(int32_t n, SymbolAt symbol_at, CountAt count_at, bool me
     cigar += last;
     return cigar;
 }
+FormattedAlignment format_states(const std::string& query, const std::string& target, const std::vector<AlignmentState>& states,
+                                 int32_t maximal_line_length)
+{
+    FormattedAlignment out;
+    out.linebreak_after = maximal_line_length < 0 ? 0 : static_cast<uint32_t>(maximal_line_length);
+    int64_t t = 0, q = 0;
+    for (AlignmentState s : states)
+    {
+        switch (s)
+        {
+        case AlignmentState::match:
+        case AlignmentState::mismatch:
+            out.target += target[t++];
+            out.query += query[q++];
+            out.pairing += (s == AlignmentState::match ? '|' : 'x');
+            break;
+        case AlignmentState::deletion:
+            out.target += '-';
+            out.query += query[q++];
+            out.pairing += ' ';
+            break;
+        case AlignmentState::insertion:
+            out.target += target[t++];
+            out.query += '-';
+            out.pairing += ' ';
+            break;
+        default: throw std::runtime_error("Unknown alignment state");
+        }
+    }
+    return out;
+}
 } // namespace
 
 AlignmentImpl::AlignmentImpl(const char* query, int32_t query_length, const char* target, int32_t target_length)
@@ -92,33 +124,104 @@ int32_t AlignmentImpl::get_edit_distance() const
 
 FormattedAlignment AlignmentImpl::format_alignment(int32_t maximal_line_length) const
 {
-    FormattedAlignment out;
-    out.linebreak_after = maximal_line_length < 0 ? 0 : static_cast<uint32_t>(maximal_line_length);
-    int64_t t = 0, q = 0;
-    for (AlignmentState s : alignment_)
-    {
-        switch (s)
+    return format_states(query_, target_, alignment_, maximal_line_length);
+}
+
+// ---- PackedAlignment: a view into the block one sync_alignments() produced -------------------------------------
+PackedAlignmentBlock::~PackedAlignmentBlock()
+{
+    if (pinned != nullptr) pinned_release(pinned, pinned_bytes);
+}
+
+void PackedAlignment::materialise_sequences() const
+{
+    std::call_once(seq_once_, [this] {
+        const int64_t* st = block_->seq_starts.data() + 2 * static_cast<size_t>(index_);
+        query_.assign(block_->sequences.data() + st[0], block_->sequences.data() + st[1]);
+        target_.assign(block_->sequences.data() + st[1], block_->sequences.data() + st[2]);
+    });
+}
+
+void PackedAlignment::materialise_runs() const
+{
+    std::call_once(runs_once_, [this] {
+        const int32_t n = num_runs();
+        if (block_->expand_states)
         {
-        case AlignmentState::match:
-        case AlignmentState::mismatch:
-            out.target += target_[t++];
-            out.query += query_[q++];
-            out.pairing += (s == AlignmentState::match ? '|' : 'x');
-            break;
-        case AlignmentState::deletion:
-            out.target += '-';
-            out.query += query_[q++];
-            out.pairing += ' ';
-            break;
-        case AlignmentState::insertion:
-            out.target += target_[t++];
-            out.query += '-';
-            out.pairing += ' ';
-            break;
-        default: throw std::runtime_error("Unknown alignment state");
+            size_t total = 0;
+            for (int32_t k = 0; k < n; ++k) total += static_cast<size_t>(count(k));
+            alignment_.reserve(total);
+            for (int32_t k = 0; k < n; ++k) alignment_.insert(alignment_.end(), static_cast<size_t>(count(k)), static_cast<AlignmentState>(op(k)));
         }
+        else
+        {
+            action_.resize(static_cast<size_t>(n));
+            runlength_.resize(static_cast<size_t>(n));
+            for (int32_t k = 0; k < n; ++k)
+            {
+                action_[static_cast<size_t>(k)]    = op(k);
+                runlength_[static_cast<size_t>(k)] = count(k);
+            }
+        }
+    });
+}
+
+const std::string& PackedAlignment::get_query_sequence() const
+{
+    materialise_sequences();
+    return query_;
+}
+
+const std::string& PackedAlignment::get_target_sequence() const
+{
+    materialise_sequences();
+    return target_;
+}
+
+const std::vector<AlignmentState>& PackedAlignment::get_alignment() const
+{
+    materialise_runs();
+    return alignment_;
+}
+
+const std::vector<int8_t>& PackedAlignment::get_actions() const
+{
+    materialise_runs();
+    return action_;
+}
+
+const std::vector<int32_t>& PackedAlignment::get_runlengths() const
+{
+    materialise_runs();
+    return runlength_;
+}
+
+std::string PackedAlignment::convert_to_cigar(CigarFormat format) const
+{
+    const bool ext = (format == CigarFormat::extended);
+    if (block_->expand_states)
+    {
+        // per-position form: equal symbols merge in both formats (AlignmentImpl::convert_to_cigar on alignment_)
+        return build_cigar(
+            num_runs(), [&](int32_t i) { return cigar_symbol(op(i), ext); }, [&](int32_t i) { return static_cast<int64_t>(count(i)); }, true);
     }
-    return out;
+    return build_cigar(
+        num_runs(), [&](int32_t i) { return cigar_symbol(op(i), ext); }, [&](int32_t i) { return static_cast<int64_t>(count(i)); }, !ext);
+}
+
+int32_t PackedAlignment::get_edit_distance() const
+{
+    int32_t d = 0;
+    for (int32_t k = 0; k < num_runs(); ++k)
+        if (op(k) != static_cast<int8_t>(AlignmentState::match)) d += count(k);
+    return d;
+}
+
+FormattedAlignment PackedAlignment::format_alignment(int32_t maximal_line_length) const
+{
+    materialise_sequences();
+    materialise_runs();
+    return format_states(query_, target_, alignment_, maximal_line_length); // renders the per-position form only, like AlignmentImpl
 }
 
 std::ostream& operator<<(std::ostream& os, const FormattedAlignment& f)

@@ -2,6 +2,10 @@
 #pragma once
 #include <claraparabricks/genomeworks/cudaaligner/alignment.hpp>
 
+#include <memory>
+#include <mutex>
+#include <vector>
+
 namespace claraparabricks
 {
 namespace genomeworks
@@ -52,6 +56,78 @@ private:
     std::vector<int32_t> runlength_;
     bool is_optimal_ = false;
 };
+
+/// Results of one sync_alignments() of the banded aligner, kept the way they left the device: the sequences of the
+/// batch back to back, the packed run-length results (each alignment back to front) and their offsets. The
+/// Alignment objects handed to the caller are views into this block (PackedAlignment) -- a batch of a million
+/// short-read alignments is materialised by one D2H copy and one pass over two index arrays, not by a million
+/// string / vector constructions (the reference builds every AlignmentImpl eagerly,
+/// aligner_global_myers_banded.cpp:402-427, which is most of its sync time on short reads). Whatever a caller asks an
+/// Alignment for is produced on first use from the block and is identical to what the eager construction held.
+class PackedAlignment;
+struct PackedAlignmentBlock
+{
+    ~PackedAlignmentBlock();
+    std::vector<char> sequences;       ///< q0 t0 q1 t1 ...
+    std::vector<int64_t> seq_starts;   ///< [2n + 1]
+    /// pinned host buffer [ops (total) | pad | counts (total x int32)] from the runtime's pinned cache
+    char* pinned          = nullptr;
+    size_t pinned_bytes   = 0;
+    const int8_t* ops     = nullptr;
+    const int32_t* counts = nullptr;
+    std::vector<PackedAlignment> alignments; ///< by index of add_alignment
+    bool expand_states = false;              ///< AlignerGlobalMyers: per-position states instead of run lengths
+};
+
+class PackedAlignment final : public Alignment
+{
+public:
+    PackedAlignment() = default;
+    void bind(const PackedAlignmentBlock* block, int32_t index, int32_t run_begin, int32_t run_end, bool has_result, bool is_optimal)
+    {
+        block_      = block;
+        index_      = index;
+        run_begin_  = run_begin;
+        run_end_    = run_end;
+        has_result_ = has_result;
+        is_optimal_ = has_result && is_optimal;
+    }
+
+    const std::string& get_query_sequence() const override;
+    const std::string& get_target_sequence() const override;
+    std::string convert_to_cigar(CigarFormat format = CigarFormat::basic) const override;
+    AlignmentType get_alignment_type() const override { return AlignmentType::global_alignment; }
+    bool is_optimal() const override { return is_optimal_; }
+    StatusType get_status() const override { return has_result_ ? StatusType::success : StatusType::uninitialized; }
+    const std::vector<AlignmentState>& get_alignment() const override;
+    const std::vector<int8_t>& get_actions() const override;
+    const std::vector<int32_t>& get_runlengths() const override;
+    int32_t get_edit_distance() const override;
+    FormattedAlignment format_alignment(int32_t maximal_line_length = 80) const override;
+
+    int32_t num_runs() const { return run_end_ - run_begin_; }
+    /// run k in forward order (the device stores an alignment back to front)
+    int8_t op(int32_t k) const { return block_->ops[run_end_ - 1 - k]; }
+    int32_t count(int32_t k) const { return block_->counts[run_end_ - 1 - k]; }
+
+private:
+    void materialise_sequences() const;
+    void materialise_runs() const;
+
+    const PackedAlignmentBlock* block_ = nullptr;
+    int32_t index_ = 0, run_begin_ = 0, run_end_ = 0;
+    bool has_result_ = false, is_optimal_ = false;
+    mutable std::once_flag seq_once_, runs_once_;
+    mutable std::string query_, target_;
+    mutable std::vector<AlignmentState> alignment_;
+    mutable std::vector<int8_t> action_;
+    mutable std::vector<int32_t> runlength_;
+};
+
+/// pinned host staging buffers, recycled process-wide (hipHostMalloc / hipHostFree cost far more than the copies
+/// they serve); thread-safe
+char* pinned_acquire(size_t bytes, size_t* capacity);
+void pinned_release(char* p, size_t capacity);
 
 } // namespace cudaaligner
 } // namespace genomeworks

@@ -14,6 +14,7 @@
 #include "poa_batch_impl.hpp"
 #include "aligner_impl.hpp"
 #include "aligner_global.hpp"
+#include "alignment_impl.hpp"
 #include <claraparabricks/genomeworks/utils/cudautils.hpp>
 #include <stdexcept>
 #include <claraparabricks/genomeworks/cudaaligner/aligner.hpp>
@@ -391,6 +392,103 @@ int32_t gw_alignment_states(gw_aligner* a, int32_t i, int8_t* out, int32_t cap)
     return n;
 }
 
+int64_t gw_aligner_get_runs(gw_aligner* a, int64_t* offsets, int8_t* ops, int32_t* counts, int64_t capacity, int32_t* status,
+                            int32_t* optimal)
+{
+    GW_TRY
+    const auto& all = a->aligner->get_alignments();
+    int64_t total   = 0;
+    for (size_t i = 0; i < all.size(); ++i)
+    {
+        const aln::Alignment& al = *all[i];
+        if (offsets) offsets[i] = total;
+        if (status) status[i] = static_cast<int32_t>(al.get_status());
+        if (optimal) optimal[i] = al.is_optimal() ? 1 : 0;
+        auto emit = [&](int8_t op, int32_t count) {
+            if (ops && counts && total < capacity)
+            {
+                ops[total]    = op;
+                counts[total] = count;
+            }
+            ++total;
+        };
+        if (const auto* pk = dynamic_cast<const aln::PackedAlignment*>(&al))
+        {
+            if (a->impl && a->impl->expands_results())
+            {
+                // per-position results: runs of equal states
+                int8_t last = -1;
+                int32_t acc = 0;
+                for (int32_t k = 0; k < pk->num_runs(); ++k)
+                {
+                    if (pk->op(k) == last) acc += pk->count(k);
+                    else
+                    {
+                        if (last >= 0) emit(last, acc);
+                        last = pk->op(k);
+                        acc  = pk->count(k);
+                    }
+                }
+                if (last >= 0) emit(last, acc);
+            }
+            else
+                for (int32_t k = 0; k < pk->num_runs(); ++k) emit(pk->op(k), pk->count(k));
+        }
+        else if (!al.get_actions().empty())
+            for (size_t k = 0; k < al.get_actions().size(); ++k) emit(al.get_actions()[k], al.get_runlengths()[k]);
+        else
+        {
+            int8_t last = -1;
+            int32_t acc = 0;
+            for (auto st : al.get_alignment())
+            {
+                if (static_cast<int8_t>(st) == last) ++acc;
+                else
+                {
+                    if (last >= 0) emit(last, acc);
+                    last = static_cast<int8_t>(st);
+                    acc  = 1;
+                }
+            }
+            if (last >= 0) emit(last, acc);
+        }
+    }
+    if (offsets) offsets[all.size()] = total;
+    return total;
+    GW_CATCH(-1)
+}
+
+int gw_aligner_device_alignments(gw_aligner* a, int32_t* n_alignments, int64_t* total_length)
+{
+    GW_TRY
+    gw::scoped_device_switch dev(a->aligner->get_device());
+    GW_CU_CHECK_ERR(hipStreamSynchronize(a->aligner->get_stream()));
+    const aln::DeviceAlignmentsPtrs d = a->aligner->get_alignments_device();
+    if (n_alignments) *n_alignments = d.cigar_operations ? d.n_alignments : 0;
+    if (total_length) *total_length = d.cigar_operations ? d.total_length : 0;
+    return d.cigar_operations ? 0 : 1;
+    GW_CATCH(-1)
+}
+
+int gw_aligner_copy_device_alignments(gw_aligner* a, int8_t* cigar_operations, int32_t* cigar_runlengths, int32_t* cigar_offsets,
+                                      uint32_t* metadata)
+{
+    GW_TRY
+    gw::scoped_device_switch dev(a->aligner->get_device());
+    hipStream_t stream = a->aligner->get_stream();
+    GW_CU_CHECK_ERR(hipStreamSynchronize(stream));
+    const aln::DeviceAlignmentsPtrs d = a->aligner->get_alignments_device();
+    if (!d.cigar_operations) return 1;
+    const size_t n = static_cast<size_t>(d.n_alignments), total = static_cast<size_t>(d.total_length);
+    if (cigar_operations && total) GW_CU_CHECK_ERR(hipMemcpyAsync(cigar_operations, d.cigar_operations, total, hipMemcpyDeviceToHost, stream));
+    if (cigar_runlengths && total) GW_CU_CHECK_ERR(hipMemcpyAsync(cigar_runlengths, d.cigar_runlengths, total * 4, hipMemcpyDeviceToHost, stream));
+    if (cigar_offsets) GW_CU_CHECK_ERR(hipMemcpyAsync(cigar_offsets, d.cigar_offsets, (n + 1) * 4, hipMemcpyDeviceToHost, stream));
+    if (metadata && n) GW_CU_CHECK_ERR(hipMemcpyAsync(metadata, d.metadata, n * 4, hipMemcpyDeviceToHost, stream));
+    GW_CU_CHECK_ERR(hipStreamSynchronize(stream));
+    return 0;
+    GW_CATCH(-1)
+}
+
 int gw_aligner_relaunch(gw_aligner* a)
 {
     GW_TRY
@@ -484,6 +582,21 @@ int32_t gw_poa_estimate_max_poas(const gw_poa_batch_config* cfg, int32_t msa_fla
                                  cfg->alignment_band_width, cfg->max_sequences_per_poa, cfg->matrix_sequence_dimension,
                                  static_cast<poa::BandMode>(cfg->band_mode), cfg->max_banded_pred_distance);
     return poa::estimate_max_poas(c, msa_flag != 0, gpu_memory_usage_quota, mismatch_score, gap_score, match_score);
+    GW_CATCH(-1)
+}
+
+int64_t gw_poa_window_device_bytes(const gw_poa_batch_config* cfg, int32_t msa_flag, int32_t mismatch_score, int32_t gap_score,
+                                   int32_t match_score)
+{
+    GW_TRY
+    const poa::BatchConfig c(cfg->max_sequence_size, cfg->max_consensus_size, cfg->max_nodes_per_graph,
+                             cfg->alignment_band_width, cfg->max_sequences_per_poa, cfg->matrix_sequence_dimension,
+                             static_cast<poa::BandMode>(cfg->band_mode), cfg->max_banded_pred_distance);
+    const gwhip_poa_config dc = poa::make_device_config(c, static_cast<int8_t>(msa_flag ? poa::OutputType::msa : poa::OutputType::consensus),
+                                                        gap_score, mismatch_score, match_score);
+    int64_t per_poa = 0, per_matrix = 0;
+    gwhip_poa_bytes_per_window(&dc, &per_poa, &per_matrix);
+    return per_poa + per_matrix;
     GW_CATCH(-1)
 }
 

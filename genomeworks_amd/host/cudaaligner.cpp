@@ -16,7 +16,9 @@
 #include <algorithm>
 #include <climits>
 #include <numeric>
+#include <cstdlib>
 #include <stdexcept>
+#include <thread>
 
 #include "../../include/gwhip.h"
 #include "aligner_impl.hpp"
@@ -63,6 +65,7 @@ BandedAligner::~BandedAligner()
     scoped_device_switch dev(device_id_);
     (void)hipStreamSynchronize(stream_);
     free_device();
+    if (head_ != nullptr) pinned_release(head_, head_cap_);
 }
 
 void BandedAligner::reset_max_bandwidth(int32_t max_bandwidth)
@@ -127,7 +130,15 @@ StatusType BandedAligner::add_alignment(int32_t max_bandwidth, const char* query
         if (query_length > max_query_length_ || target_length > max_target_length_) return StatusType::exceeded_max_length;
         if (num_alignments() >= max_alignments_) return StatusType::exceeded_max_alignments;
     }
-    if (max_bandwidth > query_length) // keep max_bandwidth % 32 != 1 (aligner_global_myers_banded.cpp:174-178)
+    if (expand_results_)
+    {
+        // full-matrix flavour (AlignerGlobalMyers): the band always covers the whole query, and the kernel's
+        // "max_bandwidth - 1 >= |target - query|" admission test must pass for every pair inside the limits
+        // (a target of twice the query's length is a legal input of the reference class, aligner_global_myers.cpp)
+        max_bandwidth = std::max(query_length, std::abs(target_length - query_length) + 2);
+        if (max_bandwidth % kWordSize == 1) max_bandwidth += 1;
+    }
+    else if (max_bandwidth > query_length) // keep max_bandwidth % 32 != 1 (aligner_global_myers_banded.cpp:174-178)
         max_bandwidth = (query_length % kWordSize == 1 ? query_length + 1 : query_length);
 
     const int32_t n_alignments = num_alignments();
@@ -145,7 +156,10 @@ StatusType BandedAligner::add_alignment(int32_t max_bandwidth, const char* query
     const size_t wave_ws      = gwhip_myers_banded_workspace_bytes(1, starts2, &max_bandwidth); // a whole wave of this pair
     const size_t pair_ws      = wave_ws / 64 + 64;
     largest_wave_ws_          = std::max(largest_wave_ws_, wave_ws);
-    const size_t per_pair_io  = static_cast<size_t>(query_length + target_length) * (1 + 1 + 4) + 64;
+    // per base: sequences 1 + packed results 1 + 4 in the device block, per-pair result slots 1 + 4 inside the kernel
+    // workspace (plan_fixed, gwhip_myers.hip); per pair: starts, band width, order, result start, metadata, cell and
+    // run counters on both sides
+    const size_t per_pair_io  = static_cast<size_t>(query_length + target_length) * (1 + 1 + 4 + 1 + 4) + 160;
     const size_t new_estimate = workspace_bytes_estimate_ + pair_ws + pair_ws / 4 + per_pair_io;
     if (static_cast<int64_t>(new_estimate + largest_wave_ws_) + (1 << 20) >= max_device_memory_)
     {
@@ -239,6 +253,18 @@ void BandedAligner::launch()
         GW_LOG_ERROR(buf);
         GW_CU_CHECK_ERR(static_cast<hipError_t>(rc));
     }
+    // result offsets and metadata follow the kernels to the host (pinned), as the reference's align_all() does with its
+    // result_starts (aligner_global_myers_banded.cpp:372-374): sync_alignments() and get_alignments_device() read
+    // them after the stream has drained
+    const size_t un = static_cast<size_t>(a.n_alignments);
+    if (head_ == nullptr || head_cap_ < (2 * un + 1) * 4)
+    {
+        if (head_ != nullptr) pinned_release(head_, head_cap_);
+        head_ = pinned_acquire((2 * un + 1) * 4, &head_cap_);
+    }
+    GW_CU_CHECK_ERR(hipMemcpyAsync(head_, d_result_starts_, (un + 1) * 4, hipMemcpyDeviceToHost, stream_));
+    GW_CU_CHECK_ERR(hipMemcpyAsync(head_ + (un + 1) * 4, d_metadata_, un * 4, hipMemcpyDeviceToHost, stream_));
+    n_head_ = a.n_alignments;
 }
 
 void BandedAligner::relaunch_resident()
@@ -266,55 +292,71 @@ StatusType BandedAligner::sync_alignments()
     GW_NVTX_RANGE(profiler, "BandedAligner::sync");
     const int32_t n = num_alignments();
     alignments_.clear();
-    alignments_.resize(static_cast<size_t>(n));
     if (n == 0) return StatusType::success;
     scoped_device_switch dev(device_id_);
-    std::vector<int32_t> starts(static_cast<size_t>(n) + 1);
-    std::vector<uint32_t> meta(static_cast<size_t>(n));
-    GW_CU_CHECK_ERR(hipMemcpyAsync(starts.data(), d_result_starts_, starts.size() * 4, hipMemcpyDeviceToHost, stream_));
-    GW_CU_CHECK_ERR(hipMemcpyAsync(meta.data(), d_metadata_, meta.size() * 4, hipMemcpyDeviceToHost, stream_));
-    GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
-    const size_t total = static_cast<size_t>(starts.back());
-    std::vector<int8_t> ops(total);
-    std::vector<int32_t> counts(total);
+    // One block per sync: [result_starts | metadata] first (they say how many runs follow), then the packed runs into
+    // pinned memory that the block keeps; the Alignment objects are views into it (alignment_impl.hpp).
+    auto block            = std::make_shared<PackedAlignmentBlock>();
+    block->expand_states  = expand_results_;
+    const size_t un       = static_cast<size_t>(n);
+    if (!launched_ || n_head_ != n) throw std::runtime_error("sync_alignments() called before align_all()");
+    GW_CU_CHECK_ERR(hipStreamSynchronize(stream_)); // kernels + the offsets / metadata copy queued by align_all()
+    const int32_t* starts = reinterpret_cast<const int32_t*>(head_);
+    const uint32_t* meta  = reinterpret_cast<const uint32_t*>(head_) + un + 1;
+    const size_t total    = static_cast<size_t>(starts[un]);
+    const size_t counts_at = (total + 63) & ~size_t(63);
+    block->pinned         = pinned_acquire(counts_at + total * 4 + 64, &block->pinned_bytes);
+    block->ops            = reinterpret_cast<const int8_t*>(block->pinned);
+    block->counts         = reinterpret_cast<const int32_t*>(block->pinned + counts_at);
     if (total > 0)
     {
-        GW_CU_CHECK_ERR(hipMemcpyAsync(ops.data(), d_results_, total, hipMemcpyDeviceToHost, stream_));
-        GW_CU_CHECK_ERR(hipMemcpyAsync(counts.data(), d_result_counts_, total * 4, hipMemcpyDeviceToHost, stream_));
-        GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+        GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned, d_results_, total, hipMemcpyDeviceToHost, stream_));
+        GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned + counts_at, d_result_counts_, total * 4, hipMemcpyDeviceToHost, stream_));
     }
-    for (int32_t i = 0; i < n; ++i)
-    {
-        const bool is_optimal = (meta[i] >> 31) != 0;
-        const int32_t index   = static_cast<int32_t>(meta[i] & DeviceAlignmentsPtrs::index_mask);
-        const int32_t rb = starts[i], re = starts[i + 1];
-        const char* q       = seq_h_.data() + seq_starts_h_[2 * index];
-        const int32_t qlen  = static_cast<int32_t>(seq_starts_h_[2 * index + 1] - seq_starts_h_[2 * index]);
-        const char* t       = seq_h_.data() + seq_starts_h_[2 * index + 1];
-        const int32_t tlen  = static_cast<int32_t>(seq_starts_h_[2 * index + 2] - seq_starts_h_[2 * index + 1]);
-        auto alignment      = std::make_shared<AlignmentImpl>(q, qlen, t, tlen);
-        alignment->set_alignment_type(AlignmentType::global_alignment);
-        if (rb != re || (qlen == 0 && tlen == 0))
+    // while the runs are in flight: hand the batch's sequences to the block and lay out the views
+    block->sequences  = std::move(seq_h_);
+    block->seq_starts = std::move(seq_starts_h_);
+    block->alignments = std::vector<PackedAlignment>(un);
+    alignments_.resize(un);
+    auto bind_range = [&](size_t first, size_t last) {
+        for (size_t i = first; i < last; ++i)
         {
-            // the device emits each alignment back to front
-            std::vector<int8_t> a(std::make_reverse_iterator(ops.begin() + re), std::make_reverse_iterator(ops.begin() + rb));
-            std::vector<int32_t> c(std::make_reverse_iterator(counts.begin() + re), std::make_reverse_iterator(counts.begin() + rb));
-            if (expand_results_)
-            {
-                std::vector<AlignmentState> states;
-                for (size_t k = 0; k < a.size(); ++k) states.insert(states.end(), static_cast<size_t>(c[k]), static_cast<AlignmentState>(a[k]));
-                alignment->set_alignment(states, is_optimal);
-            }
-            else
-                alignment->set_alignment(std::move(a), std::move(c), is_optimal);
-            alignment->set_status(StatusType::success);
+            const bool is_optimal = (meta[i] >> 31) != 0;
+            const size_t index    = meta[i] & DeviceAlignmentsPtrs::index_mask;
+            const int64_t* st     = block->seq_starts.data() + 2 * index;
+            const bool has_result = starts[i] != starts[i + 1] || (st[0] == st[1] && st[1] == st[2]);
+            block->alignments[index].bind(block.get(), static_cast<int32_t>(index), starts[i], starts[i + 1], has_result, is_optimal);
         }
-        alignments_[static_cast<size_t>(index)] = std::move(alignment);
+    };
+    // the shared_ptr of every view aliases the block (no allocation per alignment); big batches are split over a few
+    // host threads, each with its own copy of the owner so that the reference count is not one contended cache line
+    auto publish_range = [&](size_t first, size_t last) {
+        const std::shared_ptr<PackedAlignmentBlock> owner = block;
+        for (size_t i = first; i < last; ++i) alignments_[i] = std::shared_ptr<Alignment>(owner, &block->alignments[i]);
+    };
+    const size_t n_threads = un >= 65536 ? std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (n_threads <= 1)
+    {
+        bind_range(0, un);
+        publish_range(0, un);
     }
+    else
+    {
+        const size_t chunk = (un + n_threads - 1) / n_threads;
+        std::vector<std::thread> workers;
+        for (size_t t = 1; t < n_threads; ++t)
+            workers.emplace_back([&, t] {
+                bind_range(std::min(un, t * chunk), std::min(un, (t + 1) * chunk));
+                publish_range(std::min(un, t * chunk), std::min(un, (t + 1) * chunk));
+            });
+        bind_range(0, std::min(un, chunk));
+        publish_range(0, std::min(un, chunk));
+        for (std::thread& w : workers) w.join();
+    }
+    GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
     total_length_h_ = static_cast<int64_t>(total);
     // keep the device block (device-resident results stay valid until reset()); host queues are cleared like the reference
-    seq_kept_        = std::move(seq_h_);
-    n_last_          = n;
+    n_last_ = n;
     reset_data();
     return StatusType::success;
 }
@@ -326,7 +368,8 @@ DeviceAlignmentsPtrs BandedAligner::get_alignments_device() const
     r.cigar_runlengths = d_result_counts_;
     r.cigar_offsets    = d_result_starts_;
     r.metadata         = d_metadata_;
-    r.total_length     = total_length_h_;
+    // after align_all() + a stream synchronisation the offsets are on the host; after sync_alignments() the total is kept
+    r.total_length     = (launched_ && head_ != nullptr) ? reinterpret_cast<const int32_t*>(head_)[static_cast<size_t>(n_head_)] : total_length_h_;
     r.n_alignments     = launched_ ? num_alignments() : n_last_;
     return r;
 }

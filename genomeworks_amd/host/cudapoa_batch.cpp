@@ -16,6 +16,7 @@
 #include <thread>
 #include <atomic>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <iomanip>
 #include <stdexcept>
@@ -190,6 +191,11 @@ PoaBatch::PoaBatch(int32_t device_id, cudaStream_t stream, DefaultDeviceAllocato
     }
     // ---- carve the device block: [sequences | weights | lengths | windows | consensus | coverage | msa | cells | workspace]
     int64_t guess = std::min<int64_t>(avail_mem / (per_poa + per_matrix), INT32_MAX);
+    // window_details.seq_starts and the host write offset are int32 (as in the reference, cudapoa_batch.cuh:456-537): a
+    // 288 GB device could otherwise hold more input bases than they can index
+    const int64_t per_poa_input = std::max<int64_t>(1, static_cast<int64_t>(max_sequences_per_poa_) *
+                                                           cudautils::align<int32_t, 4>(batch_size_.max_sequence_size));
+    guess = std::min<int64_t>(guess, (static_cast<int64_t>(INT32_MAX) - 8192) / per_poa_input);
     size_t o[10];
     max_poas_ = static_cast<int32_t>(std::max<int64_t>(guess, 1));
     while (max_poas_ > 1 && static_cast<int64_t>(plan(max_poas_, o)) > avail_mem) max_poas_--;
@@ -260,7 +266,8 @@ size_t PoaBatch::plan(int32_t n_poas, size_t* o) const
 {
     auto up          = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t n   = static_cast<size_t>(n_poas);
-    const size_t seq = up(n * max_sequences_per_poa_ * batch_size_.max_sequence_size + 4096);
+    // every read is padded to a multiple of 4 bytes (add_seq_to_poa)
+    const size_t seq = up(n * max_sequences_per_poa_ * static_cast<size_t>(cudautils::align<int32_t, 4>(batch_size_.max_sequence_size)) + 4096);
     size_t off       = 0;
     auto take        = [&](size_t b) { size_t at = off; off += b; return at; };
     o[0] = take(seq);
@@ -374,6 +381,18 @@ StatusType PoaBatch::add_poa_group(std::vector<StatusType>& per_seq_status, cons
     }
     const auto longest = std::max_element(poa_group.begin(), poa_group.end(),
                                           [](const Entry& a, const Entry& b) { return a.length < b.length; });
+    // input bytes this group can take (reads that will be rejected are counted too: an upper bound)
+    {
+        int64_t bytes = 0;
+        int32_t taken = 0;
+        for (const auto& entry : poa_group)
+            if (entry.length <= batch_size_.max_sequence_size && taken < max_sequences_per_poa_)
+            {
+                bytes += cudautils::align<int32_t, 4>(entry.length);
+                taken++;
+            }
+        if (static_cast<int64_t>(num_nucleotides_copied_) + bytes > static_cast<int64_t>(input_capacity_)) return StatusType::exceeded_maximum_poas;
+    }
     if (!reserve_buf(longest->length)) return StatusType::exceeded_maximum_poas;
     per_seq_status.clear();
     StatusType status = add_poa();
@@ -592,12 +611,16 @@ void PoaBatch::get_graphs(std::vector<DirectedGraph>& graphs, std::vector<Status
     if (poa_count_ == 0) return;
     const size_t mn = static_cast<size_t>(batch_size_.max_nodes_per_graph);
     const size_t W  = static_cast<size_t>(poa_count_);
-    // temporaries in the reference's array layout, filled by the export kernel
-    const size_t b_nodes = W * mn, b_cnt = W * mn * 2, b_edges = W * mn * GWHIP_MAX_NODE_EDGES * 4, b_w = W * mn * GWHIP_MAX_NODE_EDGES * 2;
-    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    auto up         = [](size_t v) { return (v + 255) & ~size_t(255); };
+    // Temporaries in the reference's array layout (303 bytes per node slot), filled by the export kernel. The batch's
+    // pool is normally fully committed to the batch block, so they come straight from the runtime -- in chunks of
+    // windows of at most ~1 GiB, so that a batch filled to device capacity can still be exported.
+    const size_t per_window   = mn * (1 + 2 + GWHIP_MAX_NODE_EDGES * (4 + 2)) + 4 * 256;
+    size_t chunk_budget       = size_t(1) << 30;
+    if (const char* e = std::getenv("GW_GRAPH_EXPORT_CHUNK_BYTES")) chunk_budget = std::max<size_t>(1, std::strtoull(e, nullptr, 10)); // tests
+    const size_t chunk        = std::max<size_t>(1, std::min(W, chunk_budget / per_window));
+    const size_t b_nodes = chunk * mn, b_cnt = chunk * mn * 2, b_edges = chunk * mn * GWHIP_MAX_NODE_EDGES * 4, b_w = chunk * mn * GWHIP_MAX_NODE_EDGES * 2;
     const size_t total = up(b_nodes) + up(b_cnt) + up(b_edges) + up(b_w);
-    // the batch's pool is normally fully committed to the batch block, so these rarely-needed temporaries come
-    // straight from the runtime
     char* d_tmp = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&d_tmp), total) != hipSuccess)
     {
@@ -609,42 +632,52 @@ void PoaBatch::get_graphs(std::vector<DirectedGraph>& graphs, std::vector<Status
     int32_t* d_edges   = reinterpret_cast<int32_t*>(d_tmp + up(b_nodes) + up(b_cnt));
     uint16_t* d_w      = reinterpret_cast<uint16_t*>(d_tmp + up(b_nodes) + up(b_cnt) + up(b_edges));
     gwhip_poa_args a   = kernel_args();
-    int rc             = gwhip_poa_export_graphs(&a, d_nodes, d_edges, d_w, d_cnt, nullptr, nullptr, stream_);
-    if (rc != 0) GW_CU_CHECK_ERR(static_cast<hipError_t>(rc));
     std::vector<uint8_t> nodes(b_nodes);
-    std::vector<uint16_t> cnt(W * mn), w(W * mn * GWHIP_MAX_NODE_EDGES);
-    std::vector<int32_t> edges(W * mn * GWHIP_MAX_NODE_EDGES);
+    std::vector<uint16_t> cnt(chunk * mn), w(chunk * mn * GWHIP_MAX_NODE_EDGES);
+    std::vector<int32_t> edges(chunk * mn * GWHIP_MAX_NODE_EDGES);
     std::vector<int32_t> lens(static_cast<size_t>(global_sequence_idx_));
-    GW_CU_CHECK_ERR(hipMemcpyAsync(nodes.data(), d_nodes, b_nodes, hipMemcpyDeviceToHost, stream_));
-    GW_CU_CHECK_ERR(hipMemcpyAsync(cnt.data(), d_cnt, b_cnt, hipMemcpyDeviceToHost, stream_));
-    GW_CU_CHECK_ERR(hipMemcpyAsync(edges.data(), d_edges, b_edges, hipMemcpyDeviceToHost, stream_));
-    GW_CU_CHECK_ERR(hipMemcpyAsync(w.data(), d_w, b_w, hipMemcpyDeviceToHost, stream_));
     GW_CU_CHECK_ERR(hipMemcpyAsync(lens.data(), d_seq_lens_, lens.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     GW_CU_CHECK_ERR(hipMemcpyAsync(h_consensus_, d_consensus_, W * batch_size_.max_consensus_size, hipMemcpyDeviceToHost, stream_));
-    GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
-    GW_CU_CHECK_ERR(hipFree(d_tmp));
-    for (int32_t poa = 0; poa < poa_count_; poa++)
+    for (size_t first = 0; first < W; first += chunk)
     {
-        const char* c = reinterpret_cast<const char*>(&h_consensus_[static_cast<size_t>(poa) * batch_size_.max_consensus_size]);
-        if (static_cast<uint8_t>(c[0]) == kKernelError)
+        const size_t n_here = std::min(chunk, W - first);
+        const int rc = gwhip_poa_export_graphs_range(&a, static_cast<int32_t>(first), static_cast<int32_t>(n_here), d_nodes, d_edges,
+                                                     d_w, d_cnt, nullptr, nullptr, stream_);
+        if (rc != 0)
         {
-            log_kernel_error(static_cast<StatusType>(c[1]), output_status);
-            continue;
+            (void)hipFree(d_tmp);
+            GW_CU_CHECK_ERR(static_cast<hipError_t>(rc));
         }
-        output_status.emplace_back(StatusType::success);
-        DirectedGraph& graph    = graphs[poa];
-        const int32_t num_nodes = lens[static_cast<size_t>(h_windows_[poa].seq_len_buffer_offset)];
-        for (int32_t n = 0; n < num_nodes; n++)
+        GW_CU_CHECK_ERR(hipMemcpyAsync(nodes.data(), d_nodes, n_here * mn, hipMemcpyDeviceToHost, stream_));
+        GW_CU_CHECK_ERR(hipMemcpyAsync(cnt.data(), d_cnt, n_here * mn * 2, hipMemcpyDeviceToHost, stream_));
+        GW_CU_CHECK_ERR(hipMemcpyAsync(edges.data(), d_edges, n_here * mn * GWHIP_MAX_NODE_EDGES * 4, hipMemcpyDeviceToHost, stream_));
+        GW_CU_CHECK_ERR(hipMemcpyAsync(w.data(), d_w, n_here * mn * GWHIP_MAX_NODE_EDGES * 2, hipMemcpyDeviceToHost, stream_));
+        GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+        for (size_t k = 0; k < n_here; k++)
         {
-            graph.set_node_label(n, std::string(1, static_cast<char>(nodes[poa * mn + n])));
-            const uint16_t ne = cnt[poa * mn + n];
-            for (int32_t e = 0; e < ne; e++)
+            const size_t poa = first + k;
+            const char* c    = reinterpret_cast<const char*>(&h_consensus_[poa * batch_size_.max_consensus_size]);
+            if (static_cast<uint8_t>(c[0]) == kKernelError)
             {
-                const size_t idx = (poa * mn + n) * GWHIP_MAX_NODE_EDGES + e;
-                graph.add_edge(edges[idx], n, w[idx]);
+                log_kernel_error(static_cast<StatusType>(c[1]), output_status);
+                continue;
+            }
+            output_status.emplace_back(StatusType::success);
+            DirectedGraph& graph    = graphs[poa];
+            const int32_t num_nodes = lens[static_cast<size_t>(h_windows_[poa].seq_len_buffer_offset)];
+            for (int32_t n = 0; n < num_nodes; n++)
+            {
+                graph.set_node_label(n, std::string(1, static_cast<char>(nodes[k * mn + n])));
+                const uint16_t ne = cnt[k * mn + n];
+                for (int32_t e = 0; e < ne; e++)
+                {
+                    const size_t idx = (k * mn + n) * GWHIP_MAX_NODE_EDGES + e;
+                    graph.add_edge(edges[idx], n, w[idx]);
+                }
             }
         }
     }
+    GW_CU_CHECK_ERR(hipFree(d_tmp));
 }
 
 uint64_t PoaBatch::total_cells()

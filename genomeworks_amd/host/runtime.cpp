@@ -10,7 +10,85 @@
 #include "../../include/gw_capi.h"
 #include "host_common.hpp"
 
+#include <mutex>
+#include <vector>
+
+#include "alignment_impl.hpp"
+
 namespace gw = claraparabricks::genomeworks;
+
+// ---- pinned host staging cache (alignment_impl.hpp) ----------------------------------------------------------------
+namespace claraparabricks
+{
+namespace genomeworks
+{
+namespace cudaaligner
+{
+namespace
+{
+struct PinnedCache
+{
+    std::mutex m;
+    std::vector<std::pair<char*, size_t>> free_list; // deliberately never released at exit (no runtime calls from static destructors)
+};
+PinnedCache& pinned_cache()
+{
+    static PinnedCache* c = new PinnedCache;
+    return *c;
+}
+constexpr size_t kPinnedKeep = 16;
+} // namespace
+
+char* pinned_acquire(size_t bytes, size_t* capacity)
+{
+    PinnedCache& c = pinned_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.m);
+        size_t best = c.free_list.size();
+        for (size_t i = 0; i < c.free_list.size(); ++i)
+            if (c.free_list[i].second >= bytes && (best == c.free_list.size() || c.free_list[i].second < c.free_list[best].second)) best = i;
+        if (best != c.free_list.size() && c.free_list[best].second <= 4 * bytes + (1u << 20))
+        {
+            auto hit = c.free_list[best];
+            c.free_list.erase(c.free_list.begin() + static_cast<long>(best));
+            *capacity = hit.second;
+            return hit.first;
+        }
+    }
+    size_t cap = 1u << 16;
+    while (cap < bytes) cap += cap / 2 > (size_t(64) << 20) ? (size_t(64) << 20) : cap; // doubles up to 128 MiB, then +64 MiB steps
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        throw std::bad_alloc();
+    }
+    *capacity = cap;
+    return static_cast<char*>(p);
+}
+
+void pinned_release(char* p, size_t capacity)
+{
+    if (p == nullptr) return;
+    PinnedCache& c = pinned_cache();
+    char* drop     = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c.m);
+        c.free_list.emplace_back(p, capacity);
+        if (c.free_list.size() > kPinnedKeep)
+        {
+            size_t smallest = 0;
+            for (size_t i = 1; i < c.free_list.size(); ++i)
+                if (c.free_list[i].second < c.free_list[smallest].second) smallest = i;
+            drop = c.free_list[smallest].first;
+            c.free_list.erase(c.free_list.begin() + static_cast<long>(smallest));
+        }
+    }
+    if (drop != nullptr) (void)hipHostFree(drop);
+}
+} // namespace cudaaligner
+} // namespace genomeworks
+} // namespace claraparabricks
 
 extern "C" {
 

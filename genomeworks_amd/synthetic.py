@@ -42,3 +42,20 @@ def generate_pairs(seed, n_pairs, length, max_mut, max_ins, max_del):
         t = bytes(buf[off:off + b]); off += int(b)
         out.append((q, t))
     return out
+
+
+def long_read_window(w, max_len=32768, min_len=2000):
+    """Window `w` of the long-read MSA set (BASELINE configs[3], SURVEY.md 8(d) "Config 4"): 8..32 reads, backbone
+    length log-uniform in [min_len, 0.93 max_len], 8-12 % divergence split 1 : 2 : 2 over substitutions :
+    insertions : deletions, seed 2000 + w. Reads the batch API would reject (>= max_len) are left out.
+    Returns list[str]."""
+    import math
+    import random
+    rng = random.Random(2000 + w)
+    n_reads = rng.randint(8, 32)
+    backbone = int(round(math.exp(rng.uniform(math.log(min_len), math.log(max_len * 0.93)))))
+    div = rng.uniform(0.08, 0.12)
+    # the generator fires each of its max_* trials with p = 0.5 (genomeutils.hpp:47-127): 2 x for the expected count
+    mut, ins, dele = (int(2 * backbone * div * f) for f in (0.2, 0.4, 0.4))
+    reads = [r.decode() for r in generate_window(2000 + w, backbone, n_reads, mut, ins, dele)]
+    return [s for s in reads if len(s) < max_len]

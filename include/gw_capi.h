@@ -132,6 +132,18 @@ int32_t gw_alignment_is_optimal(gw_aligner* a, int32_t i);
 int32_t gw_alignment_edit_distance(gw_aligner* a, int32_t i);
 const char* gw_alignment_cigar(gw_aligner* a, int32_t i, int32_t extended, int32_t* length);
 int32_t gw_alignment_states(gw_aligner* a, int32_t i, int8_t* out, int32_t cap);
+/* All alignments of the last sync_alignments() at once, as run-length CIGARs in forward order: offsets[n + 1] index
+   ops / counts (AlignmentState, repetitions); status[n] / optimal[n] may be NULL. Returns the total number of runs
+   (call with ops == NULL to size the buffers), -1 on exception. Per-position results are run-length encoded. */
+int64_t gw_aligner_get_runs(gw_aligner* a, int64_t* offsets, int8_t* ops, int32_t* counts, int64_t capacity, int32_t* status,
+                            int32_t* optimal);
+/* Aligner::get_alignments_device() (aligner.hpp:62-72,121): synchronises the aligner's stream, then reports the number
+   of alignments and packed runs resident on the device. Returns 1 for aligners without a device-resident form. */
+int gw_aligner_device_alignments(gw_aligner* a, int32_t* n_alignments, int64_t* total_length);
+/* Copies the four DeviceAlignmentsPtrs arrays to host buffers (any may be NULL): cigar_operations[total],
+   cigar_runlengths[total], cigar_offsets[n + 1], metadata[n]. What a device-side consumer would read in place. */
+int gw_aligner_copy_device_alignments(gw_aligner* a, int8_t* cigar_operations, int32_t* cigar_runlengths, int32_t* cigar_offsets,
+                                      uint32_t* metadata);
 int gw_aligner_relaunch(gw_aligner* a);
 /* 32 * band words * target length summed over band attempts and pairs of the last align_all() (device counters) */
 int gw_aligner_band_cells(gw_aligner* a, uint64_t* cells);
@@ -151,6 +163,10 @@ int gw_poa_get_multi_batch_sizes(int32_t n_groups, const int32_t* longest, const
                                  gw_poa_batch_config* batch_cfgs, int32_t* groups_per_batch, int32_t* group_ids);
 int32_t gw_poa_estimate_max_poas(const gw_poa_batch_config* cfg, int32_t msa_flag, float gpu_memory_usage_quota,
                                  int32_t mismatch_score, int32_t gap_score, int32_t match_score);
+/* Device bytes one window of this shape takes in a batch (the divisor of estimate_max_poas; host-only, no device
+   query): lets a caller plan batches for a memory budget of its choice with gw_poa_bin_groups. */
+int64_t gw_poa_window_device_bytes(const gw_poa_batch_config* cfg, int32_t msa_flag, int32_t mismatch_score, int32_t gap_score,
+                                   int32_t match_score);
 /* parse_cudapoa_file (fasta = 0, first path only) / parse_fasta_files (fasta = 1); NULL on error (gw_last_error). */
 typedef struct gw_windows gw_windows;
 gw_windows* gw_windows_parse(const char* const* paths, int32_t n_paths, int32_t fasta, int32_t total_windows);

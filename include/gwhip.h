@@ -119,6 +119,11 @@ int gwhip_poa_generate(const gwhip_poa_args* args, gwhip_stream_t stream);
 int gwhip_poa_export_graphs(const gwhip_poa_args* args, uint8_t* nodes, int32_t* incoming_edges,
                             uint16_t* incoming_edge_weights, uint16_t* incoming_edge_count, int32_t* outgoing_edges,
                             uint16_t* outgoing_edge_count, gwhip_stream_t stream);
+/* Same for windows [first_window, first_window + n_windows) of the batch only; the output arrays hold n_windows
+   graphs (window first_window + k at slot k), so a caller can export a large batch through bounded temporaries. */
+int gwhip_poa_export_graphs_range(const gwhip_poa_args* args, int32_t first_window, int32_t n_windows, uint8_t* nodes,
+                                  int32_t* incoming_edges, uint16_t* incoming_edge_weights, uint16_t* incoming_edge_count,
+                                  int32_t* outgoing_edges, uint16_t* outgoing_edge_count, gwhip_stream_t stream);
 
 /* ---- unit hooks (device pointers, reference array layout with SizeT=int32, 50 slots per node) ---- */
 typedef struct gwhip_poa_test_graph

@@ -1,0 +1,76 @@
+"""Oracle goldens of BASELINE configs[3] (long-read MSA, adaptive band): see make_config_goldens.py. TEST INFRASTRUCTURE.
+
+The set: windows 0..597 of genomeworks_amd.synthetic.long_read_window (seeds 2000 + w; 8-32 reads, backbone 2-30 kbp,
+8-12 % indel-heavy divergence), planned into batches by cudapoa.plan_multi_batch_sizes for a stated memory budget
+(0.9 x 256 GiB, so the plan does not depend on the box) with adaptive_storage_factor 4.0: at this divergence a graph
+grows to about twice its reads' length, the adaptive band widens to its 1536-column cap, and the reference's default
+factor of 2.0 leaves 23 % of the windows with exceeded_adaptive_banded_matrix_size."""
+import hashlib
+import json
+import multiprocessing as mp
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CONFIG4 = dict(windows=598, max_len=32768, band=256, band_mode=2, adaptive_storage_factor=4.0, graph_length_factor=3.0,
+               memory_budget_bytes=int(0.9 * 256 * 2 ** 30))
+
+_W = {}
+
+
+def plan(n_windows=None, windows=None):
+    """-> (windows, cfgs, groups): the deterministic batch plan of the set."""
+    from genomeworks_amd import cudapoa, synthetic
+    if windows is None:
+        windows = [synthetic.long_read_window(w, CONFIG4["max_len"]) for w in range(n_windows or CONFIG4["windows"])]
+    cfgs, groups = cudapoa.plan_multi_batch_sizes(windows, CONFIG4["memory_budget_bytes"], msa_flag=True,
+                                                  band_width=CONFIG4["band"], band_mode="adaptive_band",
+                                                  adaptive_storage_factor=CONFIG4["adaptive_storage_factor"],
+                                                  graph_length_factor=CONFIG4["graph_length_factor"])
+    return windows, cfgs, groups
+
+
+def oracle_cfg(c):
+    import oracle_poa as O
+    ocfg = O.make_cfg(c["max_sequence_size"], c["max_sequences_per_poa"], CONFIG4["band"], CONFIG4["band_mode"],
+                      storage_factor=CONFIG4["adaptive_storage_factor"], graph_factor=CONFIG4["graph_length_factor"], output_mask=2)
+    assert (ocfg.max_nodes_per_graph, ocfg.matrix_sequence_dimension) == (c["max_nodes_per_graph"], c["matrix_sequence_dimension"])
+    return ocfg
+
+
+def msa_digest(rows):
+    return hashlib.sha256("\n".join(rows).encode()).hexdigest()[:32]
+
+
+def _run(job):
+    import oracle_poa as O
+    w, c = job
+    reads = _W["windows"][w][:c["max_sequences_per_poa"]]
+    with O.Workspace(oracle_cfg(c)) as ws:
+        ref = ws.process(reads)
+    return w, ref["status"], ref["cells"], msa_digest(ref["msa"]) if ref["status"] == 0 else ""
+
+
+def make(procs, summary):
+    windows, cfgs, groups = plan()
+    _W["windows"] = windows
+    jobs = [(w, c) for c, g in zip(cfgs, groups) for w in g]
+    jobs.sort(key=lambda j: -sum(len(r) for r in windows[j[0]]))
+    with mp.get_context("fork").Pool(procs) as pool:
+        res = sorted(pool.map(_run, jobs, chunksize=1))
+    cfg_of = {w: k for k, g in enumerate(groups) for w in g}
+    out = dict(CONFIG4, batch_configs=cfgs,
+               windows_detail=[dict(w=w, cfg=cfg_of[w], status=st, cells=cells, msa_sha=sha) for w, st, cells, sha in res])
+    with open(os.path.join(HERE, "config4_long_reads.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+        f.write("\n")
+    statuses = {}
+    for _, st, _, _ in res:
+        statuses[str(st)] = statuses.get(str(st), 0) + 1
+    summary["config4"] = dict(CONFIG4, cells=int(sum(r[2] for r in res)), statuses=statuses,
+                              digest=hashlib.sha256("".join(r[3] for r in res).encode()).hexdigest())
+    print("config4:", summary["config4"])

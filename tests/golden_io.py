@@ -1,0 +1,54 @@
+"""Readers of the committed config goldens (tests/golden/make_config_goldens.py) -- TEST INFRASTRUCTURE."""
+import gzip
+import hashlib
+import importlib.util
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+_spec = importlib.util.spec_from_file_location("make_config_goldens", os.path.join(GOLDEN, "make_config_goldens.py"))
+gen = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(gen)
+
+run_fingerprints = gen.run_fingerprints
+block_digests = gen.block_digests
+
+
+def summary():
+    with open(os.path.join(GOLDEN, "config_goldens.json")) as f:
+        return json.load(f)
+
+
+def config3_windows():
+    """-> (list of dict(status, cells, consensus, coverage) by window, sha256 of the text)"""
+    with gzip.open(os.path.join(GOLDEN, "config3_windows.txt.gz"), "rb") as f:
+        text = f.read().decode()
+    rows = []
+    for line in text.splitlines():
+        w, status, cells, consensus, coverage = (line.split(" ") + ["", ""])[:5]
+        assert int(w) == len(rows)
+        rows.append(dict(status=int(status), cells=int(cells), consensus=consensus,
+                         coverage=[int(c) for c in coverage.split(",")] if coverage else []))
+    return rows, hashlib.sha256(text.encode()).hexdigest()
+
+
+def config2_pairs():
+    return dict(np.load(os.path.join(GOLDEN, "config2_pairs.npz")))
+
+
+def config5_pairs():
+    d = dict(np.load(os.path.join(GOLDEN, "config5_pairs.npz")))
+    d["optimal"] = np.unpackbits(d["optimal"])[:len(d["edit_distance"])]
+    return d
+
+
+def edit_distances(offsets, ops, counts):
+    """Per-alignment edit distance from the run-length form (every run that is not a match)."""
+    w = np.where(np.asarray(ops) != 0, np.asarray(counts, np.int64), 0)
+    c = np.concatenate([[0], np.cumsum(w)])
+    offsets = np.asarray(offsets, np.int64)
+    return c[offsets[1:]] - c[offsets[:-1]]

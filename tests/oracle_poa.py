@@ -141,7 +141,7 @@ class Workspace:
         """Returns dict(status, consensus(str, un-reversed like the host API), coverage, msa, node_count, cells)."""
         cfg = self.cfg
         # the output buffers below are sized by the config: the batch API rejects what does not fit before the kernels run
-        assert len(reads) <= cfg.max_sequences_per_poa and all(len(r) < cfg.max_sequence_size for r in reads)
+        assert len(reads) <= cfg.max_sequences_per_poa and all(len(r) <= cfg.max_sequence_size for r in reads)
         seqs, wts, lens, tot = pack_window(reads, weights)
         cons = np.zeros(cfg.max_consensus_size, np.uint8)
         cov = np.zeros(cfg.max_consensus_size, np.uint16)

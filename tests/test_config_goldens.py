@@ -1,0 +1,97 @@
+"""CPU checks of the committed config goldens: the files are what config_goldens.json says they are, and the oracle
+still reproduces a sample of every file (a drifting oracle or generator fails here, without a GPU)."""
+import hashlib
+
+import numpy as np
+
+import golden_io as G
+import oracle_aligner as A
+import oracle_poa as O
+
+
+def test_fingerprint_function_is_order_and_content_sensitive():
+    fp = G.run_fingerprints([0, 2, 4, 4, 5], np.array([0, 1, 1, 0, 2], np.int8), np.array([5, 1, 5, 1, 7], np.int32))
+    assert len(fp) == 4 and fp[2] == 0 and len({int(x) for x in fp}) == 4
+    swapped = G.run_fingerprints([0, 2], np.array([1, 0], np.int8), np.array([1, 5], np.int32))
+    assert swapped[0] != fp[0]
+
+
+def test_config3_file_matches_summary_and_oracle_sample():
+    rows, sha = G.config3_windows()
+    s = G.summary()["config3"]
+    assert sha == s["sha256"] and len(rows) == s["windows"] == 1024
+    assert sum(r["cells"] for r in rows) == s["cells"]
+    assert all(r["status"] == 0 and len(r["consensus"]) == len(r["coverage"]) for r in rows)
+    from genomeworks_amd import synthetic
+    cfg = O.make_cfg(s["max_seq"], s["max_seqs"], s["band"], s["band_mode"])
+    with O.Workspace(cfg) as ws:
+        for w in (0, 1, 77, 512, 1023):
+            ref = ws.process([r.decode() for r in synthetic.generate_window(s["first_seed"] + w)])
+            assert (ref["status"], ref["cells"], ref["consensus"], list(ref["coverage"])) == \
+                   (rows[w]["status"], rows[w]["cells"], rows[w]["consensus"], rows[w]["coverage"])
+
+
+def _check_pairs(name, cfg, golden, sample):
+    from genomeworks_amd import synthetic
+    pairs = synthetic.generate_pairs(cfg["seed"], max(sample) + 1, cfg["length"], cfg["mut"], cfg["ins"], cfg["dele"])
+    for i in sample:
+        r = A.align(pairs[i][0], pairs[i][1], cfg["max_bandwidth"])
+        ops = np.array([o for o, _ in r["runs"]], np.int8)
+        cnt = np.array([c for _, c in r["runs"]], np.int32)
+        assert r["edit_distance"] == int(golden["edit_distance"][i]), (name, i)
+        if "fingerprint" in golden:
+            assert int(G.run_fingerprints([0, len(ops)], ops, cnt)[0]) == int(golden["fingerprint"][i]), (name, i)
+
+
+def test_config2_file_matches_summary_and_oracle_sample():
+    g, s = G.config2_pairs(), G.summary()["config2"]
+    assert hashlib.sha256(g["fingerprint"].tobytes()).hexdigest() == s["fingerprint_sha256"]
+    assert len(g["fingerprint"]) == s["pairs"] == 10000 and int(g["cells"].sum()) == s["band_cells"]
+    assert int((g["status"] == 0).sum()) == 10000
+    _check_pairs("config2", s, g, [0, 1, 499, 1500])
+
+
+def test_config5_file_matches_summary_and_oracle_sample():
+    g, s = G.config5_pairs(), G.summary()["config5"]
+    assert len(g["edit_distance"]) == s["pairs"] == 1000000
+    assert len(g["block_sha"]) == (s["pairs"] + s["block"] - 1) // s["block"]
+    assert int(g["edit_distance"].astype(np.int64).sum()) == s["edit_distance_sum"]
+    _check_pairs("config5", s, g, [0, 3, 1023, 1024, 4999])
+    # the first block's digest from the oracle
+    from genomeworks_amd import synthetic
+    pairs = synthetic.generate_pairs(s["seed"], s["block"], s["length"], s["mut"], s["ins"], s["dele"])
+    offs, ops, cnt = [0], [], []
+    for q, t in pairs:
+        for o, c in A.align(q, t, s["max_bandwidth"])["runs"]:
+            ops.append(o)
+            cnt.append(c)
+        offs.append(len(ops))
+    fp = G.run_fingerprints(offs, np.array(ops, np.int8), np.array(cnt, np.int32))
+    assert G.block_digests(fp, s["block"])[0] == str(g["block_sha"][0])
+
+
+def test_config4_plan_is_reproducible_and_oracle_sample_matches():
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_long_read_goldens", os.path.join(here, "make_long_read_goldens.py"))
+    lr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lr)
+    with open(os.path.join(here, "config4_long_reads.json")) as f:
+        golden = json.load(f)
+    s = G.summary()["config4"]
+    det = golden["windows_detail"]
+    assert len(det) == 598 and sum(d["cells"] for d in det) == s["cells"]
+    assert hashlib.sha256("".join(d["msa_sha"] for d in det).encode()).hexdigest() == s["digest"]
+    assert sum(1 for d in det if d["status"] != 0) * 50 < len(det)  # < 2 % of the windows end in an error status
+    # the plan only needs the lengths: the first 40 windows are enough to check the generator, the oracle takes the smallest
+    from genomeworks_amd import synthetic
+    small = sorted(range(598), key=lambda w: det[w]["cells"])[:2]
+    for w in small:
+        reads = synthetic.long_read_window(w, golden["max_len"])
+        c = golden["batch_configs"][det[w]["cfg"]]
+        with O.Workspace(lr.oracle_cfg(c)) as ws:
+            ref = ws.process(reads[:c["max_sequences_per_poa"]])
+        assert ref["status"] == det[w]["status"] and ref["cells"] == det[w]["cells"]
+        assert lr.msa_digest(ref["msa"]) == det[w]["msa_sha"]

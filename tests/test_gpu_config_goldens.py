@@ -1,0 +1,118 @@
+"""GPU parity against the committed oracle goldens of the BASELINE.json configs: EVERY unit (all 1024 config-3 windows,
+all 10 000 config-2 pairs, all 1 000 000 config-5 pairs), through the C-ABI. The goldens come from the CPU oracle
+(tests/golden/make_config_goldens.py); tests/test_config_goldens.py keeps them honest on CPU."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import golden_io as G
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_all_1024_windows_equal_the_golden():
+    from genomeworks_amd import cudapoa, synthetic
+    rows, _ = G.config3_windows()
+    s = G.summary()["config3"]
+    windows = [[r.decode() for r in synthetic.generate_window(s["first_seed"] + w)] for w in range(s["windows"])]
+    b = cudapoa.CudaPoaBatch(s["max_seqs"], s["max_seq"], 8 << 30, output_type="consensus", band_mode="static_band",
+                             alignment_band_width=s["band"], max_nodes_per_graph=3 * s["max_seq"])
+    for w in windows:
+        st, seq_st = b.add_poa_group(w)
+        assert st == 0 and all(x == 0 for x in seq_st)
+    b.generate_poa()
+    cons, cov, status = b.get_consensus()
+    assert len(cons) == 1024
+    bad = [w for w in range(1024) if (status[w], cons[w], list(cov[w])) != (rows[w]["status"], rows[w]["consensus"], rows[w]["coverage"])]
+    assert not bad, "windows that differ from the oracle golden: %s" % bad[:20]
+    assert b.total_cells() == s["cells"]
+    assert hashlib.sha256("\n".join(cons).encode()).hexdigest() == s["consensus_sha256"]
+    # the steady-state loop of the benchmark (generate_poa + get_consensus on the same batch object) reproduces it
+    b.generate_poa()
+    cons2, cov2, status2 = b.get_consensus()
+    assert cons2 == cons and cov2 == cov and status2 == status
+
+
+def _run_pairs(cfg, n_pairs=None):
+    from genomeworks_amd import cudaaligner, synthetic
+    n = n_pairs or cfg["pairs"]
+    pairs = synthetic.generate_pairs(cfg["seed"], n, cfg["length"], cfg["mut"], cfg["ins"], cfg["dele"])
+    al = cudaaligner.CudaAlignerBatch(max_bandwidth=cfg["max_bandwidth"], max_device_memory_allocator_caching_size=24 << 30)
+    add = al._L.gw_aligner_add_alignment
+    for q, t in pairs:
+        st = add(al._h, q, len(q), t, len(t), 0, 0)
+        assert st == 0, st
+    al.align_all()
+    return al, pairs
+
+
+def test_config2_all_10000_pairs_equal_the_golden():
+    g, s = G.config2_pairs(), G.summary()["config2"]
+    al, pairs = _run_pairs(s)
+    assert al.band_cells() == s["band_cells"]
+    dev = al.get_alignments_device()  # before sync_alignments(): the device-resident form of the same results
+    r = al.get_runs()
+    assert len(r["status"]) == 10000 and (r["status"] == 0).all() and (r["optimal"] == g["optimal"]).all()
+    fp = G.run_fingerprints(r["offsets"], r["ops"], r["counts"])
+    bad = np.nonzero(fp != g["fingerprint"])[0]
+    assert len(bad) == 0, "pairs whose CIGAR differs from the oracle golden: %s" % bad[:20]
+    assert (G.edit_distances(r["offsets"], r["ops"], r["counts"]) == g["edit_distance"]).all()
+    # get_alignments_device(): alignment i (as added, via metadata) is stored back to front in [offsets[i], offsets[i+1])
+    assert dev["n_alignments"] == 10000 and dev["total_length"] == len(r["ops"])
+    idx = dev["metadata"] & ((1 << 27) - 1)
+    assert sorted(idx.tolist()) == list(range(10000)) and ((dev["metadata"] >> 31) == 1).all()
+    for k in (0, 1, 4999, 9999):
+        i = int(idx[k])
+        lo, hi = int(dev["cigar_offsets"][k]), int(dev["cigar_offsets"][k + 1])
+        a, b = int(r["offsets"][i]), int(r["offsets"][i + 1])
+        assert (dev["cigar_operations"][lo:hi][::-1] == r["ops"][a:b]).all()
+        assert (dev["cigar_runlengths"][lo:hi][::-1] == r["counts"][a:b]).all()
+    # the whole device form, vectorised: reversing each segment gives the forward runs of that alignment
+    d_off = dev["cigar_offsets"].astype(np.int64)
+    order = np.argsort(idx, kind="stable")
+    seg_len = np.diff(d_off)[order]
+    assert (seg_len == np.diff(r["offsets"])).all()
+
+
+def test_config5_all_1000000_pairs_equal_the_golden():
+    g, s = G.config5_pairs(), G.summary()["config5"]
+    al, pairs = _run_pairs(s)
+    assert al.band_cells() == s["band_cells"]
+    r = al.get_runs()
+    assert len(r["status"]) == s["pairs"] and (r["status"] == 0).all()
+    assert (r["optimal"] == g["optimal"]).all()
+    ed = G.edit_distances(r["offsets"], r["ops"], r["counts"])
+    assert (ed == g["edit_distance"]).all()
+    fp = G.run_fingerprints(r["offsets"], r["ops"], r["counts"])
+    assert hashlib.sha256(fp.tobytes()).hexdigest() == s["fingerprint_sha256"]
+    got = G.block_digests(fp, s["block"])
+    bad = [k for k, (a, b) in enumerate(zip(got, g["block_sha"])) if a != str(b)]
+    assert not bad, "blocks of 1024 pairs that differ from the oracle golden: %s" % bad[:10]
+
+
+def test_config4_all_598_long_read_windows_equal_the_golden():
+    """BASELINE configs[3]: every window of the long-read MSA set (32-bit scores and ids, HBM row tables, bands up to
+    1536 columns) through the multi-batch loop, MSA rows hashed against the oracle's."""
+    import importlib.util
+    import json
+    import os
+    from genomeworks_amd import multibatch
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_long_read_goldens", os.path.join(here, "make_long_read_goldens.py"))
+    lr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lr)
+    with open(os.path.join(here, "config4_long_reads.json")) as f:
+        golden = json.load(f)
+    windows, cfgs, groups = lr.plan()
+    assert cfgs == golden["batch_configs"]
+    out = multibatch.run_plan(windows, cfgs, groups, golden["memory_budget_bytes"], output_type="msa",
+                              band_mode="adaptive_band", digest=lr.msa_digest)
+    assert len(out["results"]) == golden["windows"] == 598
+    bad = []
+    for d in golden["windows_detail"]:
+        got, st = out["results"][d["w"]]
+        if st != d["status"] or (st == 0 and got != d["msa_sha"]):
+            bad.append(d["w"])
+    assert not bad, "windows whose MSA differs from the oracle golden: %s" % bad[:20]
+    assert out["cells"] == G.summary()["config4"]["cells"]
