@@ -2,16 +2,28 @@
 """bench.py -- the north-star metric on MI355X: GCUPS (+ POA windows/s) of the cudapoa consensus hot path on the
 1024-window short-read batch (BASELINE.json configs[2]: 1024 windows x 32 reads <= 1024 bp, static band 256).
 
-A "step" = one pass of the hot path over one 1024-window batch with the inputs already resident in HBM:
-graph-build kernel (NW + merge + topsort per read) + consensus kernel + D2H of the consensus/coverage and host
-un-reversal (get_consensus). Batch filling and the H2D upload are outside the timed region (the PCIe-inclusive
-rate is printed as `pcie_inclusive_*`, never as `value`).
+A "step" is the timed region of the reference's own benchmark (cudapoa/benchmarks/single_batch.hpp:86-93):
+generate_poa() -- H2D of the batch from pinned host memory, graph-build kernel (NW + merge + topsort per read),
+consensus kernel -- followed by get_consensus() (D2H + host un-reversal), in a steady-state loop on one Batch object.
+Batch filling (add_poa_group) is outside, as in the reference. `value` is that loop; the same kernels on inputs already
+resident in HBM are reported next to it as `kernel_only` (no H2D), and the dominant kernel's own duration (HIP events
+on the batch's stream) feeds `roofline`.
 
-Multi-GPU (torchrun, one rank per GPU): windows are independent, so each rank runs its own 1024-window batch
-(seeds rank*1024 + w): weak scaling, no data-path collective; RCCL is used only for the barrier and the max
-over ranks of the elapsed time.
+The same JSON line carries sub-records for the other BASELINE configs, each with its own roofline and CPU baseline:
+  configs[1]  cudaaligner banded Myers, 10 000 pairs x 1 kbp (align_all + sync_alignments; kernels only; device resident)
+  configs[4]  cudaaligner 1 000 000 pairs x 150 bp, index-split over the ranks
+  configs[3]  cudapoa long-read MSA, adaptive band, 598 windows through the multi-batch loop, batch-sharded over the ranks
+and, with more than one GPU, a strong-scaling record of the metric config (the same 1024 windows split over the ranks
+by estimated cost, consensus gathered by global index and hashed against the committed oracle golden).
+
+Multi-GPU (torchrun, one rank per GPU): windows and pairs are independent, so there is no data-path collective. The
+headline is weak scaling -- each rank runs its own 1024-window batch (seeds 1000 + rank * 1024 + w) -- because one
+window is one chain of 31 dependent alignments: 1024 windows already leave a single MI355X at one wavefront per SIMD,
+and splitting them further only idles SIMDs (the strong-scaling record shows exactly that). RCCL carries the barrier
+and the max / sum reductions of the timing scalars only.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -22,7 +34,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_CELL = 4             # 2 x sizeof(int16) per DP cell (one write, one predecessor read)
+BYTES_PER_CELL_LONG = 8        # long reads: 2 x sizeof(int32)
+BYTES_PER_MYERS_CELL = 0.375   # 12 B (pv, mv, score) per 32-cell band word and column
 WINDOWS = 1024
+CONFIG2 = dict(seed=1, pairs=10000, length=1000, mut=33, ins=33, dele=33, max_bandwidth=1024)
+CONFIG5 = dict(seed=3, pairs=1000000, length=150, mut=2, ins=1, dele=1, max_bandwidth=150)
 
 
 _CPU_SHARED = {}
@@ -70,6 +86,175 @@ def cpu_baseline(windows, seconds=6.0):
                             "sample": "%d windows, %.1f s" % (n1, dt1)}}
 
 
+def cpu_baseline_pairs(pairs, max_bandwidth, budget_s):
+    """Aligner CPU baseline on one host core, bounded sample of the same pairs: the reference's own CPU aligner
+    (needleman_wunsch_cpu, compiled in place into oracle/_ref: kind "reference") when that library travelled to the
+    box, else the C port of the banded Myers kernel (kind "port")."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import numpy as np
+    import oracle_aligner as A
+    R = A.ref()
+    n = cells = 0
+    out = np.zeros(2 * max(len(q) + len(t) for q, t in pairs[:64]) + 64, np.int8)
+    t0 = time.perf_counter()
+    for q, t in pairs:
+        if R is not None:
+            R.ref_needleman_wunsch_cpu(t, len(t), q, len(q), out.ctypes.data, len(out))
+            cells += len(q) * len(t)
+        else:
+            cells += A.align(q, t, max_bandwidth)["cells"]
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 1), "unit": "pairs/s", "cores": 1, "kind": "reference" if R is not None else "port",
+            "gcups": round(cells / dt / 1e9, 4),
+            "sample": "first %d pairs of the config, %.1f s, %s" % (
+                n, dt, "needleman_wunsch_cpu of the reference (full |q| x |t| matrix + backtrace)" if R is not None
+                else "C port of the banded Myers kernel (band cells)")}
+
+
+def reduce_scalars(dist, torch, values, op):
+    if dist is None:
+        return list(values)
+    t = torch.tensor(list(values), device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
+    return [float(x) for x in t.tolist()]
+
+
+def bench_aligner(name, cfg, rank, world, sync, dist, torch, reps, cpu_budget_s):
+    """One aligner config, index-split over the ranks. Timed regions: align_all() + sync_alignments() (the reference
+    benchmark's, cudaaligner/benchmarks/main.cpp:96-143), align_all() + stream sync with the results left on the
+    device (get_alignments_device), and the kernels alone (HIP events, inputs resident)."""
+    from genomeworks_amd import cudaaligner, multi_gpu, synthetic
+    pairs = synthetic.generate_pairs(cfg["seed"], cfg["pairs"], cfg["length"], cfg["mut"], cfg["ins"], cfg["dele"])
+    cpu = cpu_baseline_pairs(pairs, cfg["max_bandwidth"], cpu_budget_s) if (rank == 0 and cpu_budget_s > 0) else None
+    lo, hi = multi_gpu.shard_range(len(pairs), rank, world)
+    mine = pairs[lo:hi]
+    al = cudaaligner.CudaAlignerBatch(max_bandwidth=cfg["max_bandwidth"], max_device_memory_allocator_caching_size=32 << 30,
+                                      device_id=int(os.environ.get("LOCAL_RANK", "0")))
+    add = al._L.gw_aligner_add_alignment
+
+    def fill():
+        for q, t in mine:
+            st = add(al._h, q, len(q), t, len(t), 0, 0)
+            assert st == 0, st
+
+    fill()
+    al.align_all()
+    cells = al.band_cells()
+    k_ms = sum(al.relaunch_timed() for _ in range(reps)) / reps
+    # device resident: align_all (H2D + kernels), results stay on the device
+    t_dev = []
+    for _ in range(reps):
+        al.reset()
+        fill()
+        sync()
+        t0 = time.perf_counter()
+        al.align_all()
+        n_dev, _total = al.device_sync()
+        sync()
+        t_dev.append(time.perf_counter() - t0)
+        assert n_dev == len(mine)
+    # host materialised: align_all + sync_alignments
+    t_full = []
+    for _ in range(reps):
+        al.reset()
+        fill()
+        sync()
+        t0 = time.perf_counter()
+        al.align_all()
+        n_host = al.sync()
+        sync()
+        t_full.append(time.perf_counter() - t0)
+        assert n_host == len(mine)
+    al.reset()
+    full, dev = min(t_full), min(t_dev)
+    full, dev, k_max = reduce_scalars(dist, torch, [full, dev, k_ms], "MAX")
+    (cells_all,) = reduce_scalars(dist, torch, [float(cells)], "SUM")
+    if rank != 0:
+        return None
+    achieved = cells * BYTES_PER_MYERS_CELL / (k_ms * 1e-3) / 1e9
+    out = {"workload": name, "pairs": len(pairs), "pairs_per_gpu": len(mine), "max_bandwidth": cfg["max_bandwidth"],
+           "metric": "pairs/s, align_all() + sync_alignments()", "value": round(len(pairs) / full, 1), "unit": "pairs/s",
+           "ms": round(full * 1e3, 3), "band_cells": int(cells_all), "band_gcups": round(cells_all / full / 1e9, 2),
+           "device_resident": {"pairs_per_s": round(len(pairs) / dev, 1), "ms": round(dev * 1e3, 3),
+                               "what": "align_all() + stream sync; results read through get_alignments_device()"},
+           "kernel_only": {"pairs_per_s": round(len(pairs) / (k_max * 1e-3), 1), "ms": round(k_max, 3),
+                           "band_gcups": round(cells_all / (k_max * 1e-3) / 1e9, 2)},
+           "sync_over_kernel": round((full * 1e3 - k_max) / k_max, 2),
+           "roofline": {"bound": "hbm", "kernel": "myers_banded_kernel (+ scan, compaction)", "achieved": round(achieved, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes_per_cell": BYTES_PER_MYERS_CELL, "kernel_ms": round(k_ms, 3)}}
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    return out
+
+
+def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_windows):
+    """BASELINE configs[3]: the long-read MSA set through the planned multi-batch loop, windows dealt to the ranks by
+    estimated cost (no collective). Timed region per fill: generate_poa() + get_msa()."""
+    import importlib.util
+    from genomeworks_amd import multi_gpu, multibatch
+    spec = importlib.util.spec_from_file_location("make_long_read_goldens", os.path.join(ROOT, "tests", "golden", "make_long_read_goldens.py"))
+    lr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lr)
+    windows, cfgs, groups = lr.plan(n_windows)
+    cost = [multi_gpu.poa_window_cost(w, 256) for w in windows]
+    mine = set(multi_gpu.balanced_partition(cost, world)[rank])
+    my_groups = [[g for g in members if g in mine] for members in groups]
+    golden = {}
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "config4_long_reads.json")) as f:
+            golden = {d["w"]: d for d in json.load(f)["windows_detail"]}
+    except (OSError, ValueError):
+        pass
+    cpu = None
+    if rank == 0 and cpu_windows > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_poa as O
+        cfg_of = {w: c for c, members in zip(cfgs, groups) for w in members}
+        order = sorted(range(len(windows)), key=lambda w: cost[w])[:cpu_windows]
+        t0, c_cells = time.perf_counter(), 0
+        for w in order:
+            c = cfg_of[w]
+            with O.Workspace(lr.oracle_cfg(c)) as ws:
+                c_cells += ws.process(windows[w][:c["max_sequences_per_poa"]])["cells"]
+        dt = time.perf_counter() - t0
+        cpu = {"value": round(c_cells / dt / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": "port",
+               "windows_per_s": round(len(order) / dt, 3),
+               "sample": "the %d cheapest windows of the set, %.1f s (gcc -O2 scalar oracle, 32-bit scores)" % (len(order), dt)}
+    sync()
+    out = multibatch.run_plan(windows, cfgs, my_groups, lr.CONFIG4["memory_budget_bytes"], output_type="msa",
+                              band_mode="adaptive_band", device_id=local_rank, kernel_time=True, digest=lr.msa_digest)
+    sync()
+    n_ok = sum(1 for _r, st in out["results"].values() if st == 0)
+    checked = sum(1 for w, (sha, st) in out["results"].items() if w in golden and st == golden[w]["status"] and
+                  (st != 0 or sha == golden[w]["msa_sha"]))
+    mismatched = sum(1 for w in out["results"] if w in golden) - checked
+    seconds, k_ms = reduce_scalars(dist, torch, [out["seconds"], out["kernel_ms"]], "MAX")
+    cells, n_done, n_ok, checked, mismatched = reduce_scalars(
+        dist, torch, [float(out["cells"]), float(len(out["results"])), float(n_ok), float(checked), float(mismatched)], "SUM")
+    if rank != 0:
+        return None
+    achieved = out["cells"] * BYTES_PER_CELL_LONG / (out["kernel_ms"] * 1e-3) / 1e9
+    rec = {"workload": "BASELINE configs[3]: cudapoa long-read MSA, %d windows (8-32 reads, 2-30 kbp, 8-12 %% indel-heavy "
+                       "divergence, seeds 2000+w), adaptive band 256, adaptive_storage_factor 4, planned for a 230 GB budget"
+                       % len(windows),
+           "metric": "GCUPS, generate_poa() + get_msa() over the multi-batch loop", "value": round(cells / seconds / 1e9, 3),
+           "unit": "GCUPS", "windows": int(n_done), "windows_ok": int(n_ok), "windows_per_s": round(n_done / seconds, 2),
+           "ms": round(seconds * 1e3, 1), "cells": int(cells), "launches_rank0": out["launches"], "dtype": "int32",
+           "windows_equal_to_oracle_golden": int(checked), "windows_differing_from_golden": int(mismatched),
+           "roofline": {"bound": "hbm", "kernel": "poa_window_kernel<int32,int32,adaptive_band,HBM tables>",
+                        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes_per_cell": BYTES_PER_CELL_LONG, "kernel_ms": round(k_ms, 1)}}
+    if cpu is not None:
+        rec["cpu_baseline"] = cpu
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,7 +262,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--windows", type=int, default=WINDOWS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sub-configs", default="aligner,long_reads",
+                    help="comma list of the sub-records to measure next to the metric config: aligner, long_reads, none")
+    ap.add_argument("--long-read-windows", type=int, default=598)
     args = ap.parse_args()
+    subs = set(x for x in args.sub_configs.split(",") if x and x != "none")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -87,7 +276,8 @@ def main():
     first_seed = 1000 + rank * args.windows
     windows = [[r.decode() for r in synthetic.generate_window(first_seed + w)] for w in range(args.windows)]
     # the CPU baseline forks one worker per core: before this process makes its first device call
-    cpu = cpu_baseline(windows) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    cpu = cpu_baseline(windows) if want_cpu else None
 
     import torch
     if not torch.cuda.is_available():
@@ -99,12 +289,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    from genomeworks_amd import cudapoa
+    from genomeworks_amd import cudapoa, multi_gpu
     from genomeworks_amd.cuda import cuda_set_device
     cuda_set_device(local_rank)
 
-    batch = cudapoa.CudaPoaBatch(32, 1024, 8 << 30, output_type="consensus", band_mode="static_band",
-                                 alignment_band_width=256, max_nodes_per_graph=3072, device_id=local_rank)
+    def new_batch():
+        return cudapoa.CudaPoaBatch(32, 1024, 8 << 30, output_type="consensus", band_mode="static_band",
+                                    alignment_band_width=256, max_nodes_per_graph=3072, device_id=local_rank)
+
+    batch = new_batch()
     for w in windows:
         st, _ = batch.add_poa_group(w)
         assert st == 0, st
@@ -115,37 +308,42 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # first pass includes the H2D upload: PCIe-inclusive rate, reported separately
+    # cold pass (first launch of the process: code object load, first touch of the slabs)
     sync()
     t0 = time.perf_counter()
     batch.generate_poa()
     n_ok = batch.get_consensus_native()
-    t_pcie = time.perf_counter() - t0
+    t_cold = time.perf_counter() - t0
     cells = batch.total_cells()
     assert n_ok == args.windows
 
+    # ---- the metric: steady-state generate_poa() + get_consensus() ----
     for _ in range(args.warmup):
-        batch.relaunch()
+        batch.generate_poa()
         batch.get_consensus_native()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.generate_poa()
+        batch.get_consensus_native()
+    sync()
+    elapsed = time.perf_counter() - t0
+    (elapsed,) = reduce_scalars(dist, torch, [elapsed], "MAX")
+    (total_cells,) = reduce_scalars(dist, torch, [float(cells)], "SUM")
 
+    # ---- the same kernels on inputs resident in HBM (no H2D) ----
+    batch.relaunch()
+    batch.get_consensus_native()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         batch.relaunch()
         batch.get_consensus_native()
     sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([float(cells)], device="cuda", dtype=torch.float64)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_cells = float(c.item())
-    else:
-        total_cells = float(cells)
+    resident = time.perf_counter() - t0
+    (resident,) = reduce_scalars(dist, torch, [resident], "MAX")
 
-    # dominant kernel, timed live with HIP events on the batch's own stream (outside the timed region above)
+    # dominant kernel, timed live with HIP events on the batch's own stream (outside the timed regions above)
     kms, oms = [], []
     for _ in range(max(3, args.steps)):
         a, b = batch.relaunch_timed()
@@ -154,6 +352,60 @@ def main():
     k_ms = sum(kms) / len(kms)
     o_ms = sum(oms) / len(oms)
 
+    # ---- strong scaling of the metric config: the SAME 1024 windows over the ranks ----
+    strong = None
+    if world > 1:
+        all_windows = [[r.decode() for r in synthetic.generate_window(1000 + w)] for w in range(args.windows)]
+        cost = [multi_gpu.poa_window_cost(w, 256) for w in all_windows]
+        timing = {}
+
+        def process(units, idx):
+            sb = new_batch()
+            for w in units:
+                st, _ = sb.add_poa_group(w)
+                assert st == 0, st
+            sb.generate_poa()
+            sb.get_consensus_native()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                sb.generate_poa()
+                sb.get_consensus_native()
+            sync()
+            timing["s"] = time.perf_counter() - t1
+            cons, _cov, status = sb.get_consensus()
+            timing["cells"] = sb.total_cells()
+            return [(c, st) for c, st in zip(cons, status)]
+
+        gathered = multi_gpu.run_sharded(all_windows, process, gather=True, costs=cost)
+        s_elapsed, = reduce_scalars(dist, torch, [timing["s"]], "MAX")
+        s_cells, = reduce_scalars(dist, torch, [float(timing["cells"])], "SUM")
+        if rank == 0:
+            digest = hashlib.sha256("\n".join(c for c, _ in gathered).encode()).hexdigest()
+            golden = None
+            try:
+                golden = json.load(open(os.path.join(ROOT, "tests", "golden", "config_goldens.json")))["config3"]["consensus_sha256"]
+            except (OSError, ValueError, KeyError):
+                pass
+            strong = {"scaling": "strong", "windows": args.windows, "ms_per_step": round(s_elapsed / args.steps * 1e3, 3),
+                      "gcups": round(s_cells * args.steps / s_elapsed / 1e9, 3),
+                      "windows_per_s": round(args.windows * args.steps / s_elapsed, 1),
+                      "consensus_sha256": digest,
+                      "equals_oracle_golden": (digest == golden) if (golden and args.windows == WINDOWS) else None,
+                      "split": "balanced_partition by estimated cells, results gathered by global window index"}
+
+    # ---- sub-records: the other BASELINE configs ----
+    sub = {}
+    cpu_s = 0 if args.no_cpu_baseline else 1
+    if "aligner" in subs:
+        sub["configs[1]"] = bench_aligner("BASELINE configs[1]: cudaaligner banded Myers, 10 000 pairs x 1 kbp, <=33 sub/ins/del, "
+                                          "max_bandwidth 1024", CONFIG2, rank, world, sync, dist, torch, 3, 3.0 * cpu_s)
+        sub["configs[4]"] = bench_aligner("BASELINE configs[4]: cudaaligner 1 000 000 pairs x 150 bp, <=2 sub, <=1 ins, <=1 del, "
+                                          "max_bandwidth 150, index split over the ranks", CONFIG5, rank, world, sync, dist, torch, 2,
+                                          3.0 * cpu_s)
+    if "long_reads" in subs:
+        sub["configs[3]"] = bench_long_reads(args.long_read_windows, rank, world, local_rank, sync, dist, torch, 3 * cpu_s)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         gcups = total_cells * args.steps / elapsed / 1e9
@@ -161,18 +413,22 @@ def main():
         # HBM bytes per launch from the committed PMC pass of this same workload (rocprofv3 cannot run inside the
         # timed region; tools/pmc_passes.sh collects FETCH_SIZE / WRITE_SIZE in their own runs)
         traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pmc.get("windows") == args.windows:
-                traffic = pmc["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if pmc.get("windows") == args.windows:
+                    traffic = pmc["hbm_bytes_per_launch"]
+                    break
+            except (OSError, ValueError, KeyError):
+                continue
         out = {
             "metric": "cudapoa consensus GCUPS, 1024-window short-read batch (static band 256, 32 reads <= 1024 bp)",
             "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
             "windows_per_s": round(world * args.windows * args.steps / elapsed, 1),
+            "timed_region": "generate_poa() [H2D from pinned host + graph-build kernel + consensus kernel] + get_consensus() "
+                            "[D2H + host un-reversal], steady state on one Batch (cudapoa/benchmarks/single_batch.hpp:86-93)",
             "config": {"workload": "BASELINE configs[2]: cudapoa single-batch consensus, %d windows x 32 reads, "
                                    "backbone 960 bp, <=48 sub/24 ins/24 del, BatchConfig(1024,32,256,static_band), "
                                    "scores 8/-6/-8" % args.windows,
@@ -183,11 +439,18 @@ def main():
                          "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
                          "kernel_ms": round(k_ms, 3), "output_kernel_ms": round(o_ms, 3),
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL},
-            "pcie_inclusive_ms": round(t_pcie * 1e3, 3),
-            "pcie_inclusive_gcups": round(cells / t_pcie / 1e9, 3),
+            "kernel_only": {"what": "relaunch on inputs resident in HBM + get_consensus() (no H2D)",
+                            "ms_per_step": round(resident / args.steps * 1e3, 3),
+                            "gcups": round(total_cells * args.steps / resident / 1e9, 3),
+                            "windows_per_s": round(world * args.windows * args.steps / resident, 1)},
+            "cold_first_pass_ms": round(t_cold * 1e3, 3),
         }
         if cpu is not None:  # timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu
+        if strong is not None:
+            out["strong_scaling"] = strong
+        if sub:
+            out["sub_records"] = sub
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

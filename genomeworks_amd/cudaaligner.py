@@ -48,6 +48,7 @@ def _bind(L):
     L.gw_alignment_cigar.argtypes = [vp, i32, i32, C.POINTER(i32)]
     L.gw_alignment_states.argtypes = [vp, i32, vp, i32]
     L.gw_aligner_band_cells.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.gw_aligner_relaunch_timed.argtypes = [vp, C.POINTER(C.c_float)]
     L.gw_aligner_get_runs.restype = C.c_int64
     L.gw_aligner_get_runs.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp]
     L.gw_aligner_device_alignments.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_int64)]
@@ -140,6 +141,20 @@ class CudaAlignerBatch:
         """Benchmark helper: run the kernels again on the inputs resident in HBM (before get_alignments)."""
         if self._L.gw_aligner_relaunch(self._h) != 0:
             raise RuntimeError(self._L.gw_last_error().decode())
+
+    def relaunch_timed(self):
+        """Benchmark helper: relaunch and return the kernels' time in ms (HIP events on the aligner's stream)."""
+        ms = C.c_float(0)
+        if self._L.gw_aligner_relaunch_timed(self._h, C.byref(ms)) != 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        return ms.value
+
+    def device_sync(self):
+        """Wait for align_all() and report what get_alignments_device() holds: (n_alignments, total runs)."""
+        n, total = C.c_int32(0), C.c_int64(0)
+        if self._L.gw_aligner_device_alignments(self._h, C.byref(n), C.byref(total)) < 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        return n.value, total.value
 
     def band_cells(self):
         v = C.c_uint64(0)

@@ -42,13 +42,14 @@ public:
 
     // benchmark helpers (not part of the reference interface)
     void relaunch_resident();     ///< run the kernels again on the inputs already resident in HBM
+    float relaunch_resident_timed(); ///< same; returns the kernels' time in ms (HIP events on the aligner's stream)
     bool expands_results() const { return expand_results_; }
     uint64_t total_band_cells();  ///< 32 * band words * target length, summed over band attempts and pairs
 
 private:
     void reset_data();
     void free_device();
-    void launch();
+    void launch(void* event_before = nullptr, void* event_after = nullptr);
 
     cudaStream_t stream_;
     int32_t device_id_;

@@ -498,6 +498,15 @@ int gw_aligner_relaunch(gw_aligner* a)
     GW_CATCH(-1)
 }
 
+int gw_aligner_relaunch_timed(gw_aligner* a, float* kernels_ms)
+{
+    GW_TRY
+    if (!a->impl) return -1;
+    *kernels_ms = a->impl->relaunch_resident_timed();
+    return 0;
+    GW_CATCH(-1)
+}
+
 int gw_aligner_band_cells(gw_aligner* a, uint64_t* cells)
 {
     GW_TRY

@@ -224,7 +224,7 @@ StatusType BandedAligner::align_all()
     return StatusType::success;
 }
 
-void BandedAligner::launch()
+void BandedAligner::launch(void* event_before, void* event_after)
 {
     gwhip_myers_args a{};
     a.n_alignments          = num_alignments();
@@ -245,7 +245,9 @@ void BandedAligner::launch()
     for (size_t i = 0; i + 2 < seq_starts_h_.size(); i += 2)
         a.max_query_length = std::max(a.max_query_length, static_cast<int32_t>(seq_starts_h_[i + 1] - seq_starts_h_[i]));
     for (int32_t bw : max_bandwidths_h_) a.max_bandwidth_hint = std::max(a.max_bandwidth_hint, bw);
+    if (event_before != nullptr) GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(event_before), stream_));
     const int rc            = gwhip_myers_banded(&a, stream_);
+    if (event_after != nullptr) GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(event_after), stream_));
     if (rc != 0)
     {
         char buf[512];
@@ -272,6 +274,22 @@ void BandedAligner::relaunch_resident()
     if (!launched_) return;
     scoped_device_switch dev(device_id_);
     launch();
+}
+
+float BandedAligner::relaunch_resident_timed()
+{
+    if (!launched_) return 0.f;
+    scoped_device_switch dev(device_id_);
+    hipEvent_t e0, e1;
+    GW_CU_CHECK_ERR(hipEventCreate(&e0));
+    GW_CU_CHECK_ERR(hipEventCreate(&e1));
+    launch(e0, e1);
+    GW_CU_CHECK_ERR(hipEventSynchronize(e1));
+    float ms = 0.f;
+    GW_CU_CHECK_ERR(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return ms;
 }
 
 uint64_t BandedAligner::total_band_cells()

@@ -145,6 +145,8 @@ int gw_aligner_device_alignments(gw_aligner* a, int32_t* n_alignments, int64_t* 
 int gw_aligner_copy_device_alignments(gw_aligner* a, int8_t* cigar_operations, int32_t* cigar_runlengths, int32_t* cigar_offsets,
                                       uint32_t* metadata);
 int gw_aligner_relaunch(gw_aligner* a);
+/* same, timed with HIP events on the aligner's stream: all kernels of one align_all() (ms) */
+int gw_aligner_relaunch_timed(gw_aligner* a, float* kernels_ms);
 /* 32 * band words * target length summed over band attempts and pairs of the last align_all() (device counters) */
 int gw_aligner_band_cells(gw_aligner* a, uint64_t* cells);
 

@@ -14,8 +14,8 @@ import torch
 from genomeworks_amd import cudaaligner, synthetic
 
 
-def run(name, n_pairs, length, mut, ins, dele, max_bw, reps=5):
-    pairs = synthetic.generate_pairs(1, n_pairs, length, mut, ins, dele)
+def run(name, n_pairs, length, mut, ins, dele, max_bw, reps=5, seed=1):
+    pairs = synthetic.generate_pairs(seed, n_pairs, length, mut, ins, dele)
     al = cudaaligner.CudaAlignerBatch(max_bandwidth=max_bw, max_device_memory_allocator_caching_size=16 << 30)
     t0 = time.perf_counter()
     for q, t in pairs:
@@ -47,6 +47,6 @@ def run(name, n_pairs, length, mut, ins, dele, max_bw, reps=5):
 if __name__ == "__main__":
     n5 = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
     out = [run("configs[1]: 10k pairs x 1 kbp, <=33 sub/ins/del", 10000, 1000, 33, 33, 33, 1024),
-           run("configs[4]: %d pairs x 150 bp, <=5 sub/ins/del" % n5, n5, 150, 5, 5, 5, 128)]
+           run("configs[4]: %d pairs x 150 bp, <=2 sub, <=1 ins, <=1 del" % n5, n5, 150, 2, 1, 1, 150, seed=3)]
     for o in out:
         print(json.dumps(o))
