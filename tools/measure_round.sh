@@ -8,7 +8,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 1500 $OUT/bench.json
-(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $REPO/$OUT/stats -- python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $REPO/$OUT/stats.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $REPO/$OUT/stats -- python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --sub-configs none > $REPO/$OUT/stats.log 2>&1)
 DB=$(find $OUT/stats -name "*.db" | head -1)
 echo "db=$DB"
 [ -n "$DB" ] && python tools/rocpd_summary.py "$DB" > $OUT/kernel_stats.csv && head -5 $OUT/kernel_stats.csv

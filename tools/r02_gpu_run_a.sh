@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 for s in 0 1 3 7; do
   ( GWHIP_MYERS_SKIP=$s timeout 300 python tools/bench_aligner.py 200000 2>&1 | sed "s/^/skip=$s /" ) >> gpurun_out/r02a/aligner_ablation.txt
 done
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_a -o r02a -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --sub-configs aligner > /tmp/prof_a.log 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_a -o r02a -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --sub-configs aligner > /tmp/prof_a.log 2>&1
 cd $GRAFT_REPO_ROOT
 find /tmp/prof_a -name "*kernel_stats*" -exec cp {} gpurun_out/r02a/ \;
 tail -5 /tmp/prof_a.log > gpurun_out/r02a/prof.log
