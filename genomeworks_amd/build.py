@@ -118,10 +118,37 @@ def build_cli(force=False):
     return target
 
 
+def build_bindings(force=False):
+    """The Cython package `genomeworks` (pygenomeworks/, API of the reference's pygenomeworks): three extension modules
+    built in-tree against include/ and libgenomeworks_amd.so. Returns the package's parent directory (for sys.path)."""
+    pkg = os.path.join(ROOT, "pygenomeworks")
+    srcs = []
+    for d, _, fs in os.walk(os.path.join(pkg, "genomeworks")):
+        srcs += [os.path.join(d, f) for f in fs if f.endswith((".pyx", ".pxd"))]
+    srcs += [os.path.join(pkg, "setup.py")] + _deps("host", (".hpp",))
+    sig = _digest(srcs, "cython")
+    target = os.path.join(pkg, "genomeworks", "bindings")  # stamp only
+    import glob
+    built = all(glob.glob(os.path.join(pkg, "genomeworks", m, m + ".*.so")) for m in ("cuda", "cudapoa", "cudaaligner"))
+    stamp = target + ".stamp"
+    fresh = built and os.path.exists(stamp) and open(stamp).read().strip() == sig
+    if force or not fresh:
+        _run_in(pkg, [sys.executable, "setup.py", "-q", "build_ext", "--inplace", "--force"])
+        with open(stamp, "w") as f:
+            f.write(sig)
+    return pkg
+
+
+def _run_in(cwd, cmd):
+    print("[build] (in %s)" % cwd, " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=cwd, stdout=subprocess.DEVNULL)
+
+
 def build_all(force=False):
     k = build_kernels(force)
     h = build_host(force)
     build_cli(force)
+    build_bindings(force)
     return k, h
 
 

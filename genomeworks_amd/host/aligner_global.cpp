@@ -67,8 +67,12 @@ StatusType AlignerGlobal::add_alignment(const char* query, int32_t query_length,
     genomeutils::copy_sequence(target, target_length, seq_h_.data() + begin + query_length, reverse_complement_target);
     seq_starts_h_.push_back(begin + query_length);
     seq_starts_h_.push_back(begin + query_length + target_length);
-    // the Alignment objects are created at sync time (seq_h_ may still move while pairs are being added)
-    alignments_.push_back(nullptr);
+    // the Alignment object exists from now on (status uninitialized) and is filled in place by sync_alignments(), as in
+    // the reference (aligner_global.cpp:100-109): a caller may hold the vector from before the sync -- its Python
+    // binding does (cudaaligner.pyx:243-247)
+    auto alignment = std::make_shared<AlignmentImpl>(seq_h_.data() + begin, query_length, seq_h_.data() + begin + query_length, target_length);
+    alignment->set_alignment_type(AlignmentType::global_alignment);
+    alignments_.push_back(std::move(alignment));
     launched_ = false;
     return StatusType::success;
 }
@@ -116,12 +120,9 @@ StatusType AlignerGlobal::sync_alignments()
     const int32_t n = num_alignments();
     for (int32_t i = 0; i < n; ++i)
     {
-        const char* q      = seq_h_.data() + seq_starts_h_[2 * i];
         const int32_t qlen = static_cast<int32_t>(seq_starts_h_[2 * i + 1] - seq_starts_h_[2 * i]);
-        const char* t      = seq_h_.data() + seq_starts_h_[2 * i + 1];
         const int32_t tlen = static_cast<int32_t>(seq_starts_h_[2 * i + 2] - seq_starts_h_[2 * i + 1]);
-        auto alignment     = std::make_shared<AlignmentImpl>(q, qlen, t, tlen);
-        alignment->set_alignment_type(AlignmentType::global_alignment);
+        AlignmentImpl* alignment = dynamic_cast<AlignmentImpl*>(alignments_[static_cast<size_t>(i)].get());
         if (launched_)
         {
             const int32_t len     = result_lengths_h_[static_cast<size_t>(i)];
@@ -135,7 +136,6 @@ StatusType AlignerGlobal::sync_alignments()
                 alignment->set_status(StatusType::success);
             }
         }
-        alignments_[static_cast<size_t>(i)] = std::move(alignment);
     }
     return StatusType::success;
 }
