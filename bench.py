@@ -255,6 +255,50 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_
     return rec
 
 
+def bench_reference_shapes(windows, local_rank, sync, steps):
+    """The reference's own cudapoa benchmark shapes on the config-3 inputs (no published numbers exist for them):
+    BM_SingleBatchTest -- one batch, BatchConfig(1024, 200) = full band, generate_poa() + get_consensus()
+    (cudapoa/benchmarks/single_batch.hpp:52-54,86-93); BM_MultiBatchTest -- 1, 2, 4, 8 concurrent batches on host
+    threads sharing one device (multi_batch.hpp:41-61,72-177), here through process_windows_multi_device."""
+    from genomeworks_amd import cudapoa
+    b = cudapoa.CudaPoaBatch(200, 1024, 16 << 30, output_type="consensus", band_mode="full_band", device_id=local_rank,
+                             max_nodes_per_graph=3072, matrix_sequence_dimension=1024)
+    for w in windows:
+        st, _ = b.add_poa_group(w)
+        assert st == 0, st
+    b.generate_poa()
+    b.get_consensus_native()
+    cells = b.total_cells()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.generate_poa()
+        b.get_consensus_native()
+    sync()
+    dt = (time.perf_counter() - t0) / steps
+    k_ms, _o = b.relaunch_timed()
+    del b
+    single = {"shape": "BM_SingleBatchTest: %d windows, BatchConfig(1024, 200) full band, consensus" % len(windows),
+              "ms": round(dt * 1e3, 2), "gcups": round(cells / dt / 1e9, 2), "windows_per_s": round(len(windows) / dt, 1),
+              "cells": cells, "kernel_ms": round(k_ms, 2)}
+    multi = []
+    twice = windows + windows
+    for nb in (1, 2, 4, 8):
+        sync()
+        t0 = time.perf_counter()
+        out = cudapoa.process_windows_multi_device(twice, 32, 1024, devices=(local_rank,), batches_per_device=nb,
+                                                   memory_per_device=int(nb * 2.2e9), band_mode="static_band",
+                                                   max_nodes_per_graph=3072)
+        dt = time.perf_counter() - t0
+        assert all(s == 0 for s in out["status"])
+        multi.append({"batches": nb, "ms": round(dt * 1e3, 1), "windows_per_s": round(len(twice) / dt, 1), "launches": out["launches"]})
+    return {"single_batch_full_band": single,
+            "multi_batch": {"shape": "BM_MultiBatchTest pattern: %d windows (the 1024 config-3 windows twice), static band 256, "
+                                     "N batches on host threads sharing the device, about 550 windows per batch fill; "
+                                     "wall time incl. batch creation, filling and result marshalling" % len(twice),
+                            "runs": multi}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,8 +306,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--windows", type=int, default=WINDOWS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sub-configs", default="aligner,long_reads",
-                    help="comma list of the sub-records to measure next to the metric config: aligner, long_reads, none")
+    ap.add_argument("--sub-configs", default="aligner,long_reads,reference_shapes",
+                    help="comma list of the sub-records to measure next to the metric config: aligner, long_reads, "
+                         "reference_shapes, none")
     ap.add_argument("--long-read-windows", type=int, default=598)
     args = ap.parse_args()
     subs = set(x for x in args.sub_configs.split(",") if x and x != "none")
@@ -403,6 +448,8 @@ def main():
         sub["configs[4]"] = bench_aligner("BASELINE configs[4]: cudaaligner 1 000 000 pairs x 150 bp, <=2 sub, <=1 ins, <=1 del, "
                                           "max_bandwidth 150, index split over the ranks", CONFIG5, rank, world, sync, dist, torch, 2,
                                           3.0 * cpu_s)
+    if "reference_shapes" in subs and world == 1:
+        sub["reference_benchmark_shapes"] = bench_reference_shapes(windows, local_rank, sync, 2)
     if "long_reads" in subs:
         sub["configs[3]"] = bench_long_reads(args.long_read_windows, rank, world, local_rank, sync, dist, torch, 3 * cpu_s)
 

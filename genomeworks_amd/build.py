@@ -18,7 +18,7 @@ HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
 KERNEL_SRCS = ["csrc/gwhip_poa.hip", "csrc/gwhip_poa_hooks.hip", "csrc/gwhip_myers.hip", "csrc/gwhip_ukkonen.hip"]
 HOST_SRCS = ["host/capi.cpp", "host/cudapoa_batch.cpp", "host/cudapoa_utils.cpp", "host/cudaaligner.cpp", "host/aligner_global.cpp", "host/device_pool.cpp",
-             "host/alignment_impl.cpp", "host/runtime.cpp", "host/logging.cpp", "host/overlap_alignment.cpp"]
+             "host/alignment_impl.cpp", "host/runtime.cpp", "host/logging.cpp", "host/overlap_alignment.cpp", "host/multi_device.cpp"]
 
 # no fast-math, no FMA contraction: band placement is IEEE fp32
 KERNEL_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
@@ -62,25 +62,44 @@ def _mark(target, stamp_value):
         f.write(stamp_value)
 
 
+def _local_includes(src):
+    """Headers of csrc/ that `src` includes, transitively (plus include/gwhip.h): an object is rebuilt when its own
+    source or one of these changes -- the POA translation unit takes minutes, the aligner ones seconds."""
+    import re
+    seen, todo = set(), [src]
+    while todo:
+        f = todo.pop()
+        with open(f) as fh:
+            for name in re.findall(r'#include\s+"([^"]+)"', fh.read()):
+                path = os.path.normpath(os.path.join(os.path.dirname(f), name))
+                if os.path.exists(path) and path not in seen:
+                    seen.add(path)
+                    todo.append(path)
+    return sorted(seen)
+
+
 def build_kernels(force=False):
     os.makedirs(LIB, exist_ok=True)
     target = os.path.join(LIB, "libgwhip.so")
     srcs = [os.path.join(PKG, s) for s in KERNEL_SRCS if os.path.exists(os.path.join(PKG, s))]
-    sig = _digest(_deps("csrc", (".hip", ".h", ".hpp")), KERNEL_FLAGS)
-    if force or _stale(target, sig):
-        objs = []
-        procs = []
-        for s in srcs:
-            o = os.path.join(LIB, os.path.basename(s) + ".o")
-            objs.append(o)
+    objs, procs, sigs = [], [], []
+    for s in srcs:
+        o = os.path.join(LIB, os.path.basename(s) + ".o")
+        objs.append(o)
+        sig = _digest([s] + _local_includes(s), KERNEL_FLAGS)
+        sigs.append(sig)
+        if force or _stale(o, sig):
             cmd = [HIPCC] + KERNEL_FLAGS + ["-I", os.path.join(ROOT, "include"), "-c", s, "-o", o]
             print("[build]", " ".join(cmd), flush=True)
-            procs.append(subprocess.Popen(cmd))
-        for p in procs:
-            if p.wait() != 0:
-                raise RuntimeError("hipcc failed")
+            procs.append((subprocess.Popen(cmd), o, sig))
+    for p, o, sig in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed")
+        _mark(o, sig)
+    link_sig = _digest([], sigs)
+    if force or procs or _stale(target, link_sig):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs)
-        _mark(target, sig)
+        _mark(target, link_sig)
     return target
 
 

@@ -211,6 +211,48 @@ __device__ void diagonal_band(Band& b, const ColumnState& cs, const Table& patte
     }
 }
 
+// the three stripes of one band attempt (myers_compute_scores_edit_dist_banded, myers_gpu.cu:753-846): column 0 is
+// already in place; fills diagonal_begin / diagonal_end for the backtrace
+template <bool LDS_STATE, typename Table>
+__device__ __forceinline__ void banded_stripes(Band& b, const ColumnState& cs, const Table& patterns, int32_t n_words, const char* target,
+                                               int32_t query_size, int32_t target_size, int32_t p, int32_t n_words_band,
+                                               int32_t band_width, int32_t& diagonal_begin, int32_t& diagonal_end)
+{
+    const int32_t dlen = abs(target_size - query_size);
+    if (band_width >= query_size)
+    {
+        diagonal_begin = target_size + 1;
+        diagonal_end   = target_size + 1;
+        horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, 1, target_size + 1, query_size, n_words_band, 0);
+    }
+    else
+    {
+        const int32_t symmetric = (band_width - min(1 + 2 * p + dlen, query_size) == 0) ? 1 : 0;
+        diagonal_begin = query_size < target_size ? target_size - query_size + p + 2 : p + 2 + (1 - symmetric);
+        diagonal_end   = query_size < target_size ? query_size - p + symmetric : query_size - (query_size - target_size) - p + 1;
+        horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, 1, diagonal_begin, band_width, n_words_band, 0);
+        diagonal_band<LDS_STATE>(b, cs, patterns, n_words, target, diagonal_begin, diagonal_end, band_width, n_words_band, 0);
+        horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, diagonal_end, target_size + 1, band_width, n_words_band,
+                                   query_size - band_width);
+    }
+}
+
+// the four forward (A, C, T, G) and four back-to-front pattern words of query word w (myers_preprocess,
+// hirschberg_myers_gpu.cu:227-242; make_pattern / make_pattern_reverse in one sweep over the characters)
+__device__ __forceinline__ void pattern_words(const char* query, int32_t query_size, int32_t w, uint32_t f[4], uint32_t r[4])
+{
+    uint32_t pa = 0, pc = 0, pt = 0, pg = 0, ra = 0, rc = 0, rt = 0, rg = 0;
+    const int32_t nchar = min(query_size - w * kWord, kWord);
+    for (int32_t i = 0; i < nchar; ++i)
+    {
+        const char a = query[w * kWord + i], z = query[query_size - 1 - (w * kWord + i)];
+        pa |= (uint32_t)(a == 'A') << i; pc |= (uint32_t)(a == 'C') << i; pt |= (uint32_t)(a == 'T') << i; pg |= (uint32_t)(a == 'G') << i;
+        ra |= (uint32_t)(z == 'A') << i; rc |= (uint32_t)(z == 'C') << i; rt |= (uint32_t)(z == 'T') << i; rg |= (uint32_t)(z == 'G') << i;
+    }
+    f[0] = pa; f[1] = pc; f[2] = pt; f[3] = pg;
+    r[0] = ra; r[1] = rc; r[2] = rt; r[3] = rg;
+}
+
 #define GW_EMIT(R)                                                                                                     \
     do                                                                                                                 \
     {                                                                                                                  \
@@ -455,27 +497,6 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
             hbm_patterns[w * 4 + 0] = pa; hbm_patterns[w * 4 + 1] = pc; hbm_patterns[w * 4 + 2] = pt; hbm_patterns[w * 4 + 3] = pg;
         }
     }
-    // the two table flavours share the code below through a small dispatch
-    auto run_stripes = [&](auto patterns, int32_t p, int32_t n_words_band, int32_t band_width, int32_t& diagonal_begin,
-                           int32_t& diagonal_end) {
-        if (band_width >= query_size)
-        {
-            diagonal_begin = target_size + 1;
-            diagonal_end   = target_size + 1;
-            horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, 1, target_size + 1, query_size, n_words_band, 0);
-        }
-        else
-        {
-            const int32_t symmetric = (band_width - min(1 + 2 * p + dlen, query_size) == 0) ? 1 : 0;
-            diagonal_begin = query_size < target_size ? target_size - query_size + p + 2 : p + 2 + (1 - symmetric);
-            diagonal_end   = query_size < target_size ? query_size - p + symmetric : query_size - (query_size - target_size) - p + 1;
-            horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, 1, diagonal_begin, band_width, n_words_band, 0);
-            diagonal_band<LDS_STATE>(b, cs, patterns, n_words, target, diagonal_begin, diagonal_end, band_width, n_words_band, 0);
-            horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, diagonal_end, target_size + 1, band_width, n_words_band,
-                                       query_size - band_width);
-        }
-    };
-
     int32_t estimate = max(1, dlen + min(target_size, query_size) / 20);
     int32_t diagonal_begin = -1, diagonal_end = -1, band_width = 0;
     for (;;)
@@ -511,8 +532,10 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
             if (LDS_STATE) { cs.pv[w] = ~0u; cs.mv[w] = 0u; cs.score[w] = (uint32_t)s0; }
         }
         if (a.debug_skip & 2) {}
-        else if (LDS_STATE) run_stripes(lds_patterns, p, n_words_band, band_width, diagonal_begin, diagonal_end);
-        else run_stripes(hbm_patterns, p, n_words_band, band_width, diagonal_begin, diagonal_end);
+        else if (LDS_STATE)
+            banded_stripes<LDS_STATE>(b, cs, lds_patterns, n_words, target, query_size, target_size, p, n_words_band, band_width, diagonal_begin, diagonal_end);
+        else
+            banded_stripes<LDS_STATE>(b, cs, hbm_patterns, n_words, target, query_size, target_size, p, n_words_band, band_width, diagonal_begin, diagonal_end);
         const int32_t dist = n_words_band > 0 ? b.score[b.at(n_words_band - 1, target_size)] : target_size;
         if (dist <= estimate || band_width == query_size) break;
         if (band_width == max_bw)
@@ -794,16 +817,10 @@ __global__ __launch_bounds__(64) void hirschberg_myers_kernel(HirschbergArgs a)
     const int32_t n_words_query = ceil_div(query_size, kWord);
     for (int32_t w = 0; w < n_words_query; ++w)
     {
-        uint32_t pa = 0, pc = 0, pt = 0, pg = 0, ra = 0, rc = 0, rt = 0, rg = 0;
-        const int32_t nchar = min(query_size - w * kWord, kWord);
-        for (int32_t i = 0; i < nchar; ++i)
-        {
-            const char f = query[w * kWord + i], r = query[query_size - 1 - (w * kWord + i)];
-            pa |= (uint32_t)(f == 'A') << i; pc |= (uint32_t)(f == 'C') << i; pt |= (uint32_t)(f == 'T') << i; pg |= (uint32_t)(f == 'G') << i;
-            ra |= (uint32_t)(r == 'A') << i; rc |= (uint32_t)(r == 'C') << i; rt |= (uint32_t)(r == 'T') << i; rg |= (uint32_t)(r == 'G') << i;
-        }
-        pat_f[w * 4 + 0] = pa; pat_f[w * 4 + 1] = pc; pat_f[w * 4 + 2] = pt; pat_f[w * 4 + 3] = pg;
-        pat_r[w * 4 + 0] = ra; pat_r[w * 4 + 1] = rc; pat_r[w * 4 + 2] = rt; pat_r[w * 4 + 3] = rg;
+        uint32_t f[4], r[4];
+        pattern_words(query, query_size, w, f, r);
+        pat_f[w * 4 + 0] = f[0]; pat_f[w * 4 + 1] = f[1]; pat_f[w * 4 + 2] = f[2]; pat_f[w * 4 + 3] = f[3];
+        pat_r[w * 4 + 0] = r[0]; pat_r[w * 4 + 1] = r[1]; pat_r[w * 4 + 2] = r[2]; pat_r[w * 4 + 3] = r[3];
     }
 
     // last row of the edit-distance matrix of query[qb, qe) against target[tb, te): out[t], t = 0 .. te - tb
@@ -965,6 +982,91 @@ __global__ __launch_bounds__(64) void hirschberg_myers_kernel(HirschbergArgs a)
     a.result_lengths[idx] = ok ? len : 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Unit hooks (the reference's test kernels: Test_HirschbergMyers.cu:37-53, Test_MyersAlgorithm.cu:42-97): they run the
+// production device functions above on one pair with one active lane.
+// ------------------------------------------------------------------------------------------------
+struct PlainTable
+{
+    const uint32_t* p;
+    __device__ __forceinline__ uint32_t operator[](int32_t e) const { return p[e]; }
+};
+
+// out[w * 8 + c]: c = 0..3 forward A, C, T, G; 4..7 back to front (the layout of the reference's n_words x 8 matrix)
+__global__ void myers_patterns_hook_kernel(const char* query, int32_t query_size, uint32_t* out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int32_t n_words = ceil_div(query_size, kWord);
+    for (int32_t w = 0; w < n_words; ++w)
+    {
+        uint32_t f[4], r[4];
+        pattern_words(query, query_size, w, f, r);
+        for (int c = 0; c < 4; ++c)
+        {
+            out[w * 8 + c]     = f[c];
+            out[w * 8 + 4 + c] = r[c];
+        }
+    }
+}
+
+// out[i] = get_query_pattern(patterns, idx, i, x, reverse) for the shifts i = 0..31 (hirschberg_myers_gpu.cu:244-276);
+// table: scratch of 4 * n_words words
+__global__ void myers_get_pattern_hook_kernel(const char* query, int32_t query_size, int32_t idx, char x, int32_t reverse,
+                                              uint32_t* table, uint32_t* out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int32_t n_words = ceil_div(query_size, kWord);
+    for (int32_t w = 0; w < n_words; ++w)
+    {
+        uint32_t f[4], r[4];
+        pattern_words(query, query_size, w, f, r);
+        for (int c = 0; c < 4; ++c) table[w * 4 + c] = reverse ? r[c] : f[c];
+    }
+    const PlainTable t{table};
+    for (int32_t i = 0; i < 32; ++i) out[i] = get_pattern(t, n_words, idx, i, x);
+}
+
+// one band attempt with a given band (myers_compute_scores_edit_dist_banded_test_kernel, Test_MyersAlgorithm.cu:42-97):
+// lane 0 of one wave; ws = 64 * (3 * n_words_band * (target + 1) + 4 * n_words) words, interleaved like the production kernel
+__global__ __launch_bounds__(64) void myers_banded_matrices_hook_kernel(const char* query, const char* target, int32_t query_size,
+                                                                        int32_t target_size, int32_t band_width, int32_t p, uint32_t* ws,
+                                                                        int32_t* diag_out)
+{
+    if (threadIdx.x != 0) return;
+    const int32_t n_words      = ceil_div(query_size, kWord);
+    const int32_t n_words_band = ceil_div(band_width, kWord);
+    const int64_t me           = (int64_t)n_words_band * ((int64_t)target_size + 1);
+    Band b;
+    b.pv     = ws;
+    b.mv     = ws + 64 * me;
+    b.score  = reinterpret_cast<int32_t*>(ws + 128 * me);
+    b.n_rows = n_words_band;
+    const LaneArray patterns{ws + 192 * me};
+    for (int32_t w = 0; w < n_words; ++w)
+    {
+        uint32_t f[4], r[4];
+        pattern_words(query, query_size, w, f, r);
+        for (int c = 0; c < 4; ++c) patterns[w * 4 + c] = f[c];
+    }
+    if (band_width - (n_words_band - 1) * kWord < 2) // invalid band: everything zero (the reference's test kernel does the same)
+    {
+        for (int32_t t = 0; t <= target_size; ++t)
+            for (int32_t w = 0; w < n_words_band; ++w) { b.pv[b.at(w, t)] = 0; b.mv[b.at(w, t)] = 0; b.score[b.at(w, t)] = 0; }
+        return;
+    }
+    for (int32_t w = 0; w < n_words_band; ++w)
+    {
+        b.pv[b.at(w, 0)]    = ~0u;
+        b.mv[b.at(w, 0)]    = 0u;
+        b.score[b.at(w, 0)] = min((w + 1) * kWord, band_width);
+    }
+    ColumnState cs{};
+    int32_t diagonal_begin = -1, diagonal_end = -1;
+    banded_stripes<false>(b, cs, patterns, n_words, target, query_size, target_size, p, n_words_band, band_width, diagonal_begin, diagonal_end);
+    diag_out[0] = diagonal_begin;
+    diag_out[1] = diagonal_end;
+}
+
 static int fail(hipError_t e, const char* what)
 {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -1083,6 +1185,41 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
     return 0;
 }
 
+
+int gwhip_myers_test_patterns(const char* query_d, int32_t query_length, uint32_t* patterns_d, gwhip_stream_t stream_)
+{
+    if (!query_d || !patterns_d || query_length < 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(myers_patterns_hook_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, query_d, query_length, patterns_d);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail(e, "myers_patterns_hook_kernel launch");
+}
+
+int gwhip_myers_test_get_pattern(const char* query_d, int32_t query_length, int32_t word_index, char x, int32_t reverse,
+                                 uint32_t* scratch_d, uint32_t* out32_d, gwhip_stream_t stream_)
+{
+    if (!query_d || !scratch_d || !out32_d || query_length < 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(myers_get_pattern_hook_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, query_d, query_length, word_index, x,
+                       reverse, scratch_d, out32_d);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail(e, "myers_get_pattern_hook_kernel launch");
+}
+
+size_t gwhip_myers_test_banded_matrices_words(int32_t query_length, int32_t target_length, int32_t band_width)
+{
+    const int64_t nwb = (band_width + kWord - 1) / kWord, nw = (query_length + kWord - 1) / kWord;
+    return (size_t)(64 * (3 * nwb * ((int64_t)target_length + 1) + 4 * nw));
+}
+
+int gwhip_myers_test_banded_matrices(const char* query_d, const char* target_d, int32_t query_length, int32_t target_length,
+                                     int32_t band_width, int32_t p, uint32_t* workspace_d, int32_t* diagonals_d, gwhip_stream_t stream_)
+{
+    if (!query_d || !target_d || !workspace_d || !diagonals_d || query_length <= 0 || target_length <= 0 || band_width <= 0)
+        return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(myers_banded_matrices_hook_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, query_d, target_d, query_length,
+                       target_length, band_width, p, workspace_d, diagonals_d);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail(e, "myers_banded_matrices_hook_kernel launch");
+}
 
 size_t gwhip_hirschberg_myers_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host, int32_t max_query_length)
 {

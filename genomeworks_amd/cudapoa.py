@@ -292,6 +292,82 @@ class CudaPoaBatch:
         self._L.gw_poa_reset(self._h)
 
 
+# ---- cudapoa/multi_device.hpp -----------------------------------------------------------------------------------
+def process_windows_multi_device(windows, max_sequences_per_poa, max_sequence_size, devices=(0,), batches_per_device=1,
+                                 memory_per_device=-1, output_type="consensus", band_mode="static_band",
+                                 alignment_band_width=256, max_consensus_size=None, max_nodes_per_graph=None,
+                                 matrix_sequence_dimension=None, max_banded_pred_distance=None, gap_score=-8,
+                                 mismatch_score=-6, match_score=8):
+    """cudapoa::process_windows_multi_device: every window through one worker (host thread + stream + Batch) per entry of
+    `devices` x batches_per_device; a device id may repeat (logical shards of one device). Windows are pulled from a shared
+    cursor and results are placed by global window index, so the output does not depend on the worker layout.
+    Returns dict(consensus, coverage | msa, status, worker, launches)."""
+    L = _bind(_native.host())
+    vp, i32 = C.c_void_p, C.c_int32
+    L.gw_poa_multi_device_run.restype = vp
+    L.gw_poa_multi_device_run.argtypes = [i32, C.POINTER(i32), C.POINTER(C.c_char_p), C.POINTER(i32),
+                                          C.POINTER(_native.PoaBatchConfig), C.POINTER(i32), i32, i32, C.c_int64, C.c_int8,
+                                          C.c_int16, C.c_int16, C.c_int16]
+    for name in ("gw_poa_multi_destroy", "gw_poa_multi_launches"):
+        getattr(L, name).argtypes = [vp]
+    for name in ("gw_poa_multi_status", "gw_poa_multi_worker", "gw_poa_multi_msa_rows"):
+        getattr(L, name).argtypes = [vp, i32]
+    L.gw_poa_multi_consensus.restype = C.POINTER(C.c_char)
+    L.gw_poa_multi_consensus.argtypes = [vp, i32, C.POINTER(i32)]
+    L.gw_poa_multi_coverage.restype = C.POINTER(C.c_uint16)
+    L.gw_poa_multi_coverage.argtypes = [vp, i32, C.POINTER(i32)]
+    L.gw_poa_multi_msa_row.restype = C.POINTER(C.c_char)
+    L.gw_poa_multi_msa_row.argtypes = [vp, i32, i32, C.POINTER(i32)]
+    if band_mode not in _BAND_MODES:
+        raise RuntimeError("Unknown band_mode provided.")
+    mx_consensus = 2 * max_sequence_size if max_consensus_size is None else max_consensus_size
+    nodes = 3 * max_sequence_size if max_nodes_per_graph is None else max_nodes_per_graph
+    if matrix_sequence_dimension is None:
+        msd = max_sequence_size if band_mode == "full_band" else (
+            alignment_band_width + 8 if band_mode.startswith("static") else 2 * (alignment_band_width + 8))
+    else:
+        msd = matrix_sequence_dimension
+    pred = 2 * ((alignment_band_width + 127) // 128 * 128) if max_banded_pred_distance is None else max_banded_pred_distance
+    cfg = _native.PoaBatchConfig()
+    if L.gw_poa_batch_config_full(C.byref(cfg), max_sequence_size, mx_consensus, nodes, alignment_band_width,
+                                  max_sequences_per_poa, msd, _BAND_MODES[band_mode], pred) != 0:
+        raise ValueError(L.gw_last_error().decode())
+    raw = [[s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in w] for w in windows]
+    flat = [b for w in raw for b in w]
+    n = len(raw)
+    per_window = (i32 * max(n, 1))(*[len(w) for w in raw])
+    seqs = (C.c_char_p * max(len(flat), 1))(*flat)
+    lens = (i32 * max(len(flat), 1))(*[len(b) for b in flat])
+    devs = (i32 * len(devices))(*devices)
+    mask = 2 if output_type == "msa" else 1
+    h = L.gw_poa_multi_device_run(n, per_window, seqs, lens, C.byref(cfg), devs, len(devices), batches_per_device,
+                                  int(memory_per_device), mask, gap_score, mismatch_score, match_score)
+    if not h:
+        raise RuntimeError(L.gw_last_error().decode())
+    try:
+        out = dict(status=[L.gw_poa_multi_status(h, w) for w in range(n)], worker=[L.gw_poa_multi_worker(h, w) for w in range(n)],
+                   launches=L.gw_poa_multi_launches(h))
+        ln = i32(0)
+        if mask == 1:
+            out["consensus"], out["coverage"] = [], []
+            for w in range(n):
+                p = L.gw_poa_multi_consensus(h, w, C.byref(ln))
+                out["consensus"].append(C.string_at(p, ln.value).decode())
+                q = L.gw_poa_multi_coverage(h, w, C.byref(ln))
+                out["coverage"].append([q[k] for k in range(ln.value)])
+        else:
+            out["msa"] = []
+            for w in range(n):
+                rows = []
+                for r in range(L.gw_poa_multi_msa_rows(h, w)):
+                    p = L.gw_poa_multi_msa_row(h, w, r, C.byref(ln))
+                    rows.append(C.string_at(p, ln.value).decode())
+                out["msa"].append(rows)
+        return out
+    finally:
+        L.gw_poa_multi_destroy(h)
+
+
 # ---- cudapoa/utils.hpp: batch-shape planning and window-file readers -------------------------------------------
 def _bind_utils(L):
     if getattr(L, "_gw_poa_utils_bound", False):

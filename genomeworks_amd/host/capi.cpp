@@ -15,6 +15,7 @@
 #include "aligner_impl.hpp"
 #include "aligner_global.hpp"
 #include "alignment_impl.hpp"
+#include <claraparabricks/genomeworks/cudapoa/multi_device.hpp>
 #include <claraparabricks/genomeworks/utils/cudautils.hpp>
 #include <stdexcept>
 #include <claraparabricks/genomeworks/cudaaligner/aligner.hpp>
@@ -516,6 +517,64 @@ int gw_aligner_band_cells(gw_aligner* a, uint64_t* cells)
     GW_CATCH(-1)
 }
 
+
+// ---- cudapoa/multi_device.hpp ---------------------------------------------------------------------------------
+
+struct gw_poa_multi
+{
+    poa::MultiDeviceOutput out;
+};
+
+gw_poa_multi* gw_poa_multi_device_run(int32_t n_windows, const int32_t* reads_per_window, const char* const* seqs,
+                                      const int32_t* lengths, const gw_poa_batch_config* cfg, const int32_t* devices,
+                                      int32_t n_devices, int32_t batches_per_device, int64_t memory_per_device, int8_t output_mask,
+                                      int16_t gap_score, int16_t mismatch_score, int16_t match_score)
+{
+    GW_TRY
+    std::vector<std::vector<std::string>> windows(static_cast<size_t>(n_windows));
+    size_t at = 0;
+    for (int32_t w = 0; w < n_windows; ++w)
+        for (int32_t r = 0; r < reads_per_window[w]; ++r, ++at) windows[static_cast<size_t>(w)].emplace_back(seqs[at], static_cast<size_t>(lengths[at]));
+    const poa::BatchConfig c(cfg->max_sequence_size, cfg->max_consensus_size, cfg->max_nodes_per_graph, cfg->alignment_band_width,
+                             cfg->max_sequences_per_poa, cfg->matrix_sequence_dimension, static_cast<poa::BandMode>(cfg->band_mode),
+                             cfg->max_banded_pred_distance);
+    poa::MultiDeviceConfig mc;
+    mc.devices.assign(devices, devices + n_devices);
+    mc.batches_per_device = batches_per_device;
+    mc.memory_per_device  = memory_per_device;
+    mc.output_mask        = output_mask;
+    mc.gap_score          = gap_score;
+    mc.mismatch_score     = mismatch_score;
+    mc.match_score        = match_score;
+    auto h = std::make_unique<gw_poa_multi>();
+    poa::process_windows_multi_device(h->out, windows, c, mc);
+    return h.release();
+    GW_CATCH(nullptr)
+}
+
+void gw_poa_multi_destroy(gw_poa_multi* h) { delete h; }
+int32_t gw_poa_multi_launches(gw_poa_multi* h) { return h->out.launches; }
+int32_t gw_poa_multi_status(gw_poa_multi* h, int32_t w) { return static_cast<int32_t>(h->out.status.at(static_cast<size_t>(w))); }
+int32_t gw_poa_multi_worker(gw_poa_multi* h, int32_t w) { return h->out.worker_of_window.at(static_cast<size_t>(w)); }
+const char* gw_poa_multi_consensus(gw_poa_multi* h, int32_t w, int32_t* length)
+{
+    const std::string& s = h->out.consensus.at(static_cast<size_t>(w));
+    if (length) *length = static_cast<int32_t>(s.size());
+    return s.c_str();
+}
+const uint16_t* gw_poa_multi_coverage(gw_poa_multi* h, int32_t w, int32_t* length)
+{
+    const auto& v = h->out.coverage.at(static_cast<size_t>(w));
+    if (length) *length = static_cast<int32_t>(v.size());
+    return v.data();
+}
+int32_t gw_poa_multi_msa_rows(gw_poa_multi* h, int32_t w) { return static_cast<int32_t>(h->out.msa.at(static_cast<size_t>(w)).size()); }
+const char* gw_poa_multi_msa_row(gw_poa_multi* h, int32_t w, int32_t row, int32_t* length)
+{
+    const std::string& s = h->out.msa.at(static_cast<size_t>(w)).at(static_cast<size_t>(row));
+    if (length) *length = static_cast<int32_t>(s.size());
+    return s.c_str();
+}
 
 // ---- cudapoa/utils.hpp: batch-shape planning and window-file readers -----------------------------------------
 

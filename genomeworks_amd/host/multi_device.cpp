@@ -1,0 +1,201 @@
+// multi_device.cpp -- see include/claraparabricks/genomeworks/cudapoa/multi_device.hpp.
+#include <claraparabricks/genomeworks/cudapoa/multi_device.hpp>
+#include <claraparabricks/genomeworks/utils/allocator.hpp>
+#include <claraparabricks/genomeworks/utils/cudautils.hpp>
+#include <claraparabricks/genomeworks/utils/signed_integer_utils.hpp>
+
+#include <algorithm>
+#include <atomic>
+#include <exception>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <thread>
+
+namespace claraparabricks
+{
+namespace genomeworks
+{
+namespace cudapoa
+{
+
+namespace
+{
+struct SharedCursor
+{
+    std::mutex mutex;
+    size_t next = 0;
+};
+
+// One worker: fills its batch from the cursor, runs it, stores by global index; until the windows run out.
+void worker_loop(int32_t worker, int32_t device, cudaStream_t stream, DefaultDeviceAllocator allocator, int64_t memory,
+                 const BatchConfig& batch_size, const MultiDeviceConfig& config, const std::vector<std::vector<std::string>>& windows,
+                 SharedCursor& cursor, MultiDeviceOutput& out, std::atomic<int32_t>& launches)
+{
+    scoped_device_switch dev(device);
+    std::unique_ptr<Batch> batch = create_batch(device, stream, allocator, memory, config.output_mask, batch_size, config.gap_score,
+                                                config.mismatch_score, config.match_score);
+    const bool want_msa = (config.output_mask & OutputType::msa) != 0;
+    std::vector<size_t> in_batch;
+    for (;;)
+    {
+        batch->reset();
+        in_batch.clear();
+        {
+            // the cursor only moves under the lock: a window is taken by exactly one worker
+            std::lock_guard<std::mutex> guard(cursor.mutex);
+            while (cursor.next < windows.size())
+            {
+                const std::vector<std::string>& window = windows[cursor.next];
+                Group group;
+                group.reserve(window.size());
+                for (const std::string& read : window) group.push_back(Entry{read.c_str(), nullptr, get_size<int32_t>(read)});
+                std::vector<StatusType> per_read;
+                const StatusType st = batch->add_poa_group(per_read, group);
+                if (st == StatusType::exceeded_maximum_poas)
+                {
+                    if (in_batch.empty()) throw std::runtime_error("a batch of this configuration cannot hold a single window");
+                    break;
+                }
+                out.worker_of_window[cursor.next] = worker;
+                if (st == StatusType::success)
+                    in_batch.push_back(cursor.next);
+                else if (st == StatusType::empty_poa_group && !window.empty())
+                {
+                    // every read was refused after the batch opened a POA for the group (cudapoa_batch.cuh:122-150): the
+                    // empty POA owns an output slot of this launch; its window reports the add status
+                    out.status[cursor.next] = st;
+                    in_batch.push_back(windows.size()); // placeholder slot
+                }
+                else
+                    out.status[cursor.next] = st;
+                cursor.next++;
+            }
+        }
+        if (batch->get_total_poas() == 0) break;
+        batch->generate_poa();
+        launches++;
+        std::vector<StatusType> status;
+        if (want_msa)
+        {
+            std::vector<std::vector<std::string>> msa;
+            batch->get_msa(msa, status);
+            if (msa.size() != in_batch.size()) throw std::runtime_error("MSA count does not match the windows of the batch");
+            for (size_t k = 0; k < in_batch.size(); k++)
+                if (in_batch[k] < windows.size())
+                {
+                    out.msa[in_batch[k]]    = std::move(msa[k]);
+                    out.status[in_batch[k]] = status[k];
+                }
+        }
+        else
+        {
+            std::vector<std::string> consensus;
+            std::vector<std::vector<uint16_t>> coverage;
+            batch->get_consensus(consensus, coverage, status);
+            if (consensus.size() != in_batch.size()) throw std::runtime_error("consensus count does not match the windows of the batch");
+            for (size_t k = 0; k < in_batch.size(); k++)
+                if (in_batch[k] < windows.size())
+                {
+                    out.consensus[in_batch[k]] = std::move(consensus[k]);
+                    out.coverage[in_batch[k]]  = std::move(coverage[k]);
+                    out.status[in_batch[k]]    = status[k];
+                }
+        }
+    }
+}
+} // namespace
+
+void process_windows_multi_device(MultiDeviceOutput& out, const std::vector<std::vector<std::string>>& windows,
+                                  const BatchConfig& batch_size, const MultiDeviceConfig& config)
+{
+    if (config.devices.empty()) throw std::invalid_argument("at least one device is needed");
+    if (config.batches_per_device < 1) throw std::invalid_argument("batches_per_device has to be at least 1");
+    int32_t n_devices = 0;
+    GW_CU_CHECK_ERR(hipGetDeviceCount(&n_devices));
+    std::map<int32_t, int32_t> entries_of_device;
+    for (int32_t d : config.devices)
+    {
+        if (d < 0 || d >= n_devices) throw std::invalid_argument("device id out of range: " + std::to_string(d));
+        entries_of_device[d]++;
+    }
+    const size_t n = windows.size();
+    out            = MultiDeviceOutput{};
+    out.status.assign(n, StatusType::success);
+    out.worker_of_window.assign(n, -1);
+    if (config.output_mask & OutputType::msa)
+        out.msa.resize(n);
+    else
+    {
+        out.consensus.resize(n);
+        out.coverage.resize(n);
+    }
+    if (n == 0) return;
+
+    // one allocator per entry of `devices`, shared by that entry's batches (as multi_batch.hpp:52-60 shares one)
+    struct Group
+    {
+        int32_t device;
+        int64_t memory;
+        DefaultDeviceAllocator allocator;
+    };
+    std::vector<Group> groups;
+    for (int32_t d : config.devices)
+    {
+        scoped_device_switch dev(d);
+        int64_t memory = config.memory_per_device;
+        if (memory < 0)
+        {
+            size_t free_bytes = 0, total_bytes = 0;
+            GW_CU_CHECK_ERR(hipMemGetInfo(&free_bytes, &total_bytes));
+            // free memory is read before any group of this device allocates: the entries naming the device share it
+            memory = static_cast<int64_t>(config.memory_fraction * static_cast<double>(free_bytes)) / entries_of_device[d];
+        }
+        groups.push_back(Group{d, memory, DefaultDeviceAllocator()});
+    }
+    // allocate after all the free-memory readings
+    for (Group& g : groups)
+    {
+        scoped_device_switch dev(g.device);
+        g.allocator = DefaultDeviceAllocator(static_cast<size_t>(g.memory), nullptr);
+    }
+
+    SharedCursor cursor;
+    std::atomic<int32_t> launches{0};
+    std::vector<std::thread> threads;
+    std::vector<cudaStream_t> streams;
+    std::vector<std::exception_ptr> errors(groups.size() * static_cast<size_t>(config.batches_per_device));
+    int32_t worker = 0;
+    for (Group& g : groups)
+        for (int32_t b = 0; b < config.batches_per_device; b++, worker++)
+        {
+            scoped_device_switch dev(g.device);
+            cudaStream_t stream = nullptr;
+            GW_CU_CHECK_ERR(hipStreamCreate(&stream));
+            streams.push_back(stream);
+            const int64_t memory = g.memory / config.batches_per_device;
+            threads.emplace_back([&, worker, stream, memory, device = g.device, allocator = g.allocator]() {
+                try
+                {
+                    worker_loop(worker, device, stream, allocator, memory, batch_size, config, windows, cursor, out, launches);
+                }
+                catch (...)
+                {
+                    errors[static_cast<size_t>(worker)] = std::current_exception();
+                }
+            });
+        }
+    for (std::thread& t : threads) t.join();
+    for (size_t k = 0; k < streams.size(); k++)
+    {
+        scoped_device_switch dev(groups[k / static_cast<size_t>(config.batches_per_device)].device);
+        (void)hipStreamDestroy(streams[k]);
+    }
+    out.launches = launches.load();
+    for (const std::exception_ptr& e : errors)
+        if (e) std::rethrow_exception(e);
+}
+
+} // namespace cudapoa
+} // namespace genomeworks
+} // namespace claraparabricks

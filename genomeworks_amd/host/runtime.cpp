@@ -156,4 +156,34 @@ int64_t gw_generate_pairs(uint32_t seed, int32_t n_pairs, int32_t len, int32_t m
     }
 }
 
+int64_t gw_generate_random_length_pairs(uint32_t seed, int32_t n_pairs, int32_t max_len, char* out, int64_t out_cap, int32_t* tlens,
+                                        int32_t* qlens)
+{
+    try
+    {
+        std::minstd_rand rng(seed);
+        std::uniform_int_distribution<int> random_length(0, max_len);
+        int64_t off = 0;
+        for (int32_t i = 0; i < n_pairs; i++)
+        {
+            const std::string t = gw::genomeutils::generate_random_genome(random_length(rng), rng);
+            const int n         = static_cast<int>(t.size());
+            const std::string q = gw::genomeutils::generate_random_sequence(t, rng, n, n, n);
+            if (off + (int64_t)(q.size() + t.size()) > out_cap) return -1;
+            std::memcpy(out + off, t.data(), t.size());
+            off += (int64_t)t.size();
+            std::memcpy(out + off, q.data(), q.size());
+            off += (int64_t)q.size();
+            tlens[i] = (int32_t)t.size();
+            qlens[i] = (int32_t)q.size();
+        }
+        return off;
+    }
+    catch (const std::exception& e)
+    {
+        gwhost::set_last_error(e.what());
+        return -2;
+    }
+}
+
 } // extern "C"

@@ -59,3 +59,24 @@ def long_read_window(w, max_len=32768, min_len=2000):
     mut, ins, dele = (int(2 * backbone * div * f) for f in (0.2, 0.4, 0.4))
     reads = [r.decode() for r in generate_window(2000 + w, backbone, n_reads, mut, ins, dele)]
     return [s for s in reads if len(s) < max_len]
+
+
+def random_length_pairs(seed, n_pairs, max_len):
+    """The random pairs of the reference's aligner test cases (cudaaligner_test_cases.cpp:29-41): list of
+    (target, query) bytes."""
+    cap = n_pairs * (2 * max_len + 8) * 2
+    buf = np.zeros(cap, np.uint8)
+    tl = np.zeros(n_pairs, np.int32)
+    ql = np.zeros(n_pairs, np.int32)
+    L = _native.host()
+    L.gw_generate_random_length_pairs.restype = C.c_int64
+    n = L.gw_generate_random_length_pairs(C.c_uint32(seed), C.c_int32(n_pairs), C.c_int32(max_len), C.c_void_p(buf.ctypes.data),
+                                          C.c_int64(cap), C.c_void_p(tl.ctypes.data), C.c_void_p(ql.ctypes.data))
+    if n < 0:
+        raise RuntimeError("gw_generate_random_length_pairs failed: %d" % n)
+    out, off = [], 0
+    for a, b in zip(tl, ql):
+        t = bytes(buf[off:off + a]); off += int(a)
+        q = bytes(buf[off:off + b]); off += int(b)
+        out.append((t, q))
+    return out

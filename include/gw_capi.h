@@ -44,6 +44,12 @@ int64_t gw_generate_window(uint32_t seed, int32_t backbone_len, int32_t n_reads,
 int64_t gw_generate_pairs(uint32_t seed, int32_t n_pairs, int32_t len, int32_t max_mut, int32_t max_ins,
                           int32_t max_del, char* out, int64_t out_cap, int32_t* qlens, int32_t* tlens);
 
+/* The random test pairs of the reference's aligner tests (cudaaligner/tests/cudaaligner_test_cases.cpp:29-41): per pair
+   a target of uniform random length in [0, max_len], then query = generate_random_sequence(target, rng, len, len, len);
+   one std::minstd_rand(seed) stream. Written as t0 q0 t1 q1 ...; returns total bytes, -1 if out_cap is too small. */
+int64_t gw_generate_random_length_pairs(uint32_t seed, int32_t n_pairs, int32_t max_len, char* out, int64_t out_cap,
+                                        int32_t* tlens, int32_t* qlens);
+
 /* ---- cudapoa::BatchConfig (batch.hpp:60-86, batch.cu:34-104) ---- */
 typedef struct gw_poa_batch_config
 {
@@ -110,6 +116,25 @@ int gw_poa_relaunch(gw_poa_batch* b);
 int gw_poa_relaunch_timed(gw_poa_batch* b, float* graph_build_ms, float* output_ms);
 /* profiling aid: mean s_memtime ticks per window of {row table, NW forward, sink+traceback, graph merge, topsort, other} */
 int gw_poa_profile_phases(gw_poa_batch* b, double* out6);
+
+/* ---- cudapoa/multi_device.hpp: windows over several devices / several batches per device (one host thread, stream
+   and Batch per worker; windows pulled from a shared cursor; results by global window index; no collective) ---- */
+typedef struct gw_poa_multi gw_poa_multi;
+/* seqs / lengths: the reads of all windows back to back (reads_per_window[w] of them per window). devices[n_devices]:
+   device id per worker group (an id may repeat: logical shards of one device). memory_per_device: bytes per entry of
+   devices, -1 = 0.9 x free / entries naming the device. Returns NULL on exception (gw_last_error). */
+gw_poa_multi* gw_poa_multi_device_run(int32_t n_windows, const int32_t* reads_per_window, const char* const* seqs,
+                                      const int32_t* lengths, const gw_poa_batch_config* cfg, const int32_t* devices,
+                                      int32_t n_devices, int32_t batches_per_device, int64_t memory_per_device, int8_t output_mask,
+                                      int16_t gap_score, int16_t mismatch_score, int16_t match_score);
+void gw_poa_multi_destroy(gw_poa_multi* h);
+int32_t gw_poa_multi_launches(gw_poa_multi* h);
+int32_t gw_poa_multi_status(gw_poa_multi* h, int32_t window);
+int32_t gw_poa_multi_worker(gw_poa_multi* h, int32_t window);
+const char* gw_poa_multi_consensus(gw_poa_multi* h, int32_t window, int32_t* length);
+const uint16_t* gw_poa_multi_coverage(gw_poa_multi* h, int32_t window, int32_t* length);
+int32_t gw_poa_multi_msa_rows(gw_poa_multi* h, int32_t window);
+const char* gw_poa_multi_msa_row(gw_poa_multi* h, int32_t window, int32_t row, int32_t* length);
 
 /* ---- cudaaligner (aligner.hpp:76-219) ---- */
 gw_aligner* gw_aligner_create_banded(int32_t max_bandwidth, void* stream, int32_t device_id, int64_t max_device_memory);

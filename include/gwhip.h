@@ -238,6 +238,22 @@ int gwhip_ukkonen(const gwhip_ukkonen_args* args, gwhip_stream_t stream);
 
 /* ---- misc ---- */
 /* Copies the last error text of the calling thread (NUL terminated) and returns its length. */
+/* ---- cudaaligner unit hooks (device pointers): the production device functions on one pair ---- */
+/* myers_preprocess (hirschberg_myers_gpu.cu:227-242; Test_HirschbergMyers.cu:94-148): patterns[w * 8 + c],
+   c = 0..3 forward A, C, T, G, c = 4..7 the same for the query read back to front; ceil(len / 32) x 8 words. */
+int gwhip_myers_test_patterns(const char* query_d, int32_t query_length, uint32_t* patterns_d, gwhip_stream_t stream);
+/* get_query_pattern(patterns, word_index, shift, x, reverse) for the shifts 0..31 (hirschberg_myers_gpu.cu:244-276;
+   Test_HirschbergMyers.cu:150-211). scratch: 4 * ceil(len / 32) words. */
+int gwhip_myers_test_get_pattern(const char* query_d, int32_t query_length, int32_t word_index, char x, int32_t reverse,
+                                 uint32_t* scratch_d, uint32_t* out32_d, gwhip_stream_t stream);
+/* One band attempt of the banded Myers kernel with a given band_width and p (the reference's
+   myers_compute_scores_edit_dist_banded_test_kernel, Test_MyersAlgorithm.cu:42-97). The workspace holds, lane-interleaved
+   (element k at word k * 64): pv[nwb * (t + 1)] | mv[...] | score[...] | patterns, column-major (word w, column j at
+   j * nwb + w); diagonals_d receives {diagonal_begin, diagonal_end}. */
+size_t gwhip_myers_test_banded_matrices_words(int32_t query_length, int32_t target_length, int32_t band_width);
+int gwhip_myers_test_banded_matrices(const char* query_d, const char* target_d, int32_t query_length, int32_t target_length,
+                                     int32_t band_width, int32_t p, uint32_t* workspace_d, int32_t* diagonals_d, gwhip_stream_t stream);
+
 int gwhip_last_error_string(char* buf, size_t len);
 /* Compile-time facts a test can assert without a GPU. */
 const char* gwhip_build_arch(void); /* "gfx950" */
