@@ -160,6 +160,9 @@ gwhip_poa_config make_device_config(const BatchConfig& b, int8_t output_mask, in
 #ifdef SPOA_ACCURATE
     c.spoa_accurate = 1;
 #endif
+    // the reference selects the racon-style topological order at build time (-Dspoa_accurate=ON, cudapoa_kernels.cuh:
+    // 516-531); the kernels here take it as a run-time flag, so one build serves both -- GW_SPOA_ACCURATE=1 turns it on
+    if (const char* e = std::getenv("GW_SPOA_ACCURATE")) c.spoa_accurate = (e[0] == '1') ? 1 : c.spoa_accurate;
     return c;
 }
 

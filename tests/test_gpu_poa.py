@@ -349,3 +349,31 @@ def test_high_degree_graphs_vs_oracle():
             assert status[i] == ref["status"]
             if ref["status"] == 0:
                 assert msa[i] == ref["msa"], i
+
+
+@pytest.mark.parametrize("band_mode", ["static_band", "full_band", "adaptive_band"])
+def test_spoa_accurate_topological_order_bit_exact(band_mode, monkeypatch):
+    """The reference's -Dspoa_accurate=ON build (racon-style topological sort after every read, cudapoa_topsort.cuh:45-128)
+    as a run-time flag of the same kernels: consensus, coverage and MSA equal the oracle run with spoa_accurate = 1."""
+    from genomeworks_amd import synthetic
+    monkeypatch.setenv("GW_SPOA_ACCURATE", "1")
+    windows = [[r.decode() for r in synthetic.generate_window(8100 + w, 400, 12, 24, 12, 12)] for w in range(4)]
+    b = run_gpu(windows, band_mode, max_seq=512, max_seqs=16)
+    cons, cov, status = b.get_consensus()
+    m = run_gpu(windows, band_mode, max_seq=512, max_seqs=16, output_type="msa")
+    msa, mstatus = m.get_msa()
+    monkeypatch.delenv("GW_SPOA_ACCURATE")
+    plain = run_gpu(windows, band_mode, max_seq=512, max_seqs=16)
+    pcons, _, _ = plain.get_consensus()
+    for mask, check in ((1, "consensus"), (2, "msa")):
+        cfg = oracle_cfg(band_mode, 512, 16, output_mask=mask)
+        cfg.spoa_accurate = 1
+        with O.Workspace(cfg) as ws:
+            for i, w in enumerate(windows):
+                ref = ws.process(w)
+                assert ref["status"] == 0
+                if check == "consensus":
+                    assert status[i] == 0 and cons[i] == ref["consensus"] and cov[i] == list(ref["coverage"])
+                else:
+                    assert mstatus[i] == 0 and msa[i] == ref["msa"]
+    assert len(pcons) == len(cons)  # the default order still runs in the same process (the flag is read per batch)
