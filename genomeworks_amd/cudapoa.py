@@ -301,15 +301,16 @@ def process_windows_multi_device(windows, max_sequences_per_poa, max_sequence_si
     """cudapoa::process_windows_multi_device: every window through one worker (host thread + stream + Batch) per entry of
     `devices` x batches_per_device; a device id may repeat (logical shards of one device). Windows are pulled from a shared
     cursor and results are placed by global window index, so the output does not depend on the worker layout.
-    Returns dict(consensus, coverage | msa, status, worker, launches)."""
+    Returns dict(consensus, coverage | msa, status, worker, launches, seconds)."""
     L = _bind(_native.host())
     vp, i32 = C.c_void_p, C.c_int32
     L.gw_poa_multi_device_run.restype = vp
     L.gw_poa_multi_device_run.argtypes = [i32, C.POINTER(i32), C.POINTER(C.c_char_p), C.POINTER(i32),
                                           C.POINTER(_native.PoaBatchConfig), C.POINTER(i32), i32, i32, C.c_int64, C.c_int8,
                                           C.c_int16, C.c_int16, C.c_int16]
-    for name in ("gw_poa_multi_destroy", "gw_poa_multi_launches"):
+    for name in ("gw_poa_multi_destroy", "gw_poa_multi_launches", "gw_poa_multi_seconds"):
         getattr(L, name).argtypes = [vp]
+    L.gw_poa_multi_seconds.restype = C.c_double
     for name in ("gw_poa_multi_status", "gw_poa_multi_worker", "gw_poa_multi_msa_rows"):
         getattr(L, name).argtypes = [vp, i32]
     L.gw_poa_multi_consensus.restype = C.POINTER(C.c_char)
@@ -346,7 +347,7 @@ def process_windows_multi_device(windows, max_sequences_per_poa, max_sequence_si
         raise RuntimeError(L.gw_last_error().decode())
     try:
         out = dict(status=[L.gw_poa_multi_status(h, w) for w in range(n)], worker=[L.gw_poa_multi_worker(h, w) for w in range(n)],
-                   launches=L.gw_poa_multi_launches(h))
+                   launches=L.gw_poa_multi_launches(h), seconds=L.gw_poa_multi_seconds(h))
         ln = i32(0)
         if mask == 1:
             out["consensus"], out["coverage"] = [], []

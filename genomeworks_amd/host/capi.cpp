@@ -554,6 +554,7 @@ gw_poa_multi* gw_poa_multi_device_run(int32_t n_windows, const int32_t* reads_pe
 
 void gw_poa_multi_destroy(gw_poa_multi* h) { delete h; }
 int32_t gw_poa_multi_launches(gw_poa_multi* h) { return h->out.launches; }
+double gw_poa_multi_seconds(gw_poa_multi* h) { return h->out.seconds; }
 int32_t gw_poa_multi_status(gw_poa_multi* h, int32_t w) { return static_cast<int32_t>(h->out.status.at(static_cast<size_t>(w))); }
 int32_t gw_poa_multi_worker(gw_poa_multi* h, int32_t w) { return h->out.worker_of_window.at(static_cast<size_t>(w)); }
 const char* gw_poa_multi_consensus(gw_poa_multi* h, int32_t w, int32_t* length)

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <exception>
 #include <map>
 #include <mutex>
@@ -162,6 +163,7 @@ void process_windows_multi_device(MultiDeviceOutput& out, const std::vector<std:
 
     SharedCursor cursor;
     std::atomic<int32_t> launches{0};
+    const auto t_begin = std::chrono::steady_clock::now();
     std::vector<std::thread> threads;
     std::vector<cudaStream_t> streams;
     std::vector<std::exception_ptr> errors(groups.size() * static_cast<size_t>(config.batches_per_device));
@@ -186,6 +188,7 @@ void process_windows_multi_device(MultiDeviceOutput& out, const std::vector<std:
             });
         }
     for (std::thread& t : threads) t.join();
+    out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     for (size_t k = 0; k < streams.size(); k++)
     {
         scoped_device_switch dev(groups[k / static_cast<size_t>(config.batches_per_device)].device);

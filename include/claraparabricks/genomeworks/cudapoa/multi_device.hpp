@@ -44,6 +44,8 @@ struct MultiDeviceOutput
     std::vector<StatusType> status;                 ///< [window] add_poa_group / kernel status
     std::vector<int32_t> worker_of_window;          ///< [window] which worker ran it (diagnostics; not deterministic)
     int32_t launches = 0;                           ///< generate_poa() calls over all workers
+    double seconds   = 0;                           ///< wall time from the first worker's start to the last worker's end
+                                                    ///< (batch creation, filling, kernels, result unpacking)
 };
 
 /// Runs every window (a window = its reads) under `batch_size`. Throws what create_batch / Batch throw.

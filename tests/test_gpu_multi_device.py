@@ -22,15 +22,15 @@ def test_consensus_equals_golden_for_any_worker_layout(devices, batches):
     rows, _ = G.config3_windows()
     n = 320
     windows = config3(n)
-    # 1.2 GB per shard: about 300 windows of this shape per shard, split over its batches -> every worker fills more than once
+    # 0.6 GB per shard: about 150 windows of this shape per shard, split over its batches -> no layout holds all 320 at once
     out = cudapoa.process_windows_multi_device(windows, 32, 1024, devices=devices, batches_per_device=batches,
-                                               memory_per_device=int(1.2e9), band_mode="static_band", max_nodes_per_graph=3072)
+                                               memory_per_device=int(0.6e9), band_mode="static_band", max_nodes_per_graph=3072)
     assert out["status"] == [rows[w]["status"] for w in range(n)]
     bad = [w for w in range(n) if out["consensus"][w] != rows[w]["consensus"] or out["coverage"][w] != rows[w]["coverage"]]
     assert not bad, bad[:10]
     workers = len(devices) * batches
     assert set(out["worker"]) <= set(range(workers)) and min(out["worker"]) >= 0
-    assert out["launches"] >= workers or workers == 1
+    assert out["launches"] >= max(workers, 3) and out["seconds"] > 0
     if workers > 1:
         assert len(set(out["worker"])) > 1  # the work really was spread over the workers
 
