@@ -563,17 +563,55 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
     if (a.band_cells) a.band_cells[idx] = cells;
 }
 
-// exclusive scan of max(run_counts, 0) into result_starts[n+1] (single workgroup, chunked)
-__global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t* run_counts, int32_t* result_starts, int32_t n)
+// Exclusive scan of max(run_counts, 0) into result_starts[n + 1] in three small launches (block totals, scan of the
+// totals by one workgroup, per-block rescan with its offset): a million pairs are 489 blocks instead of 977 rounds of one.
+constexpr int kScanBlock = 256, kScanPerThread = 8, kScanChunk = kScanBlock * kScanPerThread;
+
+__device__ __forceinline__ int32_t block_exclusive_scan(int32_t v, int32_t* total)
+{
+    // wave scan (DPP-free shuffles: these kernels are not on any critical path), then the wave totals through LDS
+    __shared__ int32_t wave_total[kScanBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1)
+    {
+        const int32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    int32_t before = 0, all = 0;
+    for (int w = 0; w < kScanBlock / 64; ++w)
+    {
+        if (w < wave) before += wave_total[w];
+        all += wave_total[w];
+    }
+    __syncthreads();
+    *total = all;
+    return before + incl - v;
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_block_totals_kernel(const int32_t* run_counts, int32_t* block_totals, int32_t n)
+{
+    const int32_t base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
+    int32_t sum        = 0;
+    for (int k = 0; k < kScanPerThread; ++k)
+        if (base + k < n) sum += max(run_counts[base + k], 0);
+    int32_t total;
+    (void)block_exclusive_scan(sum, &total);
+    if (threadIdx.x == 0) block_totals[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void scan_totals_kernel(int32_t* block_totals, int32_t n_blocks, int32_t* grand_total)
 {
     __shared__ int32_t part[1024];
     __shared__ int32_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int32_t base = 0; base < n; base += 1024)
+    for (int32_t base = 0; base < n_blocks; base += 1024)
     {
         const int32_t i = base + threadIdx.x;
-        const int32_t v = i < n ? max(run_counts[i], 0) : 0;
+        const int32_t v = i < n_blocks ? block_totals[i] : 0;
         part[threadIdx.x] = v;
         __syncthreads();
         for (int off = 1; off < 1024; off <<= 1)
@@ -583,22 +621,52 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t* run_co
             part[threadIdx.x] += t;
             __syncthreads();
         }
-        if (i < n) result_starts[i] = carry + part[threadIdx.x] - v;
+        if (i < n_blocks) block_totals[i] = carry + part[threadIdx.x] - v;
         __syncthreads();
         if (threadIdx.x == 1023) carry += part[1023];
         __syncthreads();
     }
-    if (threadIdx.x == 0) result_starts[n] = carry;
+    if (threadIdx.x == 0) *grand_total = carry;
 }
 
-__global__ void compact_kernel(KernelArgs a, int8_t* results, int32_t* result_counts, const int32_t* result_starts)
+__global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const int32_t* run_counts, const int32_t* block_offsets, int32_t* result_starts, int32_t n)
 {
-    // one workgroup per pair: copy its runs from the slot to the packed position
-    const int32_t idx = blockIdx.x;
+    const int32_t base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
+    int32_t v[kScanPerThread];
+    int32_t sum = 0;
+    for (int k = 0; k < kScanPerThread; ++k)
+    {
+        v[k] = base + k < n ? max(run_counts[base + k], 0) : 0;
+        sum += v[k];
+    }
+    int32_t total;
+    int32_t at = block_offsets[blockIdx.x] + block_exclusive_scan(sum, &total);
+    for (int k = 0; k < kScanPerThread; ++k)
+        if (base + k < n)
+        {
+            result_starts[base + k] = at;
+            at += v[k];
+        }
+}
+
+// one lane per pair: its runs move from the pair's own slot to the packed position (a few runs for short reads, a few
+// dozen at 1 kbp; four copies in flight per lane)
+__global__ __launch_bounds__(256) void compact_kernel(KernelArgs a, int8_t* results, int32_t* result_counts, const int32_t* result_starts)
+{
+    const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n) return;
     const int32_t nr  = max(a.run_counts[idx], 0);
     const int64_t src = a.starts[2 * idx];
     const int32_t dst = result_starts[idx];
-    for (int32_t k = threadIdx.x; k < nr; k += blockDim.x)
+    int32_t k         = 0;
+    for (; k + 4 <= nr; k += 4)
+    {
+        const int8_t o0 = a.slot_ops[src + k], o1 = a.slot_ops[src + k + 1], o2 = a.slot_ops[src + k + 2], o3 = a.slot_ops[src + k + 3];
+        const int32_t c0 = a.slot_counts[src + k], c1 = a.slot_counts[src + k + 1], c2 = a.slot_counts[src + k + 2], c3 = a.slot_counts[src + k + 3];
+        results[dst + k] = o0; results[dst + k + 1] = o1; results[dst + k + 2] = o2; results[dst + k + 3] = o3;
+        result_counts[dst + k] = c0; result_counts[dst + k + 1] = c1; result_counts[dst + k + 2] = c2; result_counts[dst + k + 3] = c3;
+    }
+    for (; k < nr; ++k)
     {
         results[dst + k]       = a.slot_ops[src + k];
         result_counts[dst + k] = a.slot_counts[src + k];
@@ -610,7 +678,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // fixed part of the workspace (depends on n and the total sequence length only), then the per-pair matrices
 struct WsPlan
 {
-    size_t off_ws_offsets, off_run_counts, off_slot_ops, off_slot_counts, off_cells, off_identity, off_ws;
+    size_t off_ws_offsets, off_run_counts, off_slot_ops, off_slot_counts, off_cells, off_identity, off_scan, off_ws;
 };
 
 static WsPlan plan_fixed(int32_t n, int64_t total_len)
@@ -624,6 +692,7 @@ static WsPlan plan_fixed(int32_t n, int64_t total_len)
     p.off_slot_counts = take(((size_t)total_len + 16) * 4);
     p.off_cells       = take((size_t)n * 8);
     p.off_identity    = take((size_t)n * 4);
+    p.off_scan        = take(((size_t)n / kScanChunk + 2) * 4);
     p.off_ws          = off;
     return p;
 }
@@ -1172,8 +1241,14 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
                            (size_t)(ka.lds_pattern_words + 3 * ka.lds_band_words) * 64 * sizeof(uint32_t), stream, ka);
     else
         hipLaunchKernelGGL(myers_banded_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, stream, ka);
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, ka.run_counts, args->result_starts, n);
-    hipLaunchKernelGGL(compact_kernel, dim3(n), dim3(64), 0, stream, ka, args->results, args->result_counts,
+    {
+        int32_t* block_totals  = reinterpret_cast<int32_t*>(ws + p.off_scan);
+        const int32_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
+        hipLaunchKernelGGL(scan_block_totals_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, ka.run_counts, block_totals, n);
+        hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, stream, block_totals, n_blocks, args->result_starts + n);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, ka.run_counts, block_totals, args->result_starts, n);
+    }
+    hipLaunchKernelGGL(compact_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ka, args->results, args->result_counts,
                        args->result_starts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(e, "myers kernels launch");

@@ -41,6 +41,7 @@ static_assert(kReadLds + kCodeTileLds >= 3072 * 2, "the incremental topsort keep
 constexpr int kWideRingBytes = 5 * (1536 + 8) * 4; // 30880
 constexpr int kBsRingBytes   = 2048; // band starts of the ring rows (64 x 4 B) + 64 staged rows of the HBM row table (64 x 24 B)
 constexpr int kReadWinBytes  = 4096;
+constexpr int kMwLds         = 256;  // arguments and carry words of the multi-wave forward pass (poa_device.h)
 
 struct KernelArgs
 {
@@ -96,11 +97,15 @@ __device__ GraphView<IdT> carve_graph(uint8_t* slab, const PoaLayout& L)
 // LDS_TABLES: the per-row table, the topsort working set and the current read live in LDS. It is a template
 // flag (not a runtime select) so every pointer has one address space and the row loop issues ds_* ops only:
 // a flat/global load in that loop would wait on the previous row's score store (shared in-order vmcnt).
-template <typename ScoreT, typename IdT, typename TraceT, int BM, bool MSA, bool LDS_TABLES>
-__global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
+// NW: wavefronts per window. 1 everywhere but for graphs beyond the LDS tables in the adaptive band mode (long reads),
+// where the wide bands' forward pass runs one wavefront per 256-column pass (generic_forward_mw); every other phase is
+// wave 0's, the helper wavefronts wait at a barrier in between.
+template <typename ScoreT, typename IdT, typename TraceT, int BM, bool MSA, bool LDS_TABLES, int NW>
+__global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane       = threadIdx.x;
+    const int lane       = threadIdx.x & (kWave - 1);
+    const int wave       = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int32_t w      = blockIdx.x;
     const gwhip_poa_config& c = a.cfg;
     uint8_t* slab        = a.workspace + (size_t)w * a.L.per_window;
@@ -138,6 +143,25 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
         scores = reinterpret_cast<ScoreT*>(slab + a.L.scores);
     TraceT* traceback = TB ? reinterpret_cast<TraceT*>(slab + a.L.trace) : nullptr;
     const float banded_buffer_size = __fmul_rn((float)c.max_nodes_per_graph, (float)c.matrix_sequence_dimension);
+    MwArgs<ScoreT>* mw_args = nullptr;
+    MwShared* mw_shared     = nullptr;
+    if constexpr (NW > 1)
+    {
+        static_assert(!LDS_TABLES, "the multi-wave forward pass belongs to the HBM-table layout");
+        mw_args   = reinterpret_cast<MwArgs<ScoreT>*>(smem + kWideRingBytes + kBsRingBytes + kReadWinBytes);
+        mw_shared = reinterpret_cast<MwShared*>(smem + kWideRingBytes + kBsRingBytes + kReadWinBytes + 128);
+        if (wave != 0)
+        {
+            // helper wavefronts: parked at the barrier until wave 0 reaches a wide-band forward pass (or the end)
+            for (;;)
+            {
+                block_barrier();
+                const MwArgs<ScoreT> A = *mw_args;
+                if (A.op != 1) return;
+                generic_forward_mw<ScoreT, IdT, RowT>(A, g, rowinfo, ring, lds_bs_ring, lds_read_window, mw_shared, wave, lane);
+            }
+        }
+    }
 
     // ---- backbone from read 0 (cudapoa_kernels.cuh:200-238), lanes in parallel ----
     const int32_t len0 = seq_lens[0];
@@ -178,7 +202,7 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
     int32_t node_count = len0;
     uint64_t phase_acc[kPhCount] = {0, 0, 0, 0, 0, 0};
     PhaseClock pc{a.phase_cycles ? phase_acc : nullptr, 0};
-    __syncthreads();
+    wave_sync();
     pc.start();
 
     for (int32_t s = 1; s < (int32_t)wd.num_seqs; s++)
@@ -207,7 +231,7 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
             for (int32_t i = lane * 4; i < stage_bytes; i += kWave * 4)
                 *reinterpret_cast<uint32_t*>(lds_read_buf + i) = *reinterpret_cast<const uint32_t*>(sequence + i);
         }
-        __syncthreads();
+        wave_sync();
         pc.tick(kPhRowInfo);
 
         int32_t alen;
@@ -234,12 +258,14 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
         {
             alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                 banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
-                                                c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring);
+                                                c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring,
+                                                mw_args, mw_shared);
             if (alen == kShiftLeft || alen == kShiftRight)
                 alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                     banded_buffer_size, alignment_graph, alignment_read,
                                                     c.alignment_band_width, c.gap_score, c.mismatch_score, c.match_score,
-                                                    alen, cells, pc, a.debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring);
+                                                    alen, cells, pc, a.debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring,
+                                                    mw_args, mw_shared);
         }
         else if (BM == GWHIP_STATIC_BAND || BM == GWHIP_ADAPTIVE_BAND)
         {
@@ -343,7 +369,7 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
                                   g.outgoing_edges, g.outgoing_edge_count, g.local_cnt);
         }
         status_and_count = wave_first(status_and_count);
-        __syncthreads();
+        wave_sync();
         if (status_and_count >= 0 && !c.spoa_accurate && graph_fits_lds)
         {
             if constexpr (LDS_TABLES)
@@ -362,6 +388,11 @@ __global__ __launch_bounds__(kWave) void poa_window_kernel(KernelArgs a)
     if (lane == 0 && a.cells) a.cells[w] = cells;
     if (lane == 0 && a.phase_cycles)
         for (int k = 0; k < kPhCount; k++) a.phase_cycles[(size_t)w * kPhCount + k] = phase_acc[k];
+    if constexpr (NW > 1)
+    {
+        if (lane == 0) mw_args->op = 2; // the helper wavefronts leave
+        block_barrier();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,7 +458,7 @@ __global__ __launch_bounds__(kWave) void poa_msa_kernel(KernelArgs a)
             consensus[1] = kExceededMaximumSequenceSize;
         }
     }
-    __syncthreads();
+    wave_sync();
     if (consensus[0] == kKernelError) return;
     uint8_t* msa = a.msa + (size_t)w * c.max_sequences_per_poa * c.max_consensus_size;
     for (int32_t s = threadIdx.x; s < (int32_t)wd.num_seqs; s += kWave)
@@ -491,10 +522,13 @@ template <typename ScoreT, typename IdT, typename TraceT, bool MSA, bool LDS_TAB
 static hipError_t launch_window_kernel(const KernelArgs& ka, hipStream_t stream)
 {
     const size_t lds = LDS_TABLES ? (size_t)kRingBytes + kRowInfoBytes + kReadLds + kCodeTileLds
-                                  : (size_t)kWideRingBytes + kBsRingBytes + kReadWinBytes;
-    dim3 grid(ka.total_windows), block(kWave);
+                                  : (size_t)kWideRingBytes + kBsRingBytes + kReadWinBytes + kMwLds;
+    dim3 grid(ka.total_windows);
 #define GW_LAUNCH(BM)                                                                                              \
-    hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES>), grid, block, lds, stream, ka); \
+    {                                                                                                              \
+        constexpr int NW = (!LDS_TABLES && BM == GWHIP_ADAPTIVE_BAND) ? kMwWaves : 1;                              \
+        hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW>), grid, dim3(kWave * NW), lds, stream, ka); \
+    }                                                                                                              \
     break;
     switch (ka.cfg.band_mode)
     {

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kWave) void nw_hook_kernel(NwHookArgs a)
     const gwhip_poa_config& c = a.cfg;
     const int lane            = threadIdx.x;
     build_rowinfo<int32_t, RowInfo<false>>(g, a.g.graph_count, rowinfo, lane);
-    __syncthreads();
+    wave_sync();
     uint64_t cells  = 0;
     PhaseClock pc{nullptr, 0};
     const float buf = __fmul_rn((float)c.max_nodes_per_graph, (float)c.matrix_sequence_dimension);

@@ -127,6 +127,19 @@ struct PhaseClock
 };
 
 // ---- wave-level helpers ----
+// Ordering point of ONE wavefront with itself: everything the wave wrote (LDS, global) is complete and visible to
+// every lane of the same wave afterwards. A window is worked on by one wavefront in all phases but the multi-wave
+// forward pass (generic_forward_mw below), so this is what the single-wave code needs where a block-wide kernel
+// would write __syncthreads() -- and it contains no s_barrier, which the helper wavefronts of a multi-wave block
+// (parked at their own barrier) must not be released by.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+// barrier of all wavefronts of the block (multi-wave forward pass only)
+__device__ __forceinline__ void block_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ __forceinline__ int32_t wave_bcast(int32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int32_t wave_first(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -356,7 +369,7 @@ __device__ __forceinline__ int32_t traceback_banded_tiled(const BandedCtx<ScoreT
     int32_t tile_top = -1; // matrix row held in tile row 0 (-1: no tile)
 
     auto load_tile = [&](int32_t top, int32_t col) {
-        __syncthreads();
+        wave_sync();
         // lane = tile row: row = top - lane; window of 64 stored elements around column (col - lane) - 40
         const int32_t row = top - lane;
         int32_t bs = 0, e0 = 0;
@@ -372,7 +385,7 @@ __device__ __forceinline__ int32_t traceback_banded_tiled(const BandedCtx<ScoreT
                 *reinterpret_cast<Quad<ScoreT>*>(dst + k) = *reinterpret_cast<const Quad<ScoreT>*>(src + k);
         }
         tile_meta[lane] = (row >= 0) ? ((bs & 0xffff) | ((e0 - kRelShift + bs) << 16)) : 0x7fff0000;
-        __syncthreads();
+        wave_sync();
     };
     // get_score() of cudapoa_nw_banded.cuh:80-102, tile first
     auto score_at = [&](int32_t row, int32_t column) -> int32_t {
@@ -485,7 +498,7 @@ __device__ __forceinline__ int32_t traceback_banded_tiled(const BandedCtx<ScoreT
         j = prev_j;
     }
     if (loop_count >= bound) aligned_nodes = kNwLoopFailed;
-    __syncthreads();
+    wave_sync();
     return aligned_nodes;
 }
 
@@ -537,7 +550,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
 
     auto window_lo = [&](int32_t t) -> int32_t { return ((tile_col - kLead - t) & ~3) + 1; };
     auto load_tile = [&](int32_t top, int32_t col) {
-        __syncthreads();
+        wave_sync();
         tile_top = top;
         tile_col = col;
         const int32_t row = top - lane;
@@ -569,7 +582,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
 #pragma nounroll
             for (int k = 0; k < kTileCols; k++) dst[k] = (k >= klo && k <= khi) ? src[k] : (ScoreT)b.min_score;
         }
-        __syncthreads();
+        wave_sync();
     };
     // stage[k] = cell (row | column << 16) step k LEFT; the entry the reference records for a step -- graph position or
     // -1 when the row did not change, read position or -1 when the column did not change -- follows from two
@@ -613,7 +626,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         }
     };
     auto commit_codes = [&](int32_t top, int32_t col, CodeSeg (&v)[kPasses]) {
-        __syncthreads();
+        wave_sync();
         ctop = top;
         ccol = col;
         ccol_lead = col - kLead;
@@ -639,7 +652,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
             }
             *reinterpret_cast<uint4*>(ctile + t * kCodeCols + seg * 16) = make_uint4(v[pass].d[0], v[pass].d[1], v[pass].d[2], v[pass].d[3]);
         }
-        __syncthreads();
+        wave_sync();
     };
     CodeSeg ahead[kPasses] = {};
     int32_t atop = -1, acol = 0; // anchor of the tile in `ahead` (atop < 0: none)
@@ -864,7 +877,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         flush_stage(aligned_nodes & ~(kStage - 1), aligned_nodes & (kStage - 1));
     if ((dbg & 2) && prof_acc && lane == 0) *prof_acc += (uint64_t)max(aligned_nodes, 0); // profiling: all steps
     if (aligned_nodes >= bound) aligned_nodes = kNwLoopFailed;
-    __syncthreads();
+    wave_sync();
     for (int32_t k0 = lane; k0 < aligned_nodes; k0 += 4 * kWave) // 4 independent load chains per lane in flight
     {
         int32_t pos[4], node[4];
@@ -876,7 +889,7 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         for (int u = 0; u < 4; u++)
             if (pos[u] >= 0) alignment_graph[k0 + u * kWave] = node[u];
     }
-    __syncthreads();
+    wave_sync();
     if (psel == 6) pacc += clock64() - t_pp;
     if (psel && lane == 0) *prof_acc += pacc;
     return aligned_nodes;
@@ -896,7 +909,7 @@ __device__ __forceinline__ void build_rowinfo(const GraphView<IdT>& g, int32_t g
     {
 #pragma unroll
         for (int q = 0; q < 4; q++) xpred[q * kWave + lane] = 0;
-        __syncthreads();
+        wave_sync();
     }
     if (lane == 0) rowinfo[0].set(0, 0, false, 0, 0, 0); // row 0 (virtual source): no predecessors
     // Four 64-row chunks per iteration: a chunk is three dependent HBM round trips (row -> node -> its first three
@@ -1150,7 +1163,7 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
                 }
                 else
                 {
-                    if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
+                    if (hbm_dirty) { wave_sync(); hbm_dirty = false; }
                     if (valid)
                     {
                         const ScoreT* rowp = scores + (int64_t)prow * stride + (c - pbs) + kRelShift;
@@ -1177,7 +1190,7 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
                     if (slot < 0) slot += ring_rows;
                     return wave_first((int32_t)ring[slot * stride + kRelShift]);
                 }
-                if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
+                if (hbm_dirty) { wave_sync(); hbm_dirty = false; }
                 return wave_first((int32_t)scores[(int64_t)prow * stride + kRelShift]);
             };
 
@@ -1236,6 +1249,226 @@ namespace gwhip
 {
 
 // ------------------------------------------------------------------------------------------------
+// Multi-wave forward pass for wide bands (long reads: adaptive bands of 512 .. 1536 columns, HBM row table).
+//
+// A row of a 1536-column band is six 256-column passes. On one wavefront they run back to back (about 4 000 cycles per
+// row, a chain of LDS round trips), although only the horizontal carry connects them. Here every pass of a row has its
+// own wavefront (wave w of the block takes pass w): candidates and the in-pass prefix maximum are computed by all
+// waves at once, the carries are exchanged through six LDS words behind one block barrier, and a second barrier at the
+// end of the row publishes it in the LDS ring before the next row reads it as a predecessor.
+//
+// The carry exchange works in "u space" over the WHOLE band: with u[t] = v[t] - t * gap (t = 0 .. band_width - 1
+// across all passes) the row's max-plus recurrence H[t] = max(v[t], H[t - 1] + gap) is a prefix maximum of u, so the
+// exclusive prefix a pass needs from its left is max(carry-in, totals of the passes before it) -- associative, no
+// sequential hand-over. The single-wave code chains the passes through the stored (ScoreT) value of the last cell;
+// both give the same cells unless a ScoreT store wraps, which the reference excludes too.
+//
+// All waves of the block call generic_forward_mw with the same arguments (wave 0 hands them over through MwArgs in
+// LDS) and run the same wave-uniform control flow, so their barriers pair up. Wave 0 alone runs every other phase.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMwWaves = 6; // kMaxAdaptiveBand / 256
+
+template <typename ScoreT> struct MwArgs
+{
+    int32_t op; // 1 = run a forward pass, 2 = leave the kernel
+    int32_t graph_count, read_length, band_width, band_shift, max_column;
+    float gradient;
+    int32_t gap_score, mismatch_score, match_score;
+    int32_t ring_rows;
+    const uint8_t* read;
+    ScoreT* scores;
+};
+struct MwShared // in LDS, behind the regions of the single-wave layout
+{
+    int32_t totals[8]; // per pass: prefix maximum of the pass in u space (pass 0 includes the carry-in)
+};
+
+template <typename ScoreT, typename IdT, typename RowT>
+__device__ __forceinline__ void generic_forward_mw(const MwArgs<ScoreT>& A, const GraphView<IdT>& g, const RowT* rowinfo, ScoreT* ring,
+                                                   int32_t* bs_ring, uint8_t* read_window, MwShared* shared, int wave, int lane)
+{
+    const int32_t graph_count = A.graph_count, read_length = A.read_length, band_width = A.band_width;
+    const int32_t max_column = A.max_column, gap_score = A.gap_score;
+    const int32_t min_score  = Limits<ScoreT>::min / 2;
+    const int32_t stride     = band_width + kRightPad;
+    const int32_t npass      = (band_width + 255) / 256;
+    const int32_t ring_rows  = A.ring_rows;
+    ScoreT* scores           = A.scores;
+    const uint8_t* read      = A.read;
+    const int32_t pass       = wave;
+    const bool has_pass      = pass < npass;
+    RowT* ri_stage           = reinterpret_cast<RowT*>(bs_ring + 64);
+
+    // sliding LDS window over the read and the staged row table: refilled by wave 0 between two barriers
+    constexpr int32_t kWin = 4096, kWinStep = 1024;
+    int32_t staged_end = 0, ri_stage_end = 0;
+    auto stage_read = [&](int32_t need_end) { // same decision in every wave
+        block_barrier();
+        while (staged_end < need_end)
+        {
+            if (wave == 0)
+                for (int32_t i = lane * 4; i < kWinStep; i += kWave * 4)
+                {
+                    const int32_t col = staged_end + i;
+                    const uint32_t v  = col < read_length + 8 ? *reinterpret_cast<const uint32_t*>(read + col) : 0u;
+                    *reinterpret_cast<uint32_t*>(read_window + (col & (kWin - 1))) = v;
+                }
+            staged_end += kWinStep;
+        }
+        block_barrier();
+    };
+    auto fetch_ri = [&](int32_t row) -> RowT {
+        if (row >= ri_stage_end)
+        {
+            block_barrier();
+            if (wave == 0 && row + lane <= graph_count) ri_stage[(row + lane) & 63] = rowinfo[row + lane];
+            ri_stage_end = row + 64;
+            block_barrier();
+        }
+        return uniform_row(ri_stage[row & 63]);
+    };
+
+    RowT ri_next   = fetch_ri(1);
+    int32_t slot_r = 1 % ring_rows;
+    for (int32_t r = 1; r <= graph_count; r++)
+    {
+        const RowT ri = ri_next;
+        if (r < graph_count) ri_next = fetch_ri(r + 1);
+        const int32_t pred_count = ri.cnt();
+        const int32_t bs         = ri.bs();
+        const int32_t node_id    = pred_count > 3 ? (int32_t)g.sorted_poa[r - 1] : 0;
+        auto pred_row = [&](int32_t p) -> int32_t {
+            if (pred_count == 0) return 0;
+            if (p < 3) return ri.pred(p);
+            return wave_first((int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1);
+        };
+        auto in_ring = [&](int32_t row) -> bool { return r - row < ring_rows; };
+        auto slot_of = [&](int32_t row) -> int32_t {
+            const int32_t sl = slot_r - (r - row);
+            return sl < 0 ? sl + ring_rows : sl;
+        };
+        auto bs_of = [&](int32_t row) -> int32_t {
+            if (row == 0) return 0;
+            if (in_ring(row)) return bs_ring[slot_of(row)];
+            return uniform_row(rowinfo[row]).bs();
+        };
+        auto rel0_of = [&](int32_t row) -> int32_t {
+            if (in_ring(row)) return lds_ld(ring + slot_of(row) * stride + kRelShift);
+            return wave_first((int32_t)scores[(int64_t)row * stride + kRelShift]);
+        };
+        if (bs + npass * 256 + 4 > staged_end) stage_read(bs + npass * 256 + 4);
+
+        // ---- left boundary / carry-in (cudapoa_nw_banded.cuh:293-326): wave 0 owns it ----
+        int32_t fe = 0, rel0_val = min_score;
+        if (wave == 0)
+        {
+            if (pred_count == 0)
+            {
+                if (bs == 0) rel0_val = (ScoreT)gap_score; // carry-in stays 0: reference quirk
+            }
+            else
+            {
+                if (bs > kCellsPerLane && pred_count == 1)
+                    fe = min_score + gap_score;
+                else
+                {
+                    int32_t penalty = min_score;
+                    for (int32_t p = 0; p < pred_count; p++) penalty = max(penalty, rel0_of(pred_row(p)));
+                    fe = penalty + gap_score;
+                }
+                if (bs == 0) rel0_val = (ScoreT)fe;
+            }
+        }
+
+        // ---- this wave's pass: candidates from every predecessor, prefix maximum inside the pass ----
+        const int32_t tg   = pass * 256 + 4 * lane; // index of the lane's first cell in the band
+        const int32_t c    = bs + tg;               // chunk anchor column (cells c+1 .. c+4)
+        const bool active  = has_pass && tg < band_width;
+        int32_t m0 = INT32_MIN, m1 = INT32_MIN, m2 = INT32_MIN, m3 = INT32_MIN, incl = INT32_MIN;
+        if (has_pass)
+        {
+            const uint32_t rd4 = *reinterpret_cast<const uint32_t*>(read_window + (c & (kWin - 1)));
+            const int32_t cp0  = ((rd4 & 0xff) == (uint32_t)ri.base()) ? A.match_score : A.mismatch_score;
+            const int32_t cp1  = (((rd4 >> 8) & 0xff) == (uint32_t)ri.base()) ? A.match_score : A.mismatch_score;
+            const int32_t cp2  = (((rd4 >> 16) & 0xff) == (uint32_t)ri.base()) ? A.match_score : A.mismatch_score;
+            const int32_t cp3  = ((rd4 >> 24) == (uint32_t)ri.base()) ? A.match_score : A.mismatch_score;
+            int32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            const int32_t np = max(pred_count, 1);
+            for (int32_t p = 0; p < np; p++)
+            {
+                const int32_t prow = pred_row(p);
+                const int32_t pbs  = bs_of(prow);
+                const int32_t pend = min(pbs + band_width - kCellsPerLane, max_column);
+                const bool valid   = !(c > pend || c < pbs);
+                int32_t S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0; // predecessor row, columns c .. c+4
+                if (in_ring(prow)) // wave-uniform
+                {
+                    if (valid)
+                    {
+                        const ScoreT* rowp = ring + slot_of(prow) * stride + (c - pbs) + kRelShift;
+                        S0 = lds_ld(rowp);
+                        const Quad<ScoreT> qd = lds_ld_quad(rowp + 1);
+                        S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
+                    }
+                }
+                else if (valid) // far predecessor: the HBM matrix (complete: every earlier row ended with a block barrier)
+                {
+                    const ScoreT* rowp = scores + (int64_t)prow * stride + (c - pbs) + kRelShift;
+                    S0 = rowp[0];
+                    const Quad<ScoreT> qd = *reinterpret_cast<const Quad<ScoreT>*>(rowp + 1);
+                    S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
+                }
+                int32_t t0, t1, t2, t3;
+                if (valid)
+                {
+                    t0 = (ScoreT)max(S0 + cp0, S1 + gap_score);
+                    t1 = (ScoreT)max(S1 + cp1, S2 + gap_score);
+                    t2 = (ScoreT)max(S2 + cp2, S3 + gap_score);
+                    t3 = (ScoreT)max(S3 + cp3, S4 + gap_score);
+                }
+                else { t0 = t1 = t2 = t3 = min_score; }
+                if (p == 0) { s0 = t0; s1 = t1; s2 = t2; s3 = t3; }
+                else { s0 = max(s0, t0); s1 = max(s1, t1); s2 = max(s2, t2); s3 = max(s3, t3); }
+            }
+            int32_t u0 = s0 - (tg + 0) * gap_score, u1 = s1 - (tg + 1) * gap_score;
+            int32_t u2 = s2 - (tg + 2) * gap_score, u3 = s3 - (tg + 3) * gap_score;
+            if (!active) u0 = u1 = u2 = u3 = INT32_MIN;
+            m0 = u0; m1 = max(m0, u1); m2 = max(m1, u2); m3 = max(m2, u3);
+            incl = wave_inclusive_max(m3);
+            int32_t total = wave_bcast(incl, kWave - 1);
+            if (wave == 0) total = max(total, fe + gap_score); // the carry-in is element t = -1 of the band: fe - (-1) * gap
+            if (lane == 0) shared->totals[pass] = total;
+        }
+        block_barrier(); // ---- A: every pass has published its total ----
+        if (has_pass)
+        {
+            int32_t before = wave == 0 ? fe + gap_score : INT32_MIN;
+            for (int32_t k = 0; k < pass; k++) before = max(before, lds_ld(&shared->totals[k]));
+            const int32_t excl = max(wave_shr1(incl, INT32_MIN), before);
+            if (active)
+            {
+                Quad<ScoreT> out;
+                out.v[0] = (ScoreT)(max(m0, excl) + (tg + 0) * gap_score);
+                out.v[1] = (ScoreT)(max(m1, excl) + (tg + 1) * gap_score);
+                out.v[2] = (ScoreT)(max(m2, excl) + (tg + 2) * gap_score);
+                out.v[3] = (ScoreT)(max(m3, excl) + (tg + 3) * gap_score);
+                const int32_t rel = tg + 1;
+                *reinterpret_cast<Quad<ScoreT>*>(scores + (int64_t)r * stride + rel + kRelShift) = out;
+                *reinterpret_cast<Quad<ScoreT>*>(ring + slot_r * stride + rel + kRelShift)         = out;
+            }
+        }
+        if (wave == 0 && lane == 0)
+        {
+            scores[(int64_t)r * stride + kRelShift] = (ScoreT)rel0_val;
+            ring[slot_r * stride + kRelShift]       = (ScoreT)rel0_val;
+            bs_ring[slot_r]                         = bs;
+        }
+        block_barrier(); // ---- B: the row is in the ring ----
+        slot_r = slot_r + 1 == ring_rows ? 0 : slot_r + 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Banded NW (score-matrix modes): forward pass wave-wide, then sink selection (wave reduction with the
 // reference's first-maximum tie rule) and the lane-0 traceback.
 // ------------------------------------------------------------------------------------------------
@@ -1245,7 +1478,8 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                              float max_buffer_size, int32_t* alignment_graph, int32_t* alignment_read,
                              int32_t band_width, int32_t gap_score, int32_t mismatch_score, int32_t match_score,
                              int32_t rerun, uint64_t& cells, PhaseClock& pc, int32_t dbg = 0, uint8_t* codes = nullptr,
-                             uint8_t* code_tile = nullptr, uint8_t* read_window = nullptr, int32_t* bs_ring = nullptr)
+                             uint8_t* code_tile = nullptr, uint8_t* read_window = nullptr, int32_t* bs_ring = nullptr,
+                             MwArgs<ScoreT>* mw_args = nullptr, MwShared* mw_shared = nullptr)
 {
     const int lane              = threadIdx.x & (kWave - 1);
     const int32_t min_score     = Limits<ScoreT>::min / 2;
@@ -1319,7 +1553,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     for (int32_t r = 1 + lane; r <= graph_count; r += kWave)
         rowinfo[r].set_bs(band_start_for_row(r, gradient, band_width, band_shift, max_column));
     bool hbm_dirty = true; // stores since the last workgroup sync (needed before reading the HBM matrix)
-    __syncthreads();
+    wave_sync();
     hbm_dirty = false;
     // rows still in the LDS ring have their band start there too (bs_ring): with the row table in HBM a load of it
     // in the middle of a row would wait for the previous row's score stores (loads and stores return in order)
@@ -1343,7 +1577,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             }
             staged_end += kWinStep;
         }
-        __syncthreads();
+        wave_sync();
     };
 
     constexpr bool kFastOk = std::is_same<RowT, RowInfo<true>>::value && LDS_READ;
@@ -1357,7 +1591,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
         if (packed_ok)
         {
             classify_rows(rowinfo, graph_count, lane, reinterpret_cast<const uint64_t*>(code_tile), dbg, pc.acc ? &pc.acc[kPhOther] : nullptr);
-            __syncthreads();
+            wave_sync();
             banded_forward_packed<IdT>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
                                        reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score, dbg,
                                        pc.acc ? &pc.acc[kPhOther] : nullptr);
@@ -1375,6 +1609,23 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             fast_done = true;
         }
     }
+    // wide bands in a multi-wave block: one wavefront per 256-column pass (generic_forward_mw)
+    if constexpr (!std::is_same<RowT, RowInfo<true>>::value)
+    {
+        if (!fast_done && mw_args != nullptr && npass >= 2 && b.ring_rows >= 2 && bs_ring != nullptr && read_window != nullptr)
+        {
+            MwArgs<ScoreT> A;
+            A.op = 1;
+            A.graph_count = graph_count; A.read_length = read_length; A.band_width = band_width; A.band_shift = band_shift;
+            A.max_column = max_column; A.gradient = gradient;
+            A.gap_score = gap_score; A.mismatch_score = mismatch_score; A.match_score = match_score;
+            A.ring_rows = b.ring_rows; A.read = read; A.scores = scores;
+            if (lane == 0) *mw_args = A;
+            block_barrier(); // the helper wavefronts wait here for their arguments
+            generic_forward_mw<ScoreT, IdT, RowT>(A, g, rowinfo, b.ring, bs_ring, read_window, mw_shared, 0, lane);
+            fast_done = true;
+        }
+    }
     // Row table through LDS when it lives in HBM: 64 rows at a time, so the row loop itself issues no global load
     // (one would wait for the previous row's score stores: loads and stores return in order).
     RowT* ri_stage       = nullptr;
@@ -1385,10 +1636,10 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
         if (ri_stage == nullptr) return uniform_row(rowinfo[row]);
         if (row >= ri_stage_end) // wave-uniform
         {
-            __syncthreads();
+            wave_sync();
             if (row + lane <= graph_count) ri_stage[(row + lane) & 63] = rowinfo[row + lane];
             ri_stage_end = row + 64;
-            __syncthreads();
+            wave_sync();
         }
         return uniform_row(ri_stage[row & 63]);
     };
@@ -1414,7 +1665,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
         auto rel0_of = [&](int32_t row) -> int32_t {
             if (reg_path && row == r - 1) return prev_rel0;
             if (FAST || (b.ring_rows && r - row < b.ring_rows)) return lds_ld(b.ring + slot_of(row) * stride + kRelShift);
-            if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
+            if (hbm_dirty) { wave_sync(); hbm_dirty = false; }
             return scores[(int64_t)row * stride + kRelShift];
         };
 
@@ -1489,7 +1740,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                 else
                 {
                     const bool in_ring = FAST || (b.ring_rows && r - prow < b.ring_rows);
-                    if (!in_ring && hbm_dirty) { __syncthreads(); hbm_dirty = false; }
+                    if (!in_ring && hbm_dirty) { wave_sync(); hbm_dirty = false; }
                     S0 = S1 = S2 = S3 = S4 = 0;
                     if (valid)
                     {
@@ -1586,7 +1837,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             slot_r = (b.ring_rows && slot_r + 1 == b.ring_rows) ? 0 : slot_r + 1;
         }
     }
-    __syncthreads(); // score matrix complete and visible to lane 0's traceback
+    wave_sync(); // score matrix complete and visible to lane 0's traceback
     pc.tick(kPhForward);
 
     // ---- sink selection (:410-426): first row with the strictly greatest H(row, L) among sink rows ----

@@ -531,7 +531,7 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
                 const int32_t pbs  = prow == 0 ? 0 : uniform_row(rowinfo[prow]).bs();
                 const int32_t pend = min(pbs + band_width - kCellsPerLane, max_column);
                 const bool valid   = !(c > pend || c < pbs);
-                if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
+                if (hbm_dirty) { wave_sync(); hbm_dirty = false; }
                 int32_t S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0;
                 if (valid)
                 {
@@ -550,7 +550,7 @@ __device__ __forceinline__ void banded_forward_packed(const GraphView<IdT>& g, c
                 if (prow == r - 1) return prev_rel0;
                 const int32_t pbs = prow == 0 ? 0 : uniform_row(rowinfo[prow]).bs();
                 if (pbs > 0) return min_score;
-                if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
+                if (hbm_dirty) { wave_sync(); hbm_dirty = false; }
                 return wave_first((int32_t)scores[(int64_t)prow * stride + kRelShift]);
             };
             const int32_t node_id = (pred_count > 3) ? (int32_t)g.sorted_poa[r - 1] : 0;

@@ -30,7 +30,7 @@ __device__ __forceinline__ int32_t nw_full(const GraphView<IdT>& g, RowT* rowinf
         if (ring_rows) ring[j + kRelShift] = v;
     }
     bool hbm_dirty = false;
-    __syncthreads();
+    wave_sync();
 
     for (int32_t r = 1; r <= graph_count; r++)
     {
@@ -44,7 +44,7 @@ __device__ __forceinline__ int32_t nw_full(const GraphView<IdT>& g, RowT* rowinf
         };
         auto row_ptr = [&](int32_t row) -> const ScoreT* {
             if (ring_rows && r - row < ring_rows) return ring + (row % ring_rows) * stride;
-            if (hbm_dirty) { __syncthreads(); hbm_dirty = false; }
+            if (hbm_dirty) { wave_sync(); hbm_dirty = false; }
             return scores + (int64_t)row * stride;
         };
         // column 0 (:186-216): gap for sources, else gap + max over predecessors' column 0
@@ -121,7 +121,7 @@ __device__ __forceinline__ int32_t nw_full(const GraphView<IdT>& g, RowT* rowinf
         }
         hbm_dirty = true;
     }
-    __syncthreads();
+    wave_sync();
 
     auto H = [&](int32_t i, int32_t j) -> int32_t { return scores[(int64_t)i * stride + j + kRelShift]; };
 

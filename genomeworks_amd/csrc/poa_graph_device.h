@@ -173,7 +173,7 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
     };
     for (int32_t i = lane; i < (node_count + 31) / 32; i += kWave) onpath[i] = 0;
     for (int32_t i = lane; i < L; i += kWave) gnode[i] = -1;
-    __syncthreads();
+    wave_sync();
     int32_t covered = 0;
     for (int32_t base = 0; base < alen; base += 4 * kWave) // four chunks per HBM round trip
     {
@@ -196,7 +196,7 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
             covered += __popcll(__ballot(rp[u] >= 0));
         }
     }
-    __syncthreads();
+    wave_sync();
     // The map over read positions needs a complete alignment (every read position exactly once); a degenerate
     // traceback result (reference quirk: a walk that finds no predecessor at its first step) goes the serial way.
     if (covered != L) return -1;
@@ -267,7 +267,7 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
     }
     if (__any(conflict)) return -1;
     for (int off = 32; off > 0; off >>= 1) rp_nodeerr = min(rp_nodeerr, __shfl_xor(rp_nodeerr, off));
-    __syncthreads();
+    wave_sync();
 
     prof_mark(2);
     const int32_t first_new = node_count;
@@ -320,7 +320,7 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
         }
         g.node_alignment_count[cur] = (uint16_t)na_new;
     }
-    __syncthreads();
+    wave_sync();
     prof_mark(3);
 
     // ---- D: edges and coverage ----
@@ -414,7 +414,7 @@ __device__ __forceinline__ int32_t add_alignment_parallel(int32_t& new_node_coun
         }
     }
     for (int off = 32; off > 0; off >>= 1) rp_edgeerr = min(rp_edgeerr, __shfl_xor(rp_edgeerr, off));
-    __syncthreads();
+    wave_sync();
     prof_mark(4);
     if (rp_edgeerr != INT32_MAX) return (int32_t)kEdgeCountExceeded;
     new_node_count = node_count + running;
@@ -487,7 +487,7 @@ __device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_
         if (is_src) queue[tail + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)n;
         tail += __popcll(m);
     }
-    __syncthreads();
+    wave_sync();
     // phase 2: the FIFO loop, executed wave-uniformly (every lane runs the same scalar program, so node words land
     // in SGPRs). On a lone wavefront a taken branch costs ~25 cycles and an LDS round trip ~55 (tools/microbench.hip),
     // so the loop body is written branch-light: the first child is handled with selects and unconditional stores
@@ -540,7 +540,7 @@ __device__ __forceinline__ void topsort_kahn_lds(const GraphView<IdT>& g, int32_
             }
         }
     }
-    __syncthreads();
+    wave_sync();
     // phase 3 (all lanes): publish order and inverse map
     for (int32_t i = lane; i < node_count; i += kWave)
     {
@@ -606,7 +606,7 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
     };
 #pragma unroll
     for (int q = 0; q < 4; q++) wide[q * kWave + lane] = 0; // entries of the previous read are stale
-    __syncthreads();
+    wave_sync();
     // phase 1 (all lanes): node words with change flags, previous order into LDS, sources in ascending node id.
     // Four 64-node chunks per iteration share one HBM round trip (eight independent loads per node; edge slots
     // past the out-degree hold stale ids: masked).
@@ -657,7 +657,7 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
             tail += __popcll(ms);
         }
     }
-    __syncthreads();
+    wave_sync();
     if (tsel == 1) tacc += clock64() - t_p1;
     // phase 2: wave-uniform control; k = new nodes output so far, M = highest previous position output so far
     int32_t head = 0, k = 0, M = -1;
@@ -821,7 +821,7 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
         if (tsel == 3) tacc += clock64() - t_it;
         if (tsel == 6) tacc += 1000;
     }
-    __syncthreads();
+    wave_sync();
     const uint64_t t_p3 = tsel == 4 ? clock64() : 0;
     // phase 3 (all lanes): publish order, inverse map and the per-node record for the next read
     for (int32_t i0 = lane; i0 < node_count; i0 += 4 * kWave) // four chunks per HBM round trip
@@ -850,7 +850,7 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
     }
     if (tsel == 4)
     {
-        __syncthreads();
+        wave_sync();
         tacc += clock64() - t_p3;
     }
     if (tsel && lane == 0) *prof_acc += tacc;
@@ -1088,7 +1088,7 @@ __device__ __forceinline__ void generate_consensus_lds(const GraphView<IdT>& g, 
         rec[3 * n + 2] = w1 | (w2 << 16);
     }
     if (lane == 0) scores[-1] = -1;
-    __syncthreads();
+    wave_sync();
 
     // one pass of the heaviest-bundle recurrence over sorted positions [first_pos, node_count);
     // skip_cut: edges from nodes whose score was cut to -1 are ignored (branch completion)
@@ -1157,7 +1157,7 @@ __device__ __forceinline__ void generate_consensus_lds(const GraphView<IdT>& g, 
         max_score_id = bundle_pass(wave_first((int32_t)g.node_id_to_pos[node_id]) + 1, true, 0);
         loop_count++;
     }
-    __syncthreads();
+    wave_sync();
     if (loop_count >= node_count)
     {
         if (lane == 0) { consensus[0] = kKernelError; consensus[1] = kLoopCountExceeded; }
@@ -1176,7 +1176,7 @@ __device__ __forceinline__ void generate_consensus_lds(const GraphView<IdT>& g, 
             count++;
         }
     }
-    __syncthreads();
+    wave_sync();
     if (count >= max_limit_consensus_size - 1)
     {
         if (lane == 0) { consensus[0] = kKernelError; consensus[1] = kExceededMaximumSequenceSize; }

@@ -83,7 +83,7 @@ __device__ __forceinline__ int32_t nw_banded_tb(const GraphView<IdT>& g, RowT* r
         tr_store(j, 0);                               // pinned: trace row 0
         tb_set_score(t, 0, j, j * gap_score, 0);      // :335-338
     }
-    __syncthreads();
+    wave_sync();
 
     for (int32_t r = 1; r <= graph_count; r++)
     {
@@ -155,7 +155,7 @@ __device__ __forceinline__ int32_t nw_banded_tb(const GraphView<IdT>& g, RowT* r
             }
         }
         fe = wave_first(fe);
-        __syncthreads();
+        wave_sync();
 
         // A slot-0 predecessor farther than H rows is still used (:456-457) and reads whatever occupies its
         // ring slot -- possibly this row's own slot. Keep the reference's 128-column pass order there.
@@ -215,7 +215,7 @@ __device__ __forceinline__ int32_t nw_banded_tb(const GraphView<IdT>& g, RowT* r
             }
             const int last_lane = min(pass_cols, band_width - pass * pass_cols) / 4 - 1;
             carry = wave_bcast(h[3], last_lane);
-            __syncthreads(); // all loads of this pass done before its stores (reference: same warp instruction order)
+            wave_sync(); // all loads of this pass done before its stores (reference: same warp instruction order)
             if (active)
             {
                 int64_t index = (int64_t)(off + 1) + (int64_t)(r % H) * stride;
@@ -226,7 +226,7 @@ __device__ __forceinline__ int32_t nw_banded_tb(const GraphView<IdT>& g, RowT* r
 #pragma unroll
                 for (int k = 0; k < 4; k++) tr_store(index + k, tr[k]);
             }
-            __syncthreads();
+            wave_sync();
         }
     }
 

@@ -6,6 +6,8 @@
 #include <string>
 #include <vector>
 
+#include "pinned_vector.hpp"
+
 namespace claraparabricks
 {
 namespace genomeworks
@@ -34,7 +36,7 @@ public:
     DeviceAlignmentsPtrs get_alignments_device() const override;
     void reset() override;
     void free_temporary_device_buffers() override;
-    int32_t num_alignments() const override { return static_cast<int32_t>(seq_starts_h_.size() / 2); }
+    int32_t num_alignments() const override { return static_cast<int32_t>(seq_starts_h_.size() / 2); } // [2n + 1] offsets
     cudaStream_t get_stream() const override { return stream_; }
     int32_t get_device() const override { return device_id_; }
     DefaultDeviceAllocator get_device_allocator() const override { return allocator_; }
@@ -59,15 +61,19 @@ private:
     bool expand_results_;
     int32_t max_query_length_, max_target_length_, max_alignments_;
 
-    std::vector<char> seq_h_;
-    std::vector<int64_t> seq_starts_h_{0};
-    std::vector<int32_t> max_bandwidths_h_;
-    std::vector<int32_t> order_h_;
+    // staging arrays in pinned host memory: uploaded asynchronously at link speed
+    PinnedVector<char> seq_h_;
+    PinnedVector<int64_t> seq_starts_h_;
+    PinnedVector<int32_t> max_bandwidths_h_;
+    PinnedVector<int32_t> order_h_;
     std::vector<std::shared_ptr<Alignment>> alignments_;
     size_t workspace_bytes_estimate_ = 0;
     size_t largest_wave_ws_          = 0;
+    int32_t longest_query_           = 0;
+    int32_t widest_band_             = 0;
     size_t workspace_bytes_          = 0;
     bool launched_                   = false;
+    bool uploads_in_flight_          = false;
     int64_t total_length_h_          = 0;
     int32_t n_last_                  = 0;
     char* head_                      = nullptr; ///< pinned: result_starts[n + 1] | metadata[n] of the last launch

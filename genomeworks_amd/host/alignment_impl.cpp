@@ -130,37 +130,71 @@ FormattedAlignment AlignmentImpl::format_alignment(int32_t maximal_line_length) 
 // ---- PackedAlignment: a view into the block one sync_alignments() produced -------------------------------------
 PackedAlignmentBlock::~PackedAlignmentBlock()
 {
+    if (alignments != nullptr)
+    {
+        for (size_t i = 0; i < n_alignments; ++i) alignments[i].~PackedAlignment();
+        ::operator delete(static_cast<void*>(alignments));
+    }
     if (pinned != nullptr) pinned_release(pinned, pinned_bytes);
+    if (sequences_buffer != nullptr) pinned_release(sequences_buffer, sequences_bytes);
+    if (seq_starts_buffer != nullptr) pinned_release(seq_starts_buffer, seq_starts_bytes);
+}
+
+void PackedAlignmentBlock::allocate_views(size_t n)
+{
+    alignments   = static_cast<PackedAlignment*>(::operator new(std::max<size_t>(n, 1) * sizeof(PackedAlignment)));
+    n_alignments = 0; // raised by the caller once the views are constructed
+}
+
+PackedAlignment::~PackedAlignment()
+{
+    delete lazy_.load(std::memory_order_acquire);
+}
+
+PackedAlignment::Lazy& PackedAlignment::lazy() const
+{
+    Lazy* l = lazy_.load(std::memory_order_acquire);
+    if (l == nullptr)
+    {
+        Lazy* fresh = new Lazy;
+        if (lazy_.compare_exchange_strong(l, fresh, std::memory_order_acq_rel))
+            l = fresh;
+        else
+            delete fresh; // another thread was first; l now holds its object
+    }
+    return *l;
 }
 
 void PackedAlignment::materialise_sequences() const
 {
-    std::call_once(seq_once_, [this] {
-        const int64_t* st = block_->seq_starts.data() + 2 * static_cast<size_t>(index_);
-        query_.assign(block_->sequences.data() + st[0], block_->sequences.data() + st[1]);
-        target_.assign(block_->sequences.data() + st[1], block_->sequences.data() + st[2]);
+    Lazy& l = lazy();
+    std::call_once(l.seq_once, [&] {
+        const int64_t* st = block_->seq_starts + 2 * static_cast<size_t>(index_);
+        l.query.assign(block_->sequences + st[0], block_->sequences + st[1]);
+        l.target.assign(block_->sequences + st[1], block_->sequences + st[2]);
     });
 }
 
 void PackedAlignment::materialise_runs() const
 {
-    std::call_once(runs_once_, [this] {
+    Lazy& l = lazy();
+    std::call_once(l.runs_once, [&] {
         const int32_t n = num_runs();
         if (block_->expand_states)
         {
             size_t total = 0;
             for (int32_t k = 0; k < n; ++k) total += static_cast<size_t>(count(k));
-            alignment_.reserve(total);
-            for (int32_t k = 0; k < n; ++k) alignment_.insert(alignment_.end(), static_cast<size_t>(count(k)), static_cast<AlignmentState>(op(k)));
+            l.alignment.reserve(total);
+            for (int32_t k = 0; k < n; ++k) l.alignment.insert(l.alignment.end(), static_cast<size_t>(count(k)), static_cast<AlignmentState>(op(k)));
         }
         else
         {
-            action_.resize(static_cast<size_t>(n));
-            runlength_.resize(static_cast<size_t>(n));
+            l.action.resize(static_cast<size_t>(n));
+            l.runlength.resize(static_cast<size_t>(n));
             for (int32_t k = 0; k < n; ++k)
             {
-                action_[static_cast<size_t>(k)]    = op(k);
-                runlength_[static_cast<size_t>(k)] = count(k);
+                l.action[static_cast<size_t>(k)]    = op(k);
+                l.runlength[static_cast<size_t>(k)] = count(k);
             }
         }
     });
@@ -169,31 +203,31 @@ void PackedAlignment::materialise_runs() const
 const std::string& PackedAlignment::get_query_sequence() const
 {
     materialise_sequences();
-    return query_;
+    return lazy().query;
 }
 
 const std::string& PackedAlignment::get_target_sequence() const
 {
     materialise_sequences();
-    return target_;
+    return lazy().target;
 }
 
 const std::vector<AlignmentState>& PackedAlignment::get_alignment() const
 {
     materialise_runs();
-    return alignment_;
+    return lazy().alignment;
 }
 
 const std::vector<int8_t>& PackedAlignment::get_actions() const
 {
     materialise_runs();
-    return action_;
+    return lazy().action;
 }
 
 const std::vector<int32_t>& PackedAlignment::get_runlengths() const
 {
     materialise_runs();
-    return runlength_;
+    return lazy().runlength;
 }
 
 std::string PackedAlignment::convert_to_cigar(CigarFormat format) const
@@ -221,7 +255,8 @@ FormattedAlignment PackedAlignment::format_alignment(int32_t maximal_line_length
 {
     materialise_sequences();
     materialise_runs();
-    return format_states(query_, target_, alignment_, maximal_line_length); // renders the per-position form only, like AlignmentImpl
+    const Lazy& l = lazy();
+    return format_states(l.query, l.target, l.alignment, maximal_line_length); // renders the per-position form only, like AlignmentImpl
 }
 
 std::ostream& operator<<(std::ostream& os, const FormattedAlignment& f)

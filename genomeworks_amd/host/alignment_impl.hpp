@@ -2,8 +2,10 @@
 #pragma once
 #include <claraparabricks/genomeworks/cudaaligner/alignment.hpp>
 
+#include <atomic>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace claraparabricks
@@ -68,30 +70,40 @@ class PackedAlignment;
 struct PackedAlignmentBlock
 {
     ~PackedAlignmentBlock();
-    std::vector<char> sequences;       ///< q0 t0 q1 t1 ...
-    std::vector<int64_t> seq_starts;   ///< [2n + 1]
+    /// q0 t0 q1 t1 ... and the [2n + 1] offsets into it: the batch's own (pinned) staging arrays, handed over by the
+    /// aligner at sync time; returned to the pinned cache with the block
+    const char* sequences     = nullptr;
+    const int64_t* seq_starts = nullptr;
+    char* sequences_buffer    = nullptr;
+    size_t sequences_bytes    = 0;
+    char* seq_starts_buffer   = nullptr;
+    size_t seq_starts_bytes   = 0;
+    std::vector<char> sequences_owned;      ///< tests / callers without pinned buffers
+    std::vector<int64_t> seq_starts_owned;
     /// pinned host buffer [ops (total) | pad | counts (total x int32)] from the runtime's pinned cache
     char* pinned          = nullptr;
     size_t pinned_bytes   = 0;
     const int8_t* ops     = nullptr;
     const int32_t* counts = nullptr;
-    std::vector<PackedAlignment> alignments; ///< by index of add_alignment
-    bool expand_states = false;              ///< AlignerGlobalMyers: per-position states instead of run lengths
+    PackedAlignment* alignments = nullptr;   ///< [n_alignments] by index of add_alignment (raw storage, see allocate_views)
+    size_t n_alignments         = 0;
+    bool expand_states          = false;     ///< AlignerGlobalMyers: per-position states instead of run lengths
+    void allocate_views(size_t n);           ///< uninitialised storage for n views (constructed by the binder threads)
 };
 
 class PackedAlignment final : public Alignment
 {
 public:
-    PackedAlignment() = default;
-    void bind(const PackedAlignmentBlock* block, int32_t index, int32_t run_begin, int32_t run_end, bool has_result, bool is_optimal)
+    PackedAlignment(const PackedAlignmentBlock* block, int32_t index, int32_t run_begin, int32_t run_end, bool has_result, bool is_optimal)
+        : block_(block)
+        , index_(index)
+        , run_begin_(run_begin)
+        , run_end_(run_end)
+        , has_result_(has_result)
+        , is_optimal_(has_result && is_optimal)
     {
-        block_      = block;
-        index_      = index;
-        run_begin_  = run_begin;
-        run_end_    = run_end;
-        has_result_ = has_result;
-        is_optimal_ = has_result && is_optimal;
     }
+    ~PackedAlignment() override;
 
     const std::string& get_query_sequence() const override;
     const std::string& get_target_sequence() const override;
@@ -109,19 +121,27 @@ public:
     /// run k in forward order (the device stores an alignment back to front)
     int8_t op(int32_t k) const { return block_->ops[run_end_ - 1 - k]; }
     int32_t count(int32_t k) const { return block_->counts[run_end_ - 1 - k]; }
+    bool materialised() const { return lazy_.load(std::memory_order_acquire) != nullptr; }
 
 private:
+    /// what the accessors that return references need to own; built on first use, one allocation per alignment that is
+    /// actually inspected (a view itself is 40 bytes: a million-pair batch costs 40 MB, not a million string pairs)
+    struct Lazy
+    {
+        std::once_flag seq_once, runs_once;
+        std::string query, target;
+        std::vector<AlignmentState> alignment;
+        std::vector<int8_t> action;
+        std::vector<int32_t> runlength;
+    };
+    Lazy& lazy() const;
     void materialise_sequences() const;
     void materialise_runs() const;
 
-    const PackedAlignmentBlock* block_ = nullptr;
-    int32_t index_ = 0, run_begin_ = 0, run_end_ = 0;
-    bool has_result_ = false, is_optimal_ = false;
-    mutable std::once_flag seq_once_, runs_once_;
-    mutable std::string query_, target_;
-    mutable std::vector<AlignmentState> alignment_;
-    mutable std::vector<int8_t> action_;
-    mutable std::vector<int32_t> runlength_;
+    const PackedAlignmentBlock* block_;
+    int32_t index_, run_begin_, run_end_;
+    bool has_result_, is_optimal_;
+    mutable std::atomic<Lazy*> lazy_{nullptr};
 };
 
 /// pinned host staging buffers, recycled process-wide (hipHostMalloc / hipHostFree cost far more than the copies

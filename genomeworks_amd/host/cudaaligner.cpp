@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <new>
 #include <numeric>
 #include <cstdlib>
 #include <stdexcept>
@@ -57,6 +58,7 @@ BandedAligner::BandedAligner(int64_t max_device_memory, int32_t max_bandwidth, D
     , max_target_length_(max_target_length)
     , max_alignments_(max_alignments)
 {
+    seq_starts_h_.assign(1, 0);
     reset_max_bandwidth(max_bandwidth);
 }
 
@@ -94,6 +96,8 @@ void BandedAligner::reset_data()
     max_bandwidths_h_.clear();
     workspace_bytes_estimate_ = 0;
     largest_wave_ws_          = 0;
+    longest_query_            = 0;
+    widest_band_              = 0;
     launched_                 = false;
 }
 
@@ -101,6 +105,7 @@ void BandedAligner::reset()
 {
     scoped_device_switch dev(device_id_);
     (void)hipStreamSynchronize(stream_);
+    uploads_in_flight_ = false;
     reset_data();
     free_device();
     alignments_.clear();
@@ -122,6 +127,13 @@ StatusType BandedAligner::add_alignment(int32_t max_bandwidth, const char* query
                                         int32_t target_length, bool reverse_complement_query, bool reverse_complement_target)
 {
     GW_NVTX_RANGE(profiler, "BandedAligner::add_alignment");
+    if (uploads_in_flight_)
+    {
+        // the staging arrays may be read by copies queued in align_all(): let them drain before the arrays can move
+        scoped_device_switch dev(device_id_);
+        GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+        uploads_in_flight_ = false;
+    }
     if (max_bandwidth < 0 || query_length < 0 || target_length < 0 || query == nullptr || target == nullptr)
         return StatusType::generic_error;
     if (max_query_length_ >= 0)
@@ -173,6 +185,8 @@ StatusType BandedAligner::add_alignment(int32_t max_bandwidth, const char* query
     seq_starts_h_.push_back(seq_start + query_length);
     seq_starts_h_.push_back(new_len_sum);
     max_bandwidths_h_.push_back(max_bandwidth);
+    longest_query_            = std::max(longest_query_, query_length);
+    widest_band_              = std::max(widest_band_, max_bandwidth);
     workspace_bytes_estimate_ = new_estimate;
     return StatusType::success;
 }
@@ -185,11 +199,27 @@ StatusType BandedAligner::align_all()
     scoped_device_switch dev(device_id_);
     const int64_t total_len = seq_starts_h_.back();
     // longest pairs first (aligner_global_myers_banded.cpp:306-309): lanes of one wave get similar work
-    std::vector<int32_t> order(static_cast<size_t>(n));
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        return (seq_starts_h_[2 * a + 2] - seq_starts_h_[2 * a]) > (seq_starts_h_[2 * b + 2] - seq_starts_h_[2 * b]);
-    });
+    PinnedVector<int32_t> order;
+    order.resize(static_cast<size_t>(n));
+    {
+        int64_t longest = 0;
+        for (int32_t i = 0; i < n; ++i) longest = std::max(longest, seq_starts_h_[2 * i + 2] - seq_starts_h_[2 * i]);
+        if (n >= 4096 && longest < (int64_t(1) << 22))
+        {
+            // a stable counting sort by descending pair length: linear in n (a million short pairs sort in a few ms)
+            std::vector<int32_t> first(static_cast<size_t>(longest) + 2, 0);
+            for (int32_t i = 0; i < n; ++i) first[static_cast<size_t>(longest - (seq_starts_h_[2 * i + 2] - seq_starts_h_[2 * i])) + 1]++;
+            for (size_t k = 1; k < first.size(); ++k) first[k] += first[k - 1];
+            for (int32_t i = 0; i < n; ++i) order[static_cast<size_t>(first[static_cast<size_t>(longest - (seq_starts_h_[2 * i + 2] - seq_starts_h_[2 * i]))]++)] = i;
+        }
+        else
+        {
+            std::iota(order.data(), order.data() + n, 0);
+            std::stable_sort(order.data(), order.data() + n, [&](int32_t a, int32_t b) {
+                return (seq_starts_h_[2 * a + 2] - seq_starts_h_[2 * a]) > (seq_starts_h_[2 * b + 2] - seq_starts_h_[2 * b]);
+            });
+        }
+    }
 
     workspace_bytes_ = gwhip_myers_banded_workspace_bytes_ordered(n, seq_starts_h_.data(), max_bandwidths_h_.data(), order.data());
     size_t off       = 0;
@@ -220,7 +250,8 @@ StatusType BandedAligner::align_all()
     GW_CU_CHECK_ERR(hipMemcpyAsync(d_bw_, max_bandwidths_h_.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, stream_));
     GW_CU_CHECK_ERR(hipMemcpyAsync(d_order_, order_h_.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, stream_));
     launch();
-    launched_ = true;
+    launched_          = true;
+    uploads_in_flight_ = true;
     return StatusType::success;
 }
 
@@ -242,9 +273,8 @@ void BandedAligner::launch(void* event_before, void* event_after)
     a.scheduling_index      = d_order_;
     a.band_cells            = d_cells_;
     // hints for the LDS-cached kernel variant: longest query and widest band of this batch
-    for (size_t i = 0; i + 2 < seq_starts_h_.size(); i += 2)
-        a.max_query_length = std::max(a.max_query_length, static_cast<int32_t>(seq_starts_h_[i + 1] - seq_starts_h_[i]));
-    for (int32_t bw : max_bandwidths_h_) a.max_bandwidth_hint = std::max(a.max_bandwidth_hint, bw);
+    a.max_query_length   = longest_query_;
+    a.max_bandwidth_hint = widest_band_;
     if (event_before != nullptr) GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(event_before), stream_));
     const int rc            = gwhip_myers_banded(&a, stream_);
     if (event_after != nullptr) GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(event_after), stream_));
@@ -319,6 +349,7 @@ StatusType BandedAligner::sync_alignments()
     const size_t un       = static_cast<size_t>(n);
     if (!launched_ || n_head_ != n) throw std::runtime_error("sync_alignments() called before align_all()");
     GW_CU_CHECK_ERR(hipStreamSynchronize(stream_)); // kernels + the offsets / metadata copy queued by align_all()
+    uploads_in_flight_ = false;
     const int32_t* starts = reinterpret_cast<const int32_t*>(head_);
     const uint32_t* meta  = reinterpret_cast<const uint32_t*>(head_) + un + 1;
     const size_t total    = static_cast<size_t>(starts[un]);
@@ -331,19 +362,21 @@ StatusType BandedAligner::sync_alignments()
         GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned, d_results_, total, hipMemcpyDeviceToHost, stream_));
         GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned + counts_at, d_result_counts_, total * 4, hipMemcpyDeviceToHost, stream_));
     }
-    // while the runs are in flight: hand the batch's sequences to the block and lay out the views
-    block->sequences  = std::move(seq_h_);
-    block->seq_starts = std::move(seq_starts_h_);
-    block->alignments = std::vector<PackedAlignment>(un);
+    // while the runs are in flight: hand the batch's (pinned) sequence arrays to the block and lay out the views
+    block->sequences_buffer  = seq_h_.detach(&block->sequences_bytes);
+    block->sequences         = block->sequences_buffer;
+    block->seq_starts_buffer = reinterpret_cast<char*>(seq_starts_h_.detach(&block->seq_starts_bytes));
+    block->seq_starts        = reinterpret_cast<const int64_t*>(block->seq_starts_buffer);
+    block->allocate_views(un);
     alignments_.resize(un);
     auto bind_range = [&](size_t first, size_t last) {
         for (size_t i = first; i < last; ++i)
         {
             const bool is_optimal = (meta[i] >> 31) != 0;
-            const size_t index    = meta[i] & DeviceAlignmentsPtrs::index_mask;
-            const int64_t* st     = block->seq_starts.data() + 2 * index;
+            const size_t index    = meta[i] & DeviceAlignmentsPtrs::index_mask; // the kernels write metadata[i] for pair i: a bijection
+            const int64_t* st     = block->seq_starts + 2 * index;
             const bool has_result = starts[i] != starts[i + 1] || (st[0] == st[1] && st[1] == st[2]);
-            block->alignments[index].bind(block.get(), static_cast<int32_t>(index), starts[i], starts[i + 1], has_result, is_optimal);
+            new (&block->alignments[index]) PackedAlignment(block.get(), static_cast<int32_t>(index), starts[i], starts[i + 1], has_result, is_optimal);
         }
     };
     // the shared_ptr of every view aliases the block (no allocation per alignment); big batches are split over a few
@@ -371,6 +404,7 @@ StatusType BandedAligner::sync_alignments()
         publish_range(0, std::min(un, chunk));
         for (std::thread& w : workers) w.join();
     }
+    block->n_alignments = un;
     GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
     total_length_h_ = static_cast<int64_t>(total);
     // keep the device block (device-resident results stay valid until reset()); host queues are cleared like the reference

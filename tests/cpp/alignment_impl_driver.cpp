@@ -4,6 +4,7 @@
 // tests/test_alignment_impl.py against the vectors of the reference's Test_AlignmentImpl.cpp:36-204. No device calls.
 #include <iostream>
 #include <memory>
+#include <new>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -61,9 +62,11 @@ int main()
         {
             auto block           = std::make_shared<PackedAlignmentBlock>();
             block->expand_states = expand != 0;
-            block->sequences.assign(q.begin(), q.end());
-            block->sequences.insert(block->sequences.end(), t.begin(), t.end());
-            block->seq_starts = {0, static_cast<int64_t>(q.size()), static_cast<int64_t>(q.size() + t.size())};
+            block->sequences_owned.assign(q.begin(), q.end());
+            block->sequences_owned.insert(block->sequences_owned.end(), t.begin(), t.end());
+            block->seq_starts_owned = {0, static_cast<int64_t>(q.size()), static_cast<int64_t>(q.size() + t.size())};
+            block->sequences        = block->sequences_owned.data();
+            block->seq_starts       = block->seq_starts_owned.data();
             std::vector<int8_t> ops;
             std::vector<int32_t> counts;
             for (size_t i = states.size(); i-- > 0;)
@@ -74,8 +77,9 @@ int main()
             }
             block->ops        = ops.data();
             block->counts     = counts.data();
-            block->alignments = std::vector<PackedAlignment>(1);
-            block->alignments[0].bind(block.get(), 0, 0, static_cast<int32_t>(ops.size()), true, optimal != 0);
+            block->allocate_views(1);
+            new (&block->alignments[0]) PackedAlignment(block.get(), 0, 0, static_cast<int32_t>(ops.size()), true, optimal != 0);
+            block->n_alignments = 1;
             std::shared_ptr<Alignment> view(block, &block->alignments[0]);
             report(expand ? "PackedAlignment(states)" : "PackedAlignment(runs)", *view);
             if (!expand)
