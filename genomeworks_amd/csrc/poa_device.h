@@ -503,6 +503,201 @@ __device__ __forceinline__ int32_t traceback_banded_tiled(const BandedCtx<ScoreT
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tiled traceback for graphs whose row table lives in HBM (long reads). traceback_banded_tiled keeps the score matrix
+// around the path in LDS, but with the row table, the read and the output arrays in HBM every step still paid global
+// round trips behind its own stores (about 1 450 cycles per step). Here everything a step touches is staged with the
+// tile, by all lanes, in the same round trip: the row-table records of the 64 tile rows, 256 characters of the read
+// around the anchor column, and the walk's output (cells, 64 per flush; graph positions are translated to node ids by
+// all lanes after the walk). Same decision sequence as traceback_banded (cudapoa_nw_banded.cuh:428-549).
+// LDS (the forward pass's ring, dead by now): tile[64][64] | meta[64] | rows[64] | read[256] | stage[64].
+// ------------------------------------------------------------------------------------------------
+template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE>
+__device__ __forceinline__ int32_t traceback_banded_tiled_staged(const BandedCtx<ScoreT>& b, const GraphView<IdT>& g,
+                                                                 const RowT* rowinfo, int32_t graph_count, const uint8_t* read,
+                                                                 int32_t read_length, int32_t start_i, int32_t* alignment_graph,
+                                                                 int32_t* alignment_read, int32_t gap_score, int32_t mismatch_score,
+                                                                 int32_t match_score, int32_t rerun, uint8_t* lds)
+{
+    constexpr int kTileRows = 64, kTileCols = 64, kReanchor = 44, kReadWin = 256, kStage = 64;
+    ScoreT* tile       = reinterpret_cast<ScoreT*>(lds);
+    int32_t* tile_meta = reinterpret_cast<int32_t*>(lds + kTileRows * kTileCols * sizeof(ScoreT));
+    RowT* ri_tile      = reinterpret_cast<RowT*>(reinterpret_cast<uint8_t*>(tile_meta) + kTileRows * sizeof(int32_t));
+    uint8_t* rd_tile   = reinterpret_cast<uint8_t*>(ri_tile) + kTileRows * sizeof(RowT);
+    uint64_t* stage    = reinterpret_cast<uint64_t*>(rd_tile + kReadWin);
+    const int lane      = threadIdx.x & (kWave - 1);
+    const int32_t bound = read_length + graph_count + 2;
+    int32_t aligned_nodes = 0;
+    int32_t i = start_i, j = read_length, prev_i = 0, prev_j = 0;
+    int32_t tile_top = -1, rd_lo = 0;
+
+    auto load_tile = [&](int32_t top, int32_t col) {
+        wave_sync();
+        const int32_t row = top - lane;
+        int32_t bs = 0, e0 = 0;
+        if (row >= 0)
+        {
+            bs = band_start_for_row(row, b.gradient, b.band_width, b.band_shift, b.max_column);
+            e0 = (col - lane - 40) - bs + kRelShift;
+            e0 = min(max(e0 & ~3, 0), b.stride - kTileCols);
+            const ScoreT* src = b.scores + (int64_t)row * b.stride + e0;
+            ScoreT* dst       = tile + lane * kTileCols;
+#pragma unroll
+            for (int k = 0; k < kTileCols; k += 4)
+                *reinterpret_cast<Quad<ScoreT>*>(dst + k) = *reinterpret_cast<const Quad<ScoreT>*>(src + k);
+            if (row >= 1) ri_tile[lane] = rowinfo[row];
+        }
+        tile_meta[lane] = (row >= 0) ? ((bs & 0xffff) | ((e0 - kRelShift + bs) << 16)) : 0x7fff0000;
+        // read characters of columns [rd_lo + 1, rd_lo + 256]: the walk only moves left, at most one tile width plus the
+        // window's own drift before the next re-anchor (the input buffer keeps zero slack behind the last read)
+        rd_lo = max(col - 192, 0) & ~3;
+        *reinterpret_cast<uint32_t*>(rd_tile + 4 * lane) = *reinterpret_cast<const uint32_t*>(read + rd_lo + 4 * lane);
+        wave_sync();
+    };
+    auto score_at = [&](int32_t row, int32_t column) -> int32_t {
+        const int32_t rr = tile_top - row;
+        if (tile_top >= 0 && rr >= 0 && rr < kTileRows)
+        {
+            const int32_t meta = tile_meta[rr];
+            const int32_t bs   = meta & 0xffff;
+            const int32_t lo   = meta >> 16;
+            const int32_t bend = min(bs + b.band_width, b.max_column);
+            if ((column > bend || column < bs) && column != -1) return b.min_score;
+            const int32_t col = column == -1 ? bs : column;
+            if (col == bs && bs > 0 && row > 0) return b.min_score;
+            const int32_t off = col - lo;
+            if (off >= 0 && off < kTileCols) return tile[rr * kTileCols + off];
+        }
+        return get_score(b, row, column);
+    };
+    // stage[k] = the cell step k left; the reference's entry for a step follows from two consecutive cells
+    auto flush_stage = [&](int32_t first, int32_t count) {
+        if (lane < count)
+        {
+            const uint64_t cur = stage[lane];
+            const uint64_t nxt = lane + 1 < count ? stage[lane + 1] : ((uint64_t)(uint32_t)i | ((uint64_t)(uint32_t)j << 32));
+            const int32_t ci = (int32_t)(uint32_t)cur, cj = (int32_t)(cur >> 32);
+            const int32_t ni = (int32_t)(uint32_t)nxt, nj = (int32_t)(nxt >> 32);
+            alignment_graph[first + lane] = ci == ni ? -1 : ci - 1; // sorted position; node ids are filled in below
+            alignment_read[first + lane]  = cj == nj ? -1 : cj - 1;
+        }
+    };
+
+    bool rerun_break = false;
+    while (!(i == 0 && j == 0) && aligned_nodes < bound) // every step appends one entry: the reference's loop counter
+    {
+        {
+            const int32_t rr = tile_top - i;
+            bool reload      = tile_top < 0 || rr < 0 || rr >= kReanchor;
+            if (!reload)
+            {
+                const int32_t meta = tile_meta[rr];
+                const int32_t off  = j - (meta >> 16);
+                reload             = (off < 2 || off >= kTileCols);
+            }
+            reload = reload || (j - 1 - rd_lo) < 0; // (cannot happen between two re-anchors; kept as a guard)
+            if (reload && i > 0)
+            {
+                tile_top = i;
+                load_tile(i, j);
+            }
+        }
+        const int32_t scores_ij = score_at(i, j);
+        bool pred_found         = false;
+        RowT ri{};
+        int32_t pred_count = 0, node_id = 0;
+        if (i != 0)
+        {
+            ri         = uniform_row(ri_tile[tile_top - i]);
+            pred_count = ri.cnt();
+        }
+        auto pred_row = [&](int32_t p) -> int32_t {
+            if (pred_count == 0) return 0;
+            if (p < 3) return ri.pred(p);
+            return (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
+        };
+        if (i != 0 && pred_count > 3) node_id = g.sorted_poa[i - 1];
+        if (i != 0 && j != 0)
+        {
+            if (ADAPTIVE)
+            {
+                if (rerun == 0 && b.band_width < kMaxAdaptiveBand)
+                {
+                    int32_t threshold = max(1, b.max_column / 1024);
+                    if (j > threshold && j < b.max_column - threshold)
+                    {
+                        int32_t bs = band_start_for_row(i, b.gradient, b.band_width, b.band_shift, b.max_column);
+                        if (j <= bs + threshold) { aligned_nodes = kShiftLeft; rerun_break = true; }
+                        else if (j >= (bs + b.band_width - threshold)) { aligned_nodes = kShiftRight; rerun_break = true; }
+                    }
+                }
+            }
+            if (!rerun_break)
+            {
+                const int32_t rc   = j - 1 - rd_lo;
+                const uint32_t ch  = (uint32_t)rc < (uint32_t)kReadWin ? rd_tile[rc] : read[j - 1];
+                int32_t match_cost = ((uint32_t)ri.base() == ch ? match_score : mismatch_score);
+                int32_t np         = max(pred_count, 1);
+                for (int32_t p = 0; p < np; p++)
+                {
+                    int32_t pi = pred_row(p);
+                    if (scores_ij == score_at(pi, j - 1) + match_cost)
+                    {
+                        prev_i = pi; prev_j = j - 1; pred_found = true;
+                        break;
+                    }
+                }
+            }
+        }
+        if (rerun_break) break;
+        if (!pred_found && i != 0)
+        {
+            int32_t np = max(pred_count, 1);
+            for (int32_t p = 0; p < np; p++)
+            {
+                int32_t pi = pred_row(p);
+                if (scores_ij == score_at(pi, j) + gap_score)
+                {
+                    prev_i = pi; prev_j = j; pred_found = true;
+                    break;
+                }
+            }
+        }
+        if (!pred_found && scores_ij == score_at(i, j - 1) + gap_score)
+        {
+            prev_i = i; prev_j = j - 1; pred_found = true;
+        }
+        if (lane == 0) stage[aligned_nodes & (kStage - 1)] = (uint64_t)(uint32_t)i | ((uint64_t)(uint32_t)j << 32);
+        aligned_nodes++;
+        i = prev_i;
+        j = prev_j;
+        if ((aligned_nodes & (kStage - 1)) == 0)
+        {
+            wave_sync();
+            flush_stage(aligned_nodes - kStage, kStage);
+        }
+    }
+    if (rerun_break) return aligned_nodes;
+    wave_sync();
+    if (aligned_nodes > 0 && (aligned_nodes & (kStage - 1)) != 0)
+        flush_stage(aligned_nodes & ~(kStage - 1), aligned_nodes & (kStage - 1));
+    if (aligned_nodes >= bound) aligned_nodes = kNwLoopFailed;
+    wave_sync();
+    for (int32_t k0 = lane; k0 < aligned_nodes; k0 += 4 * kWave) // positions -> node ids, four load chains per lane
+    {
+        int32_t pos[4], node[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) pos[u] = (k0 + u * kWave < aligned_nodes) ? alignment_graph[k0 + u * kWave] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; u++) node[u] = (int32_t)g.sorted_poa[max(pos[u], 0)];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (pos[u] >= 0) alignment_graph[k0 + u * kWave] = node[u];
+    }
+    wave_sync();
+    return aligned_nodes;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Traceback by recomputation, candidate-per-lane. Same decision sequence as cudapoa_nw_banded.cuh:428-549
 // (diagonal move through predecessor 0..n-1, then vertical through predecessor 0..n-1, then horizontal; first
 // equality wins), but one step evaluates every candidate at once: lanes 0..30 test the diagonal moves, lanes
@@ -1875,7 +2070,17 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             tb_done = true;
         }
     }
+    constexpr bool kStagedOk = std::is_same<RowT, RowInfo<false>>::value && !LDS_READ;
+    const bool staged_fits   = (int32_t)(64 * 64 * sizeof(ScoreT) + 64 * 4 + 64 * sizeof(RowT) + 256 + 64 * 8) <= ring_bytes;
     if (tb_done) {}
+    else if (kStagedOk && staged_fits && b.stride >= 64 && !(dbg & 128))
+    {
+        // graphs beyond the LDS tables: score tile, row records, read window and output all staged in the dead ring
+        aligned_nodes = traceback_banded_tiled_staged<ScoreT, IdT, RowT, ADAPTIVE>(b, g, rowinfo, graph_count, read, read_length,
+                                                                                  wave_first(best_i), alignment_graph, alignment_read,
+                                                                                  gap_score, mismatch_score, match_score, rerun,
+                                                                                  reinterpret_cast<uint8_t*>(ring_base));
+    }
     else if (LDS_READ && tile_fits && !(dbg & 128))
     {
         // the LDS ring is dead after the forward pass: reuse it as the traceback tile

@@ -8,16 +8,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-import bench_long_read_msa as B  # noqa: E402
-from genomeworks_amd import cudapoa  # noqa: E402
+from genomeworks_amd import cudapoa, synthetic  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 max_seq = int(sys.argv[3]) if len(sys.argv) > 3 else 30106
-b = cudapoa.CudaPoaBatch(32, max_seq, 100 << 30, output_type="msa", band_mode="adaptive_band")
+b = cudapoa.CudaPoaBatch(32, max_seq, 100 << 30, output_type="msa", band_mode="adaptive_band",
+                         matrix_sequence_dimension=4 * 264, max_nodes_per_graph=3 * max_seq)
 n = 0
 for w in range(first, first + count):
-    reads = [s for s in B.make_window(w, 32768) if len(s) < max_seq]
+    reads = [s for s in synthetic.long_read_window(w, 32768) if len(s) < max_seq]
     if reads and b.add_poa_group(reads)[0] == 0:
         n += 1
 b.generate_poa()
