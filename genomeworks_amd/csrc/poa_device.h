@@ -140,6 +140,12 @@ __device__ __forceinline__ void block_barrier()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// barrier that orders LDS traffic only: outstanding global stores keep draining behind it (a full block_barrier()
+// would make every row of the multi-wave forward pass wait for the acknowledgement of its own score stores)
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __device__ __forceinline__ int32_t wave_bcast(int32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int32_t wave_first(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -1542,44 +1548,30 @@ __device__ __forceinline__ void generic_forward_mw(const MwArgs<ScoreT>& A, cons
             const int32_t sl = slot_r - (r - row);
             return sl < 0 ? sl + ring_rows : sl;
         };
+        // band start of an earlier row: arithmetic (a dozen ALU operations) instead of a dependent LDS / HBM read
         auto bs_of = [&](int32_t row) -> int32_t {
-            if (row == 0) return 0;
-            if (in_ring(row)) return bs_ring[slot_of(row)];
-            return uniform_row(rowinfo[row]).bs();
+            return row == 0 ? 0 : band_start_for_row(row, A.gradient, band_width, A.band_shift, max_column);
         };
         auto rel0_of = [&](int32_t row) -> int32_t {
             if (in_ring(row)) return lds_ld(ring + slot_of(row) * stride + kRelShift);
             return wave_first((int32_t)scores[(int64_t)row * stride + kRelShift]);
         };
-        if (bs + npass * 256 + 4 > staged_end) stage_read(bs + npass * 256 + 4);
-
-        // ---- left boundary / carry-in (cudapoa_nw_banded.cuh:293-326): wave 0 owns it ----
-        int32_t fe = 0, rel0_val = min_score;
-        if (wave == 0)
+        // a predecessor that has left the ring is read from the HBM matrix, possibly written by another wavefront: make
+        // every wavefront's stores complete first (rare: about 2 % of the rows; the decision is the same in all waves)
         {
-            if (pred_count == 0)
-            {
-                if (bs == 0) rel0_val = (ScoreT)gap_score; // carry-in stays 0: reference quirk
-            }
-            else
-            {
-                if (bs > kCellsPerLane && pred_count == 1)
-                    fe = min_score + gap_score;
-                else
-                {
-                    int32_t penalty = min_score;
-                    for (int32_t p = 0; p < pred_count; p++) penalty = max(penalty, rel0_of(pred_row(p)));
-                    fe = penalty + gap_score;
-                }
-                if (bs == 0) rel0_val = (ScoreT)fe;
-            }
+            bool far = false;
+            const int32_t npred = max(pred_count, 1);
+            for (int32_t p = 0; p < npred; p++) far = far || !in_ring(pred_row(p));
+            if (far) block_barrier();
         }
+        if (bs + npass * 256 + 4 > staged_end) stage_read(bs + npass * 256 + 4);
 
         // ---- this wave's pass: candidates from every predecessor, prefix maximum inside the pass ----
         const int32_t tg   = pass * 256 + 4 * lane; // index of the lane's first cell in the band
         const int32_t c    = bs + tg;               // chunk anchor column (cells c+1 .. c+4)
         const bool active  = has_pass && tg < band_width;
         int32_t m0 = INT32_MIN, m1 = INT32_MIN, m2 = INT32_MIN, m3 = INT32_MIN, incl = INT32_MIN;
+        int32_t fe = 0, rel0_val = min_score;
         if (has_pass)
         {
             const uint32_t rd4 = *reinterpret_cast<const uint32_t*>(read_window + (c & (kWin - 1)));
@@ -1630,11 +1622,35 @@ __device__ __forceinline__ void generic_forward_mw(const MwArgs<ScoreT>& A, cons
             if (!active) u0 = u1 = u2 = u3 = INT32_MIN;
             m0 = u0; m1 = max(m0, u1); m2 = max(m1, u2); m3 = max(m2, u3);
             incl = wave_inclusive_max(m3);
+        }
+        // ---- left boundary / carry-in (cudapoa_nw_banded.cuh:293-326): wave 0 owns it ----
+        if (wave == 0)
+        {
+            if (pred_count == 0)
+            {
+                if (bs == 0) rel0_val = (ScoreT)gap_score; // carry-in stays 0: reference quirk
+            }
+            else
+            {
+                if (bs > kCellsPerLane && pred_count == 1)
+                    fe = min_score + gap_score;
+                else
+                {
+                    int32_t penalty = min_score;
+                    for (int32_t p = 0; p < pred_count; p++) penalty = max(penalty, rel0_of(pred_row(p)));
+                    fe = penalty + gap_score;
+                }
+                if (bs == 0) rel0_val = (ScoreT)fe;
+            }
+        }
+
+        if (has_pass)
+        {
             int32_t total = wave_bcast(incl, kWave - 1);
             if (wave == 0) total = max(total, fe + gap_score); // the carry-in is element t = -1 of the band: fe - (-1) * gap
             if (lane == 0) shared->totals[pass] = total;
         }
-        block_barrier(); // ---- A: every pass has published its total ----
+        lds_barrier(); // ---- A: every pass has published its total ----
         if (has_pass)
         {
             int32_t before = wave == 0 ? fe + gap_score : INT32_MIN;
@@ -1658,9 +1674,10 @@ __device__ __forceinline__ void generic_forward_mw(const MwArgs<ScoreT>& A, cons
             ring[slot_r * stride + kRelShift]       = (ScoreT)rel0_val;
             bs_ring[slot_r]                         = bs;
         }
-        block_barrier(); // ---- B: the row is in the ring ----
+        lds_barrier(); // ---- B: the row is in the ring ----
         slot_r = slot_r + 1 == ring_rows ? 0 : slot_r + 1;
     }
+    block_barrier(); // the score matrix is complete in HBM (wave 0's traceback reads it)
 }
 
 // ------------------------------------------------------------------------------------------------
