@@ -359,7 +359,22 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
             }
         }
         pc.tick(kPhAddAlignment);
-        if (lane == 0 && status_and_count >= 0)
+        status_and_count = wave_first(status_and_count);
+        // graphs beyond the LDS tables in the banded score-matrix modes: Kahn order with an LDS cache of node records
+        // filled along the previous order (the ring and the score matrix are idle here)
+        constexpr bool kCachedSort = !LDS_TABLES && !TB && BM != GWHIP_FULL_BAND;
+        bool sorted_here = false;
+        if constexpr (kCachedSort)
+        {
+            if (status_and_count >= 0 && !c.spoa_accurate && !(a.debug_flags & (1 << 21)) &&
+                (int64_t)a.L.scores_elems * (int64_t)sizeof(ScoreT) >= (int64_t)(2 * ((node_count + 63) & ~63)) * 4)
+            {
+                wave_sync();
+                topsort_kahn_cached<IdT>(g, node_count, status_and_count, smem, reinterpret_cast<int32_t*>(scores), lane);
+                sorted_here = true;
+            }
+        }
+        if (lane == 0 && status_and_count >= 0 && !sorted_here)
         {
             const int32_t new_count = status_and_count;
             if (c.spoa_accurate)
@@ -368,7 +383,6 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
                 topsort_kahn<IdT>(g.sorted_poa, g.node_id_to_pos, new_count, g.incoming_edge_count,
                                   g.outgoing_edges, g.outgoing_edge_count, g.local_cnt);
         }
-        status_and_count = wave_first(status_and_count);
         wave_sync();
         if (status_and_count >= 0 && !c.spoa_accurate && graph_fits_lds)
         {

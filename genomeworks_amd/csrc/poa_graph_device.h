@@ -455,6 +455,157 @@ __device__ void topsort_kahn(IdT* sorted_poa, IdT* node_map, int32_t node_count,
     }
 }
 
+// Kahn order for graphs whose tables live in HBM (long reads: up to ~100 k nodes, 32-bit ids), same output as
+// topsort_kahn. The order-defining loop is a pointer chase -- pop a node, read its out-edges, decrement the children's
+// counters -- and with the graph in HBM every dependent step was a cold round trip (about 2 000 cycles per node on
+// one lane). The chase itself cannot be parallelised (FIFO Kahn order is defined by it), but what it will touch can be
+// predicted: one read changes the graph in a few places, so the new order is almost the previous order, and the nodes
+// that follow node u in the PREVIOUS order are the ones the loop is about to pop and to decrement. They are fetched 64
+// at a time by all lanes (one round trip) into a direct-mapped LDS cache of node records, so the serial loop -- run
+// wave-uniformly on the scalar unit -- pays LDS latency per step. The cache is write-through for the in-edge counters
+// (local_cnt in HBM always holds the current value), so an eviction loses nothing and a refill reads the truth.
+//   LDS (the forward pass's ring, idle during the sort): records[1024] {node, out-degree | unvisited in-edges << 16,
+//   out-edge 0, out-edge 1} | previous position[1024] | the queue's most recent 2048 entries.
+//   scratch (HBM, 2 x n_old int32: the score matrix, dead until the next forward pass): previous order and positions.
+template <typename IdT>
+__device__ __forceinline__ void topsort_kahn_cached(const GraphView<IdT>& g, int32_t n_old, int32_t node_count, uint8_t* lds,
+                                                    int32_t* scratch, int lane)
+{
+    constexpr int32_t kSlots = 1024, kQueue = 2048, kAhead = 16;
+    uint4* rec        = reinterpret_cast<uint4*>(lds);
+    int32_t* rec_pos  = reinterpret_cast<int32_t*>(lds + kSlots * sizeof(uint4));
+    int32_t* qring    = rec_pos + kSlots;
+    int32_t* old_order = scratch;
+    int32_t* old_pos   = scratch + ((n_old + 63) & ~63);
+    for (int32_t i = lane; i < kSlots; i += kWave) rec[i] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+    // pre-pass (all lanes): counters, previous order / positions into scratch, sources in ascending node id
+    int32_t tail = 0;
+    for (int32_t base = 0; base < node_count; base += kWave)
+    {
+        const int32_t n = base + lane;
+        bool is_src     = false;
+        if (n < node_count)
+        {
+            const uint16_t c = g.incoming_edge_count[n];
+            g.local_cnt[n]   = c;
+            is_src           = c == 0;
+            if (n < n_old)
+            {
+                old_order[n] = (int32_t)g.sorted_poa[n];
+                old_pos[n]   = (int32_t)g.node_id_to_pos[n];
+            }
+        }
+        const unsigned long long m = __ballot(is_src);
+        wave_sync(); // old_order / old_pos of this chunk are read before the sources below overwrite sorted_poa / node_id_to_pos
+        if (is_src)
+        {
+            const int32_t at     = tail + __popcll(m & ((1ull << lane) - 1));
+            g.sorted_poa[at]     = (IdT)n;
+            g.node_id_to_pos[n]  = (IdT)at;
+            qring[at & (kQueue - 1)] = n;
+        }
+        tail += __popcll(m);
+    }
+    wave_sync();
+    // fills the record of `node` (all lanes pass the same node): returns the record
+    auto fill_one = [&](int32_t node) -> uint4 {
+        const uint32_t oc = g.outgoing_edge_count[node];
+        const uint32_t ic = g.local_cnt[node];
+        const uint32_t e0 = (uint32_t)(int32_t)g.outgoing_edges[(int64_t)node * kEdges];
+        const uint32_t e1 = (uint32_t)(int32_t)g.outgoing_edges[(int64_t)node * kEdges + 1];
+        const int32_t op  = node < n_old ? old_pos[node] : -1;
+        const uint4 r     = make_uint4((uint32_t)node, (oc & 0xffffu) | (ic << 16), e0, e1);
+        if (lane == 0)
+        {
+            rec[node & (kSlots - 1)]     = r;
+            rec_pos[node & (kSlots - 1)] = op;
+        }
+        asm volatile("" ::: "memory"); // LDS executes one wavefront's operations in order: no wait needed
+        return r;
+    };
+    auto lookup = [&](int32_t node, int32_t& oldp) -> uint4 {
+        const uint4 r  = rec[node & (kSlots - 1)];
+        const int32_t q = rec_pos[node & (kSlots - 1)];
+        uint4 u;
+        u.x = (uint32_t)wave_first((int32_t)r.x); u.y = (uint32_t)wave_first((int32_t)r.y);
+        u.z = (uint32_t)wave_first((int32_t)r.z); u.w = (uint32_t)wave_first((int32_t)r.w);
+        oldp = wave_first(q);
+        if ((int32_t)u.x != node)
+        {
+            u    = fill_one(node);
+            u.x = (uint32_t)wave_first((int32_t)u.x); u.y = (uint32_t)wave_first((int32_t)u.y);
+            u.z = (uint32_t)wave_first((int32_t)u.z); u.w = (uint32_t)wave_first((int32_t)u.w);
+            oldp = node < n_old ? wave_first(old_pos[node]) : -1;
+        }
+        return u;
+    };
+    // the nodes at previous positions [from, from + 64): one lane each, records that are already cached stay as they are
+    auto prefetch = [&](int32_t from) {
+        const int32_t p = from + lane;
+        if (p < n_old)
+        {
+            const int32_t node = old_order[p];
+            const uint32_t oc  = g.outgoing_edge_count[node];
+            const uint32_t ic  = g.local_cnt[node];
+            const uint32_t e0  = (uint32_t)(int32_t)g.outgoing_edges[(int64_t)node * kEdges];
+            const uint32_t e1  = (uint32_t)(int32_t)g.outgoing_edges[(int64_t)node * kEdges + 1];
+            const uint32_t tag = rec[node & (kSlots - 1)].x;
+            if (tag != (uint32_t)node)
+            {
+                rec[node & (kSlots - 1)] = make_uint4((uint32_t)node, (oc & 0xffffu) | (ic << 16), e0, e1);
+                asm volatile("" ::: "memory");
+                // two lanes of one block may map to the same slot: whichever record landed owns the position word too
+                if (rec[node & (kSlots - 1)].x == (uint32_t)node) rec_pos[node & (kSlots - 1)] = p;
+            }
+        }
+        asm volatile("" ::: "memory");
+    };
+    int32_t pref_end = 0;
+    prefetch(0);
+    pref_end = kWave;
+    // the FIFO loop, wave-uniform
+    for (int32_t n = 0; n < tail; n++)
+    {
+        int32_t node;
+        if (tail - n <= kQueue) node = wave_first(qring[n & (kQueue - 1)]);
+        else node = wave_first((int32_t)g.sorted_poa[n]); // a queue longer than the ring: its old entries from HBM
+        int32_t oldp;
+        const uint4 r = lookup(node, oldp);
+        if (oldp >= 0 && oldp + kAhead >= pref_end && pref_end < n_old)
+        {
+            const int32_t from = max(pref_end, oldp + 1);
+            prefetch(from);
+            pref_end = from + kWave;
+        }
+        const int32_t oc = (int32_t)(r.y & 0xffffu);
+        for (int32_t e = 0; e < oc; e++)
+        {
+            const int32_t child = e == 0 ? (int32_t)r.z : (e == 1 ? (int32_t)r.w
+                                 : wave_first((int32_t)g.outgoing_edges[(int64_t)node * kEdges + e]));
+            int32_t cp;
+            const uint4 cr      = lookup(child, cp);
+            const uint32_t left = (cr.y >> 16) - 1u;
+            if (lane == 0)
+            {
+                rec[child & (kSlots - 1)].y = (cr.y & 0xffffu) | (left << 16);
+                g.local_cnt[child]          = (uint16_t)left; // write-through
+            }
+            if ((left & 0xffffu) == 0)
+            {
+                if (lane == 0)
+                {
+                    g.sorted_poa[tail]          = (IdT)child;
+                    g.node_id_to_pos[child]     = (IdT)tail;
+                    qring[tail & (kQueue - 1)]  = child;
+                }
+                tail++;
+            }
+            asm volatile("" ::: "memory"); // (no wait: the counter's write-through store must not stall the chase)
+        }
+    }
+    wave_sync();
+}
+
 // Kahn with its working set in LDS (node counts <= 3072, 16-bit ids): the order-defining serial loop then pays
 // LDS latency per dependent step instead of an HBM round trip. Same output as topsort_kahn.
 //   ent[n]  : one 64-bit word per node (first two out-edges, out-degree, unvisited in-edges)   24 KB (row-table region)
