@@ -132,17 +132,59 @@ __device__ __forceinline__ int32_t advance_word(uint32_t hbit, uint32_t eq, uint
     return out_x;
 }
 
+// The target characters of a pair, 64 at a time through a per-lane LDS buffer (LDS_STATE kernels). A per-column global
+// load -- even one requested a column ahead -- has to wait for the column's own pv / mv / score stores (loads and stores
+// share the in-order vmcnt counter), i.e. for an HBM write acknowledgement per column; with the buffer that wait
+// happens once per 64 columns. Lanes of a wave walk their targets in step, so they refill together.
+struct TargetStream
+{
+    const char* target;
+    int32_t size;
+    LaneArray buf; // 16 words per lane
+    int32_t lo;    // buf holds target[lo, lo + 64)
+    __device__ __forceinline__ void refill(int32_t idx)
+    {
+        lo = idx;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+        {
+            uint32_t w = 0;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+            {
+                const int32_t p = idx + 4 * k + bb;
+                const uint32_t c = p < size ? (uint32_t)(unsigned char)target[p] : 0u;
+                w |= c << (8 * bb);
+            }
+            buf[k] = w;
+        }
+    }
+    __device__ __forceinline__ char at(int32_t idx)
+    {
+        if (idx < lo || idx >= lo + 64) refill(idx);
+        const uint32_t w = buf[(idx - lo) >> 2];
+        return (char)((w >> (8 * ((idx - lo) & 3))) & 0xffu);
+    }
+};
+
 // horizontal stripe: columns [t_begin, t_end), fixed rows (myers_gpu.cu:629-674)
 template <bool LDS_STATE, typename Table>
-__device__ void horizontal_band(Band& b, const ColumnState& cs, const Table& patterns, int32_t n_words_query, const char* target,
-                                int32_t t_begin, int32_t t_end, int32_t width, int32_t n_words, int32_t pattern_offset)
+__device__ __forceinline__ void horizontal_band(Band& b, const ColumnState& cs, const Table& patterns, int32_t n_words_query, const char* target,
+                                int32_t t_begin, int32_t t_end, int32_t width, int32_t n_words, int32_t pattern_offset,
+                                TargetStream* ts = nullptr)
 {
-    char tc_next = t_begin < t_end ? target[t_begin - 1] : 0;
+    char tc_next = (!LDS_STATE && t_begin < t_end) ? target[t_begin - 1] : 0;
     for (int32_t t = t_begin; t < t_end; ++t)
     {
         int32_t h = 1; // worst case for the top border of the band
-        const char tc = tc_next;
-        if (t + 1 < t_end) tc_next = target[t]; // next column's character: its latency overlaps this column
+        char tc;
+        if (LDS_STATE)
+            tc = ts->at(t - 1);
+        else
+        {
+            tc = tc_next;
+            if (t + 1 < t_end) tc_next = target[t]; // next column's character: its latency overlaps this column
+        }
         for (int32_t w = 0; w < n_words; ++w)
         {
             uint32_t pv, mv;
@@ -163,15 +205,22 @@ __device__ void horizontal_band(Band& b, const ColumnState& cs, const Table& pat
 
 // diagonal part: the band slides one row per column (myers_gpu.cu:676-751)
 template <bool LDS_STATE, typename Table>
-__device__ void diagonal_band(Band& b, const ColumnState& cs, const Table& patterns, int32_t n_words_query, const char* target,
-                              int32_t t_begin, int32_t t_end, int32_t band_width, int32_t n_words, int32_t pattern_offset)
+__device__ __forceinline__ void diagonal_band(Band& b, const ColumnState& cs, const Table& patterns, int32_t n_words_query, const char* target,
+                              int32_t t_begin, int32_t t_end, int32_t band_width, int32_t n_words, int32_t pattern_offset,
+                              TargetStream* ts = nullptr)
 {
-    char tc_next = t_begin < t_end ? target[t_begin - 1] : 0;
+    char tc_next = (!LDS_STATE && t_begin < t_end) ? target[t_begin - 1] : 0;
     for (int32_t t = t_begin; t < t_end; ++t)
     {
-        int32_t h     = 1;
-        const char tc = tc_next;
-        if (t + 1 < t_end) tc_next = target[t];
+        int32_t h = 1;
+        char tc;
+        if (LDS_STATE)
+            tc = ts->at(t - 1);
+        else
+        {
+            tc = tc_next;
+            if (t + 1 < t_end) tc_next = target[t];
+        }
         // word w of the new column needs words w and w + 1 of the previous one; the column state is updated in
         // place in increasing w, so word w + 1 still holds the previous column when word w is computed
         uint32_t cur_pv, cur_mv;
@@ -216,24 +265,25 @@ __device__ void diagonal_band(Band& b, const ColumnState& cs, const Table& patte
 template <bool LDS_STATE, typename Table>
 __device__ __forceinline__ void banded_stripes(Band& b, const ColumnState& cs, const Table& patterns, int32_t n_words, const char* target,
                                                int32_t query_size, int32_t target_size, int32_t p, int32_t n_words_band,
-                                               int32_t band_width, int32_t& diagonal_begin, int32_t& diagonal_end)
+                                               int32_t band_width, int32_t& diagonal_begin, int32_t& diagonal_end,
+                                               TargetStream* ts = nullptr)
 {
     const int32_t dlen = abs(target_size - query_size);
     if (band_width >= query_size)
     {
         diagonal_begin = target_size + 1;
         diagonal_end   = target_size + 1;
-        horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, 1, target_size + 1, query_size, n_words_band, 0);
+        horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, 1, target_size + 1, query_size, n_words_band, 0, ts);
     }
     else
     {
         const int32_t symmetric = (band_width - min(1 + 2 * p + dlen, query_size) == 0) ? 1 : 0;
         diagonal_begin = query_size < target_size ? target_size - query_size + p + 2 : p + 2 + (1 - symmetric);
         diagonal_end   = query_size < target_size ? query_size - p + symmetric : query_size - (query_size - target_size) - p + 1;
-        horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, 1, diagonal_begin, band_width, n_words_band, 0);
-        diagonal_band<LDS_STATE>(b, cs, patterns, n_words, target, diagonal_begin, diagonal_end, band_width, n_words_band, 0);
+        horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, 1, diagonal_begin, band_width, n_words_band, 0, ts);
+        diagonal_band<LDS_STATE>(b, cs, patterns, n_words, target, diagonal_begin, diagonal_end, band_width, n_words_band, 0, ts);
         horizontal_band<LDS_STATE>(b, cs, patterns, n_words, target, diagonal_end, target_size + 1, band_width, n_words_band,
-                                   query_size - band_width);
+                                   query_size - band_width, ts);
     }
 }
 
@@ -533,7 +583,12 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
         }
         if (a.debug_skip & 2) {}
         else if (LDS_STATE)
-            banded_stripes<LDS_STATE>(b, cs, lds_patterns, n_words, target, query_size, target_size, p, n_words_band, band_width, diagonal_begin, diagonal_end);
+        {
+            TargetStream ts{target, target_size,
+                            LaneArray{myers_lds + (size_t)(a.lds_pattern_words + 3 * a.lds_band_words) * 64 + (threadIdx.x & 63)}, -(1 << 30)};
+            banded_stripes<LDS_STATE>(b, cs, lds_patterns, n_words, target, query_size, target_size, p, n_words_band, band_width, diagonal_begin,
+                                      diagonal_end, &ts);
+        }
         else
             banded_stripes<LDS_STATE>(b, cs, hbm_patterns, n_words, target, query_size, target_size, p, n_words_band, band_width, diagonal_begin, diagonal_end);
         const int32_t dist = n_words_band > 0 ? b.score[b.at(n_words_band - 1, target_size)] : target_size;
@@ -1222,7 +1277,7 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
     {
         const int32_t qwords = (args->max_query_length + kWord - 1) / kWord;
         const int32_t bwords = (std::min(args->max_bandwidth_hint + 2, args->max_query_length) + kWord - 1) / kWord + 1;
-        const int32_t per_lane_words = 4 * qwords + 3 * bwords;
+        const int32_t per_lane_words = 4 * qwords + 3 * bwords + 16; // + the target window (TargetStream)
         if (per_lane_words <= 252)
         {
             use_lds              = true;
@@ -1238,7 +1293,7 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
     if (myers_dbg && myers_dbg[0] == '1') use_lds = false;
     if (use_lds)
         hipLaunchKernelGGL(myers_banded_kernel<true>, dim3((n + 63) / 64), dim3(64),
-                           (size_t)(ka.lds_pattern_words + 3 * ka.lds_band_words) * 64 * sizeof(uint32_t), stream, ka);
+                           (size_t)(ka.lds_pattern_words + 3 * ka.lds_band_words + 16) * 64 * sizeof(uint32_t), stream, ka);
     else
         hipLaunchKernelGGL(myers_banded_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, stream, ka);
     {
