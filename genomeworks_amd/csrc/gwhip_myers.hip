@@ -622,20 +622,21 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
 // totals by one workgroup, per-block rescan with its offset): a million pairs are 489 blocks instead of 977 rounds of one.
 constexpr int kScanBlock = 256, kScanPerThread = 8, kScanChunk = kScanBlock * kScanPerThread;
 
-__device__ __forceinline__ int32_t block_exclusive_scan(int32_t v, int32_t* total)
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T* total)
 {
     // wave scan (DPP-free shuffles: these kernels are not on any critical path), then the wave totals through LDS
-    __shared__ int32_t wave_total[kScanBlock / 64];
+    __shared__ T wave_total[kScanBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int32_t incl = v;
+    T incl = v;
     for (int off = 1; off < 64; off <<= 1)
     {
-        const int32_t t = __shfl_up(incl, off);
+        const T t = (T)__shfl_up((long long)incl, off);
         if (lane >= off) incl += t;
     }
     if (lane == 63) wave_total[wave] = incl;
     __syncthreads();
-    int32_t before = 0, all = 0;
+    T before = 0, all = 0;
     for (int w = 0; w < kScanBlock / 64; ++w)
     {
         if (w < wave) before += wave_total[w];
@@ -653,25 +654,26 @@ __global__ __launch_bounds__(kScanBlock) void scan_block_totals_kernel(const int
     for (int k = 0; k < kScanPerThread; ++k)
         if (base + k < n) sum += max(run_counts[base + k], 0);
     int32_t total;
-    (void)block_exclusive_scan(sum, &total);
+    (void)block_exclusive_scan<int32_t>(sum, &total);
     if (threadIdx.x == 0) block_totals[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(1024) void scan_totals_kernel(int32_t* block_totals, int32_t n_blocks, int32_t* grand_total)
+template <typename T>
+__global__ __launch_bounds__(1024) void scan_totals_kernel(T* block_totals, int32_t n_blocks, T* grand_total)
 {
-    __shared__ int32_t part[1024];
-    __shared__ int32_t carry;
+    __shared__ T part[1024];
+    __shared__ T carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (int32_t base = 0; base < n_blocks; base += 1024)
     {
         const int32_t i = base + threadIdx.x;
-        const int32_t v = i < n_blocks ? block_totals[i] : 0;
+        const T v       = i < n_blocks ? block_totals[i] : 0;
         part[threadIdx.x] = v;
         __syncthreads();
         for (int off = 1; off < 1024; off <<= 1)
         {
-            int32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            T t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
             __syncthreads();
             part[threadIdx.x] += t;
             __syncthreads();
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const int32_t* r
         sum += v[k];
     }
     int32_t total;
-    int32_t at = block_offsets[blockIdx.x] + block_exclusive_scan(sum, &total);
+    int32_t at = block_offsets[blockIdx.x] + block_exclusive_scan<int32_t>(sum, &total);
     for (int k = 0; k < kScanPerThread; ++k)
         if (base + k < n)
         {
@@ -747,56 +749,64 @@ static WsPlan plan_fixed(int32_t n, int64_t total_len)
     p.off_slot_counts = take(((size_t)total_len + 16) * 4);
     p.off_cells       = take((size_t)n * 8);
     p.off_identity    = take((size_t)n * 4);
-    p.off_scan        = take(((size_t)n / kScanChunk + 2) * 4);
+    p.off_scan        = take(((size_t)n / kScanChunk + 2) * 8);
     p.off_ws          = off;
     return p;
 }
 
-// per-wave workspace sizes (64 slots of the processing order each), then an in-place exclusive scan by one workgroup
-__global__ __launch_bounds__(1024) void ws_offsets_kernel(const int64_t* starts, const int32_t* max_bws, const int32_t* order,
-                                                          int64_t* offsets, int32_t* identity, int32_t n)
+// per-wave workspace sizes (64 slots of the processing order each): one thread per wave, then the same three-launch
+// exclusive scan as the run counts (64-bit: a million pairs need more than 2^31 workspace words)
+__global__ __launch_bounds__(kScanBlock) void ws_sizes_kernel(const int64_t* starts, const int32_t* max_bws, const int32_t* order,
+                                                              int64_t* sizes, int32_t* identity, int32_t n)
 {
-    __shared__ int64_t part[1024];
-    __shared__ int64_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    for (int32_t i = threadIdx.x; i < n; i += 1024) identity[i] = i;
-    __threadfence();
-    __syncthreads();
+    const int32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int32_t i = gid; i < n; i += gridDim.x * blockDim.x) identity[i] = i;
     const int32_t n_waves = (n + 63) / 64;
-    for (int32_t base = 0; base < n_waves; base += 1024)
+    if (gid >= n_waves) return;
+    int64_t me_max = 0;
+    int32_t pw_max = 0;
+    for (int32_t s = gid * 64; s < min(n, gid * 64 + 64); s++)
     {
-        const int32_t wv = base + threadIdx.x;
-        int64_t v        = 0;
-        if (wv < n_waves)
-        {
-            int64_t me_max = 0;
-            int32_t pw_max = 0;
-            for (int32_t s = wv * 64; s < min(n, wv * 64 + 64); s++)
-            {
-                const int32_t i = order[s];
-                int64_t me;
-                int32_t pw;
-                pair_ws_dims((int32_t)(starts[2 * i + 1] - starts[2 * i]), (int32_t)(starts[2 * i + 2] - starts[2 * i + 1]), max_bws[i], me, pw);
-                me_max = max(me_max, me);
-                pw_max = max(pw_max, pw);
-            }
-            v = 64 * (3 * me_max + pw_max);
-        }
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1)
-        {
-            int64_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-            __syncthreads();
-            part[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (wv < n_waves) offsets[wv] = carry + part[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += part[1023];
-        __syncthreads();
+        const int32_t i = order[s];
+        int64_t me;
+        int32_t pw;
+        pair_ws_dims((int32_t)(starts[2 * i + 1] - starts[2 * i]), (int32_t)(starts[2 * i + 2] - starts[2 * i + 1]), max_bws[i], me, pw);
+        me_max = max(me_max, me);
+        pw_max = max(pw_max, pw);
     }
-    if (threadIdx.x == 0) offsets[n_waves] = carry;
+    sizes[gid] = 64 * (3 * me_max + pw_max);
+}
+
+__global__ __launch_bounds__(kScanBlock) void ws_block_totals_kernel(const int64_t* sizes, int64_t* block_totals, int32_t n_waves)
+{
+    const int32_t base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
+    int64_t sum        = 0;
+    for (int k = 0; k < kScanPerThread; ++k)
+        if (base + k < n_waves) sum += sizes[base + k];
+    int64_t total;
+    (void)block_exclusive_scan<int64_t>(sum, &total);
+    if (threadIdx.x == 0) block_totals[blockIdx.x] = total;
+}
+
+// in place: sizes[w] becomes the first word of wave w's region; sizes[n_waves] the total
+__global__ __launch_bounds__(kScanBlock) void ws_apply_kernel(int64_t* sizes, const int64_t* block_offsets, int32_t n_waves)
+{
+    const int32_t base = blockIdx.x * kScanChunk + threadIdx.x * kScanPerThread;
+    int64_t v[kScanPerThread];
+    int64_t sum = 0;
+    for (int k = 0; k < kScanPerThread; ++k)
+    {
+        v[k] = base + k < n_waves ? sizes[base + k] : 0;
+        sum += v[k];
+    }
+    int64_t total;
+    int64_t at = block_offsets[blockIdx.x] + block_exclusive_scan<int64_t>(sum, &total);
+    for (int k = 0; k < kScanPerThread; ++k)
+        if (base + k < n_waves)
+        {
+            sizes[base + k] = at;
+            at += v[k];
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1269,8 +1279,18 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
     ka.metadata       = args->result_metadata;
 
     ka.ws_capacity_words = ((int64_t)args->workspace_bytes - (int64_t)p.off_ws) / 4;
-    hipLaunchKernelGGL(ws_offsets_kernel, dim3(1), dim3(1024), 0, stream, args->sequence_starts, args->max_bandwidths,
-                       ka.order, const_cast<int64_t*>(ka.ws_offsets), identity, n);
+    {
+        const int32_t n_waves  = (n + 63) / 64;
+        int64_t* offsets       = const_cast<int64_t*>(ka.ws_offsets);
+        int64_t* block_totals  = reinterpret_cast<int64_t*>(ws + p.off_scan);
+        const int32_t n_blocks = (n_waves + kScanChunk - 1) / kScanChunk;
+        const int32_t id_blocks = std::max(1, std::min((n + kScanBlock - 1) / kScanBlock, 4096));
+        hipLaunchKernelGGL(ws_sizes_kernel, dim3(std::max(id_blocks, (n_waves + kScanBlock - 1) / kScanBlock)), dim3(kScanBlock), 0, stream,
+                           args->sequence_starts, args->max_bandwidths, ka.order, offsets, identity, n);
+        hipLaunchKernelGGL(ws_block_totals_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, offsets, block_totals, n_waves);
+        hipLaunchKernelGGL(scan_totals_kernel<int64_t>, dim3(1), dim3(1024), 0, stream, block_totals, n_blocks, offsets + n_waves);
+        hipLaunchKernelGGL(ws_apply_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, offsets, block_totals, n_waves);
+    }
     // LDS flavour when every pair's pattern table and column state fit one wave's share (<= 1 KiB per lane)
     bool use_lds = false;
     if (args->max_query_length > 0 && args->max_bandwidth_hint > 0)
@@ -1300,7 +1320,7 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
         int32_t* block_totals  = reinterpret_cast<int32_t*>(ws + p.off_scan);
         const int32_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
         hipLaunchKernelGGL(scan_block_totals_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, ka.run_counts, block_totals, n);
-        hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, stream, block_totals, n_blocks, args->result_starts + n);
+        hipLaunchKernelGGL(scan_totals_kernel<int32_t>, dim3(1), dim3(1024), 0, stream, block_totals, n_blocks, args->result_starts + n);
         hipLaunchKernelGGL(scan_apply_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, ka.run_counts, block_totals, args->result_starts, n);
     }
     hipLaunchKernelGGL(compact_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ka, args->results, args->result_counts,
