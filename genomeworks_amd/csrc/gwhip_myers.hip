@@ -322,9 +322,48 @@ __device__ __forceinline__ void pattern_words(const char* query, int32_t query_s
     } while (0)
 
 // three-phase backtrace with the implicit worst-case row 0 (myers_gpu.cu:444-627); emits reversed RLE
+// `tile` (LDS_STATE kernels; tile_words per lane, 0 = none): the walk reads columns j and j - 1 only and never moves right,
+// so the band's pv / mv / score words of the next few columns are fetched together -- one HBM round trip per window of
+// columns instead of one per step (a step's nine loads were one dependent round trip each time). All lanes of the wave
+// refill together (each for its own position) as soon as one of them runs out.
 __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b, int32_t diagonal_begin, int32_t diagonal_end,
-                                    int32_t band_width, int32_t target_size)
+                                    int32_t band_width, int32_t target_size, LaneArray tile = LaneArray{nullptr}, int32_t tile_words = 0)
 {
+    const int32_t tile_cols = (tile_words > 0 && b.n_rows > 0) ? tile_words / (3 * b.n_rows) : 0;
+    int32_t tile_lo = 1, tile_hi = 0; // cached columns [tile_lo, tile_hi] (empty)
+    auto refill = [&](int32_t j) {
+        tile_hi = j;
+        tile_lo = max(0, j - tile_cols + 1);
+        const int32_t n  = (tile_hi - tile_lo + 1) * b.n_rows;
+        const size_t src = b.at(0, tile_lo); // columns are contiguous in (column, word) order
+        constexpr int kU = 8;                // 24 independent loads in flight per lane, then their LDS stores
+        for (int32_t e0 = 0; e0 < n; e0 += kU)
+        {
+            uint32_t p[kU], m[kU], sc[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+            {
+                const size_t at = src + (size_t)min(e0 + u, n - 1) * 64;
+                p[u]  = b.pv[at];
+                m[u]  = b.mv[at];
+                sc[u] = (uint32_t)b.score[at];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if (e0 + u < n)
+                {
+                    tile[3 * (e0 + u) + 0] = p[u];
+                    tile[3 * (e0 + u) + 1] = m[u];
+                    tile[3 * (e0 + u) + 2] = sc[u];
+                }
+        }
+    };
+    // before a step at column j: columns j - 1 and j must be cached (wave-uniform decision over the lanes still walking)
+    auto ensure = [&](int32_t j) {
+        if (tile_cols < 2) return;
+        const bool need = j > tile_hi || max(j - 1, 0) < tile_lo;
+        if (__any(need)) refill(j);
+    };
     const int32_t out_of_band = INT32_MAX - 1;
     int32_t i = band_width, j = target_size;
     const uint32_t last_mask = band_width % kWord != 0 ? ((1u << (band_width % kWord)) - 1) : ~0u;
@@ -351,9 +390,25 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
         ref(i0, j0, x0, m0);
         ref(i1, j1, x1, m1);
         ref(i2, j2, x2, m2);
-        const int32_t c0 = b.score[x0], c1 = b.score[x1], c2 = b.score[x2];
-        const uint32_t p0 = b.pv[x0], p1 = b.pv[x1], p2 = b.pv[x2];
-        const uint32_t n0 = b.mv[x0], n1 = b.mv[x1], n2 = b.mv[x2];
+        int32_t c0, c1, c2;
+        uint32_t p0, p1, p2, n0, n1, n2;
+        const int32_t jj0 = max(j0, 0), jj1 = max(j1, 0), jj2 = max(j2, 0);
+        const bool cached = tile_cols >= 2 && min(jj0, min(jj1, jj2)) >= tile_lo && max(jj0, max(jj1, jj2)) <= tile_hi;
+        if (cached)
+        {
+            // element of (word w, column j) in the tile: ((j - tile_lo) * n_rows + w) * 3; x / 64 is (j * n_rows + w)
+            const int32_t base = tile_lo * b.n_rows;
+            const int32_t e0 = ((int32_t)(x0 / 64) - base) * 3, e1 = ((int32_t)(x1 / 64) - base) * 3, e2 = ((int32_t)(x2 / 64) - base) * 3;
+            p0 = tile[e0]; n0 = tile[e0 + 1]; c0 = (int32_t)tile[e0 + 2];
+            p1 = tile[e1]; n1 = tile[e1 + 1]; c1 = (int32_t)tile[e1 + 2];
+            p2 = tile[e2]; n2 = tile[e2 + 1]; c2 = (int32_t)tile[e2 + 2];
+        }
+        else
+        {
+            c0 = b.score[x0]; c1 = b.score[x1]; c2 = b.score[x2];
+            p0 = b.pv[x0]; p1 = b.pv[x1]; p2 = b.pv[x2];
+            n0 = b.mv[x0]; n1 = b.mv[x1]; n2 = b.mv[x2];
+        }
         s0 = c0 - __popc(m0 & p0) + __popc(m0 & n0);
         s1 = c1 - __popc(m1 & p1) + __popc(m1 & n1);
         s2 = c2 - __popc(m2 & p2) + __popc(m2 & n2);
@@ -361,6 +416,7 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
     while (j >= diagonal_end)
     {
         int32_t above, diag, left;
+        ensure(j);
         fetch3(i - 1, j, i - 1, j - 1, i, j - 1, above, diag, left);
         if (i <= 1) { above = last_diag + j - diagonal_end; diag = last_diag + j - 1 - diagonal_end; }
         if (i < 1) left = last_diag + j - 1 - diagonal_end;
@@ -373,6 +429,7 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
     while (j >= diagonal_begin)
     {
         int32_t above, diag, left;
+        ensure(j);
         fetch3(i - 1, j, i, j - 1, i + 1, j - 1, above, diag, left);
         if (i <= 1) above = out_of_band;
         if (i <= 0) diag = j - 1;
@@ -386,6 +443,7 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
     while (i > 0 && j > 0)
     {
         int32_t above, diag, left;
+        ensure(j);
         fetch3(i - 1, j, i - 1, j - 1, i, j - 1, above, diag, left);
         if (i == 1) { above = j; diag = j - 1; }
         if (i > band_width) left = out_of_band;
@@ -607,7 +665,11 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
     }
     else if (band_width != 0)
     {
-        a.run_counts[idx] = backtrace_banded(path, counts, b, diagonal_begin, diagonal_end, abs(band_width), target_size);
+        if (LDS_STATE) // every LDS word of the lane is free after the forward pass: the backtrace's column window
+            a.run_counts[idx] = backtrace_banded(path, counts, b, diagonal_begin, diagonal_end, abs(band_width), target_size,
+                                                 LaneArray{myers_lds + (threadIdx.x & 63)}, a.lds_pattern_words + 3 * a.lds_band_words + 16);
+        else
+            a.run_counts[idx] = backtrace_banded(path, counts, b, diagonal_begin, diagonal_end, abs(band_width), target_size);
         a.metadata[idx]   = (uint32_t)idx | (band_width > 0 ? (1u << 31) : 0u);
     }
     else

@@ -292,6 +292,7 @@ void PoaBatch::reset()
     global_sequence_idx_    = 0;
     next_scores_offset_     = 0;
     avail_buf_mem_          = score_buffer_bytes_;
+    unit_weights_only_      = true;
 }
 
 // reserve_buf, cudapoa_batch.cuh:545-570
@@ -360,7 +361,10 @@ StatusType PoaBatch::add_seq_to_poa(const char* seq, const int8_t* weights, int3
     if (weights == nullptr)
         std::memset(&h_weights_[num_nucleotides_copied_], 1, static_cast<size_t>(seq_len));
     else
+    {
         std::memcpy(&h_weights_[num_nucleotides_copied_], weights, static_cast<size_t>(seq_len));
+        unit_weights_only_ = false;
+    }
     // padding to the 4-byte boundary: the reference leaves stale bytes there; we zero them (never consumed)
     const int32_t padded = cudautils::align<int32_t, 4>(seq_len);
     for (int32_t i = seq_len; i < padded; i++)
@@ -431,7 +435,12 @@ gwhip_poa_args PoaBatch::kernel_args() const
 void PoaBatch::upload_inputs()
 {
     GW_CU_CHECK_ERR(hipMemcpyAsync(d_sequences_, h_sequences_, static_cast<size_t>(num_nucleotides_copied_), hipMemcpyHostToDevice, stream_));
-    GW_CU_CHECK_ERR(hipMemcpyAsync(d_weights_, h_weights_, static_cast<size_t>(num_nucleotides_copied_), hipMemcpyHostToDevice, stream_));
+    // a batch whose reads all came without base weights (the common case, and the benchmark's) needs no weight upload:
+    // every consumed byte is 1 (padding bytes are never read), so the device array is filled in place
+    if (unit_weights_only_)
+        GW_CU_CHECK_ERR(hipMemsetAsync(d_weights_, 1, static_cast<size_t>(num_nucleotides_copied_), stream_));
+    else
+        GW_CU_CHECK_ERR(hipMemcpyAsync(d_weights_, h_weights_, static_cast<size_t>(num_nucleotides_copied_), hipMemcpyHostToDevice, stream_));
     // zero the 2 KiB read-ahead slack behind the last read (it may hold an older batch's bases)
     GW_CU_CHECK_ERR(hipMemsetAsync(d_sequences_ + num_nucleotides_copied_, 0, 2048, stream_));
     GW_CU_CHECK_ERR(hipMemcpyAsync(d_windows_, h_windows_, static_cast<size_t>(poa_count_) * sizeof(gwhip_window_details), hipMemcpyHostToDevice, stream_));

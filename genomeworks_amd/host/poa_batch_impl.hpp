@@ -72,6 +72,7 @@ private:
     // host-side counters (reset() zeroes them)
     int32_t poa_count_              = 0;
     int32_t num_nucleotides_copied_ = 0;
+    bool unit_weights_only_         = true; ///< no read of the batch carried base weights so far
     int32_t global_sequence_idx_    = 0;
     size_t avail_buf_mem_           = 0;
     size_t next_scores_offset_      = 0;
