@@ -329,7 +329,10 @@ __device__ __forceinline__ void pattern_words(const char* query, int32_t query_s
 __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b, int32_t diagonal_begin, int32_t diagonal_end,
                                     int32_t band_width, int32_t target_size, LaneArray tile = LaneArray{nullptr}, int32_t tile_words = 0)
 {
-    const int32_t tile_cols = (tile_words > 0 && b.n_rows > 0) ? tile_words / (3 * b.n_rows) : 0;
+    // Only for narrow bands: a refill issues 6 instructions per cached (word, column), which a walk through a 6-word band
+    // does not win back (measured on configs[1]: 1.04 ms with the window, 0.85 ms without); short-read bands of 1-3 words do
+    int32_t tile_cols = (tile_words > 0 && b.n_rows > 0) ? tile_words / (3 * b.n_rows) : 0;
+    if (tile_cols < 24) tile_cols = 0;
     int32_t tile_lo = 1, tile_hi = 0; // cached columns [tile_lo, tile_hi] (empty)
     auto refill = [&](int32_t j) {
         tile_hi = j;
