@@ -369,6 +369,127 @@ def process_windows_multi_device(windows, max_sequences_per_poa, max_sequence_si
         L.gw_poa_multi_destroy(h)
 
 
+class SizeClassPlan:
+    """cudapoa::plan_size_classes: windows binned geometrically by their longest read, one BatchConfig per class, so
+    that all classes are resident and run at once (process_windows_size_classes). Host-only.
+    .configs (BatchConfig dicts), .groups (window indices per class), .bytes_per_window, .total_bytes."""
+
+    def __init__(self, windows, msa_flag=False, band_width=256, band_mode="adaptive_band", adaptive_storage_factor=2.0,
+                 graph_length_factor=3.0, max_pred_distance=0, mismatch_score=-6, gap_score=-8, match_score=8):
+        L = _bind(_native.host())
+        vp, i32 = C.c_void_p, C.c_int32
+        L.gw_poa_plan_size_classes.restype = vp
+        L.gw_poa_plan_size_classes.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), i32, i32, i32, C.c_float, C.c_float, i32, i32, i32, i32]
+        L.gw_poa_size_plan_destroy.argtypes = [vp]
+        L.gw_poa_size_plan_classes.argtypes = [vp]
+        L.gw_poa_size_plan_total_bytes.restype = C.c_int64
+        L.gw_poa_size_plan_total_bytes.argtypes = [vp]
+        L.gw_poa_size_plan_class.argtypes = [vp, i32, C.POINTER(_native.PoaBatchConfig), C.POINTER(C.c_int64), C.POINTER(i32)]
+        L.gw_poa_size_plan_windows.argtypes = [vp, i32, C.POINTER(i32)]
+        self._L = L
+        n = len(windows)
+        longest = (i32 * max(n, 1))(*[max((len(s) for s in g), default=0) for g in windows])
+        reads = (i32 * max(n, 1))(*[len(g) for g in windows])
+        self._h = L.gw_poa_plan_size_classes(n, longest, reads, int(msa_flag), band_width, _BAND_MODES[band_mode],
+                                             adaptive_storage_factor, graph_length_factor, max_pred_distance, mismatch_score,
+                                             gap_score, match_score)
+        if not self._h:
+            raise RuntimeError(L.gw_last_error().decode())
+        fields = [f[0] for f in _native.PoaBatchConfig._fields_]
+        self.configs, self.groups, self.bytes_per_window = [], [], []
+        for k in range(L.gw_poa_size_plan_classes(self._h)):
+            cfg, b, m = _native.PoaBatchConfig(), C.c_int64(0), i32(0)
+            L.gw_poa_size_plan_class(self._h, k, C.byref(cfg), C.byref(b), C.byref(m))
+            ids = (i32 * max(m.value, 1))()
+            L.gw_poa_size_plan_windows(self._h, k, ids)
+            self.configs.append({f: getattr(cfg, f) for f in fields})
+            self.groups.append([ids[i] for i in range(m.value)])
+            self.bytes_per_window.append(b.value)
+        self.total_bytes = L.gw_poa_size_plan_total_bytes(self._h)
+
+    def keep(self, window_ids):
+        """Restrict the plan to these windows (a rank's share of a multi-GPU job); the configs stay those of the whole set."""
+        n = max(max((max(g) for g in self.groups if g), default=-1), max(window_ids, default=-1)) + 1
+        flags = (C.c_uint8 * max(n, 1))()
+        for w in window_ids:
+            flags[w] = 1
+        self._L.gw_poa_size_plan_keep.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32]
+        if self._L.gw_poa_size_plan_keep(self._h, flags, n) != 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        wanted = set(window_ids)
+        self.groups = [[w for w in g if w in wanted] for g in self.groups]
+        self.total_bytes = self._L.gw_poa_size_plan_total_bytes(self._h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.gw_poa_size_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def process_windows_size_classes(windows, plan, device=0, memory_budget=-1, output_type="msa", gap_score=-8, mismatch_score=-6,
+                                 match_score=8, collect=True, digest=None):
+    """cudapoa::process_windows_size_classes: every class of `plan` (SizeClassPlan) in its own batch on its own host
+    thread and stream, all at once. Returns dict(status, worker (= class), launches, seconds (workers' wall time),
+    compute_seconds (from all first fills to the last end), consensus + coverage | msa). digest(rows) replaces the MSA
+    rows of a successful window as they are fetched."""
+    L = _bind(_native.host())
+    vp, i32 = C.c_void_p, C.c_int32
+    L.gw_poa_size_classes_run.restype = vp
+    L.gw_poa_size_classes_run.argtypes = [i32, C.POINTER(i32), C.POINTER(C.c_char_p), C.POINTER(i32), vp, i32, C.c_int64, C.c_int8,
+                                          C.c_int16, C.c_int16, C.c_int16, C.POINTER(C.c_double)]
+    for name in ("gw_poa_multi_destroy", "gw_poa_multi_launches", "gw_poa_multi_seconds"):
+        getattr(L, name).argtypes = [vp]
+    L.gw_poa_multi_seconds.restype = C.c_double
+    for name in ("gw_poa_multi_status", "gw_poa_multi_worker", "gw_poa_multi_msa_rows"):
+        getattr(L, name).argtypes = [vp, i32]
+    L.gw_poa_multi_consensus.restype = C.POINTER(C.c_char)
+    L.gw_poa_multi_consensus.argtypes = [vp, i32, C.POINTER(i32)]
+    L.gw_poa_multi_coverage.restype = C.POINTER(C.c_uint16)
+    L.gw_poa_multi_coverage.argtypes = [vp, i32, C.POINTER(i32)]
+    L.gw_poa_multi_msa_row.restype = C.POINTER(C.c_char)
+    L.gw_poa_multi_msa_row.argtypes = [vp, i32, i32, C.POINTER(i32)]
+    if memory_budget < 0:
+        from .cuda import cuda_get_mem_info
+        memory_budget = int(0.9 * cuda_get_mem_info(device)[0])
+    raw = [[s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in w] for w in windows]
+    flat = [b for w in raw for b in w]
+    n = len(raw)
+    per_window = (i32 * max(n, 1))(*[len(w) for w in raw])
+    seqs = (C.c_char_p * max(len(flat), 1))(*flat)
+    lens = (i32 * max(len(flat), 1))(*[len(b) for b in flat])
+    mask = 2 if output_type == "msa" else 1
+    compute = C.c_double(0)
+    h = L.gw_poa_size_classes_run(n, per_window, seqs, lens, plan._h, device, int(memory_budget), mask, gap_score, mismatch_score,
+                                  match_score, C.byref(compute))
+    if not h:
+        raise RuntimeError(L.gw_last_error().decode())
+    try:
+        out = dict(status=[L.gw_poa_multi_status(h, w) for w in range(n)], worker=[L.gw_poa_multi_worker(h, w) for w in range(n)],
+                   launches=L.gw_poa_multi_launches(h), seconds=L.gw_poa_multi_seconds(h), compute_seconds=compute.value)
+        ln = i32(0)
+        if collect and mask == 1:
+            out["consensus"], out["coverage"] = [], []
+            for w in range(n):
+                p = L.gw_poa_multi_consensus(h, w, C.byref(ln))
+                out["consensus"].append(C.string_at(p, ln.value).decode())
+                q = L.gw_poa_multi_coverage(h, w, C.byref(ln))
+                out["coverage"].append([q[k] for k in range(ln.value)])
+        elif collect:
+            out["msa"] = []
+            for w in range(n):
+                rows = []
+                for r in range(L.gw_poa_multi_msa_rows(h, w)):
+                    p = L.gw_poa_multi_msa_row(h, w, r, C.byref(ln))
+                    rows.append(C.string_at(p, ln.value).decode("utf-8"))
+                out["msa"].append(digest(rows) if (digest and out["status"][w] == success) else rows)
+        return out
+    finally:
+        L.gw_poa_multi_destroy(h)
+
+
 # ---- cudapoa/utils.hpp: batch-shape planning and window-file readers -------------------------------------------
 def _bind_utils(L):
     if getattr(L, "_gw_poa_utils_bound", False):

@@ -577,6 +577,87 @@ const char* gw_poa_multi_msa_row(gw_poa_multi* h, int32_t w, int32_t row, int32_
     return s.c_str();
 }
 
+struct gw_poa_size_plan
+{
+    poa::SizeClassPlan plan;
+};
+
+gw_poa_size_plan* gw_poa_plan_size_classes(int32_t n_windows, const int32_t* longest, const int32_t* reads, int32_t msa_flag,
+                                           int32_t band_width, int32_t band_mode, float adaptive_storage_factor, float graph_length_factor,
+                                           int32_t max_pred_distance, int32_t mismatch_score, int32_t gap_score, int32_t match_score)
+{
+    GW_TRY
+    auto h = std::make_unique<gw_poa_size_plan>();
+    poa::plan_size_classes(h->plan, std::vector<int32_t>(longest, longest + n_windows), std::vector<int32_t>(reads, reads + n_windows),
+                           msa_flag != 0, band_width, static_cast<poa::BandMode>(band_mode), adaptive_storage_factor, graph_length_factor,
+                           max_pred_distance, mismatch_score, gap_score, match_score);
+    return h.release();
+    GW_CATCH(nullptr)
+}
+void gw_poa_size_plan_destroy(gw_poa_size_plan* p) { delete p; }
+int32_t gw_poa_size_plan_classes(gw_poa_size_plan* p) { return static_cast<int32_t>(p->plan.configs.size()); }
+int64_t gw_poa_size_plan_total_bytes(gw_poa_size_plan* p) { return p->plan.total_bytes; }
+int gw_poa_size_plan_class(gw_poa_size_plan* p, int32_t k, gw_poa_batch_config* cfg, int64_t* bytes_per_window, int32_t* n_windows)
+{
+    GW_TRY
+    const poa::BatchConfig& c = p->plan.configs.at(static_cast<size_t>(k));
+    if (cfg)
+    {
+        cfg->max_sequence_size         = c.max_sequence_size;
+        cfg->max_consensus_size        = c.max_consensus_size;
+        cfg->max_nodes_per_graph       = c.max_nodes_per_graph;
+        cfg->matrix_sequence_dimension = c.matrix_sequence_dimension;
+        cfg->alignment_band_width      = c.alignment_band_width;
+        cfg->max_sequences_per_poa     = c.max_sequences_per_poa;
+        cfg->band_mode                 = static_cast<int32_t>(c.band_mode);
+        cfg->max_banded_pred_distance  = c.max_banded_pred_distance;
+    }
+    if (bytes_per_window) *bytes_per_window = p->plan.bytes_per_window.at(static_cast<size_t>(k));
+    if (n_windows) *n_windows = static_cast<int32_t>(p->plan.groups.at(static_cast<size_t>(k)).size());
+    return 0;
+    GW_CATCH(-1)
+}
+int gw_poa_size_plan_windows(gw_poa_size_plan* p, int32_t k, int32_t* window_ids)
+{
+    GW_TRY
+    const auto& g = p->plan.groups.at(static_cast<size_t>(k));
+    std::copy(g.begin(), g.end(), window_ids);
+    return 0;
+    GW_CATCH(-1)
+}
+
+int gw_poa_size_plan_keep(gw_poa_size_plan* p, const uint8_t* keep, int32_t n_windows)
+{
+    GW_TRY
+    p->plan.total_bytes = 0;
+    for (size_t k = 0; k < p->plan.groups.size(); ++k)
+    {
+        std::vector<int32_t> kept;
+        for (int32_t w : p->plan.groups[k])
+            if (w < n_windows && keep[w]) kept.push_back(w);
+        p->plan.groups[k] = std::move(kept);
+        p->plan.total_bytes += static_cast<int64_t>(p->plan.groups[k].size()) * p->plan.bytes_per_window[k];
+    }
+    return 0;
+    GW_CATCH(-1)
+}
+
+gw_poa_multi* gw_poa_size_classes_run(int32_t n_windows, const int32_t* reads_per_window, const char* const* seqs, const int32_t* lengths,
+                                      gw_poa_size_plan* plan, int32_t device, int64_t memory_budget, int8_t output_mask, int16_t gap_score,
+                                      int16_t mismatch_score, int16_t match_score, double* compute_seconds)
+{
+    GW_TRY
+    std::vector<std::vector<std::string>> windows(static_cast<size_t>(n_windows));
+    size_t at = 0;
+    for (int32_t w = 0; w < n_windows; ++w)
+        for (int32_t r = 0; r < reads_per_window[w]; ++r, ++at) windows[static_cast<size_t>(w)].emplace_back(seqs[at], static_cast<size_t>(lengths[at]));
+    auto h = std::make_unique<gw_poa_multi>();
+    poa::process_windows_size_classes(h->out, windows, plan->plan, device, memory_budget, output_mask, gap_score, mismatch_score, match_score,
+                                      compute_seconds);
+    return h.release();
+    GW_CATCH(nullptr)
+}
+
 // ---- cudapoa/utils.hpp: batch-shape planning and window-file readers -----------------------------------------
 
 struct gw_windows

@@ -4,6 +4,9 @@
 #include <claraparabricks/genomeworks/utils/cudautils.hpp>
 #include <claraparabricks/genomeworks/utils/signed_integer_utils.hpp>
 
+#include "../../include/gwhip.h"
+#include "poa_batch_impl.hpp"
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -194,6 +197,193 @@ void process_windows_multi_device(MultiDeviceOutput& out, const std::vector<std:
         scoped_device_switch dev(groups[k / static_cast<size_t>(config.batches_per_device)].device);
         (void)hipStreamDestroy(streams[k]);
     }
+    out.launches = launches.load();
+    for (const std::exception_ptr& e : errors)
+        if (e) std::rethrow_exception(e);
+}
+
+// ---- size classes -------------------------------------------------------------------------------------------------------
+void plan_size_classes(SizeClassPlan& plan, const std::vector<int32_t>& longest, const std::vector<int32_t>& reads, bool msa_flag,
+                       int32_t band_width, BandMode band_mode, float adaptive_storage_factor, float graph_length_factor,
+                       int32_t max_pred_distance, int32_t mismatch_score, int32_t gap_score, int32_t match_score)
+{
+    if (longest.size() != reads.size()) throw std::invalid_argument("one read count per window");
+    plan = SizeClassPlan{};
+    int32_t top = 0;
+    for (int32_t l : longest) top = std::max(top, l);
+    if (top <= 0) return;
+    // class k: longest read in (top / 2^(k+1), top / 2^k]; everything below top / 64 shares the last class
+    constexpr int kClasses = 6;
+    std::vector<std::vector<int32_t>> members(kClasses);
+    for (size_t w = 0; w < longest.size(); ++w)
+    {
+        int k = 0;
+        while (k + 1 < kClasses && static_cast<int64_t>(longest[w]) * (int64_t(2) << k) <= top) ++k;
+        members[static_cast<size_t>(k)].push_back(static_cast<int32_t>(w));
+    }
+    for (const std::vector<int32_t>& m : members)
+    {
+        if (m.empty()) continue;
+        int32_t len = 0, most = 0;
+        for (int32_t w : m)
+        {
+            len  = std::max(len, longest[static_cast<size_t>(w)]);
+            most = std::max(most, reads[static_cast<size_t>(w)]);
+        }
+        // a band cannot be wider than the reads it is laid over (batch.cu:96-97): short classes keep the requested width only if they can
+        const BatchConfig cfg(std::max(len, band_width), most, band_width, band_mode, adaptive_storage_factor, graph_length_factor, max_pred_distance);
+        const gwhip_poa_config dc = make_device_config(cfg, static_cast<int8_t>(msa_flag ? OutputType::msa : OutputType::consensus), gap_score,
+                                                       mismatch_score, match_score);
+        int64_t per_poa = 0, per_matrix = 0;
+        gwhip_poa_bytes_per_window(&dc, &per_poa, &per_matrix);
+        plan.configs.push_back(cfg);
+        plan.groups.push_back(m);
+        plan.bytes_per_window.push_back(per_poa + per_matrix);
+        plan.total_bytes += static_cast<int64_t>(m.size()) * (per_poa + per_matrix);
+    }
+}
+
+void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std::vector<std::string>>& windows,
+                                  const SizeClassPlan& plan, int32_t device, int64_t memory_budget, int8_t output_mask,
+                                  int16_t gap_score, int16_t mismatch_score, int16_t match_score, double* compute_seconds)
+{
+    const size_t n = windows.size();
+    out            = MultiDeviceOutput{};
+    out.status.assign(n, StatusType::success);
+    out.worker_of_window.assign(n, -1);
+    const bool want_msa = (output_mask & OutputType::msa) != 0;
+    if (want_msa)
+        out.msa.resize(n);
+    else
+    {
+        out.consensus.resize(n);
+        out.coverage.resize(n);
+    }
+    if (compute_seconds) *compute_seconds = 0;
+    const size_t classes = plan.configs.size();
+    if (n == 0 || classes == 0) return;
+    scoped_device_switch dev(device);
+    size_t active_classes = 0;
+    for (size_t k = 0; k < classes; ++k) active_classes += plan.groups[k].empty() ? 0 : 1;
+    if (active_classes == 0) return;
+    // every class gets its planned bytes (+ slack for alignment and one spare window), scaled down when the plan exceeds the budget
+    const int64_t slack_total = static_cast<int64_t>(classes) * (int64_t(64) << 20);
+    std::vector<int64_t> share(classes);
+    double scale = 1.0;
+    {
+        int64_t want = slack_total;
+        for (size_t k = 0; k < classes; ++k) want += (static_cast<int64_t>(plan.groups[k].size()) + 1) * plan.bytes_per_window[k];
+        if (want > memory_budget) scale = static_cast<double>(memory_budget - slack_total) / static_cast<double>(want - slack_total);
+        for (size_t k = 0; k < classes; ++k)
+        {
+            const int64_t planned = (static_cast<int64_t>(plan.groups[k].size()) + 1) * plan.bytes_per_window[k];
+            share[k] = std::max<int64_t>(2 * plan.bytes_per_window[k], static_cast<int64_t>(scale * static_cast<double>(planned))) + (int64_t(64) << 20);
+        }
+    }
+    std::atomic<int32_t> launches{0}, filled{0};
+    std::mutex start_mutex;
+    std::chrono::steady_clock::time_point compute_begin{};
+    std::vector<std::exception_ptr> errors(classes);
+    std::vector<std::thread> threads;
+    const auto t_begin = std::chrono::steady_clock::now();
+    for (size_t k = 0; k < classes; ++k)
+    {
+        if (plan.groups[k].empty()) continue;
+        threads.emplace_back([&, k]() {
+            bool counted = false;
+            auto arrive  = [&] { // first fill of this worker is done (or it failed): the compute clock starts when all have arrived
+                if (counted) return;
+                counted = true;
+                if (filled.fetch_add(1) + 1 == static_cast<int32_t>(active_classes))
+                {
+                    std::lock_guard<std::mutex> g(start_mutex);
+                    compute_begin = std::chrono::steady_clock::now();
+                }
+                while (filled.load() < static_cast<int32_t>(active_classes)) std::this_thread::yield();
+            };
+            try
+            {
+                scoped_device_switch d(device);
+                cudaStream_t stream = nullptr;
+                GW_CU_CHECK_ERR(hipStreamCreate(&stream));
+                {
+                    DefaultDeviceAllocator allocator(static_cast<size_t>(share[k]), stream);
+                    std::unique_ptr<Batch> batch = create_batch(device, stream, allocator, share[k], output_mask, plan.configs[k], gap_score,
+                                                                mismatch_score, match_score);
+                    const std::vector<int32_t>& mine = plan.groups[k];
+                    size_t next = 0;
+                    std::vector<size_t> in_batch;
+                    while (next < mine.size())
+                    {
+                        batch->reset();
+                        in_batch.clear();
+                        while (next < mine.size())
+                        {
+                            const size_t w = static_cast<size_t>(mine[next]);
+                            Group group;
+                            for (const std::string& read : windows[w]) group.push_back(Entry{read.c_str(), nullptr, get_size<int32_t>(read)});
+                            std::vector<StatusType> per_read;
+                            const StatusType st = batch->add_poa_group(per_read, group);
+                            if (st == StatusType::exceeded_maximum_poas)
+                            {
+                                if (in_batch.empty()) throw std::runtime_error("a batch of this size class cannot hold a single window");
+                                break;
+                            }
+                            out.worker_of_window[w] = static_cast<int32_t>(k);
+                            if (st == StatusType::success)
+                                in_batch.push_back(w);
+                            else
+                            {
+                                out.status[w] = st;
+                                if (st == StatusType::empty_poa_group && !windows[w].empty()) in_batch.push_back(n); // its empty POA owns a slot
+                            }
+                            next++;
+                        }
+                        arrive();
+                        if (batch->get_total_poas() == 0) continue;
+                        batch->generate_poa();
+                        launches++;
+                        std::vector<StatusType> status;
+                        if (want_msa)
+                        {
+                            std::vector<std::vector<std::string>> msa;
+                            batch->get_msa(msa, status);
+                            for (size_t i = 0; i < in_batch.size(); i++)
+                                if (in_batch[i] < n)
+                                {
+                                    out.msa[in_batch[i]]    = std::move(msa[i]);
+                                    out.status[in_batch[i]] = status[i];
+                                }
+                        }
+                        else
+                        {
+                            std::vector<std::string> consensus;
+                            std::vector<std::vector<uint16_t>> coverage;
+                            batch->get_consensus(consensus, coverage, status);
+                            for (size_t i = 0; i < in_batch.size(); i++)
+                                if (in_batch[i] < n)
+                                {
+                                    out.consensus[in_batch[i]] = std::move(consensus[i]);
+                                    out.coverage[in_batch[i]]  = std::move(coverage[i]);
+                                    out.status[in_batch[i]]    = status[i];
+                                }
+                        }
+                    }
+                    arrive();
+                }
+                (void)hipStreamDestroy(stream);
+            }
+            catch (...)
+            {
+                errors[k] = std::current_exception();
+                arrive();
+            }
+        });
+    }
+    for (std::thread& t : threads) t.join();
+    const auto t_end = std::chrono::steady_clock::now();
+    out.seconds      = std::chrono::duration<double>(t_end - t_begin).count();
+    if (compute_seconds) *compute_seconds = std::chrono::duration<double>(t_end - compute_begin).count();
     out.launches = launches.load();
     for (const std::exception_ptr& e : errors)
         if (e) std::rethrow_exception(e);

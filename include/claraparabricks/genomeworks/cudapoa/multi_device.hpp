@@ -48,6 +48,37 @@ struct MultiDeviceOutput
                                                     ///< (batch creation, filling, kernels, result unpacking)
 };
 
+/// Windows binned by size so that every bin's batch is resident at the same time (MI355X addition). get_multi_batch_sizes
+/// (utils.hpp:36-69) bins windows to run the bins one after the other, and folds smaller bins into a larger one's batch
+/// whenever they fit -- on a 288 GB device a whole long-read set then shares the shape of its longest window, needs several
+/// fills, and every fill lasts as long as its heaviest window. Here the classes are geometric in the longest read (class k:
+/// longest read in (L / 2^(k+1), L / 2^k]), each with the BatchConfig of its own largest member, so the set's slabs add up to a
+/// fraction of the single-shape plan and all classes can run concurrently (process_windows_size_classes): the wall time is
+/// the heaviest class's, not the sum of the fills.
+struct SizeClassPlan
+{
+    std::vector<BatchConfig> configs;            ///< one per non-empty class, largest reads first
+    std::vector<std::vector<int32_t>> groups;    ///< window indices of each class (ascending)
+    std::vector<int64_t> bytes_per_window;       ///< device bytes of one window under configs[k]
+    int64_t total_bytes = 0;                     ///< sum over classes of windows x bytes_per_window
+};
+
+/// Host-only (no device query). longest / reads: per window its longest read and its number of reads.
+void plan_size_classes(SizeClassPlan& plan, const std::vector<int32_t>& longest, const std::vector<int32_t>& reads, bool msa_flag,
+                       int32_t band_width = 256, BandMode band_mode = BandMode::adaptive_band, float adaptive_storage_factor = 2.0f,
+                       float graph_length_factor = 3.0f, int32_t max_pred_distance = 0, int32_t mismatch_score = -6,
+                       int32_t gap_score = -8, int32_t match_score = 8);
+
+/// One worker (host thread, stream, allocator slice, Batch) per class of the plan on `device`, all at once; a class whose
+/// windows do not fit its slice takes several fills. memory_budget: device bytes for all classes together (each class gets
+/// its share of the plan's total, scaled down if the total exceeds the budget). out.seconds = wall time of the workers
+/// including batch creation and filling; *compute_seconds (optional) = from the moment every worker has filled its first
+/// batch to the last worker's end (generate_poa + get_consensus / get_msa and any further fills).
+void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std::vector<std::string>>& windows,
+                                  const SizeClassPlan& plan, int32_t device, int64_t memory_budget, int8_t output_mask,
+                                  int16_t gap_score = -8, int16_t mismatch_score = -6, int16_t match_score = 8,
+                                  double* compute_seconds = nullptr);
+
 /// Runs every window (a window = its reads) under `batch_size`. Throws what create_batch / Batch throw.
 void process_windows_multi_device(MultiDeviceOutput& out, const std::vector<std::vector<std::string>>& windows,
                                   const BatchConfig& batch_size, const MultiDeviceConfig& config);

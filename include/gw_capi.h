@@ -137,6 +137,24 @@ const uint16_t* gw_poa_multi_coverage(gw_poa_multi* h, int32_t window, int32_t* 
 int32_t gw_poa_multi_msa_rows(gw_poa_multi* h, int32_t window);
 const char* gw_poa_multi_msa_row(gw_poa_multi* h, int32_t window, int32_t row, int32_t* length);
 
+/* Size classes (multi_device.hpp): windows binned geometrically by their longest read, one BatchConfig per class, all
+   classes resident and running at once. Planning is host-only. gw_poa_size_classes_run returns a gw_poa_multi handle
+   (accessors above); *compute_seconds = from all workers' first fill to the last worker's end. */
+typedef struct gw_poa_size_plan gw_poa_size_plan;
+gw_poa_size_plan* gw_poa_plan_size_classes(int32_t n_windows, const int32_t* longest, const int32_t* reads, int32_t msa_flag,
+                                           int32_t band_width, int32_t band_mode, float adaptive_storage_factor, float graph_length_factor,
+                                           int32_t max_pred_distance, int32_t mismatch_score, int32_t gap_score, int32_t match_score);
+void gw_poa_size_plan_destroy(gw_poa_size_plan* p);
+int32_t gw_poa_size_plan_classes(gw_poa_size_plan* p);
+int64_t gw_poa_size_plan_total_bytes(gw_poa_size_plan* p);
+int gw_poa_size_plan_class(gw_poa_size_plan* p, int32_t k, gw_poa_batch_config* cfg, int64_t* bytes_per_window, int32_t* n_windows);
+int gw_poa_size_plan_windows(gw_poa_size_plan* p, int32_t k, int32_t* window_ids);
+/* keep[w] != 0: window w stays in the plan (a rank of a multi-GPU job keeps its share; configs stay those of the whole set) */
+int gw_poa_size_plan_keep(gw_poa_size_plan* p, const uint8_t* keep, int32_t n_windows);
+gw_poa_multi* gw_poa_size_classes_run(int32_t n_windows, const int32_t* reads_per_window, const char* const* seqs, const int32_t* lengths,
+                                      gw_poa_size_plan* plan, int32_t device, int64_t memory_budget, int8_t output_mask, int16_t gap_score,
+                                      int16_t mismatch_score, int16_t match_score, double* compute_seconds);
+
 /* ---- cudaaligner (aligner.hpp:76-219) ---- */
 gw_aligner* gw_aligner_create_banded(int32_t max_bandwidth, void* stream, int32_t device_id, int64_t max_device_memory);
 gw_aligner* gw_aligner_create(int32_t max_query_length, int32_t max_target_length, int32_t max_alignments,

@@ -1,10 +1,11 @@
 """Oracle goldens of BASELINE configs[3] (long-read MSA, adaptive band): see make_config_goldens.py. TEST INFRASTRUCTURE.
 
 The set: windows 0..597 of genomeworks_amd.synthetic.long_read_window (seeds 2000 + w; 8-32 reads, backbone 2-30 kbp,
-8-12 % indel-heavy divergence), planned into batches by cudapoa.plan_multi_batch_sizes for a stated memory budget
-(0.9 x 256 GiB, so the plan does not depend on the box) with adaptive_storage_factor 4.0: at this divergence a graph
-grows to about twice its reads' length, the adaptive band widens to its 1536-column cap, and the reference's default
-factor of 2.0 leaves 23 % of the windows with exceeded_adaptive_banded_matrix_size."""
+8-12 % indel-heavy divergence), planned into size classes by cudapoa.SizeClassPlan (geometric in the longest read, one
+BatchConfig per class, host-only: the plan does not depend on the box) with adaptive_storage_factor 4.0: at this
+divergence a graph grows to about twice its reads' length, the adaptive band widens to its 1536-column cap, and the
+reference's default factor of 2.0 leaves 23 % of the windows with exceeded_adaptive_banded_matrix_size (SURVEY.md 8(d),
+VERDICT r1)."""
 import hashlib
 import json
 import multiprocessing as mp
@@ -22,16 +23,20 @@ CONFIG4 = dict(windows=598, max_len=32768, band=256, band_mode=2, adaptive_stora
 _W = {}
 
 
+def size_plan(windows):
+    from genomeworks_amd import cudapoa
+    return cudapoa.SizeClassPlan(windows, msa_flag=True, band_width=CONFIG4["band"], band_mode="adaptive_band",
+                                 adaptive_storage_factor=CONFIG4["adaptive_storage_factor"],
+                                 graph_length_factor=CONFIG4["graph_length_factor"])
+
+
 def plan(n_windows=None, windows=None):
-    """-> (windows, cfgs, groups): the deterministic batch plan of the set."""
-    from genomeworks_amd import cudapoa, synthetic
+    """-> (windows, cfgs, groups): the deterministic size-class plan of the set."""
+    from genomeworks_amd import synthetic
     if windows is None:
         windows = [synthetic.long_read_window(w, CONFIG4["max_len"]) for w in range(n_windows or CONFIG4["windows"])]
-    cfgs, groups = cudapoa.plan_multi_batch_sizes(windows, CONFIG4["memory_budget_bytes"], msa_flag=True,
-                                                  band_width=CONFIG4["band"], band_mode="adaptive_band",
-                                                  adaptive_storage_factor=CONFIG4["adaptive_storage_factor"],
-                                                  graph_length_factor=CONFIG4["graph_length_factor"])
-    return windows, cfgs, groups
+    p = size_plan(windows)
+    return windows, p.configs, p.groups
 
 
 def oracle_cfg(c):

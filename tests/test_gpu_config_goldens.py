@@ -93,11 +93,12 @@ def test_config5_all_1000000_pairs_equal_the_golden():
 
 def test_config4_all_598_long_read_windows_equal_the_golden():
     """BASELINE configs[3]: every window of the long-read MSA set (32-bit scores and ids, HBM row tables, bands up to
-    1536 columns) through the multi-batch loop, MSA rows hashed against the oracle's."""
+    1536 columns, one wavefront per 256-column pass) through the size-class plan -- four batches of different shapes
+    resident and running at once on host threads -- MSA rows hashed against the oracle's."""
     import importlib.util
     import json
     import os
-    from genomeworks_amd import multibatch
+    from genomeworks_amd import cudapoa
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     spec = importlib.util.spec_from_file_location("make_long_read_goldens", os.path.join(here, "make_long_read_goldens.py"))
     lr = importlib.util.module_from_spec(spec)
@@ -105,14 +106,44 @@ def test_config4_all_598_long_read_windows_equal_the_golden():
     with open(os.path.join(here, "config4_long_reads.json")) as f:
         golden = json.load(f)
     windows, cfgs, groups = lr.plan()
-    assert cfgs == golden["batch_configs"]
-    out = multibatch.run_plan(windows, cfgs, groups, golden["memory_budget_bytes"], output_type="msa",
-                              band_mode="adaptive_band", digest=lr.msa_digest)
-    assert len(out["results"]) == golden["windows"] == 598
+    assert cfgs == golden["batch_configs"] and len(cfgs) >= 3
+    plan = lr.size_plan(windows)
+    out = cudapoa.process_windows_size_classes(windows, plan, memory_budget=golden["memory_budget_bytes"], output_type="msa",
+                                               digest=lr.msa_digest)
+    assert len(out["status"]) == golden["windows"] == 598
     bad = []
     for d in golden["windows_detail"]:
-        got, st = out["results"][d["w"]]
-        if st != d["status"] or (st == 0 and got != d["msa_sha"]):
-            bad.append(d["w"])
+        w = d["w"]
+        assert out["worker"][w] == d["cfg"]
+        if out["status"][w] != d["status"] or (d["status"] == 0 and out["msa"][w] != d["msa_sha"]):
+            bad.append(w)
     assert not bad, "windows whose MSA differs from the oracle golden: %s" % bad[:20]
-    assert out["cells"] == G.summary()["config4"]["cells"]
+    assert out["launches"] == len(cfgs) and 0 < out["compute_seconds"] <= out["seconds"]
+
+
+def test_long_read_windows_through_the_sequential_multi_batch_loop():
+    """The reference's own flow (get_multi_batch_sizes-style single plan, fills one after the other,
+    cudapoa/src/main.cpp:197-326) on a part of the same set: same MSAs as the size-class run wherever both succeed."""
+    import importlib.util
+    import os
+    from genomeworks_amd import cudapoa, multibatch, synthetic
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_long_read_goldens", os.path.join(here, "make_long_read_goldens.py"))
+    lr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lr)
+    import json
+    with open(os.path.join(here, "config4_long_reads.json")) as f:
+        golden = {d["w"]: d for d in json.load(f)["windows_detail"]}
+    ids = list(range(0, 598, 9))
+    windows = [synthetic.long_read_window(w, 32768) for w in ids]
+    cfgs, groups = cudapoa.plan_multi_batch_sizes(windows, int(40e9), msa_flag=True, band_width=256, band_mode="adaptive_band",
+                                                  adaptive_storage_factor=4.0)
+    out = multibatch.run_plan(windows, cfgs, groups, int(40e9), output_type="msa", band_mode="adaptive_band", digest=lr.msa_digest)
+    assert len(out["results"]) == len(ids) and out["launches"] >= 2
+    both = 0
+    for k, w in enumerate(ids):
+        got, st = out["results"][k]
+        if st == 0 and golden[w]["status"] == 0:
+            assert got == golden[w]["msa_sha"], w
+            both += 1
+    assert both >= len(ids) - 4
