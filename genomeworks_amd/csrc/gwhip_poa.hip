@@ -147,6 +147,18 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
     MwShared* mw_shared     = nullptr;
     if constexpr (NW > 1)
     {
+        // Issue priority by the window's weight (its bases: 2^16 .. 2^19 and more -> 0 .. 3). A launch -- or several
+        // concurrent launches of different size classes -- lasts as long as its heaviest window, one chain of dependent
+        // steps; when lighter windows share its SIMDs, the arbiter should serve the heavy one first.
+        {
+            int32_t bases = lane < (int32_t)wd.num_seqs ? seq_lens[lane] : 0;
+            for (int off = 32; off > 0; off >>= 1) bases += __shfl_xor(bases, off);
+            bases = __builtin_amdgcn_readfirstlane(bases);
+            const int32_t level = bases >= (1 << 19) ? 3 : (bases >= (1 << 18) ? 2 : (bases >= (1 << 17) ? 1 : 0));
+            if (level == 3) __builtin_amdgcn_s_setprio(3);
+            else if (level == 2) __builtin_amdgcn_s_setprio(2);
+            else if (level == 1) __builtin_amdgcn_s_setprio(1);
+        }
         static_assert(!LDS_TABLES, "the multi-wave forward pass belongs to the HBM-table layout");
         mw_args   = reinterpret_cast<MwArgs<ScoreT>*>(smem + kWideRingBytes + kBsRingBytes + kReadWinBytes);
         mw_shared = reinterpret_cast<MwShared*>(smem + kWideRingBytes + kBsRingBytes + kReadWinBytes + 128);
