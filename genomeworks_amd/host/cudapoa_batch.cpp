@@ -599,20 +599,46 @@ StatusType PoaBatch::get_msa(std::vector<std::vector<std::string>>& msa, std::ve
         GW_CU_CHECK_ERR(hipMemcpyAsync(h_consensus_, d_consensus_, static_cast<size_t>(poa_count_) * row, hipMemcpyDeviceToHost, stream_));
     }
     GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
-    for (int32_t poa = 0; poa < poa_count_; poa++)
-    {
-        msa.emplace_back(std::vector<std::string>());
-        const char* c = reinterpret_cast<const char*>(&h_consensus_[static_cast<size_t>(poa) * row]);
-        if (static_cast<uint8_t>(c[0]) == kKernelError)
-            log_kernel_error(static_cast<StatusType>(c[1]), output_status);
-        else
+    // rows are unpacked behind whatever the caller's vectors already hold; long-read MSAs are hundreds of megabytes of
+    // rows, so the windows are split over a few host threads (statuses are logged afterwards, in window order)
+    const size_t base_m = msa.size(), base_s = output_status.size();
+    const size_t count  = static_cast<size_t>(poa_count_);
+    msa.resize(base_m + count);
+    output_status.resize(base_s + count, StatusType::success);
+    auto unpack = [&](size_t first, size_t last) {
+        for (size_t poa = first; poa < last; poa++)
         {
-            output_status.emplace_back(StatusType::success);
+            const char* c = reinterpret_cast<const char*>(&h_consensus_[poa * row]);
+            if (static_cast<uint8_t>(c[0]) == kKernelError)
+            {
+                output_status[base_s + poa] = static_cast<StatusType>(c[1]);
+                continue;
+            }
             const uint16_t num_seqs = h_windows_[poa].num_seqs;
+            std::vector<std::string>& rows = msa[base_m + poa];
+            rows.reserve(num_seqs);
             for (int32_t i = 0; i < num_seqs; i++)
-                msa[poa].emplace_back(std::string(reinterpret_cast<const char*>(&h_msa_[(static_cast<size_t>(poa) * max_sequences_per_poa_ + i) * row])));
+                rows.emplace_back(reinterpret_cast<const char*>(&h_msa_[(poa * max_sequences_per_poa_ + static_cast<size_t>(i)) * row]));
         }
+    };
+    const size_t bytes     = count * static_cast<size_t>(max_sequences_per_poa_) * row;
+    const size_t n_threads = bytes >= (size_t(8) << 20) ? std::min<size_t>(8, std::max<size_t>(1, count)) : 1;
+    if (n_threads == 1)
+        unpack(0, count);
+    else
+    {
+        std::vector<std::thread> workers;
+        const size_t chunk = (count + n_threads - 1) / n_threads;
+        for (size_t t = 1; t < n_threads; t++) workers.emplace_back(unpack, std::min(count, t * chunk), std::min(count, (t + 1) * chunk));
+        unpack(0, std::min(count, chunk));
+        for (std::thread& w : workers) w.join();
     }
+    for (size_t poa = 0; poa < count; poa++)
+        if (output_status[base_s + poa] != StatusType::success)
+        {
+            std::vector<StatusType> sink; // log_kernel_error appends the code; the status slot is already filled
+            log_kernel_error(output_status[base_s + poa], sink);
+        }
     return StatusType::success;
 }
 
