@@ -41,7 +41,8 @@ static_assert(kReadLds + kCodeTileLds >= 3072 * 2, "the incremental topsort keep
 constexpr int kWideRingBytes = 5 * (1536 + 8) * 4; // 30880
 constexpr int kBsRingBytes   = 2048; // band starts of the ring rows (64 x 4 B) + 64 staged rows of the HBM row table (64 x 24 B)
 constexpr int kReadWinBytes  = 4096;
-constexpr int kMwLds         = 256;  // arguments and carry words of the multi-wave forward pass (poa_device.h)
+constexpr int kMwLds         = 256;
+constexpr size_t kReservedCuLds = 128 * 1024; // 160 KB per CU: nothing else of this kernel family (>= 35 KB per block) fits beside it  // arguments and carry words of the multi-wave forward pass (poa_device.h)
 
 struct KernelArgs
 {
@@ -550,10 +551,25 @@ static hipError_t launch_window_kernel(const KernelArgs& ka, hipStream_t stream)
     const size_t lds = LDS_TABLES ? (size_t)kRingBytes + kRowInfoBytes + kReadLds + kCodeTileLds
                                   : (size_t)kWideRingBytes + kBsRingBytes + kReadWinBytes + kMwLds;
     dim3 grid(ka.total_windows);
+    // A launch of few, heavy windows (long reads: at most one per CU, reads of 16 kbp and more) asks for more LDS than a
+    // block uses, so that no block of a concurrently running launch of lighter windows fits beside it: the heavy window
+    // is the critical path of the whole set (one chain of dependent steps) and keeps its CU's issue slots to itself.
+    int cus = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const bool reserve_cu = !LDS_TABLES && ka.cfg.band_mode == GWHIP_ADAPTIVE_BAND && ka.total_windows <= cus &&
+                            ka.cfg.max_sequence_size >= 16384 && !std::getenv("GWHIP_NO_CU_RESERVATION");
 #define GW_LAUNCH(BM)                                                                                              \
     {                                                                                                              \
         constexpr int NW = (!LDS_TABLES && BM == GWHIP_ADAPTIVE_BAND) ? kMwWaves : 1;                              \
-        hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW>), grid, dim3(kWave * NW), lds, stream, ka); \
+        size_t lds_req = lds;                                                                                      \
+        if (reserve_cu && NW > 1)                                                                                  \
+        {                                                                                                          \
+            lds_req = kReservedCuLds;                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReservedCuLds);             \
+        }                                                                                                          \
+        hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW>), grid, dim3(kWave * NW), lds_req, stream, ka); \
     }                                                                                                              \
     break;
     switch (ka.cfg.band_mode)
