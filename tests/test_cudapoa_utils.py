@@ -146,3 +146,27 @@ def test_cli_matches_batch_api(tmp_path):
     r = subprocess.run([_cli(), "-i", str(p), "-b", "1", "-w", "128", "-a", "-M", "2"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert len(r.stdout.split()) == 16
+
+
+def test_size_class_plan_is_a_partition_with_geometric_shapes():
+    """cudapoa::plan_size_classes (host-only): windows binned by their longest read into classes (L / 2^(k+1), L / 2^k],
+    one BatchConfig per class sized by the class's own largest member."""
+    from genomeworks_amd import cudapoa
+    lengths = [30000, 29000, 15001, 15000, 14000, 7600, 7000, 3000, 2999, 400, 90]
+    reads = [8, 32, 10, 12, 9, 31, 8, 20, 8, 8, 3]
+    windows = [["A" * n] + ["C" * max(n - 7, 1)] * (r - 1) for n, r in zip(lengths, reads)]
+    plan = cudapoa.SizeClassPlan(windows, msa_flag=True, adaptive_storage_factor=4.0)
+    assert sorted(w for g in plan.groups for w in g) == list(range(len(windows)))
+    # L = 30000: (15000, 30000], (7500, 15000], (3750, 7500], (1875, 3750], (937.5, 1875] (empty here), everything below
+    assert plan.groups == [[0, 1, 2], [3, 4, 5], [6], [7, 8], [9, 10]]
+    for cfg, g, b in zip(plan.configs, plan.groups, plan.bytes_per_window):
+        assert cfg["max_sequence_size"] == max(max(lengths[w] for w in g), 256)
+        assert cfg["max_sequences_per_poa"] == max(reads[w] for w in g)
+        assert cfg["max_nodes_per_graph"] == (3 * cfg["max_sequence_size"] + 3) // 4 * 4 and cfg["matrix_sequence_dimension"] == 4 * 264
+        assert b > 0
+    sizes = [b for b in plan.bytes_per_window]
+    assert sizes == sorted(sizes, reverse=True)
+    assert plan.total_bytes == sum(len(g) * b for g, b in zip(plan.groups, plan.bytes_per_window))
+    plan.keep([1, 6, 10])
+    assert plan.groups == [[1], [], [6], [], [10]] and plan.total_bytes == sizes[0] + sizes[2] + sizes[4]
+    assert cudapoa.SizeClassPlan([], msa_flag=False).configs == []
