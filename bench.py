@@ -192,7 +192,7 @@ def bench_aligner(name, cfg, rank, world, sync, dist, torch, reps, cpu_budget_s)
     return out
 
 
-def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_windows):
+def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_windows, ranks_per_device=1):
     """BASELINE configs[3]: the long-read MSA set, windows dealt to the ranks by estimated cost (no collective). The set is
     planned into size classes (cudapoa::plan_size_classes: geometric in the longest read, one BatchConfig per class) and
     all classes run at once, one host thread + stream + Batch each (process_windows_size_classes) -- the multi-batch
@@ -204,11 +204,13 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_
     spec = importlib.util.spec_from_file_location("make_long_read_goldens", os.path.join(ROOT, "tests", "golden", "make_long_read_goldens.py"))
     lr = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lr)
-    windows, cfgs, groups = lr.plan(n_windows)
+    # the plan (and with it every window's BatchConfig) is that of the whole 598-window set, also when only the first
+    # n_windows are run or when the windows are dealt to several ranks: the goldens are keyed to it
+    windows, cfgs, groups = lr.plan(max(n_windows, lr.CONFIG4["windows"]))
     plan = lr.size_plan(windows)
-    cost = [multi_gpu.poa_window_cost(w, 256) for w in windows]
-    mine = multi_gpu.balanced_partition(cost, world)[rank]
-    if world > 1:
+    cost = [multi_gpu.poa_window_cost(w, 256) if k < n_windows else 0 for k, w in enumerate(windows)]
+    mine = [w for w in multi_gpu.balanced_partition(cost, world)[rank] if w < n_windows]
+    if world > 1 or n_windows < len(windows):
         plan.keep(mine)
     golden = {}
     try:
@@ -221,7 +223,7 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_poa as O
         cfg_of = {w: c for c, members in zip(cfgs, groups) for w in members}
-        order = sorted(range(len(windows)), key=lambda w: cost[w])[:cpu_windows]
+        order = sorted(range(n_windows), key=lambda w: cost[w])[:cpu_windows]
         t0, c_cells = time.perf_counter(), 0
         for w in order:
             c = cfg_of[w]
@@ -232,7 +234,8 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_
                "windows_per_s": round(len(order) / dt, 3),
                "sample": "the %d cheapest windows of the set, %.1f s (gcc -O2 scalar oracle, 32-bit scores)" % (len(order), dt)}
     sync()
-    out = cudapoa.process_windows_size_classes(windows, plan, device=local_rank, memory_budget=lr.CONFIG4["memory_budget_bytes"],
+    out = cudapoa.process_windows_size_classes(windows, plan, device=local_rank,
+                                               memory_budget=lr.CONFIG4["memory_budget_bytes"] // ranks_per_device,
                                                output_type="msa", digest=lr.msa_digest)
     sync()
     my_cells = sum(golden[w]["cells"] for w in mine if w in golden)  # the kernels' counters equal the oracle's (asserted by the GPU tests)
@@ -248,7 +251,7 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_
     achieved = my_cells * BYTES_PER_CELL_LONG / out["compute_seconds"] / 1e9
     rec = {"workload": "BASELINE configs[3]: cudapoa long-read MSA, %d windows (8-32 reads, 2-30 kbp, 8-12 %% indel-heavy "
                        "divergence, seeds 2000+w), adaptive band 256, adaptive_storage_factor 4, %d size classes resident and "
-                       "running at once (%.0f GB of slabs)" % (len(windows), len(cfgs), plan.total_bytes / 1e9),
+                       "running at once (%.0f GB of slabs on rank 0)" % (n_windows, len(cfgs), plan.total_bytes / 1e9),
            "metric": "GCUPS, generate_poa() + get_msa() of all size classes (concurrent batches)", "value": round(cells / seconds / 1e9, 3),
            "unit": "GCUPS", "windows": int(n_done), "windows_ok": int(n_ok), "windows_per_s": round(n_done / seconds, 2),
            "ms": round(seconds * 1e3, 1), "ms_with_batch_creation_and_filling": round(total_s * 1e3, 1), "cells": int(cells),
@@ -327,6 +330,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # test aid (tools/r02_gpu_run_multirank.sh): several ranks on ONE device over gloo, to exercise the multi-rank code
+    # paths on a single-GPU box; never set by the driver
+    ranks_per_device = max(1, int(os.environ.get("GW_BENCH_RANKS_PER_DEVICE", "1")))
+    if ranks_per_device > 1:
+        local_rank = local_rank // ranks_per_device
 
     from genomeworks_amd import synthetic
     first_seed = 1000 + rank * args.windows
@@ -343,7 +351,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if ranks_per_device > 1 else "nccl", rank=rank, world_size=world)
 
     from genomeworks_amd import cudapoa, multi_gpu
     from genomeworks_amd.cuda import cuda_set_device
@@ -462,7 +470,8 @@ def main():
     if "reference_shapes" in subs and world == 1:
         sub["reference_benchmark_shapes"] = bench_reference_shapes(windows, local_rank, sync, 2)
     if "long_reads" in subs:
-        sub["configs[3]"] = bench_long_reads(args.long_read_windows, rank, world, local_rank, sync, dist, torch, 3 * cpu_s)
+        sub["configs[3]"] = bench_long_reads(args.long_read_windows, rank, world, local_rank, sync, dist, torch, 3 * cpu_s,
+                                             ranks_per_device)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
