@@ -123,7 +123,7 @@ def reduce_scalars(dist, torch, values, op):
     return [float(x) for x in t.tolist()]
 
 
-def bench_aligner(name, cfg, rank, world, sync, dist, torch, reps, cpu_budget_s):
+def bench_aligner(name, cfg, rank, world, local_rank, sync, dist, torch, reps, cpu_budget_s):
     """One aligner config, index-split over the ranks. Timed regions: align_all() + sync_alignments() (the reference
     benchmark's, cudaaligner/benchmarks/main.cpp:96-143), align_all() + stream sync with the results left on the
     device (get_alignments_device), and the kernels alone (HIP events, inputs resident)."""
@@ -133,7 +133,7 @@ def bench_aligner(name, cfg, rank, world, sync, dist, torch, reps, cpu_budget_s)
     lo, hi = multi_gpu.shard_range(len(pairs), rank, world)
     mine = pairs[lo:hi]
     al = cudaaligner.CudaAlignerBatch(max_bandwidth=cfg["max_bandwidth"], max_device_memory_allocator_caching_size=32 << 30,
-                                      device_id=int(os.environ.get("LOCAL_RANK", "0")))
+                                      device_id=local_rank)
     add = al._L.gw_aligner_add_alignment
 
     def fill():
@@ -463,9 +463,9 @@ def main():
     cpu_s = 0 if args.no_cpu_baseline else 1
     if "aligner" in subs:
         sub["configs[1]"] = bench_aligner("BASELINE configs[1]: cudaaligner banded Myers, 10 000 pairs x 1 kbp, <=33 sub/ins/del, "
-                                          "max_bandwidth 1024", CONFIG2, rank, world, sync, dist, torch, 3, 3.0 * cpu_s)
+                                          "max_bandwidth 1024", CONFIG2, rank, world, local_rank, sync, dist, torch, 3, 3.0 * cpu_s)
         sub["configs[4]"] = bench_aligner("BASELINE configs[4]: cudaaligner 1 000 000 pairs x 150 bp, <=2 sub, <=1 ins, <=1 del, "
-                                          "max_bandwidth 150, index split over the ranks", CONFIG5, rank, world, sync, dist, torch, 2,
+                                          "max_bandwidth 150, index split over the ranks", CONFIG5, rank, world, local_rank, sync, dist, torch, 2,
                                           3.0 * cpu_s)
     if "reference_shapes" in subs and world == 1:
         sub["reference_benchmark_shapes"] = bench_reference_shapes(windows, local_rank, sync, 2)
