@@ -16,6 +16,10 @@
 namespace gwhip
 {
 
+// This file is compiled five times: as it stands (everything but the graph-build kernel's instantiations) and, through
+// gwhip_poa_part{0..3}.hip, once per (score type, id type) pair with GWHIP_POA_PART defined -- those translation units hold
+// nothing but that pair's poa_window_kernel instantiations and their launcher, so the four heavy compilations run in parallel.
+#ifndef GWHIP_POA_PART
 thread_local std::string g_last_error;
 
 static int fail(hipError_t e, const char* what)
@@ -28,6 +32,7 @@ static int fail_msg(int code, const std::string& msg)
     g_last_error = msg;
     return code;
 }
+#endif
 
 constexpr int kRingBytes   = 8448;  // LDS ring of recent score rows: 16 rows of a 256-band int16 row (264 x 2 B)
 constexpr int kRowInfoLds  = 3074;  // rows of the LDS row table (covers max_nodes_per_graph <= 3072)
@@ -38,10 +43,10 @@ static_assert(kReadLds + kCodeTileLds >= 3072 * 2, "the incremental topsort keep
 // Graphs that do not fit the LDS tables (long reads: HBM row table, 32-bit cells, bands up to 1536 columns) spend their
 // LDS on the forward pass instead: a ring of the most recent score rows wide enough for 5 rows of the widest band,
 // the band starts of those rows, and a sliding window of the read. 4 blocks per CU still fit (4 x 35 KB).
-constexpr int kWideRingBytes = 5 * (1536 + 8) * 4; // 30880
+constexpr int kWideRingBytes = 57344; // 9 rows of the widest band (1544 x 4 B); two blocks per CU
 constexpr int kBsRingBytes   = 2048; // band starts of the ring rows (64 x 4 B) + 64 staged rows of the HBM row table (64 x 24 B)
 constexpr int kReadWinBytes  = 4096;
-constexpr int kMwLds         = 256;
+constexpr int kMwLds         = 512;
 constexpr size_t kReservedCuLds = 128 * 1024; // 160 KB per CU: nothing else of this kernel family (>= 35 KB per block) fits beside it  // arguments and carry words of the multi-wave forward pass (poa_device.h)
 
 struct KernelArgs
@@ -62,6 +67,7 @@ struct KernelArgs
     uint64_t* phase_cycles; // optional [windows][kPhCount]
     int32_t debug_flags;    // profiling ablations (GWHIP_DEBUG env var); 0 in production
     int32_t cons_lds_nodes; // node capacity of the consensus kernel's LDS tables (poa_graph_device.h)
+    int32_t wide_ring_bytes; // HBM-table layout: bytes of the LDS ring of score rows (the other regions follow it)
 };
 
 template <typename IdT>
@@ -124,9 +130,9 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
     uint8_t* lds_rowinfo_region = smem + kRingBytes;
     uint8_t* lds_read_buf       = smem + kRingBytes + kRowInfoBytes;
     uint8_t* lds_code_tile      = LDS_TABLES ? smem + kRingBytes + kRowInfoBytes + kReadLds : nullptr;
-    constexpr int32_t ring_bytes = LDS_TABLES ? kRingBytes : kWideRingBytes;
-    int32_t* lds_bs_ring        = LDS_TABLES ? nullptr : reinterpret_cast<int32_t*>(smem + kWideRingBytes);
-    uint8_t* lds_read_window    = LDS_TABLES ? nullptr : smem + kWideRingBytes + kBsRingBytes;
+    const int32_t ring_bytes    = LDS_TABLES ? kRingBytes : a.wide_ring_bytes;
+    int32_t* lds_bs_ring        = LDS_TABLES ? nullptr : reinterpret_cast<int32_t*>(smem + ring_bytes);
+    uint8_t* lds_read_window    = LDS_TABLES ? nullptr : smem + ring_bytes + kBsRingBytes;
     uint8_t* codes              = a.L.codes ? slab + a.L.codes : nullptr;
     constexpr bool graph_fits_lds = LDS_TABLES;
     using RowT = RowInfo<LDS_TABLES>;
@@ -161,8 +167,8 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
             else if (level == 1) __builtin_amdgcn_s_setprio(1);
         }
         static_assert(!LDS_TABLES, "the multi-wave forward pass belongs to the HBM-table layout");
-        mw_args   = reinterpret_cast<MwArgs<ScoreT>*>(smem + kWideRingBytes + kBsRingBytes + kReadWinBytes);
-        mw_shared = reinterpret_cast<MwShared*>(smem + kWideRingBytes + kBsRingBytes + kReadWinBytes + 128);
+        mw_args   = reinterpret_cast<MwArgs<ScoreT>*>(smem + ring_bytes + kBsRingBytes + kReadWinBytes);
+        mw_shared = reinterpret_cast<MwShared*>(smem + ring_bytes + kBsRingBytes + kReadWinBytes + 128);
         if (wave != 0)
         {
             // helper wavefronts: parked at the barrier until wave 0 reaches a wide-band forward pass (or the end)
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
                 block_barrier();
                 const MwArgs<ScoreT> A = *mw_args;
                 if (A.op != 1) return;
-                generic_forward_mw<ScoreT, IdT, RowT>(A, g, rowinfo, ring, lds_bs_ring, lds_read_window, mw_shared, wave, lane);
+                generic_forward_skew<ScoreT, IdT, RowT>(A, g, rowinfo, ring, mw_shared, wave, lane);
             }
         }
     }
@@ -422,6 +428,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
     }
 }
 
+#ifndef GWHIP_POA_PART
 // ------------------------------------------------------------------------------------------------
 // Consensus kernel: one wavefront per window (the reference runs one THREAD per window,
 // cudapoa_generate_consensus.cuh:286-354, 512 per block => 2 blocks for 1024 windows).
@@ -523,10 +530,13 @@ __global__ void poa_export_graph_kernel(KernelArgs a, int32_t first_window, uint
     }
 }
 
+#endif // GWHIP_POA_PART
+
 // ------------------------------------------------------------------------------------------------
 // host side of the C-ABI
 // ------------------------------------------------------------------------------------------------
 #ifndef GWHIP_DEVICE_ONLY // tools/isa_dump.sh compiles a single kernel instantiation without the host dispatch
+#ifndef GWHIP_POA_PART
 static size_t full_score_bytes(const gwhip_poa_config& c, int32_t windows, uint64_t sum_scores_width)
 {
     if (c.band_mode != GWHIP_FULL_BAND) return 0;
@@ -544,28 +554,34 @@ static bool validate(const gwhip_poa_args* args)
     if (!c.size32 && c.max_nodes_per_graph > 32767) return false;
     return true;
 }
+#endif // GWHIP_POA_PART
 
 template <typename ScoreT, typename IdT, typename TraceT, bool MSA, bool LDS_TABLES>
-static hipError_t launch_window_kernel(const KernelArgs& ka, hipStream_t stream)
+static hipError_t launch_window_kernel(const KernelArgs& ka_in, hipStream_t stream)
 {
-    const size_t lds = LDS_TABLES ? (size_t)kRingBytes + kRowInfoBytes + kReadLds + kCodeTileLds
-                                  : (size_t)kWideRingBytes + kBsRingBytes + kReadWinBytes + kMwLds;
+    KernelArgs ka = ka_in;
+    constexpr size_t wide_rest = (size_t)kBsRingBytes + kReadWinBytes + kMwLds;
+    // multi-wave blocks of long reads (16 kbp and more): 9 ring rows of the widest band, two blocks per CU; shorter reads
+    // keep four blocks per CU (their bands are mostly narrow: 14 rows of a 512-column band, 5 of the widest)
+    ka.wide_ring_bytes = ka.cfg.max_sequence_size >= 16384 ? kWideRingBytes : 5 * (kMaxAdaptiveBand + kRightPad) * 4;
+    size_t lds = LDS_TABLES ? (size_t)kRingBytes + kRowInfoBytes + kReadLds + kCodeTileLds : (size_t)ka.wide_ring_bytes + wide_rest;
     dim3 grid(ka.total_windows);
     // A launch of few, heavy windows (long reads: at most one per CU, reads of 16 kbp and more) asks for more LDS than a
     // block uses, so that no block of a concurrently running launch of lighter windows fits beside it: the heavy window
     // is the critical path of the whole set (one chain of dependent steps) and keeps its CU's issue slots to itself.
-    int cus = 0, dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    const bool reserve_cu = !LDS_TABLES && ka.cfg.band_mode == GWHIP_ADAPTIVE_BAND && ka.total_windows <= cus &&
-                            ka.cfg.max_sequence_size >= 16384 && !std::getenv("GWHIP_NO_CU_RESERVATION");
 #define GW_LAUNCH(BM)                                                                                              \
     {                                                                                                              \
-        constexpr int NW = (!LDS_TABLES && BM == GWHIP_ADAPTIVE_BAND) ? kMwWaves : 1;                              \
+        constexpr int NW = (!LDS_TABLES && BM == GWHIP_ADAPTIVE_BAND) ? kSkWaves : 1;                              \
         size_t lds_req = lds;                                                                                      \
-        if (reserve_cu && NW > 1)                                                                                  \
+        if (!LDS_TABLES && NW == 1) /* single-wave HBM-table kernels: five rows of the widest band, four blocks per CU */ \
         {                                                                                                          \
-            lds_req = kReservedCuLds;                                                                              \
+            ka.wide_ring_bytes = 5 * (kMaxAdaptiveBand + kRightPad) * 4;                                           \
+            lds_req            = (size_t)ka.wide_ring_bytes + wide_rest;                                           \
+        }                                                                                                          \
+        if (NW > 1) /* multi-wave blocks: the register count allows one 8-wave block per CU, which then owns its LDS */ \
+        {                                                                                                          \
+            lds_req            = kReservedCuLds;                                                                   \
+            ka.wide_ring_bytes = (int32_t)(kReservedCuLds - wide_rest); /* the whole reservation is put to use */  \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReservedCuLds);             \
         }                                                                                                          \
@@ -602,13 +618,28 @@ static hipError_t launch_msa_split(const KernelArgs& ka, hipStream_t stream)
 }
 
 template <typename ScoreT, typename IdT>
-static hipError_t launch_trace_split(const KernelArgs& ka, hipStream_t stream)
+hipError_t launch_trace_split(const KernelArgs& ka, hipStream_t stream)
 {
     // TraceT only matters in the traceback modes; the other modes share the int8_t instantiation
     const bool tb = ka.cfg.band_mode == GWHIP_STATIC_BAND_TRACEBACK || ka.cfg.band_mode == GWHIP_ADAPTIVE_BAND_TRACEBACK;
     if (tb && ka.cfg.trace16) return launch_msa_split<ScoreT, IdT, int16_t>(ka, stream);
     return launch_msa_split<ScoreT, IdT, int8_t>(ka, stream);
 }
+#ifdef GWHIP_POA_PART
+#if GWHIP_POA_PART == 0
+template hipError_t launch_trace_split<int32_t, int32_t>(const KernelArgs&, hipStream_t);
+#elif GWHIP_POA_PART == 1
+template hipError_t launch_trace_split<int32_t, int16_t>(const KernelArgs&, hipStream_t);
+#elif GWHIP_POA_PART == 2
+template hipError_t launch_trace_split<int16_t, int32_t>(const KernelArgs&, hipStream_t);
+#else
+template hipError_t launch_trace_split<int16_t, int16_t>(const KernelArgs&, hipStream_t);
+#endif
+#else
+extern template hipError_t launch_trace_split<int32_t, int32_t>(const KernelArgs&, hipStream_t);
+extern template hipError_t launch_trace_split<int32_t, int16_t>(const KernelArgs&, hipStream_t);
+extern template hipError_t launch_trace_split<int16_t, int32_t>(const KernelArgs&, hipStream_t);
+extern template hipError_t launch_trace_split<int16_t, int16_t>(const KernelArgs&, hipStream_t);
 
 static KernelArgs make_kernel_args(const gwhip_poa_args* args)
 {
@@ -633,11 +664,12 @@ static KernelArgs make_kernel_args(const gwhip_poa_args* args)
     }
     return ka;
 }
+#endif // GWHIP_POA_PART
 
 #endif // GWHIP_DEVICE_ONLY
 } // namespace gwhip
 
-#ifndef GWHIP_DEVICE_ONLY
+#if !defined(GWHIP_DEVICE_ONLY) && !defined(GWHIP_POA_PART)
 using namespace gwhip;
 
 extern "C" {

@@ -176,6 +176,48 @@ template <typename ScoreT> __device__ __forceinline__ Quad<ScoreT> lds_ld_quad(c
     return r;
 }
 
+// four cells as one 8 / 16-byte store through an explicit LDS or global pointer (a struct cannot be assigned through
+// an address-space pointer, a vector can)
+template <typename ScoreT> struct QuadVec;
+template <> struct QuadVec<int16_t> { typedef short type __attribute__((ext_vector_type(4))); };
+template <> struct QuadVec<int32_t> { typedef int type __attribute__((ext_vector_type(4))); };
+template <typename ScoreT> __device__ __forceinline__ void lds_st_quad(ScoreT* p, ScoreT a, ScoreT b, ScoreT c, ScoreT d)
+{
+    typedef typename QuadVec<ScoreT>::type V;
+    V v = {a, b, c, d};
+    *(__attribute__((address_space(3))) V*)p = v;
+}
+template <typename ScoreT>
+__device__ __forceinline__ void global_st_quad(__attribute__((address_space(1))) ScoreT* p, ScoreT a, ScoreT b, ScoreT c, ScoreT d)
+{
+    typedef typename QuadVec<ScoreT>::type V;
+    V v = {a, b, c, d};
+    *(__attribute__((address_space(1))) V*)p = v;
+}
+
+// loads through an LDS byte address
+template <typename ScoreT> __device__ __forceinline__ typename QuadVec<ScoreT>::type lds_ld_qv(uint32_t addr)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) typename QuadVec<ScoreT>::type*>(addr);
+}
+template <typename ScoreT> __device__ __forceinline__ ScoreT lds_ld_at(uint32_t addr)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) ScoreT*>(addr);
+}
+
+// a row-table record from LDS, dword by dword through an explicit LDS pointer
+template <typename RowT> __device__ __forceinline__ RowT lds_ld_row(const RowT* p)
+{
+    static_assert(sizeof(RowT) % 4 == 0, "whole dwords");
+    uint32_t w[sizeof(RowT) / 4];
+    const __attribute__((address_space(3))) uint32_t* q = (const __attribute__((address_space(3))) uint32_t*)p;
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(RowT) / 4); k++) w[k] = q[k];
+    RowT r;
+    __builtin_memcpy(&r, w, sizeof(r));
+    return r;
+}
+
 // every lane loaded the same record: moving it to scalar registers lets the row loop branch and index on the scalar unit
 template <> __device__ __forceinline__ RowInfo<false> uniform_row(RowInfo<false> r)
 {
@@ -1452,22 +1494,42 @@ namespace gwhip
 // ------------------------------------------------------------------------------------------------
 // Multi-wave forward pass for wide bands (long reads: adaptive bands of 512 .. 1536 columns, HBM row table).
 //
-// A row of a 1536-column band is six 256-column passes. On one wavefront they run back to back (about 4 000 cycles per
-// row, a chain of LDS round trips), although only the horizontal carry connects them. Here every pass of a row has its
-// own wavefront (wave w of the block takes pass w): candidates and the in-pass prefix maximum are computed by all
-// waves at once, the carries are exchanged through six LDS words behind one block barrier, and a second barrier at the
-// end of the row publishes it in the LDS ring before the next row reads it as a predecessor.
+// A row of a 1536-column band is six 256-column passes; on one wavefront they run back to back (about 4 000 cycles per
+// row). Round 2 first gave every pass of a row its own wavefront with two block barriers per row (carries exchanged in
+// "u space"): about 2 300 cycles per row, because record decode, the LDS round trips and the two barriers are per row.
+// This version has no per-row barrier at all: it is a pipeline of wavefronts over ABSOLUTE column blocks.
 //
-// The carry exchange works in "u space" over the WHOLE band: with u[t] = v[t] - t * gap (t = 0 .. band_width - 1
-// across all passes) the row's max-plus recurrence H[t] = max(v[t], H[t - 1] + gap) is a prefix maximum of u, so the
-// exclusive prefix a pass needs from its left is max(carry-in, totals of the passes before it) -- associative, no
-// sequential hand-over. The single-wave code chains the passes through the stored (ScoreT) value of the last cell;
-// both give the same cells unless a ScoreT store wraps, which the reference excludes too.
+//   * Block b is the chunk anchors c in [256 b, 256 b + 256), i.e. the cells of columns 256 b + 1 .. 256 b + 256; it
+//     belongs to wave b mod kSkWaves for every row. Band starts only move right, so a wave keeps its block until the band
+//     has passed it and then moves on to block b + kSkWaves; a band of at most 1536 columns touches at most 7 blocks, so
+//     with 8 waves no wave ever owns two blocks of a row. A lane's columns are the same in every row: its four read
+//     characters are loaded once per block, not once per row.
+//   * Everything a block of row r needs from other wavefronts comes from the block to its LEFT: the horizontal carry
+//     (the cell of column 256 b of row r) and, for the lane at the block's first chunk, the cell of column 256 b of each
+//     predecessor row. Wave w therefore runs one row (or more) behind wave w - 1 and never waits for a wave on its
+//     right -- except for ring space, see below. All of it goes through the LDS ring of recent rows; the only
+//     synchronisation is one progress word per wave (done[w] = last row the wave has finished or skipped), written
+//     after the row's ring stores (one wavefront's LDS operations execute in order) and polled by the neighbours.
+//     Candidates and the in-block prefix maximum do not depend on the carry, so the poll for the left neighbour's row r
+//     comes after them and normally finds it there.
+//   * Ring space: slot r mod R is rewritten by row r, so a wave may not run more than kSkLead rows ahead of its right
+//     neighbour, and a predecessor counts as "in the ring" only up to R - kSkLead - 1 rows back. Rows with a predecessor
+//     farther back (or with more than three predecessors) read it from the HBM matrix, which other wavefronts have
+//     written: all waves take a block barrier in front of such a row (the decision is the same in all of them).
+//   * The row table is read 64 rows at a time into registers (lane l holds row base + l, a row's record is six
+//     v_readlane), prefetched one batch ahead, so the row loop issues no load that would wait for the score stores.
 //
-// All waves of the block call generic_forward_mw with the same arguments (wave 0 hands them over through MwArgs in
-// LDS) and run the same wave-uniform control flow, so their barriers pair up. Wave 0 alone runs every other phase.
+// The pass also writes the trace codes of poa_forward_packed.h (one byte per cell: the move the reference's traceback
+// takes from that cell, 0 = undecided), which turn the traceback of wide bands into table lookups
+// (traceback_codes_staged). A code is written only where the forward pass saw exactly the operands the traceback's
+// get_score() would see: not in chunks outside some predecessor's band, not in the band's first cell (its horizontal
+// operand is the carry-in), not where only predecessor slot 3 or later attains the maximum.
+//
+// All waves of the block call generic_forward_skew with the same arguments (wave 0 hands them over through MwArgs in
+// LDS). Wave 0 alone runs every other phase.
 // ------------------------------------------------------------------------------------------------
-constexpr int kMwWaves = 6; // kMaxAdaptiveBand / 256
+constexpr int kSkWaves = 8; // > kMaxAdaptiveBand / 256 + 1 blocks of a row
+constexpr int kSkLead  = 4; // rows a wave may run ahead of its right neighbour
 
 template <typename ScoreT> struct MwArgs
 {
@@ -1478,206 +1540,827 @@ template <typename ScoreT> struct MwArgs
     int32_t ring_rows;
     const uint8_t* read;
     ScoreT* scores;
+    uint8_t* codes;
+    int32_t dbg; // GWHIP_DEBUG (profiling counters, bits 12-15)
 };
 struct MwShared // in LDS, behind the regions of the single-wave layout
 {
-    int32_t totals[8]; // per pass: prefix maximum of the pass in u space (pass 0 includes the carry-in)
+    int32_t done[kSkWaves];     // per wave: last row finished or skipped
+    int32_t carry[kSkWaves][8]; // per wave: the last cell of its block in row r at [r & 7] (a wave is never more than kSkLead + 1 rows ahead of its reader)
+    unsigned long long prof;    // profiling: the selected counter, summed over the waves
 };
 
-template <typename ScoreT, typename IdT, typename RowT>
-__device__ __forceinline__ void generic_forward_mw(const MwArgs<ScoreT>& A, const GraphView<IdT>& g, const RowT* rowinfo, ScoreT* ring,
-                                                   int32_t* bs_ring, uint8_t* read_window, MwShared* shared, int wave, int lane)
+__device__ __forceinline__ int32_t lds_poll(const int32_t* p)
 {
+    const int32_t v = *(const volatile __attribute__((address_space(3))) int32_t*)p;
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <typename ScoreT, typename IdT, typename RowT>
+__device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, const GraphView<IdT>& g, const RowT* rowinfo, ScoreT* ring,
+                                                     MwShared* shared, int wave, int lane, uint64_t* prof_out = nullptr)
+{
+    // profiling (GWHIP_DEBUG bits 12-15, sum over the waves, arrives in the "other" phase): 1 rows worked on, 2 rows
+    // skipped, 3 block barriers (x 1000), 4 cycles in the pass, 5 cycles waiting for the left neighbour, 6 cycles waiting
+    // for ring space, 7 rows on the general path, 8 cycles in the row bodies (waits included), 9 polls, 10 cycles waiting
+    // for the left neighbour at the start of a row, 11 cycles in the bodies of first-block rows, 12 their number, 13 cycles
+    // in the row-table batches
+    const int32_t sksel = (A.dbg >> 12) & 15;
+    uint64_t skacc      = 0;
+    const uint64_t t_pass = sksel == 4 ? clock64() : 0;
+    static_assert(sizeof(RowT) == 24, "the register copy of the row table holds six dwords per row");
     const int32_t graph_count = A.graph_count, read_length = A.read_length, band_width = A.band_width;
     const int32_t max_column = A.max_column, gap_score = A.gap_score;
     const int32_t min_score  = Limits<ScoreT>::min / 2;
     const int32_t stride     = band_width + kRightPad;
-    const int32_t npass      = (band_width + 255) / 256;
     const int32_t ring_rows  = A.ring_rows;
-    ScoreT* scores           = A.scores;
-    const uint8_t* read      = A.read;
-    const int32_t pass       = wave;
-    const bool has_pass      = pass < npass;
-    RowT* ri_stage           = reinterpret_cast<RowT*>(bs_ring + 64);
+    const int32_t near_rows  = ring_rows - kSkLead - 1; // a predecessor closer than this is read from the ring
+    // explicit global pointers: the arguments come out of an LDS struct, and behind a pointer of unknown address space
+    // every access would be a flat instruction, which the row loop must not contain (it waits on both memory counters)
+    typedef __attribute__((address_space(1))) ScoreT GScore;
+    typedef __attribute__((address_space(1))) uint8_t GByte;
+    GScore* scores           = (GScore*)A.scores;
+    GByte* codes             = (GByte*)A.codes;
+    const GByte* read        = (const GByte*)A.read;
+    const int left = (wave + kSkWaves - 1) % kSkWaves, right = (wave + 1) % kSkWaves;
 
-    // sliding LDS window over the read and the staged row table: refilled by wave 0 between two barriers
-    constexpr int32_t kWin = 4096, kWinStep = 1024;
-    int32_t staged_end = 0, ri_stage_end = 0;
-    auto stage_read = [&](int32_t need_end) { // same decision in every wave
-        block_barrier();
-        while (staged_end < need_end)
-        {
-            if (wave == 0)
-                for (int32_t i = lane * 4; i < kWinStep; i += kWave * 4)
-                {
-                    const int32_t col = staged_end + i;
-                    const uint32_t v  = col < read_length + 8 ? *reinterpret_cast<const uint32_t*>(read + col) : 0u;
-                    *reinterpret_cast<uint32_t*>(read_window + (col & (kWin - 1))) = v;
-                }
-            staged_end += kWinStep;
-        }
-        block_barrier();
+    // ---- this wave's block: per-lane values that only change when the wave moves on to its next block ----
+    int32_t blk = wave;
+    uint32_t rd4;                           // read characters of columns c .. c+3 (the characters of cells c+1 .. c+4)
+    int32_t cvec;                           // chunk anchor column c = 256 blk + 4 lane
+    int32_t cg0, cg1, cg2, cg3;             // (c + k) * gap: the cells' offsets in "u space"
+    bool c_in_read;                         // c <= max_column
+    int32_t blk_carry_gap;                  // u-space offset of the left neighbour's last cell (column 256 blk)
+    auto enter_block = [&](int32_t block) {
+        cvec = block * 256 + 4 * lane;
+        uint32_t v = cvec < read_length + 8 ? *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(read + cvec) : 0u;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory"); // here, once per block, not at its first use in the row loop
+        rd4 = v;
+        cg0 = cvec * gap_score; cg1 = cg0 + gap_score; cg2 = cg1 + gap_score; cg3 = cg2 + gap_score;
+        c_in_read = cvec <= max_column;
+        blk_carry_gap = (256 * block - 1) * gap_score;
     };
-    auto fetch_ri = [&](int32_t row) -> RowT {
-        if (row >= ri_stage_end)
-        {
-            block_barrier();
-            if (wave == 0 && row + lane <= graph_count) ri_stage[(row + lane) & 63] = rowinfo[row + lane];
-            ri_stage_end = row + 64;
-            block_barrier();
-        }
-        return uniform_row(ri_stage[row & 63]);
-    };
+    enter_block(blk);
 
-    RowT ri_next   = fetch_ri(1);
-    int32_t slot_r = 1 % ring_rows;
-    for (int32_t r = 1; r <= graph_count; r++)
-    {
-        const RowT ri = ri_next;
-        if (r < graph_count) ri_next = fetch_ri(r + 1);
-        const int32_t pred_count = ri.cnt();
-        const int32_t bs         = ri.bs();
-        const int32_t node_id    = pred_count > 3 ? (int32_t)g.sorted_poa[r - 1] : 0;
-        auto pred_row = [&](int32_t p) -> int32_t {
-            if (pred_count == 0) return 0;
-            if (p < 3) return ri.pred(p);
-            return wave_first((int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1);
+    // ---- row table in registers, 64 rows at a time: lane l holds row batch_base + l ----
+    // raw dwords of the next batch (prefetched), and of the current one what the row loop reads with v_readlane:
+    //   m0 = base [0:8) | predecessor count [8:15) | general path [15] | distance to predecessor 0 [16:24) | 1 [24:32)
+    //   m1 = distance to predecessor 2 [0:8) | (band start - predecessor k's band start) / 4 for k = 0, 1, 2 [8:16) [16:24) [24:32)
+    // A row takes the general path when it has more than three predecessors, or one that is not safely in the ring, or
+    // one whose band start is too far left to encode.
+    int32_t nxt[6];
+    int32_t m0v = 0, m1v = 0, bsv = 0, p0v = 0, p1v = 0, p2v = 0, prev_bsv = 0;
+    auto load_batch = [&](int32_t base, int32_t (&dst)[6]) {
+        const int32_t row = min(base + lane, graph_count);
+        const __attribute__((address_space(1))) int32_t* src = (const __attribute__((address_space(1))) int32_t*)(rowinfo + row);
+#pragma unroll
+        for (int k = 0; k < 6; k++) dst[k] = src[k];
+        // wait for the batch here, once per 64 rows: left to the compiler the wait lands in front of every row's first
+        // use of the registers (it cannot prove across the loop that the load has landed), i.e. behind every row's stores
+        asm volatile("" : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4]), "+v"(dst[5]));
+    };
+    auto adopt_batch = [&](int32_t base) { // nxt holds rows base .. base + 63
+        prev_bsv          = bsv;
+        const int32_t row = base + lane;
+        const int32_t w0  = nxt[0];
+        const int32_t cnt = (w0 >> 8) & 0x7f;
+        bsv = nxt[1];
+        p0v = cnt > 0 ? nxt[2] : 0;
+        p1v = nxt[3];
+        p2v = nxt[4];
+        auto band_start_of = [&](int32_t p) -> int32_t { // band start of row p <= row, from this batch or the previous one
+            const int32_t idx = p - base;
+            const int32_t cur = __builtin_amdgcn_ds_bpermute((idx & 63) << 2, bsv);
+            const int32_t prv = __builtin_amdgcn_ds_bpermute(((idx + 64) & 63) << 2, prev_bsv);
+            return p == 0 ? 0 : (idx >= 0 ? cur : prv);
         };
-        auto in_ring = [&](int32_t row) -> bool { return r - row < ring_rows; };
-        auto slot_of = [&](int32_t row) -> int32_t {
-            const int32_t sl = slot_r - (r - row);
+        const int32_t d0 = row - p0v, d1 = cnt > 1 ? row - p1v : 0, d2 = cnt > 2 ? row - p2v : 0;
+        // (the three permutes run with every lane active: a lane that is switched off supplies no value)
+        const int32_t q0 = band_start_of(p0v), q1 = band_start_of(p1v), q2 = band_start_of(p2v);
+        const int32_t e0 = bsv - q0, e1 = cnt > 1 ? bsv - q1 : 0, e2 = cnt > 2 ? bsv - q2 : 0;
+        const int32_t dmax = max(d0, max(d1, d2)), emax = max(e0, max(e1, e2));
+        const bool general = cnt > 3 || dmax >= near_rows || dmax > 63 || emax > 1020 || row > graph_count;
+        m0v = (w0 & 0x7fff) | (general ? 0x8000 : 0) | ((d0 & 0xff) << 16) | ((d1 & 0xff) << 24);
+        m1v = (d2 & 0xff) | (((e0 >> 2) & 0xff) << 8) | (((e1 >> 2) & 0xff) << 16) | (((e2 >> 2) & 0xff) << 24);
+    };
+    load_batch(1, nxt);
+    adopt_batch(1);
+    load_batch(65, nxt);
+
+    // ---- the neighbours' progress: done[w] = last row wave w has finished or skipped; carry[w][r & 3] = its last cell of row r ----
+    typedef __attribute__((address_space(3))) const volatile int32_t* LdsWord;
+    const LdsWord left_word  = (LdsWord)&shared->done[left];
+    const LdsWord right_word = (LdsWord)&shared->done[right];
+    const LdsWord left_carry_words = (LdsWord)&shared->carry[left][0];
+    const uint32_t my_word   = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&shared->done[wave];
+    const uint32_t my_carry  = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&shared->carry[wave][0];
+    auto publish = [&](int32_t row, int32_t carry) { // behind the row's ring stores: LDS runs one wave's operations in order
+        const uint32_t ca = my_carry + 4u * (uint32_t)(row & 7);
+        asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, -1" ::"v"(ca), "v"(carry), "v"(my_word), "v"(row)
+                     : "memory");
+    };
+    int32_t left_done = 0, right_done = 0; // cached copies
+    // Waits are bounded: a protocol error must end as a wrong result the parity tests catch, not as a wavefront spinning
+    // forever (after the first timeout the waves stop waiting altogether).
+    bool gave_up = false;
+    auto wait_left = [&](int32_t row) {
+        const uint64_t t_w = sksel == 5 ? clock64() : 0;
+        int32_t spins = 0;
+        while (left_done < row && !gave_up)
+        {
+            if (sksel == 9) skacc++;
+            left_done = wave_first(*left_word);
+            if (left_done < row)
+            {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) gave_up = true;
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (sksel == 5) skacc += clock64() - t_w;
+    };
+    auto wait_right = [&](int32_t row) {
+        const uint64_t t_w = sksel == 6 ? clock64() : 0;
+        int32_t spins = 0;
+        while (right_done < row && !gave_up)
+        {
+            if (sksel == 9) skacc++;
+            right_done = wave_first(*right_word);
+            if (right_done < row)
+            {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) gave_up = true;
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (sksel == 6) skacc += clock64() - t_w;
+    };
+
+    // per-row state kept incrementally: the ring slot of row r, its byte offset, the row's HBM score / code rows
+    const uint32_t ring_lds = lds_addr(ring);
+    const int32_t row_bytes = stride * (int32_t)sizeof(ScoreT);
+    const int32_t ring_span = ring_rows * row_bytes;
+    int32_t slot_r      = 1 % ring_rows;
+    uint32_t ring_off_r = (uint32_t)(slot_r * row_bytes);
+    GScore* scores_row  = scores + stride;
+    GByte* codes_row    = codes ? codes + stride : codes;
+    auto next_row = [&]() {
+        slot_r     = slot_r + 1 == ring_rows ? 0 : slot_r + 1;
+        ring_off_r = slot_r == 0 ? 0u : ring_off_r + (uint32_t)row_bytes;
+        scores_row += stride;
+        codes_row += stride;
+    };
+    for (int32_t r = 1; r <= graph_count; r++, next_row())
+    {
+        const int32_t ridx = (r - 1) & 63;
+        if (ridx == 0 && r > 1)
+        {
+            const uint64_t t_b = sksel == 13 ? clock64() : 0;
+            adopt_batch(r);
+            load_batch(r + 64, nxt);
+            if (sksel == 13) skacc += clock64() - t_b;
+        }
+        const uint32_t m0        = (uint32_t)__builtin_amdgcn_readlane(m0v, ridx);
+        const uint32_t m1        = (uint32_t)__builtin_amdgcn_readlane(m1v, ridx);
+        const int32_t bs         = __builtin_amdgcn_readlane(bsv, ridx);
+        const uint32_t base      = m0 & 0xffu;
+        const int32_t pred_count = (int32_t)((m0 >> 8) & 0x7fu);
+        const bool general       = (m0 & 0x8000u) != 0;
+        auto slot_back = [&](int32_t d) -> int32_t { // slot of row r - d, d < ring_rows
+            const int32_t sl = slot_r - d;
             return sl < 0 ? sl + ring_rows : sl;
         };
-        // band start of an earlier row: arithmetic (a dozen ALU operations) instead of a dependent LDS / HBM read
-        auto bs_of = [&](int32_t row) -> int32_t {
-            return row == 0 ? 0 : band_start_for_row(row, A.gradient, band_width, A.band_shift, max_column);
-        };
-        auto rel0_of = [&](int32_t row) -> int32_t {
-            if (in_ring(row)) return lds_ld(ring + slot_of(row) * stride + kRelShift);
-            return wave_first((int32_t)scores[(int64_t)row * stride + kRelShift]);
-        };
-        // a predecessor that has left the ring is read from the HBM matrix, possibly written by another wavefront: make
-        // every wavefront's stores complete first (rare: about 2 % of the rows; the decision is the same in all waves)
+        // A predecessor that is not safely in the ring comes from the HBM matrix, written by other wavefronts: every wave
+        // finishes its earlier rows and its stores first (same decision in all waves).
+        int32_t p0 = 0, p1 = 0, p2 = 0;
+        bool far = false;
+        if (general)
         {
-            bool far = false;
-            const int32_t npred = max(pred_count, 1);
-            for (int32_t p = 0; p < npred; p++) far = far || !in_ring(pred_row(p));
+            p0 = __builtin_amdgcn_readlane(p0v, ridx);
+            p1 = __builtin_amdgcn_readlane(p1v, ridx);
+            p2 = __builtin_amdgcn_readlane(p2v, ridx);
+            if (pred_count <= 3)
+                far = (r - p0 >= near_rows) || (pred_count > 1 && r - p1 >= near_rows) || (pred_count > 2 && r - p2 >= near_rows);
+            else
+            {
+                const int32_t node_id = wave_first((int32_t)g.sorted_poa[r - 1]);
+                for (int32_t p = 0; p < pred_count; p++)
+                {
+                    const int32_t prow = p == 0 ? p0 : (p == 1 ? p1 : (p == 2 ? p2 : wave_first((int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1)));
+                    far                = far || (r - prow >= near_rows);
+                }
+            }
             if (far) block_barrier();
+            if (far && sksel == 3) skacc += 1000;
         }
-        if (bs + npass * 256 + 4 > staged_end) stage_read(bs + npass * 256 + 4);
 
-        // ---- this wave's pass: candidates from every predecessor, prefix maximum inside the pass ----
-        const int32_t tg   = pass * 256 + 4 * lane; // index of the lane's first cell in the band
-        const int32_t c    = bs + tg;               // chunk anchor column (cells c+1 .. c+4)
-        const bool active  = has_pass && tg < band_width;
-        int32_t m0 = INT32_MIN, m1 = INT32_MIN, m2 = INT32_MIN, m3 = INT32_MIN, incl = INT32_MIN;
-        int32_t fe = 0, rel0_val = min_score;
-        if (has_pass)
+        while (bs >= 256 * (blk + 1)) // the band has passed this wave's block: on to the next one
         {
-            const uint32_t rd4 = *reinterpret_cast<const uint32_t*>(read_window + (c & (kWin - 1)));
-            const int32_t cp0  = ((rd4 & 0xff) == (uint32_t)ri.base()) ? A.match_score : A.mismatch_score;
-            const int32_t cp1  = (((rd4 >> 8) & 0xff) == (uint32_t)ri.base()) ? A.match_score : A.mismatch_score;
-            const int32_t cp2  = (((rd4 >> 16) & 0xff) == (uint32_t)ri.base()) ? A.match_score : A.mismatch_score;
-            const int32_t cp3  = ((rd4 >> 24) == (uint32_t)ri.base()) ? A.match_score : A.mismatch_score;
-            int32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            blk += kSkWaves;
+            enter_block(blk);
+        }
+        if (256 * blk >= bs + band_width) // the band has not reached this block yet
+        {
+            publish(r, 0);
+            if (sksel == 2) skacc++;
+            continue;
+        }
+        const bool first_block = (bs >> 8) == blk;
+        const int32_t tg       = cvec - bs; // index of the lane's first cell in the band
+        // cells of column 256 blk of the predecessor rows are the left neighbour's: it must be past row r - 1
+        const uint64_t t_ws = sksel == 10 ? clock64() : 0;
+        wait_left(r - 1);
+        if (sksel == 10) skacc += clock64() - t_ws;
+        if (sksel == 1) skacc++;
+        if (sksel == 12 && first_block) skacc++;
+        const uint64_t t_rb = (sksel == 8 || (sksel == 11 && first_block)) ? clock64() : 0;
+
+        // what the two row bodies leave behind
+        int32_t H0, H1, H2, H3;
+        uint32_t code4;
+        int32_t rel0_val = min_score;
+
+        // match / mismatch costs of the row's base against the lane's four read characters
+        const int32_t cp0 = ((rd4 & 0xff) == base) ? A.match_score : A.mismatch_score;
+        const int32_t cp1 = (((rd4 >> 8) & 0xff) == base) ? A.match_score : A.mismatch_score;
+        const int32_t cp2 = (((rd4 >> 16) & 0xff) == base) ? A.match_score : A.mismatch_score;
+        const int32_t cp3 = ((rd4 >> 24) == base) ? A.match_score : A.mismatch_score;
+        // the row's finish, shared by both bodies: prefix maximum in u space (u = v - (c + k) * gap, an offset common to the
+        // whole row, so the carry is converted with the column it belongs to), the hand-over from the left, H and the stores
+        int32_t probe_carry = 0; // the left neighbour's carry of this row, if an early read has it
+        bool have_carry     = false;
+        auto finish_row = [&](int32_t s0, int32_t s1, int32_t s2, int32_t s3, int32_t fe_if_first) {
+            int32_t u0 = s0 - cg0, u1 = s1 - cg1, u2 = s2 - cg2, u3 = s3 - cg3;
+            if (first_block) // lanes left of the band start carry no cells (lanes right of its end feed nobody)
+            {
+                const bool dead = tg < 0;
+                u0 = dead ? INT32_MIN : u0; u1 = dead ? INT32_MIN : u1; u2 = dead ? INT32_MIN : u2; u3 = dead ? INT32_MIN : u3;
+            }
+            const int32_t m0_ = u0, m1_ = max(m0_, u1), m2_ = max(m1_, u2), m3_ = max(m2_, u3);
+            const int32_t incl = wave_inclusive_max(m3_);
+            int32_t carry_u;
+            if (first_block)
+                carry_u = fe_if_first - (bs - 1) * gap_score; // the carry-in is the element of column bs - 1
+            else
+            {
+                if (left_done < r) wait_left(r); // the probe came too early (or there was none)
+                const int32_t hl = have_carry ? probe_carry : wave_first(left_carry_words[r & 7]);
+                carry_u          = hl - (256 * blk - 1) * gap_score; // the left neighbour's cell of column 256 blk
+            }
+            const int32_t excl = max(wave_shr1(incl, INT32_MIN), carry_u);
+            H0 = (ScoreT)(max(m0_, excl) + cg0);
+            H1 = (ScoreT)(max(m1_, excl) + cg1);
+            H2 = (ScoreT)(max(m2_, excl) + cg2);
+            H3 = (ScoreT)(max(m3_, excl) + cg3);
+        };
+
+        if (!general)
+        {
+            // ========= at most three predecessors, all in the ring: no global load, no loop, its own tail =========
+            // (one straight-line instantiation per predecessor count and per "first block of the row": a lone wavefront
+            // pays about 7 cycles per issued instruction, so the row's length in instructions is the row's time)
+            auto fast_row = [&](auto np_tag, auto first_tag) {
+                constexpr int NP     = decltype(np_tag)::value;
+                constexpr bool FIRST = decltype(first_tag)::value;
+                constexpr uint32_t esz = sizeof(ScoreT);
+                asm volatile("; FASTROW_BEGIN %0 %1" ::"n"(NP), "n"((int)FIRST));
+                const int32_t wlim = band_width - kCellsPerLane;
+                auto pred_base = [&](int32_t d, int32_t e) -> uint32_t { // LDS byte address of that row's element (tg = 0) + kRelShift
+                    int32_t o = (int32_t)ring_off_r - d * row_bytes;
+                    o         = o < 0 ? o + ring_span : o;
+                    return ring_lds + (uint32_t)o + (uint32_t)(kRelShift + e) * esz;
+                };
+                const int32_t d0 = (int32_t)((m0 >> 16) & 0xff), e0 = (int32_t)((m1 >> 8) & 0xff) << 2;
+                const int32_t tg4 = tg * (int32_t)esz;
+                // predecessor k: cells of columns c .. c+4 sit at ring element (c - pbs) + kRelShift of its row; a read outside
+                // the LDS allocation (chunks that lie outside that row's band) returns zero and is masked below
+                const uint32_t a0 = pred_base(d0, e0) + (uint32_t)tg4;
+                const int32_t Sa  = lds_ld_at<ScoreT>(a0);
+                const auto qa     = lds_ld_qv<ScoreT>(a0 + esz);
+                const bool va     = (uint32_t)(tg + e0) <= (uint32_t)wlim && c_in_read;
+                int32_t Sb = 0, Sc = 0;
+                typename QuadVec<ScoreT>::type qb = {0, 0, 0, 0}, qc = {0, 0, 0, 0};
+                bool vb = true, vc = true;
+                if constexpr (NP > 1)
+                {
+                    const int32_t d1 = (int32_t)(m0 >> 24), e1 = (int32_t)((m1 >> 16) & 0xff) << 2;
+                    const uint32_t a1 = pred_base(d1, e1) + (uint32_t)tg4;
+                    Sb = lds_ld_at<ScoreT>(a1);
+                    qb = lds_ld_qv<ScoreT>(a1 + esz);
+                    vb = (uint32_t)(tg + e1) <= (uint32_t)wlim && c_in_read;
+                }
+                if constexpr (NP > 2)
+                {
+                    const int32_t d2 = (int32_t)(m1 & 0xff), e2 = (int32_t)(m1 >> 24) << 2;
+                    const uint32_t a2 = pred_base(d2, e2) + (uint32_t)tg4;
+                    Sc = lds_ld_at<ScoreT>(a2);
+                    qc = lds_ld_qv<ScoreT>(a2 + esz);
+                    vc = (uint32_t)(tg + e2) <= (uint32_t)wlim && c_in_read;
+                }
+                // the left neighbour's progress word and its carry of this row are requested now, looked at after the arithmetic
+                int32_t probe_done = left_done, probe_c = 0;
+                if constexpr (!FIRST)
+                {
+                    if (left_done < r) probe_done = *left_word;
+                    probe_c = left_carry_words[r & 7]; // (behind the progress word: valid if that one says r or more)
+                }
+                // match / mismatch costs of the row's base against the lane's four read characters
+                const int32_t cp0 = ((rd4 & 0xff) == base) ? A.match_score : A.mismatch_score;
+                const int32_t cp1 = (((rd4 >> 8) & 0xff) == base) ? A.match_score : A.mismatch_score;
+                const int32_t cp2 = (((rd4 >> 16) & 0xff) == base) ? A.match_score : A.mismatch_score;
+                const int32_t cp3 = ((rd4 >> 24) == base) ? A.match_score : A.mismatch_score;
+                int32_t D[4], V[4], s[4];
+                D[0] = Sa + cp0; D[1] = (int32_t)qa.x + cp1; D[2] = (int32_t)qa.y + cp2; D[3] = (int32_t)qa.z + cp3;
+                V[0] = (int32_t)qa.x + gap_score; V[1] = (int32_t)qa.y + gap_score; V[2] = (int32_t)qa.z + gap_score; V[3] = (int32_t)qa.w + gap_score;
+#pragma unroll
+                for (int k = 0; k < 4; k++) s[k] = va ? (int32_t)(ScoreT)max(D[k], V[k]) : min_score;
+                uint32_t kD[4] = {0, 0, 0, 0}, kV[4] = {0, 0, 0, 0};
+                bool undecided = !va;
+                if constexpr (NP > 1)
+                {
+                    int32_t Db[4], Vb[4];
+                    Db[0] = Sb + cp0; Db[1] = (int32_t)qb.x + cp1; Db[2] = (int32_t)qb.y + cp2; Db[3] = (int32_t)qb.z + cp3;
+                    Vb[0] = (int32_t)qb.x + gap_score; Vb[1] = (int32_t)qb.y + gap_score; Vb[2] = (int32_t)qb.z + gap_score; Vb[3] = (int32_t)qb.w + gap_score;
+                    undecided = undecided || !vb;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        s[k]  = max(s[k], vb ? (int32_t)(ScoreT)max(Db[k], Vb[k]) : min_score);
+                        kD[k] = Db[k] > D[k] ? 1u : 0u; D[k] = max(D[k], Db[k]);
+                        kV[k] = Vb[k] > V[k] ? 1u : 0u; V[k] = max(V[k], Vb[k]);
+                    }
+                }
+                if constexpr (NP > 2)
+                {
+                    int32_t Dc[4], Vc[4];
+                    Dc[0] = Sc + cp0; Dc[1] = (int32_t)qc.x + cp1; Dc[2] = (int32_t)qc.y + cp2; Dc[3] = (int32_t)qc.z + cp3;
+                    Vc[0] = (int32_t)qc.x + gap_score; Vc[1] = (int32_t)qc.y + gap_score; Vc[2] = (int32_t)qc.z + gap_score; Vc[3] = (int32_t)qc.w + gap_score;
+                    undecided = undecided || !vc;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        s[k]  = max(s[k], vc ? (int32_t)(ScoreT)max(Dc[k], Vc[k]) : min_score);
+                        kD[k] = Dc[k] > D[k] ? 2u : kD[k]; D[k] = max(D[k], Dc[k]);
+                        kV[k] = Vc[k] > V[k] ? 2u : kV[k]; V[k] = max(V[k], Vc[k]);
+                    }
+                }
+                // prefix maximum in u space (u = v - (c + k) * gap: an offset common to the whole row, so a carry is converted
+                // with the column it belongs to)
+                int32_t u0 = s[0] - cg0, u1 = s[1] - cg1, u2 = s[2] - cg2, u3 = s[3] - cg3;
+                if constexpr (FIRST) // lanes left of the band start carry no cells (lanes right of its end feed nobody)
+                {
+                    const bool dead = tg < 0;
+                    u0 = dead ? INT32_MIN : u0; u1 = dead ? INT32_MIN : u1; u2 = dead ? INT32_MIN : u2; u3 = dead ? INT32_MIN : u3;
+                }
+                const int32_t m0_ = u0, m1_ = max(m0_, u1), m2_ = max(m1_, u2), m3_ = max(m2_, u3);
+                const int32_t incl = wave_inclusive_max(m3_);
+                int32_t carry_u, rel0 = min_score;
+                if constexpr (FIRST)
+                {
+                    // left boundary (cudapoa_nw_banded.cuh:293-326); the relative-0 slot of a row whose band starts past column
+                    // 0 holds min_score, so only the rows at the top of the matrix read their predecessors' slots
+                    int32_t fe = 0;
+                    if (pred_count == 0)
+                    {
+                        if (bs == 0) rel0 = (ScoreT)gap_score; // carry-in stays 0: reference quirk
+                    }
+                    else
+                    {
+                        if (bs > kCellsPerLane && NP == 1)
+                            fe = min_score + gap_score;
+                        else
+                        {
+                            auto rel0_of = [&](int32_t d, int32_t e) -> int32_t {
+                                if (bs - e > 0) return min_score;
+                                return wave_first((int32_t)lds_ld_at<ScoreT>(pred_base(d, -kRelShift) + kRelShift * esz));
+                            };
+                            int32_t penalty = max(min_score, rel0_of(d0, e0));
+                            if constexpr (NP > 1) penalty = max(penalty, rel0_of((int32_t)(m0 >> 24), (int32_t)((m1 >> 16) & 0xff) << 2));
+                            if constexpr (NP > 2) penalty = max(penalty, rel0_of((int32_t)(m1 & 0xff), (int32_t)(m1 >> 24) << 2));
+                            fe = penalty + gap_score;
+                        }
+                        if (bs == 0) rel0 = (ScoreT)fe;
+                    }
+                    carry_u = fe - (bs - 1) * gap_score; // the carry-in is the element of column bs - 1
+                }
+                else
+                {
+                    if (left_done < r) left_done = wave_first(probe_done);
+                    int32_t hl;
+                    if (left_done >= r)
+                        hl = wave_first(probe_c);
+                    else // the probe came too early
+                    {
+                        wait_left(r);
+                        hl = wave_first(left_carry_words[r & 7]);
+                    }
+                    carry_u = hl - blk_carry_gap; // the left neighbour's cell of column 256 blk
+                }
+                const int32_t excl = max(wave_shr1(incl, INT32_MIN), carry_u);
+                const int32_t Hk[4] = {(int32_t)(ScoreT)(max(m0_, excl) + cg0), (int32_t)(ScoreT)(max(m1_, excl) + cg1),
+                                       (int32_t)(ScoreT)(max(m2_, excl) + cg2), (int32_t)(ScoreT)(max(m3_, excl) + cg3)};
+                // move codes: diagonal through the first slot attaining H, else vertical, else horizontal
+                uint32_t code4 = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const uint32_t ck = Hk[k] == D[k] ? (uint32_t)kCodeDiag + kD[k] : (Hk[k] == V[k] ? (uint32_t)kCodeVert + kV[k] : (uint32_t)kCodeHoriz);
+                    code4 |= ck << (8 * k);
+                }
+                if constexpr (FIRST) code4 = tg == 0 ? (code4 & 0xffffff00u) : code4; // the band's first cell
+                code4 = undecided ? 0u : code4;
+                // flow control: slot r mod R still holds row r - R, which the right neighbour may need until it has finished
+                // row r - kSkLead - 1
+                if (right_done < r - kSkLead - 1) wait_right(r - kSkLead - 1);
+                if ((uint32_t)tg < (uint32_t)band_width)
+                {
+                    typedef typename QuadVec<ScoreT>::type V4;
+                    const V4 out = {(ScoreT)Hk[0], (ScoreT)Hk[1], (ScoreT)Hk[2], (ScoreT)Hk[3]};
+                    // explicit LDS store: the progress word below is ordered behind it by the LDS queue, not by a wait
+                    *reinterpret_cast<__attribute__((address_space(3))) V4*>(ring_lds + ring_off_r + (uint32_t)(kRelShift + 1) * esz + (uint32_t)tg4) = out;
+                    *reinterpret_cast<__attribute__((address_space(1))) V4*>(scores_row + kRelShift + 1 + tg) = out;
+                    if (codes) *reinterpret_cast<__attribute__((address_space(1))) uint32_t*>(codes_row + kRelShift + 1 + tg) = code4;
+                }
+                if constexpr (FIRST)
+                {
+                    if (lane == 0)
+                    {
+                        *reinterpret_cast<__attribute__((address_space(3))) ScoreT*>(ring_lds + ring_off_r + (uint32_t)kRelShift * esz) = (ScoreT)rel0;
+                        scores_row[kRelShift] = (ScoreT)rel0;
+                    }
+                }
+                publish(r, __builtin_amdgcn_readlane(Hk[3], kWave - 1));
+                asm volatile("; FASTROW_END %0 %1" ::"n"(NP), "n"((int)FIRST));
+            };
+            if (first_block)
+            {
+                if (pred_count <= 1) fast_row(std::integral_constant<int, 1>{}, std::true_type{});
+                else if (pred_count == 2) fast_row(std::integral_constant<int, 2>{}, std::true_type{});
+                else fast_row(std::integral_constant<int, 3>{}, std::true_type{});
+            }
+            else
+            {
+                if (pred_count <= 1) fast_row(std::integral_constant<int, 1>{}, std::false_type{});
+                else if (pred_count == 2) fast_row(std::integral_constant<int, 2>{}, std::false_type{});
+                else fast_row(std::integral_constant<int, 3>{}, std::false_type{});
+            }
+            if (sksel == 8 || (sksel == 11 && first_block)) skacc += clock64() - t_rb;
+            continue;
+        }
+        else
+        {
+            // ================= general row: any number of predecessors, far ones from the HBM matrix =================
+            if (sksel == 7) skacc++;
+            const bool many       = pred_count > 3;
+            const int32_t node_id = many ? wave_first((int32_t)g.sorted_poa[r - 1]) : 0;
+            auto pred_row = [&](int32_t p) -> int32_t {
+                if (pred_count == 0) return 0;
+                if (p < 3) return p == 0 ? p0 : (p == 1 ? p1 : p2);
+                return wave_first((int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1);
+            };
+            auto bs_of = [&](int32_t row) -> int32_t {
+                return row == 0 ? 0 : band_start_for_row(row, A.gradient, band_width, A.band_shift, max_column);
+            };
             const int32_t np = max(pred_count, 1);
+            int32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            int32_t bD0 = 0, bD1 = 0, bD2 = 0, bD3 = 0, bV0 = 0, bV1 = 0, bV2 = 0, bV3 = 0;
+            int32_t kD0 = 0, kD1 = 0, kD2 = 0, kD3 = 0, kV0 = 0, kV1 = 0, kV2 = 0, kV3 = 0;
+            bool undecided = false;
             for (int32_t p = 0; p < np; p++)
             {
                 const int32_t prow = pred_row(p);
                 const int32_t pbs  = bs_of(prow);
                 const int32_t pend = min(pbs + band_width - kCellsPerLane, max_column);
-                const bool valid   = !(c > pend || c < pbs);
+                const bool valid   = !(cvec > pend || cvec < pbs);
                 int32_t S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0; // predecessor row, columns c .. c+4
-                if (in_ring(prow)) // wave-uniform
+                if (r - prow < near_rows) // wave-uniform
                 {
                     if (valid)
                     {
-                        const ScoreT* rowp = ring + slot_of(prow) * stride + (c - pbs) + kRelShift;
+                        const ScoreT* rowp = ring + slot_back(r - prow) * stride + (cvec - pbs) + kRelShift;
                         S0 = lds_ld(rowp);
                         const Quad<ScoreT> qd = lds_ld_quad(rowp + 1);
                         S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
                     }
                 }
-                else if (valid) // far predecessor: the HBM matrix (complete: every earlier row ended with a block barrier)
+                else if (valid) // the HBM matrix (complete: block barrier above)
                 {
-                    const ScoreT* rowp = scores + (int64_t)prow * stride + (c - pbs) + kRelShift;
-                    S0 = rowp[0];
-                    const Quad<ScoreT> qd = *reinterpret_cast<const Quad<ScoreT>*>(rowp + 1);
-                    S1 = qd.v[0]; S2 = qd.v[1]; S3 = qd.v[2]; S4 = qd.v[3];
+                    const GScore* rowp = scores + (int64_t)prow * stride + (cvec - pbs) + kRelShift;
+                    S0 = rowp[0]; S1 = rowp[1]; S2 = rowp[2]; S3 = rowp[3]; S4 = rowp[4];
                 }
-                int32_t t0, t1, t2, t3;
+                int32_t D0, D1, D2, D3, V0, V1, V2, V3, t0, t1, t2, t3;
                 if (valid)
                 {
-                    t0 = (ScoreT)max(S0 + cp0, S1 + gap_score);
-                    t1 = (ScoreT)max(S1 + cp1, S2 + gap_score);
-                    t2 = (ScoreT)max(S2 + cp2, S3 + gap_score);
-                    t3 = (ScoreT)max(S3 + cp3, S4 + gap_score);
+                    D0 = S0 + cp0; D1 = S1 + cp1; D2 = S2 + cp2; D3 = S3 + cp3;
+                    V0 = S1 + gap_score; V1 = S2 + gap_score; V2 = S3 + gap_score; V3 = S4 + gap_score;
+                    t0 = (ScoreT)max(D0, V0); t1 = (ScoreT)max(D1, V1); t2 = (ScoreT)max(D2, V2); t3 = (ScoreT)max(D3, V3);
                 }
-                else { t0 = t1 = t2 = t3 = min_score; }
-                if (p == 0) { s0 = t0; s1 = t1; s2 = t2; s3 = t3; }
-                else { s0 = max(s0, t0); s1 = max(s1, t1); s2 = max(s2, t2); s3 = max(s3, t3); }
-            }
-            int32_t u0 = s0 - (tg + 0) * gap_score, u1 = s1 - (tg + 1) * gap_score;
-            int32_t u2 = s2 - (tg + 2) * gap_score, u3 = s3 - (tg + 3) * gap_score;
-            if (!active) u0 = u1 = u2 = u3 = INT32_MIN;
-            m0 = u0; m1 = max(m0, u1); m2 = max(m1, u2); m3 = max(m2, u3);
-            incl = wave_inclusive_max(m3);
-        }
-        // ---- left boundary / carry-in (cudapoa_nw_banded.cuh:293-326): wave 0 owns it ----
-        if (wave == 0)
-        {
-            if (pred_count == 0)
-            {
-                if (bs == 0) rel0_val = (ScoreT)gap_score; // carry-in stays 0: reference quirk
-            }
-            else
-            {
-                if (bs > kCellsPerLane && pred_count == 1)
-                    fe = min_score + gap_score;
                 else
                 {
-                    int32_t penalty = min_score;
-                    for (int32_t p = 0; p < pred_count; p++) penalty = max(penalty, rel0_of(pred_row(p)));
-                    fe = penalty + gap_score;
+                    D0 = D1 = D2 = D3 = V0 = V1 = V2 = V3 = t0 = t1 = t2 = t3 = min_score;
+                    undecided = true;
                 }
-                if (bs == 0) rel0_val = (ScoreT)fe;
+                if (p == 0)
+                {
+                    s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+                    bD0 = D0; bD1 = D1; bD2 = D2; bD3 = D3; bV0 = V0; bV1 = V1; bV2 = V2; bV3 = V3;
+                }
+                else
+                {
+                    s0 = max(s0, t0); s1 = max(s1, t1); s2 = max(s2, t2); s3 = max(s3, t3);
+                    if (D0 > bD0) { bD0 = D0; kD0 = p; }
+                    if (D1 > bD1) { bD1 = D1; kD1 = p; }
+                    if (D2 > bD2) { bD2 = D2; kD2 = p; }
+                    if (D3 > bD3) { bD3 = D3; kD3 = p; }
+                    if (V0 > bV0) { bV0 = V0; kV0 = p; }
+                    if (V1 > bV1) { bV1 = V1; kV1 = p; }
+                    if (V2 > bV2) { bV2 = V2; kV2 = p; }
+                    if (V3 > bV3) { bV3 = V3; kV3 = p; }
+                }
             }
+            int32_t fe = 0;
+            if (first_block) // cudapoa_nw_banded.cuh:293-326
+            {
+                auto rel0_of = [&](int32_t row) -> int32_t {
+                    if (r - row < near_rows) return wave_first((int32_t)lds_ld(ring + slot_back(r - row) * stride + kRelShift));
+                    return wave_first((int32_t)scores[(int64_t)row * stride + kRelShift]);
+                };
+                if (pred_count == 0)
+                {
+                    if (bs == 0) rel0_val = (ScoreT)gap_score; // carry-in stays 0: reference quirk
+                }
+                else
+                {
+                    if (bs > kCellsPerLane && pred_count == 1)
+                        fe = min_score + gap_score;
+                    else
+                    {
+                        int32_t penalty = min_score;
+                        for (int32_t p = 0; p < pred_count; p++) penalty = max(penalty, rel0_of(pred_row(p)));
+                        fe = penalty + gap_score;
+                    }
+                    if (bs == 0) rel0_val = (ScoreT)fe;
+                }
+            }
+            // This path's global loads end here, explicitly: the compiler merges the two paths' common tail, and a join
+            // with loads possibly in flight on one side gets a vmcnt(0) wait that the load-free path would pay as well --
+            // behind its own score stores, one HBM acknowledgement per row.
+            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+            finish_row(s0, s1, s2, s3, fe);
+            auto code_of = [&](int32_t H, int32_t bD, int32_t kD, int32_t bV, int32_t kV) -> uint32_t {
+                const uint32_t cd = kD < 3 ? (uint32_t)(kCodeDiag + kD) : 0u;
+                const uint32_t cv = kV < 3 ? (uint32_t)(kCodeVert + kV) : 0u;
+                return H == bD ? cd : (H == bV ? cv : (uint32_t)kCodeHoriz);
+            };
+            code4 = code_of(H0, bD0, kD0, bV0, kV0) | (code_of(H1, bD1, kD1, bV1, kV1) << 8) |
+                    (code_of(H2, bD2, kD2, bV2, kV2) << 16) | (code_of(H3, bD3, kD3, bV3, kV3) << 24);
+            if (tg == 0) code4 &= 0xffffff00u; // the band's first cell
+            if (undecided) code4 = 0u;
         }
 
-        if (has_pass)
+        // flow control: slot r mod R still holds row r - R, which the right neighbour may need until it has finished row
+        // r - kSkLead - 1
+        wait_right(r - kSkLead - 1);
+        if ((uint32_t)tg < (uint32_t)band_width)
         {
-            int32_t total = wave_bcast(incl, kWave - 1);
-            if (wave == 0) total = max(total, fe + gap_score); // the carry-in is element t = -1 of the band: fe - (-1) * gap
-            if (lane == 0) shared->totals[pass] = total;
+            const int32_t rel = tg + 1;
+            // explicit LDS stores: the progress word below is ordered behind them by the LDS queue, not by a wait
+            lds_st_quad<ScoreT>(ring + slot_r * stride + rel + kRelShift, (ScoreT)H0, (ScoreT)H1, (ScoreT)H2, (ScoreT)H3);
+            global_st_quad<ScoreT>(scores + (int64_t)r * stride + rel + kRelShift, (ScoreT)H0, (ScoreT)H1, (ScoreT)H2, (ScoreT)H3);
+            if (codes) *reinterpret_cast<__attribute__((address_space(1))) uint32_t*>(codes + (int64_t)r * stride + rel + kRelShift) = code4;
         }
-        lds_barrier(); // ---- A: every pass has published its total ----
-        if (has_pass)
+        if (first_block && lane == 0)
         {
-            int32_t before = wave == 0 ? fe + gap_score : INT32_MIN;
-            for (int32_t k = 0; k < pass; k++) before = max(before, lds_ld(&shared->totals[k]));
-            const int32_t excl = max(wave_shr1(incl, INT32_MIN), before);
-            if (active)
-            {
-                Quad<ScoreT> out;
-                out.v[0] = (ScoreT)(max(m0, excl) + (tg + 0) * gap_score);
-                out.v[1] = (ScoreT)(max(m1, excl) + (tg + 1) * gap_score);
-                out.v[2] = (ScoreT)(max(m2, excl) + (tg + 2) * gap_score);
-                out.v[3] = (ScoreT)(max(m3, excl) + (tg + 3) * gap_score);
-                const int32_t rel = tg + 1;
-                *reinterpret_cast<Quad<ScoreT>*>(scores + (int64_t)r * stride + rel + kRelShift) = out;
-                *reinterpret_cast<Quad<ScoreT>*>(ring + slot_r * stride + rel + kRelShift)         = out;
-            }
+            *(__attribute__((address_space(3))) ScoreT*)(ring + slot_r * stride + kRelShift) = (ScoreT)rel0_val;
+            scores[(int64_t)r * stride + kRelShift]                                          = (ScoreT)rel0_val;
         }
-        if (wave == 0 && lane == 0)
-        {
-            scores[(int64_t)r * stride + kRelShift] = (ScoreT)rel0_val;
-            ring[slot_r * stride + kRelShift]       = (ScoreT)rel0_val;
-            bs_ring[slot_r]                         = bs;
-        }
-        lds_barrier(); // ---- B: the row is in the ring ----
-        slot_r = slot_r + 1 == ring_rows ? 0 : slot_r + 1;
+        publish(r, __builtin_amdgcn_readlane(H3, kWave - 1));
+        if (sksel == 8 || (sksel == 11 && first_block)) skacc += clock64() - t_rb;
     }
-    block_barrier(); // the score matrix is complete in HBM (wave 0's traceback reads it)
+    if (sksel == 4) skacc += clock64() - t_pass;
+    if (sksel && lane == 0) __hip_atomic_fetch_add(&shared->prof, (unsigned long long)skacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    block_barrier(); // the score and code matrices are complete in HBM (wave 0's traceback reads them)
+    if (sksel && prof_out && lane == 0) *prof_out += shared->prof;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Traceback by table lookup for graphs whose row table lives in HBM (long reads), on the trace codes the pipelined
+// forward pass (generic_forward_skew) left in HBM. Same decision sequence as traceback_banded (cudapoa_nw_banded.cuh:
+// 428-549): a code names the move the reference's search order (diagonal through predecessor 0..n-1, vertical through
+// predecessor 0..n-1, horizontal; first equality wins) takes from that cell. The walk is wave-uniform; all lanes stage
+// 64 rows x 64 columns of codes around the path together with the row-table records of those rows (one HBM round
+// trip), so a step is two LDS reads. Undecided cells (code 0: band edges, predecessor slots beyond 2) and row 0 are
+// stepped by recomputation from the HBM score matrix, exactly as traceback_banded does. The walk's output is staged in
+// LDS and flushed 64 steps at a time; graph positions are translated to node ids by all lanes after the walk.
+// LDS (the forward pass's ring, dead by now): codes[64][64] | rows[64] | stage[64].
+// ------------------------------------------------------------------------------------------------
+template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE>
+__device__ __forceinline__ int32_t traceback_codes_staged(const BandedCtx<ScoreT>& b, const GraphView<IdT>& g, const RowT* rowinfo,
+                                                          int32_t graph_count, const uint8_t* read, int32_t read_length,
+                                                          int32_t start_i, int32_t* alignment_graph, int32_t* alignment_read,
+                                                          int32_t gap_score, int32_t mismatch_score, int32_t match_score,
+                                                          int32_t rerun, uint8_t* lds, const uint8_t* codes, int32_t dbg = 0,
+                                                          uint64_t* prof_acc = nullptr)
+{
+    constexpr int kRows = 64, kCols = 64, kReanchor = 60, kLead = 40, kStage = 64;
+    // LDS: codes[64][64] | per tile row: predecessor rows of slots 0..2 and the band start (4 x 64 words) | stage[64]
+    typedef __attribute__((address_space(3))) uint8_t LByte;
+    typedef __attribute__((address_space(3))) int32_t LWord;
+    LByte* ctile  = (LByte*)lds;
+    LWord* rowmeta = (LWord*)(lds + kRows * kCols); // [k * 64 + t]: k = 0..2 predecessor row of slot k, k = 3 band start
+    const uint32_t stage_lds = lds_addr(lds + kRows * kCols + 4 * kRows * 4);
+    __attribute__((address_space(3))) const unsigned long long* stage = (__attribute__((address_space(3))) const unsigned long long*)(lds + kRows * kCols + 4 * kRows * 4);
+    const int lane      = threadIdx.x & (kWave - 1);
+    const int32_t bound = read_length + graph_count + 2;
+    int32_t aligned_nodes = 0;
+    int32_t i = start_i, j = read_length, prev_i = 0, prev_j = 0;
+    int32_t ctop = -(1 << 20), ccol = 0;
+
+    auto lo_of = [&](int32_t col, int32_t t) -> int32_t { return ((col - kLead - t) & ~3) + 1; };
+    struct __attribute__((packed, aligned(4))) CodeSeg { uint32_t d[4]; };
+    // 4 lanes per tile row (16 bytes each), 16 rows per pass; bytes that are not cells of the band become code 0
+    auto load_codes = [&](int32_t top, int32_t col) {
+        wave_sync();
+        ctop = top;
+        ccol = col;
+        const int seg = lane & 3;
+        CodeSeg v[4];
+        int32_t e0s[4];
+#pragma unroll
+        for (int pass = 0; pass < 4; pass++)
+        {
+            const int32_t t    = pass * 16 + (lane >> 2);
+            const int32_t rowc = max(top - t, 1);
+            const int32_t bs   = band_start_for_row(rowc, b.gradient, b.band_width, b.band_shift, b.max_column);
+            const int32_t e0   = lo_of(col, t) - bs + kRelShift; // byte index in the code row, multiple of 4
+            e0s[pass]          = e0;
+            const int32_t ec   = min(max(e0 + seg * 16, 0), b.stride - 16); // keep the load inside the row
+            v[pass] = *reinterpret_cast<const CodeSeg*>(codes + (int64_t)rowc * b.stride + ec);
+        }
+        {
+            const int32_t rrow = max(top - lane, 1);
+            const RowT ri      = rowinfo[rrow];
+            const bool none    = ri.cnt() == 0 || top - lane < 1;
+            rowmeta[0 * kRows + lane] = none ? 0 : ri.pred(0);
+            rowmeta[1 * kRows + lane] = ri.pred(1);
+            rowmeta[2 * kRows + lane] = ri.pred(2);
+            rowmeta[3 * kRows + lane] = band_start_for_row(rrow, b.gradient, b.band_width, b.band_shift, b.max_column);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; pass++)
+        {
+            const int32_t t   = pass * 16 + (lane >> 2);
+            const int32_t row = top - t;
+            const int32_t e0  = e0s[pass];
+            const int32_t ec  = min(max(e0 + seg * 16, 0), b.stride - 16);
+            const int32_t klo = row >= 1 ? (1 + kRelShift) - e0 : 1; // window bytes that are cells of the band
+            const int32_t khi = row >= 1 ? (b.band_width + kRelShift) - e0 : 0;
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+            {
+                const int32_t k0 = seg * 16 + d * 4;
+                const int32_t lo = min(max(klo - k0, 0), 4), hi = min(max(khi - k0 + 1, 0), 4);
+                const uint32_t mhi = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
+                const uint32_t mlo = lo >= 4 ? 0xffffffffu : ((1u << (8 * lo)) - 1u);
+                // a clamped load (window reaching past the row's storage) holds other bytes: those are outside the band too
+                v[pass].d[d] = (ec == e0 + seg * 16 && hi > lo) ? (v[pass].d[d] & mhi & ~mlo) : 0u;
+            }
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 w = {v[pass].d[0], v[pass].d[1], v[pass].d[2], v[pass].d[3]};
+            *(__attribute__((address_space(3))) u32x4*)(ctile + t * kCols + seg * 16) = w;
+        }
+        wave_sync();
+    };
+    // stage[k] = the cell step k left; the reference's entry for a step follows from two consecutive cells
+    auto flush_stage = [&](int32_t first, int32_t count) {
+        if (lane < count)
+        {
+            const uint64_t cur = stage[lane];
+            const uint64_t nxt = lane + 1 < count ? (uint64_t)stage[lane + 1] : ((uint64_t)(uint32_t)i | ((uint64_t)(uint32_t)j << 32));
+            const int32_t ci = (int32_t)(uint32_t)cur, cj = (int32_t)(cur >> 32);
+            const int32_t ni = (int32_t)(uint32_t)nxt, nj = (int32_t)(nxt >> 32);
+            alignment_graph[first + lane] = ci == ni ? -1 : ci - 1; // sorted position; node ids are filled in below
+            alignment_read[first + lane]  = cj == nj ? -1 : cj - 1;
+        }
+    };
+    auto stage_cell = [&](int32_t slot, int32_t ci, int32_t cj) { // lane-0 LDS store without a branch
+        const uint64_t v  = (uint64_t)(uint32_t)ci | ((uint64_t)(uint32_t)cj << 32);
+        const uint32_t ad = stage_lds + 8u * (uint32_t)slot;
+        asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(ad), "v"(v) : "memory");
+    };
+    const bool shift_check = ADAPTIVE && rerun == 0 && b.band_width < kMaxAdaptiveBand;
+    const int32_t threshold = max(1, b.max_column / 1024);
+
+    // profiling (GWHIP_DEBUG bits 22-24): 6 steps, 2 cycles in tile loads, 3 tile loads x 1000, 4 cycles in recomputed
+    // steps, 5 recomputed steps x 1000
+    const int32_t psel = prof_acc ? (dbg >> 22) & 7 : 0;
+    uint64_t pacc      = 0;
+    bool rerun_break = false;
+    while (!(i == 0 && j == 0) && aligned_nodes < bound) // every step appends one entry: the reference's loop counter
+    {
+        uint32_t code = 0;
+        int32_t pr0 = 0, pr1 = 0, pr2 = 0, bs_i = 0;
+        if (i > 0)
+        {
+            const int32_t t   = ctop - i;
+            const int32_t off = j - lo_of(ccol, t);
+            if (((uint32_t)t >= (uint32_t)kReanchor) | ((uint32_t)(off - 2) >= (uint32_t)(kCols - 2)))
+            {
+                const uint64_t t_l = psel == 2 ? clock64() : 0;
+                load_codes(i, j);
+                if (psel == 2) pacc += clock64() - t_l;
+                if (psel == 3) pacc += 1000;
+                continue;
+            }
+            // one LDS round trip: the cell's code, the row's predecessor rows and its band start
+            const uint32_t cv = ctile[t * kCols + off];
+            const int32_t a0 = rowmeta[t], a1 = rowmeta[kRows + t], a2 = rowmeta[2 * kRows + t], a3 = rowmeta[3 * kRows + t];
+            code = (uint32_t)wave_first((int32_t)cv);
+            pr0 = wave_first(a0); pr1 = wave_first(a1); pr2 = wave_first(a2); bs_i = wave_first(a3);
+        }
+        if (shift_check && i != 0 && j != 0 && j > threshold && j < b.max_column - threshold)
+        {
+            if (j <= bs_i + threshold) { aligned_nodes = kShiftLeft; rerun_break = true; }
+            else if (j >= (bs_i + b.band_width - threshold)) { aligned_nodes = kShiftRight; rerun_break = true; }
+        }
+        if (rerun_break) break;
+        if (code != 0)
+        {
+            const int32_t k  = code >= (uint32_t)kCodeVert ? (int32_t)code - kCodeVert : (int32_t)code - kCodeDiag;
+            const int32_t pr = k == 0 ? pr0 : (k == 1 ? pr1 : pr2);
+            prev_i = code == (uint32_t)kCodeHoriz ? i : pr;
+            prev_j = code >= (uint32_t)kCodeVert ? j : j - 1;
+        }
+        else
+        {
+            // one step of traceback_banded, from the HBM matrix and the HBM row table
+            const uint64_t t_rc = psel == 4 ? clock64() : 0;
+            if (psel == 5) pacc += 1000;
+            const int32_t scores_ij = wave_first(get_score(b, i, j));
+            bool pred_found         = false;
+            RowT ri{};
+            int32_t pred_count = 0, node_id = 0;
+            if (i != 0)
+            {
+                ri         = uniform_row(rowinfo[i]);
+                pred_count = ri.cnt();
+            }
+            auto pred_row = [&](int32_t p) -> int32_t {
+                if (pred_count == 0) return 0;
+                if (p < 3) return ri.pred(p);
+                return wave_first((int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1);
+            };
+            if (i != 0 && pred_count > 3) node_id = wave_first((int32_t)g.sorted_poa[i - 1]);
+            const int32_t np = max(pred_count, 1);
+            if (i != 0 && j != 0)
+            {
+                const int32_t match_cost = ((uint32_t)ri.base() == (uint32_t)wave_first((int32_t)read[j - 1]) ? match_score : mismatch_score);
+                for (int32_t p = 0; p < np && !pred_found; p++)
+                {
+                    const int32_t pi = pred_row(p);
+                    if (scores_ij == wave_first(get_score(b, pi, j - 1)) + match_cost) { prev_i = pi; prev_j = j - 1; pred_found = true; }
+                }
+            }
+            if (!pred_found && i != 0)
+                for (int32_t p = 0; p < np && !pred_found; p++)
+                {
+                    const int32_t pi = pred_row(p);
+                    if (scores_ij == wave_first(get_score(b, pi, j)) + gap_score) { prev_i = pi; prev_j = j; pred_found = true; }
+                }
+            if (!pred_found && scores_ij == wave_first(get_score(b, i, j - 1)) + gap_score) { prev_i = i; prev_j = j - 1; pred_found = true; }
+            if (psel == 4) pacc += clock64() - t_rc;
+        }
+        stage_cell(aligned_nodes & (kStage - 1), i, j);
+        aligned_nodes++;
+        i = prev_i;
+        j = prev_j;
+        if ((aligned_nodes & (kStage - 1)) == 0)
+        {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the staged cells (this wave's own LDS stores)
+            flush_stage(aligned_nodes - kStage, kStage);
+        }
+    }
+    if (psel == 6) pacc += (uint64_t)max(aligned_nodes, 0);
+    if (psel && lane == 0) *prof_acc += pacc;
+    if (rerun_break) return aligned_nodes;
+    wave_sync();
+    if (aligned_nodes > 0 && (aligned_nodes & (kStage - 1)) != 0)
+        flush_stage(aligned_nodes & ~(kStage - 1), aligned_nodes & (kStage - 1));
+    if (aligned_nodes >= bound) aligned_nodes = kNwLoopFailed;
+    wave_sync();
+    for (int32_t k0 = lane; k0 < aligned_nodes; k0 += 4 * kWave) // positions -> node ids, four load chains per lane
+    {
+        int32_t pos[4], node[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) pos[u] = (k0 + u * kWave < aligned_nodes) ? alignment_graph[k0 + u * kWave] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; u++) node[u] = (int32_t)g.sorted_poa[max(pos[u], 0)];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (pos[u] >= 0) alignment_graph[k0 + u * kWave] = node[u];
+    }
+    wave_sync();
+    return aligned_nodes;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1821,21 +2504,28 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             fast_done = true;
         }
     }
-    // wide bands in a multi-wave block: one wavefront per 256-column pass (generic_forward_mw)
+    // wide bands in a multi-wave block: a pipeline of wavefronts over absolute 256-column blocks (generic_forward_skew)
     if constexpr (!std::is_same<RowT, RowInfo<true>>::value)
     {
-        if (!fast_done && mw_args != nullptr && npass >= 2 && b.ring_rows >= 2 && bs_ring != nullptr && read_window != nullptr)
+        // rows the ring may hold there: the band start must move less than one block between a row and the row that
+        // reuses its slot (see the function's header)
+        const int32_t sk_rows = min(b.ring_rows, (int32_t)(200.0f / (gradient + 1.0f)));
+        if (!fast_done && mw_args != nullptr && npass >= 2 && sk_rows >= kSkLead + 3 && !(dbg & (1 << 18)))
         {
             MwArgs<ScoreT> A;
             A.op = 1;
             A.graph_count = graph_count; A.read_length = read_length; A.band_width = band_width; A.band_shift = band_shift;
             A.max_column = max_column; A.gradient = gradient;
             A.gap_score = gap_score; A.mismatch_score = mismatch_score; A.match_score = match_score;
-            A.ring_rows = b.ring_rows; A.read = read; A.scores = scores;
+            A.ring_rows = sk_rows; A.read = read; A.scores = scores; A.codes = codes; A.dbg = dbg;
             if (lane == 0) *mw_args = A;
+            if (lane < kSkWaves) mw_shared->done[lane] = 0;
+            if (lane < kSkWaves * 8) (&mw_shared->carry[0][0])[lane] = 0;
+            if (lane == 0) mw_shared->prof = 0;
             block_barrier(); // the helper wavefronts wait here for their arguments
-            generic_forward_mw<ScoreT, IdT, RowT>(A, g, rowinfo, b.ring, bs_ring, read_window, mw_shared, 0, lane);
-            fast_done = true;
+            generic_forward_skew<ScoreT, IdT, RowT>(A, g, rowinfo, b.ring, mw_shared, 0, lane, pc.acc ? &pc.acc[kPhOther] : nullptr);
+            fast_done   = true;
+            codes_valid = codes != nullptr;
         }
     }
     // Row table through LDS when it lives in HBM: 64 rows at a time, so the row loop itself issues no global load
@@ -2055,6 +2745,29 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     // ---- sink selection (:410-426): first row with the strictly greatest H(row, L) among sink rows ----
     const uint64_t t_sink = (pc.acc && ((dbg >> 22) & 7) == 1) ? clock64() : 0;
     int32_t best = min_score, best_i = 0;
+    if constexpr (std::is_same<RowT, RowInfo<false>>::value)
+    {
+        // row table in HBM: eight rows per lane in flight (one row per round trip was 470 dependent round trips for a 30 k
+        // row graph, per read); per lane the rows are visited in ascending order, as below
+        constexpr int kU = 8;
+        for (int32_t base = 1 + lane; base <= graph_count; base += kU * kWave)
+        {
+            bool sk[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++) sk[u] = rowinfo[min(base + u * kWave, graph_count)].sink();
+#pragma unroll
+            for (int u = 0; u < kU; u++)
+            {
+                const int32_t idx = base + u * kWave;
+                if (idx <= graph_count && sk[u])
+                {
+                    int32_t s = get_score(b, idx, read_length);
+                    if (best < s) { best = s; best_i = idx; }
+                }
+            }
+        }
+    }
+    else
     for (int32_t idx = 1 + lane; idx <= graph_count; idx += kWave)
     {
         if (rowinfo[idx].sink())
@@ -2089,6 +2802,19 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     }
     constexpr bool kStagedOk = std::is_same<RowT, RowInfo<false>>::value && !LDS_READ;
     const bool staged_fits   = (int32_t)(64 * 64 * sizeof(ScoreT) + 64 * 4 + 64 * sizeof(RowT) + 256 + 64 * 8) <= ring_bytes;
+    if constexpr (kStagedOk)
+    {
+        if (codes_valid && codes != nullptr && staged_fits && b.stride >= 80 && !(dbg & 64))
+        {
+            // wide bands, graphs beyond the LDS tables: the pipelined forward pass left trace codes
+            aligned_nodes = traceback_codes_staged<ScoreT, IdT, RowT, ADAPTIVE>(b, g, rowinfo, graph_count, read, read_length,
+                                                                               wave_first(best_i), alignment_graph, alignment_read,
+                                                                               gap_score, mismatch_score, match_score, rerun,
+                                                                               reinterpret_cast<uint8_t*>(ring_base), codes, dbg,
+                                                                               pc.acc ? &pc.acc[kPhOther] : nullptr);
+            tb_done = true;
+        }
+    }
     if (tb_done) {}
     else if (kStagedOk && staged_fits && b.stride >= 64 && !(dbg & 128))
     {

@@ -48,7 +48,7 @@ struct PoaLayout
     size_t marks, check, to_visit;  // racon topsort scratch
     size_t out_cov, out_cov_cnt, msa_pos, seq_begin; // MSA only
     size_t trace;                   // TraceT matrix (traceback modes)
-    size_t codes;                   // one move code per score cell (score-matrix banded modes with int16 scores), else 0
+    size_t codes;                   // one move code per score cell (banded score-matrix modes: int16 scores, or long reads), else 0
     size_t scores;                  // score matrix, or score ring in traceback modes
     size_t scores_elems, trace_elems;
     size_t per_window;              // slab size (banded modes; full band adds the variable score region)
@@ -110,7 +110,8 @@ inline PoaLayout make_poa_layout(const gwhip_poa_config& c)
     }
     else if (c.band_mode != GWHIP_FULL_BAND)
     {
-        if (!c.score32) L.codes = take(mn * msd + 64); // poa_forward_packed.h
+        // int16 scores: poa_forward_packed.h; 32-bit ids in the adaptive band mode (long reads): generic_forward_skew
+        if (!c.score32 || (c.size32 && c.band_mode == GWHIP_ADAPTIVE_BAND)) L.codes = take(mn * msd + 64);
         L.scores_elems = mn * msd;
         L.scores       = take(L.scores_elems * L.score_bytes + 64);
     }
