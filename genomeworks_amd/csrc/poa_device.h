@@ -1978,7 +1978,9 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                     const V4 out = {(ScoreT)Hk[0], (ScoreT)Hk[1], (ScoreT)Hk[2], (ScoreT)Hk[3]};
                     // explicit LDS store: the progress word below is ordered behind it by the LDS queue, not by a wait
                     *reinterpret_cast<__attribute__((address_space(3))) V4*>(ring_lds + ring_off_r + (uint32_t)(kRelShift + 1) * esz + (uint32_t)tg4) = out;
-                    *reinterpret_cast<__attribute__((address_space(1))) V4*>(scores_row + kRelShift + 1 + tg) = out;
+                    // (streaming store: the matrix is read again only by far predecessors, the sink scan and recomputed steps,
+                    // and 1 TB of it per long-read set should not push the graphs and the trace codes out of the L2)
+                    __builtin_nontemporal_store(out, reinterpret_cast<__attribute__((address_space(1))) V4*>(scores_row + kRelShift + 1 + tg));
                     if (codes) *reinterpret_cast<__attribute__((address_space(1))) uint32_t*>(codes_row + kRelShift + 1 + tg) = code4;
                 }
                 if constexpr (FIRST)

@@ -281,6 +281,47 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
         }
     }
     std::atomic<int32_t> launches{0}, filled{0};
+    // The classes' first launches are submitted in plan order (longest reads first) and on streams whose priority falls in
+    // the same order: a window is one chain of dependent steps on one CU, the set lasts at least as long as its heaviest
+    // window, so that window's class must own its CUs from the first moment instead of queueing behind hundreds of light
+    // blocks that happened to be submitted a millisecond earlier.
+    std::atomic<int32_t> launch_turn{0};
+    std::vector<int32_t> launch_rank(classes, 0);
+    {
+        int32_t rank = 0;
+        for (size_t k = 0; k < classes; ++k)
+            if (!plan.groups[k].empty()) launch_rank[k] = rank++;
+    }
+    int priority_least = 0, priority_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&priority_least, &priority_greatest);
+    // Admission by residency: a window occupies a CU for its whole life, so the device holds about one window per CU at
+    // a time. Classes are admitted in plan order while their windows (a quarter more than there are CUs: the first to
+    // finish make room at once) fit; the next group of classes is gated, on the device, on the end of the lightest class
+    // of the group before it. Admitting everything at once only makes the long chains of the heavy classes queue for CUs
+    // behind light windows -- and those chains are what the set waits for at the end.
+    std::vector<int32_t> gate_on(classes, -1);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        const int64_t room = static_cast<int64_t>(cus) + cus / 4;
+        int64_t in_group   = 0;
+        int32_t prev_last = -1, last = -1;
+        for (size_t k = 0; k < classes; ++k)
+        {
+            if (plan.groups[k].empty()) continue;
+            const int64_t w = static_cast<int64_t>(plan.groups[k].size());
+            if (last >= 0 && in_group + w > room)
+            {
+                prev_last = last;
+                in_group  = 0;
+            }
+            gate_on[k] = prev_last;
+            in_group += w;
+            last = static_cast<int32_t>(k);
+        }
+    }
+    std::vector<hipEvent_t> class_done(classes, nullptr);
+    for (size_t k = 0; k < classes; ++k) GW_CU_CHECK_ERR(hipEventCreateWithFlags(&class_done[k], hipEventDisableTiming));
     std::mutex start_mutex;
     std::chrono::steady_clock::time_point compute_begin{};
     std::vector<std::exception_ptr> errors(classes);
@@ -305,12 +346,29 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
             {
                 scoped_device_switch d(device);
                 cudaStream_t stream = nullptr;
-                GW_CU_CHECK_ERR(hipStreamCreate(&stream));
+                // numerically lower = more urgent; the range is narrow (three levels on this hardware), later classes share the last
+                const int priority = std::min(priority_least, priority_greatest + launch_rank[k]);
+                GW_CU_CHECK_ERR(hipStreamCreateWithPriority(&stream, hipStreamDefault, priority));
                 {
                     DefaultDeviceAllocator allocator(static_cast<size_t>(share[k]), stream);
                     std::unique_ptr<Batch> batch = create_batch(device, stream, allocator, share[k], output_mask, plan.configs[k], gap_score,
                                                                 mismatch_score, match_score);
-                    const std::vector<int32_t>& mine = plan.groups[k];
+                    // heaviest windows first: blocks are dispatched in window order, and a class that does not fit the free CUs
+                    // at once should not keep its long chains for the end
+                    std::vector<int32_t> mine = plan.groups[k];
+                    {
+                        auto bases = [&](int32_t w) {
+                            int64_t b = 0;
+                            for (const std::string& read : windows[static_cast<size_t>(w)]) b += static_cast<int64_t>(read.size());
+                            return b;
+                        };
+                        std::vector<std::pair<int64_t, int32_t>> keyed;
+                        keyed.reserve(mine.size());
+                        for (int32_t w : mine) keyed.emplace_back(-bases(w), w);
+                        std::stable_sort(keyed.begin(), keyed.end());
+                        for (size_t i = 0; i < mine.size(); i++) mine[i] = keyed[i].second;
+                    }
+                    bool first_launch = true;
                     size_t next = 0;
                     std::vector<size_t> in_batch;
                     while (next < mine.size())
@@ -340,8 +398,20 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                             next++;
                         }
                         arrive();
+                        if (first_launch) // submission order of the classes' first launches
+                        {
+                            while (launch_turn.load() < launch_rank[k]) std::this_thread::yield();
+                            // (the gate's event was recorded before its class passed the turn on)
+                            if (gate_on[k] >= 0) GW_CU_CHECK_ERR(hipStreamWaitEvent(stream, class_done[static_cast<size_t>(gate_on[k])], 0));
+                        }
+                        if (batch->get_total_poas() > 0) batch->generate_poa();
+                        if (first_launch)
+                        {
+                            first_launch = false;
+                            GW_CU_CHECK_ERR(hipEventRecord(class_done[k], stream));
+                            launch_turn.fetch_add(1);
+                        }
                         if (batch->get_total_poas() == 0) continue;
-                        batch->generate_poa();
                         launches++;
                         std::vector<StatusType> status;
                         if (want_msa)
@@ -377,11 +447,17 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
             {
                 errors[k] = std::current_exception();
                 arrive();
+                // a class that failed before its first launch still passes the turn on
+                while (launch_turn.load() < launch_rank[k]) std::this_thread::yield();
+                int32_t mine_turn = launch_rank[k];
+                launch_turn.compare_exchange_strong(mine_turn, launch_rank[k] + 1);
             }
         });
     }
     for (std::thread& t : threads) t.join();
     const auto t_end = std::chrono::steady_clock::now();
+    for (hipEvent_t e : class_done)
+        if (e) (void)hipEventDestroy(e);
     out.seconds      = std::chrono::duration<double>(t_end - t_begin).count();
     if (compute_seconds) *compute_seconds = std::chrono::duration<double>(t_end - compute_begin).count();
     out.launches = launches.load();
