@@ -311,8 +311,11 @@ __device__ __forceinline__ void pattern_words(const char* query, int32_t query_s
         {                                                                                                              \
             if (prev_r != -1)                                                                                          \
             {                                                                                                          \
-                path[pos]   = prev_r;                                                                                  \
-                counts[pos] = r_count;                                                                                 \
+                if (writer)                                                                                            \
+                {                                                                                                      \
+                    path[pos]   = prev_r;                                                                              \
+                    counts[pos] = r_count;                                                                             \
+                }                                                                                                      \
                 ++pos;                                                                                                 \
             }                                                                                                          \
             prev_r  = r_;                                                                                              \
@@ -326,13 +329,18 @@ __device__ __forceinline__ void pattern_words(const char* query, int32_t query_s
 // so the band's pv / mv / score words of the next few columns are fetched together -- one HBM round trip per window of
 // columns instead of one per step (a step's nine loads were one dependent round trip each time). All lanes of the wave
 // refill together (each for its own position) as soon as one of them runs out.
+// G > 1: the G lanes of a pair's group (myers_banded_group_kernel) run the walk together, in lockstep on identical values;
+// what they share is the refill of the column window (the loads of a refill are dealt to the lanes), only `writer` stores.
+template <int G = 1>
 __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b, int32_t diagonal_begin, int32_t diagonal_end,
-                                    int32_t band_width, int32_t target_size, LaneArray tile = LaneArray{nullptr}, int32_t tile_words = 0)
+                                    int32_t band_width, int32_t target_size, LaneArray tile = LaneArray{nullptr}, int32_t tile_words = 0,
+                                    bool writer = true)
 {
-    // Only for narrow bands: a refill issues 6 instructions per cached (word, column), which a walk through a 6-word band
-    // does not win back (measured on configs[1]: 1.04 ms with the window, 0.85 ms without); short-read bands of 1-3 words do
+    // One lane: only for narrow bands -- a refill issues 6 instructions per cached (word, column), which a walk through a
+    // 6-word band does not win back (measured on configs[1]: 1.04 ms with the window, 0.85 ms without); short-read bands of
+    // 1-3 words do. A group shares that cost among its lanes.
     int32_t tile_cols = (tile_words > 0 && b.n_rows > 0) ? tile_words / (3 * b.n_rows) : 0;
-    if (tile_cols < 24) tile_cols = 0;
+    if (tile_cols < (G > 1 ? 8 : 24)) tile_cols = 0;
     int32_t tile_lo = 1, tile_hi = 0; // cached columns [tile_lo, tile_hi] (empty)
     auto refill = [&](int32_t j) {
         tile_hi = j;
@@ -340,7 +348,7 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
         const int32_t n  = (tile_hi - tile_lo + 1) * b.n_rows;
         const size_t src = b.at(0, tile_lo); // columns are contiguous in (column, word) order
         constexpr int kU = 8;                // 24 independent loads in flight per lane, then their LDS stores
-        for (int32_t e0 = 0; e0 < n; e0 += kU)
+        for (int32_t e0 = G > 1 ? (int32_t)(threadIdx.x & (G - 1)) * kU : 0; e0 < n; e0 += G * kU)
         {
             uint32_t p[kU], m[kU], sc[kU];
 #pragma unroll
@@ -360,6 +368,7 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
                     tile[3 * (e0 + u) + 2] = sc[u];
                 }
         }
+        if (G > 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // the other lanes' part of the window
     };
     // before a step at column j: columns j - 1 and j must be cached (wave-uniform decision over the lanes still walking)
     auto ensure = [&](int32_t j) {
@@ -456,11 +465,19 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
         else { r = diag == myscore ? kMatch : kMismatch; myscore = diag; --i; --j; }
         GW_EMIT(r);
     }
+    auto flush_run = [&]() {
+        if (writer)
+        {
+            path[pos]   = prev_r;
+            counts[pos] = r_count;
+        }
+        ++pos;
+    };
     if (i > 0)
     {
         if (prev_r != kDeletion)
         {
-            if (prev_r != -1) { path[pos] = prev_r; counts[pos] = r_count; ++pos; }
+            if (prev_r != -1) flush_run();
             prev_r  = kDeletion;
             r_count = 0;
         }
@@ -470,13 +487,13 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
     {
         if (prev_r != kInsertion)
         {
-            if (prev_r != -1) { path[pos] = prev_r; counts[pos] = r_count; ++pos; }
+            if (prev_r != -1) flush_run();
             prev_r  = kInsertion;
             r_count = 0;
         }
         r_count += j;
     }
-    if (r_count != 0) { path[pos] = prev_r; counts[pos] = r_count; ++pos; }
+    if (r_count != 0) flush_run();
     return pos;
 }
 #undef GW_EMIT
@@ -681,6 +698,396 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
         a.metadata[idx]   = (uint32_t)idx;
     }
     if (a.band_cells) a.band_cells[idx] = cells;
+}
+
+// ------------------------------------------------------------------------------------------------
+// G lanes per pair (small batches of long pairs: BASELINE configs[1] is 10 000 pairs -- 157 wavefronts at one lane per
+// pair on 1024 SIMDs, and a pair is one chain of (columns x band words) dependent word steps). Here the band's words of
+// a column are advanced by G neighbouring lanes at once, as in the reference's warp decomposition (myers_gpu.cu:
+// 257-442: add with carry and shifts across the lanes), so a column costs one word step instead of n_words:
+//   * lane k of the group owns band word k; pv / mv / score of the previous column stay in its registers;
+//   * the multi-word addition of Myers' Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq is a carry-lookahead over the group: every lane
+//     adds its word alone and reports "generates a carry" / "would propagate one"; the two ballots are added as integers
+//     (an integer addition ripples carries through runs of propagate bits), which yields every lane's carry-in at once;
+//     groups are cut apart by clearing both bits at each group's last lane. The horizontal deltas that the one-lane form
+//     chains from word to word (advance_word's hin) are exactly these carries and the bits shifted across the word
+//     boundary, so both forms fill identical pv / mv / score columns;
+//   * a block is G wavefronts and still owns 64 pairs and the same interleaved workspace region as a wave of the
+//     one-lane kernel (pair slot s at offset s), so the host's sizing and the planning kernels do not change;
+//   * the pattern table (shared by the group), 64 target characters per pair and the backtrace's column window are in
+//     LDS, per pair; the backtrace itself is the one-lane walk, run by the group's first lane.
+// Attempts whose band needs more than G words fall back to the one-lane stripes on the group's first lane.
+// ------------------------------------------------------------------------------------------------
+struct PairTable // pattern table of one pair in LDS
+{
+    uint32_t* base;
+    __device__ __forceinline__ uint32_t operator[](int32_t e) const { return base[e]; }
+};
+
+template <int G> struct GroupCtx
+{
+    int gl;              // lane within the group
+    uint64_t top_mask;   // last lane of every group
+    uint32_t* tbuf;      // 16 words: target[lo, lo + 64)
+    const char* target;
+    int32_t target_size;
+    int32_t lo;
+};
+
+// target character of column t (1-based): refilled by the group's lanes together, 64 characters at a time
+template <int G> __device__ __forceinline__ char group_target_char(GroupCtx<G>& c, int32_t idx)
+{
+    if (idx < c.lo || idx >= c.lo + 64)
+    {
+        c.lo = idx;
+        for (int k = c.gl; k < 16; k += G)
+        {
+            uint32_t w = 0;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+            {
+                const int32_t q  = idx + 4 * k + bb;
+                const uint32_t ch = q < c.target_size ? (uint32_t)(unsigned char)c.target[q] : 0u;
+                w |= ch << (8 * bb);
+            }
+            c.tbuf[k] = w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    const uint32_t w = c.tbuf[(idx - c.lo) >> 2];
+    return (char)((w >> (8 * ((idx - c.lo) & 3))) & 0xffu);
+}
+
+// one column of the band for the whole group: lane k holds word k (pv, mv as they enter the column: for the sliding band
+// already shifted down by one row). Returns ph / mh (before the shift) for the deltas.
+template <int G>
+__device__ __forceinline__ void group_advance(const GroupCtx<G>& c, uint32_t eq, uint32_t& pv, uint32_t& mv, uint32_t& ph_out, uint32_t& mh_out)
+{
+    const int lane     = threadIdx.x & 63;
+    const uint32_t xv  = eq | mv;
+    const uint32_t a   = eq & pv;
+    const uint32_t s0  = a + pv;
+    const uint64_t gen = __ballot(s0 < a), prp = __ballot(s0 == 0xffffffffu);
+    const uint64_t A   = (gen | prp) & ~c.top_mask, B = gen & ~c.top_mask;
+    const uint64_t cin = (A + B) ^ (prp & ~c.top_mask);
+    const uint32_t sum = s0 + (uint32_t)((cin >> lane) & 1u);
+    const uint32_t xh  = (sum ^ pv) | eq;
+    const uint32_t ph  = mv | ~(xh | pv);
+    const uint32_t mh  = pv & xh;
+    // bits shifted in from the word below (the band's top border is the worst case: +1)
+    uint32_t ph_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(ph >> 31), 0x111, 0xf, 0xf, false); // row_shr:1
+    uint32_t mh_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(mh >> 31), 0x111, 0xf, 0xf, false);
+    if (c.gl == 0)
+    {
+        ph_lo = 1u;
+        mh_lo = 0u;
+    }
+    const uint32_t phs = (ph << 1) | ph_lo, mhs = (mh << 1) | mh_lo;
+    pv     = mhs | ~(xv | phs);
+    mv     = phs & xv;
+    ph_out = ph;
+    mh_out = mh;
+}
+
+template <int G>
+__device__ __forceinline__ void group_horizontal_band(Band& b, GroupCtx<G>& c, const PairTable& patterns, int32_t n_words_query, int32_t t_begin,
+                                                      int32_t t_end, int32_t width, int32_t n_words, int32_t pattern_offset, uint32_t& pv,
+                                                      uint32_t& mv, int32_t& sc)
+{
+    const int32_t k     = c.gl;
+    const uint32_t hbit = 1u << (k == n_words - 1 ? width - (n_words - 1) * kWord - 1 : kWord - 1);
+    for (int32_t t = t_begin; t < t_end; ++t)
+    {
+        const char tc     = group_target_char<G>(c, t - 1);
+        const uint32_t eq = get_pattern(patterns, n_words_query, k, pattern_offset, tc);
+        uint32_t ph, mh;
+        group_advance<G>(c, eq, pv, mv, ph, mh);
+        sc += ((ph & hbit) ? 1 : 0) - ((mh & hbit) ? 1 : 0);
+        if (k < n_words)
+        {
+            b.score[b.at(k, t)] = sc;
+            b.pv[b.at(k, t)]    = pv;
+            b.mv[b.at(k, t)]    = mv;
+        }
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void group_diagonal_band(Band& b, GroupCtx<G>& c, const PairTable& patterns, int32_t n_words_query, int32_t t_begin,
+                                                    int32_t t_end, int32_t band_width, int32_t n_words, int32_t pattern_offset, uint32_t& pv,
+                                                    uint32_t& mv, int32_t& sc)
+{
+    const int32_t k    = c.gl;
+    const uint32_t drb = 1u << (k == n_words - 1 ? band_width - (n_words - 1) * kWord - 2 : kWord - 2);
+    const uint32_t ddb = drb << 1;
+    for (int32_t t = t_begin; t < t_end; ++t)
+    {
+        const char tc = group_target_char<G>(c, t - 1);
+        // the band slides one row down: word k takes the low bit of word k + 1 as its top bit
+        const uint32_t pv_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)pv, 0x101, 0xf, 0xf, false); // row_shl:1
+        const uint32_t mv_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)mv, 0x101, 0xf, 0xf, false);
+        pv >>= 1;
+        mv >>= 1;
+        if (k + 1 < n_words)
+        {
+            pv |= pv_up << (kWord - 1);
+            mv |= mv_up << (kWord - 1);
+        }
+        if (k == n_words - 1)
+        {
+            pv |= ddb; // bottom bit has no left neighbour: assume the worst case (+1)
+            mv &= ~ddb;
+        }
+        const uint32_t eq = get_pattern(patterns, n_words_query, k, pattern_offset + t - t_begin + 1, tc);
+        uint32_t ph, mh;
+        group_advance<G>(c, eq, pv, mv, ph, mh);
+        const int32_t hx   = ((ph & drb) ? 1 : 0) - ((mh & drb) ? 1 : 0);
+        const int32_t down = ((pv & ddb) ? 1 : 0) - ((mv & ddb) ? 1 : 0);
+        sc += hx + down;
+        if (k < n_words)
+        {
+            b.score[b.at(k, t)] = sc;
+            b.pv[b.at(k, t)]    = pv;
+            b.mv[b.at(k, t)]    = mv;
+        }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(64 * G) void myers_banded_group_kernel(KernelArgs a)
+{
+    extern __shared__ uint32_t myers_lds[];
+    constexpr int kPairsPerWave = 64 / G;
+    const int lane  = threadIdx.x & 63;
+    const int wave  = threadIdx.x >> 6;
+    const int gl    = lane & (G - 1);
+    const int s     = wave * kPairsPerWave + lane / G; // pair slot of the block: 0 .. 63
+    const int32_t slot = blockIdx.x * 64 + s;
+    // the block's workspace region is sized by its largest pair: every wave reduces over all 64 slots
+    int64_t me_max = 0;
+    int32_t pw_max = 0;
+    {
+        const int32_t sj = blockIdx.x * 64 + lane;
+        if (sj < a.n)
+        {
+            const int32_t i = a.order[sj];
+            pair_ws_dims((int32_t)(a.starts[2 * i + 1] - a.starts[2 * i]), (int32_t)(a.starts[2 * i + 2] - a.starts[2 * i + 1]),
+                         a.max_bandwidths[i], me_max, pw_max);
+        }
+        for (int off = 32; off > 0; off >>= 1)
+        {
+            me_max = max(me_max, (int64_t)__shfl_xor((long long)me_max, off));
+            pw_max = max(pw_max, __shfl_xor(pw_max, off));
+        }
+    }
+    if (slot >= a.n) return;
+    const bool leader        = gl == 0;
+    const int32_t idx        = a.order[slot];
+    const char* query        = a.sequences + a.starts[2 * idx];
+    const char* target       = a.sequences + a.starts[2 * idx + 1];
+    const int32_t query_size  = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
+    const int32_t target_size = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
+    const int32_t max_bw     = a.max_bandwidths[idx];
+    int8_t* path             = a.slot_ops + a.starts[2 * idx];
+    int32_t* counts          = a.slot_counts + a.starts[2 * idx];
+    const int32_t dlen       = abs(target_size - query_size);
+    uint64_t cells           = 0;
+
+    if (max_bw - 1 < dlen && query_size != 0 && target_size != 0)
+    {
+        if (leader)
+        {
+            a.run_counts[idx] = -1;
+            a.metadata[idx]   = (uint32_t)idx;
+        }
+        return;
+    }
+    if (target_size == 0 || query_size == 0)
+    {
+        if (leader)
+        {
+            if (query_size == 0 && target_size == 0)
+                a.run_counts[idx] = 0;
+            else
+            {
+                path[0]           = query_size == 0 ? kInsertion : kDeletion;
+                counts[0]         = query_size + target_size;
+                a.run_counts[idx] = 1;
+            }
+            a.metadata[idx] = (uint32_t)idx | (1u << 31);
+        }
+        return;
+    }
+    const int32_t n_words   = ceil_div(query_size, kWord);
+    const int32_t pmax      = (max_bw + 1) / 2;
+    const int64_t max_elems = (int64_t)ceil_div(min(1 + 2 * pmax, query_size), kWord) * ((int64_t)target_size + 1);
+    const int64_t region    = a.ws_offsets[blockIdx.x];
+    if (region + 64 * (3 * me_max + pw_max) > a.ws_capacity_words) // workspace was sized for a different order
+    {
+        if (leader)
+        {
+            a.run_counts[idx] = -1;
+            a.metadata[idx]   = (uint32_t)idx;
+        }
+        return;
+    }
+    uint32_t* base = a.ws + region + s;
+    Band b;
+    b.pv     = base;
+    b.mv     = base + 64 * me_max;
+    b.score  = reinterpret_cast<int32_t*>(base + 128 * me_max);
+    b.n_rows = 0;
+    // LDS: per pair the pattern table (odd stride: the lanes of a group read neighbouring words), 17 words of target
+    // characters, and the backtrace's column window (interleaved over the 64 pairs like the workspace)
+    const int32_t pstride = a.lds_pattern_words + 1;
+    uint32_t* pat_lds     = myers_lds + (size_t)s * pstride;
+    uint32_t* tbuf        = myers_lds + (size_t)64 * pstride + (size_t)s * 17;
+    uint32_t* tile_lds    = myers_lds + (size_t)64 * pstride + 64 * 17;
+    const PairTable patterns{pat_lds};
+    if (!(a.debug_skip & 4))
+        for (int32_t w = gl; w < n_words; w += G)
+        {
+            uint32_t pa = 0, pc = 0, pt = 0, pg = 0;
+            const int32_t nchar = min(query_size - w * kWord, kWord);
+            const char* qw      = query + w * kWord;
+            for (int32_t i = 0; i < nchar; ++i)
+            {
+                const char ch = qw[i];
+                pa |= (uint32_t)(ch == 'A') << i;
+                pc |= (uint32_t)(ch == 'C') << i;
+                pt |= (uint32_t)(ch == 'T') << i;
+                pg |= (uint32_t)(ch == 'G') << i;
+            }
+            pat_lds[w * 4 + 0] = pa; pat_lds[w * 4 + 1] = pc; pat_lds[w * 4 + 2] = pt; pat_lds[w * 4 + 3] = pg;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    GroupCtx<G> ctx;
+    ctx.gl          = gl;
+    ctx.top_mask    = 0;
+#pragma unroll
+    for (int j = 0; j < kPairsPerWave; j++) ctx.top_mask |= 1ull << (j * G + G - 1);
+    ctx.tbuf        = tbuf;
+    ctx.target      = target;
+    ctx.target_size = target_size;
+    ctx.lo          = -(1 << 30);
+
+    int32_t estimate = max(1, dlen + min(target_size, query_size) / 20);
+    int32_t diagonal_begin = -1, diagonal_end = -1, band_width = 0;
+    for (;;)
+    {
+        int32_t p      = min(min(target_size, query_size), (estimate - dlen) / 2);
+        int32_t bw_new = min(1 + 2 * p + dlen, query_size);
+        if (bw_new % kWord == 1 && bw_new != query_size) // at least two bits in the last word
+        {
+            p += 1;
+            bw_new = min(1 + 2 * p + dlen, query_size);
+        }
+        if (bw_new > max_bw)
+        {
+            bw_new = max_bw;
+            p      = (bw_new - 1 - dlen) / 2;
+        }
+        const int32_t n_words_band = ceil_div(bw_new, kWord);
+        if ((int64_t)n_words_band * (int64_t)(target_size + 1) > max_elems)
+        {
+            band_width = -band_width;
+            break;
+        }
+        band_width = bw_new;
+        b.n_rows   = n_words_band;
+        cells += (uint64_t)n_words_band * kWord * (uint64_t)target_size;
+        int32_t dist;
+        if (n_words_band <= G)
+        {
+            // column 0, then the three stripes (myers_compute_scores_edit_dist_banded, myers_gpu.cu:753-846)
+            uint32_t pv = ~0u, mv = 0u;
+            int32_t sc  = min((gl + 1) * kWord, band_width);
+            if (gl < n_words_band)
+            {
+                b.pv[b.at(gl, 0)]    = pv;
+                b.mv[b.at(gl, 0)]    = mv;
+                b.score[b.at(gl, 0)] = sc;
+            }
+            ctx.lo = -(1 << 30);
+            if (!(a.debug_skip & 2))
+            {
+                if (band_width >= query_size)
+                {
+                    diagonal_begin = target_size + 1;
+                    diagonal_end   = target_size + 1;
+                    group_horizontal_band<G>(b, ctx, patterns, n_words, 1, target_size + 1, query_size, n_words_band, 0, pv, mv, sc);
+                }
+                else
+                {
+                    const int32_t symmetric = (band_width - min(1 + 2 * p + dlen, query_size) == 0) ? 1 : 0;
+                    diagonal_begin = query_size < target_size ? target_size - query_size + p + 2 : p + 2 + (1 - symmetric);
+                    diagonal_end   = query_size < target_size ? query_size - p + symmetric : query_size - (query_size - target_size) - p + 1;
+                    group_horizontal_band<G>(b, ctx, patterns, n_words, 1, diagonal_begin, band_width, n_words_band, 0, pv, mv, sc);
+                    group_diagonal_band<G>(b, ctx, patterns, n_words, diagonal_begin, diagonal_end, band_width, n_words_band, 0, pv, mv, sc);
+                    group_horizontal_band<G>(b, ctx, patterns, n_words, diagonal_end, target_size + 1, band_width, n_words_band,
+                                             query_size - band_width, pv, mv, sc);
+                }
+            }
+            // the last word's score in the last column, to every lane of the group
+            dist = __shfl(sc, (lane & ~(G - 1)) + n_words_band - 1);
+            if (a.debug_skip & 2) dist = b.score[b.at(n_words_band - 1, target_size)];
+        }
+        else
+        {
+            // a band wider than the group: the one-lane stripes on the group's first lane (state in the HBM workspace)
+            if (leader)
+            {
+                for (int32_t w = 0; w < n_words_band; ++w)
+                {
+                    b.pv[b.at(w, 0)]    = ~0u;
+                    b.mv[b.at(w, 0)]    = 0u;
+                    b.score[b.at(w, 0)] = min((w + 1) * kWord, band_width);
+                }
+                ColumnState none{};
+                if (!(a.debug_skip & 2))
+                    banded_stripes<false>(b, none, patterns, n_words, target, query_size, target_size, p, n_words_band, band_width, diagonal_begin,
+                                          diagonal_end);
+            }
+            diagonal_begin = __shfl(diagonal_begin, lane & ~(G - 1));
+            diagonal_end   = __shfl(diagonal_end, lane & ~(G - 1));
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            dist = leader ? b.score[b.at(n_words_band - 1, target_size)] : 0;
+            dist = __shfl(dist, lane & ~(G - 1));
+        }
+        if (dist <= estimate || band_width == query_size) break;
+        if (band_width == max_bw)
+        {
+            band_width = -band_width;
+            break;
+        }
+        estimate *= 2;
+    }
+    if (band_width != 0 && (a.debug_skip & 1))
+    {
+        if (leader)
+        {
+            a.run_counts[idx] = 0;
+            a.metadata[idx]   = (uint32_t)idx;
+        }
+    }
+    else if (band_width != 0)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // the group's column stores, before the walk reads them
+        // the whole group walks (in lockstep, on the same values) and shares the refills of the column window
+        const int32_t runs = backtrace_banded<G>(path, counts, b, diagonal_begin, diagonal_end, abs(band_width), target_size,
+                                                 LaneArray{tile_lds + s}, a.lds_band_words, leader);
+        if (leader)
+        {
+            a.run_counts[idx] = runs;
+            a.metadata[idx]   = (uint32_t)idx | (band_width > 0 ? (1u << 31) : 0u);
+        }
+    }
+    else if (leader)
+    {
+        a.run_counts[idx] = -1;
+        a.metadata[idx]   = (uint32_t)idx;
+    }
+    if (leader && a.band_cells) a.band_cells[idx] = cells;
 }
 
 // Exclusive scan of max(run_counts, 0) into result_starts[n + 1] in three small launches (block totals, scan of the
@@ -1376,7 +1783,31 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
     }
     const char* myers_dbg = std::getenv("GWHIP_MYERS_HBM_STATE"); // debugging: force the HBM-state kernel
     if (myers_dbg && myers_dbg[0] == '1') use_lds = false;
-    if (use_lds)
+    // Small batches of long pairs: eight lanes per pair (myers_banded_group_kernel). Worth it while the one-lane kernel
+    // would leave SIMDs empty (fewer wavefronts than SIMDs) and a pair is a long chain (queries of 256 bases and more).
+    bool use_group = false;
+    {
+        const char* gdbg = std::getenv("GWHIP_MYERS_GROUP"); // debugging: 0 = never, 1 = whenever the LDS tables fit
+        int cus = 0, dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        const int32_t qwords = args->max_query_length > 0 ? (args->max_query_length + kWord - 1) / kWord : 0;
+        const bool fits      = qwords > 0 && (size_t)(64 * (4 * qwords + 1) + 64 * 17 + 64 * 288) * 4 <= 128 * 1024;
+        use_group = fits && (n + 63) / 64 < 4 * cus && args->max_query_length >= 256;
+        if (gdbg && gdbg[0] == '0') use_group = false;
+        if (gdbg && gdbg[0] == '1') use_group = fits;
+        if (use_group)
+        {
+            ka.lds_pattern_words = 4 * qwords;
+            ka.lds_band_words    = 288; // words of the backtrace's column window per pair
+        }
+    }
+    if (use_group)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&myers_banded_group_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (use_group)
+        hipLaunchKernelGGL(myers_banded_group_kernel<8>, dim3((n + 63) / 64), dim3(64 * 8),
+                           (size_t)(64 * (ka.lds_pattern_words + 1) + 64 * 17 + 64 * ka.lds_band_words) * sizeof(uint32_t), stream, ka);
+    else if (use_lds)
         hipLaunchKernelGGL(myers_banded_kernel<true>, dim3((n + 63) / 64), dim3(64),
                            (size_t)(ka.lds_pattern_words + 3 * ka.lds_band_words + 16) * 64 * sizeof(uint32_t), stream, ka);
     else
