@@ -258,7 +258,7 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_
            "launches_rank0": out["launches"], "dtype": "int32",
            "windows_equal_to_oracle_golden": int(checked), "windows_differing_from_golden": int(mismatched),
            "size_classes": [{"max_sequence_size": c["max_sequence_size"], "windows": len(g)} for c, g in zip(cfgs, plan.groups)],
-           "roofline": {"bound": "hbm", "kernel": "poa_window_kernel<int32,int32,adaptive_band,HBM tables, 6 waves per window> (4 concurrent launches)",
+           "roofline": {"bound": "hbm", "kernel": "poa_window_kernel<int32,int32,adaptive_band,HBM tables, 8 waves per window> (4 launches, admitted by residency)",
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                         "algorithmic_bytes_per_cell": BYTES_PER_CELL_LONG,

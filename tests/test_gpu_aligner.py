@@ -76,6 +76,30 @@ def test_random_pairs_bit_exact_vs_oracle(max_bw):
             assert r.edit_distance == ref["edit_distance"]
 
 
+def test_group_kernel_equals_one_lane_kernel(monkeypatch):
+    """A/B of the two banded Myers kernels: eight lanes per pair (carry-lookahead over the lanes; picked for small batches
+    of long pairs) against one lane per pair (GWHIP_MYERS_GROUP=0), and the group kernel forced on short queries too
+    (=1): same CIGARs, optimality flags and edit distances, including bands wider than the group (more than 8 words:
+    its one-lane fallback) and pairs the band rejects."""
+    rng = random.Random(77)
+    pairs = [("A" * 300, "C" * 300), ("ACGT" * 100, "ACGT" * 100)]
+    for _ in range(260):
+        n = rng.choice([1, 33, 64, 255, 256, 257, 300, 512, 777, 1000, 1024, 1500])
+        q = "".join(rng.choice("ACGT") for _ in range(n))
+        t = _mutate(rng, q, rng.choice([0, 1, 3, n // 25 + 1, n // 6 + 1, n // 3 + 1])) or "A"
+        pairs.append((q, t))
+    for max_bw in (2048, 200):
+        got = {}
+        for mode in ("0", "1", None):
+            if mode is None:
+                monkeypatch.delenv("GWHIP_MYERS_GROUP", raising=False)
+            else:
+                monkeypatch.setenv("GWHIP_MYERS_GROUP", mode)
+            got[mode] = [(r.status, r.cigar_extended, r.is_optimal, r.edit_distance) for r in run(pairs, max_bandwidth=max_bw)]
+        assert got["0"] == got["1"]
+        assert got["0"] == got[None]
+
+
 def test_config2_sample_and_cell_counts():
     # BASELINE config 2 generator: 1000-bp query, target = generate_random_sequence(query, rng, 33, 33, 33), minstd_rand(1)
     from genomeworks_amd import cudaaligner, synthetic

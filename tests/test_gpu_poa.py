@@ -219,6 +219,36 @@ def test_long_read_adaptive_msa_32bit_path():
             assert [r.replace("-", "") for r in msa[i]] == w
 
 
+def test_long_read_forward_and_traceback_variants_agree(monkeypatch):
+    """A/B inside the long-read kernel (graphs beyond the LDS tables, adaptive band): the pipelined multi-wave forward
+    pass with trace codes and the table-lookup traceback (default) against the table-lookup traceback switched off
+    (GWHIP_DEBUG bit 6: recomputation from the score matrix) and against the single-wave forward pass (bit 18), on
+    divergent long reads whose bands widen to 512 .. 1536 columns: identical MSA, status and cell counts, and equal to
+    the oracle."""
+    from genomeworks_amd import synthetic
+    windows = [[r.decode() for r in synthetic.generate_window(9100 + w, 5200 + 700 * w, 7, 260, 330, 330)] for w in range(3)]
+    windows.append([r.decode() for r in synthetic.generate_window(9200, 6000, 10, 900, 40, 40)])   # four predecessors and more
+    windows.append([r.decode() for r in synthetic.generate_window(9201, 3000, 5, 20, 900, 20)])    # reads much longer than the backbone
+    out = {}
+    for name, flag in (("default", None), ("recomputed_traceback", str(1 << 6)), ("single_wave", str(1 << 18))):
+        if flag is None:
+            monkeypatch.delenv("GWHIP_DEBUG", raising=False)
+        else:
+            monkeypatch.setenv("GWHIP_DEBUG", flag)
+        b = run_gpu(windows, "adaptive_band", max_seq=8192, max_seqs=12, output_type="msa", nodes=4 * 8192)
+        out[name] = (b.get_msa(), b.total_cells())
+    assert out["default"] == out["recomputed_traceback"]
+    assert out["default"] == out["single_wave"]
+    (msa, status), _ = out["default"]
+    cfg = oracle_cfg("adaptive_band", 8192, 12, output_mask=2, nodes=4 * 8192)
+    with O.Workspace(cfg) as ws:
+        for i, w in enumerate(windows):
+            ref = ws.process(w)
+            assert status[i] == ref["status"]
+            if ref["status"] == 0:
+                assert msa[i] == ref["msa"]
+
+
 def test_group_with_every_read_rejected_keeps_its_output_slot():
     """Reference quirk (cudapoa_batch.cuh:122-150): add_poa_group opens the POA before it tries the reads, so a group
     whose reads are all rejected returns empty_poa_group but stays in the batch with zero reads and owns an output
