@@ -853,21 +853,28 @@ __device__ __forceinline__ void group_diagonal_band(Band& b, GroupCtx<G>& c, con
     }
 }
 
-template <int G>
-__global__ __launch_bounds__(64 * G) void myers_banded_group_kernel(KernelArgs a)
+// PAIRS pairs per block (a divisor of 64): the workspace regions stay those of 64 slots -- block j works on slots
+// [PAIRS j, PAIRS j + PAIRS) of region PAIRS j / 64 -- but a block is PAIRS G / 64 wavefronts, so that a small batch spreads
+// over all CUs with one busy wavefront per SIMD (the column step is vector work back to back: two such wavefronts on one
+// SIMD halve each other).
+template <int G, int PAIRS>
+__global__ __launch_bounds__(PAIRS * G) void myers_banded_group_kernel(KernelArgs a)
 {
     extern __shared__ uint32_t myers_lds[];
     constexpr int kPairsPerWave = 64 / G;
+    static_assert(64 % PAIRS == 0 && (PAIRS * G) % 64 == 0, "whole wavefronts, whole regions");
     const int lane  = threadIdx.x & 63;
     const int wave  = threadIdx.x >> 6;
     const int gl    = lane & (G - 1);
-    const int s     = wave * kPairsPerWave + lane / G; // pair slot of the block: 0 .. 63
-    const int32_t slot = blockIdx.x * 64 + s;
-    // the block's workspace region is sized by its largest pair: every wave reduces over all 64 slots
+    const int sb    = wave * kPairsPerWave + lane / G;           // pair of the block: 0 .. PAIRS - 1
+    const int32_t slot = blockIdx.x * PAIRS + sb;
+    const int32_t region_index = slot / 64;
+    const int s     = slot - region_index * 64;                   // slot inside its 64-slot workspace region
+    // the region is sized by its largest pair: every wave reduces over all 64 slots of the region
     int64_t me_max = 0;
     int32_t pw_max = 0;
     {
-        const int32_t sj = blockIdx.x * 64 + lane;
+        const int32_t sj = region_index * 64 + lane;
         if (sj < a.n)
         {
             const int32_t i = a.order[sj];
@@ -921,7 +928,7 @@ __global__ __launch_bounds__(64 * G) void myers_banded_group_kernel(KernelArgs a
     const int32_t n_words   = ceil_div(query_size, kWord);
     const int32_t pmax      = (max_bw + 1) / 2;
     const int64_t max_elems = (int64_t)ceil_div(min(1 + 2 * pmax, query_size), kWord) * ((int64_t)target_size + 1);
-    const int64_t region    = a.ws_offsets[blockIdx.x];
+    const int64_t region    = a.ws_offsets[region_index];
     if (region + 64 * (3 * me_max + pw_max) > a.ws_capacity_words) // workspace was sized for a different order
     {
         if (leader)
@@ -940,9 +947,9 @@ __global__ __launch_bounds__(64 * G) void myers_banded_group_kernel(KernelArgs a
     // LDS: per pair the pattern table (odd stride: the lanes of a group read neighbouring words), 17 words of target
     // characters, and the backtrace's column window (interleaved over the 64 pairs like the workspace)
     const int32_t pstride = a.lds_pattern_words + 1;
-    uint32_t* pat_lds     = myers_lds + (size_t)s * pstride;
-    uint32_t* tbuf        = myers_lds + (size_t)64 * pstride + (size_t)s * 17;
-    uint32_t* tile_lds    = myers_lds + (size_t)64 * pstride + 64 * 17;
+    uint32_t* pat_lds     = myers_lds + (size_t)sb * pstride;
+    uint32_t* tbuf        = myers_lds + (size_t)PAIRS * pstride + (size_t)sb * 17;
+    uint32_t* tile_lds    = myers_lds + (size_t)PAIRS * pstride + PAIRS * 17; // interleaved over 64 slots like the workspace (a block uses PAIRS of them)
     const PairTable patterns{pat_lds};
     if (!(a.debug_skip & 4))
         for (int32_t w = gl; w < n_words; w += G)
@@ -1792,21 +1799,21 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         const int32_t qwords = args->max_query_length > 0 ? (args->max_query_length + kWord - 1) / kWord : 0;
-        const bool fits      = qwords > 0 && (size_t)(64 * (4 * qwords + 1) + 64 * 17 + 64 * 288) * 4 <= 128 * 1024;
+        const bool fits      = qwords > 0 && (size_t)(32 * (4 * qwords + 1) + 32 * 17 + 64 * 224) * 4 <= 80 * 1024; // two blocks per CU
         use_group = fits && (n + 63) / 64 < 4 * cus && args->max_query_length >= 256;
         if (gdbg && gdbg[0] == '0') use_group = false;
         if (gdbg && gdbg[0] == '1') use_group = fits;
         if (use_group)
         {
             ka.lds_pattern_words = 4 * qwords;
-            ka.lds_band_words    = 288; // words of the backtrace's column window per pair
+            ka.lds_band_words    = 224; // words of the backtrace's column window per pair
         }
     }
     if (use_group)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&myers_banded_group_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&myers_banded_group_kernel<8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (use_group)
-        hipLaunchKernelGGL(myers_banded_group_kernel<8>, dim3((n + 63) / 64), dim3(64 * 8),
-                           (size_t)(64 * (ka.lds_pattern_words + 1) + 64 * 17 + 64 * ka.lds_band_words) * sizeof(uint32_t), stream, ka);
+        hipLaunchKernelGGL((myers_banded_group_kernel<8, 32>), dim3((n + 31) / 32), dim3(32 * 8),
+                           (size_t)(32 * (ka.lds_pattern_words + 1) + 32 * 17 + 64 * ka.lds_band_words) * sizeof(uint32_t), stream, ka);
     else if (use_lds)
         hipLaunchKernelGGL(myers_banded_kernel<true>, dim3((n + 63) / 64), dim3(64),
                            (size_t)(ka.lds_pattern_words + 3 * ka.lds_band_words + 16) * 64 * sizeof(uint32_t), stream, ka);
