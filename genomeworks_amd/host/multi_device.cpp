@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <chrono>
 #include <exception>
 #include <map>
@@ -286,6 +287,7 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
     // window, so that window's class must own its CUs from the first moment instead of queueing behind hundreds of light
     // blocks that happened to be submitted a millisecond earlier.
     std::atomic<int32_t> launch_turn{0};
+    std::atomic<int64_t> results_done_ns{0}; // when the last class handed over its last results, relative to t_begin
     std::vector<int32_t> launch_rank(classes, 0);
     {
         int32_t rank = 0;
@@ -404,7 +406,11 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                             // (the gate's event was recorded before its class passed the turn on)
                             if (gate_on[k] >= 0) GW_CU_CHECK_ERR(hipStreamWaitEvent(stream, class_done[static_cast<size_t>(gate_on[k])], 0));
                         }
+                        const bool trace = std::getenv("GW_SIZE_CLASS_TRACE") != nullptr; // debugging: host-side timeline on stderr
+                        auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+                        if (trace) std::fprintf(stderr, "[size classes] class %zu: generate_poa() called at %.1f ms\n", k, since());
                         if (batch->get_total_poas() > 0) batch->generate_poa();
+                        if (trace) std::fprintf(stderr, "[size classes] class %zu: generate_poa() returned at %.1f ms\n", k, since());
                         if (first_launch)
                         {
                             first_launch = false;
@@ -417,7 +423,13 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                         if (want_msa)
                         {
                             std::vector<std::vector<std::string>> msa;
+                            if (trace)
+                            {
+                                GW_CU_CHECK_ERR(hipStreamSynchronize(stream));
+                                std::fprintf(stderr, "[size classes] class %zu: kernels done at %.1f ms\n", k, since());
+                            }
                             batch->get_msa(msa, status);
+                            if (trace) std::fprintf(stderr, "[size classes] class %zu: get_msa() returned at %.1f ms\n", k, since());
                             for (size_t i = 0; i < in_batch.size(); i++)
                                 if (in_batch[i] < n)
                                 {
@@ -437,6 +449,13 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                                     out.coverage[in_batch[i]]  = std::move(coverage[i]);
                                     out.status[in_batch[i]]    = status[i];
                                 }
+                        }
+                        // the compute clock stops when the last results have been handed over: releasing the slabs (hundreds
+                        // of GB for a long-read set, most of a second) is not part of generate_poa() + get_msa()
+                        {
+                            const int64_t now_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+                            int64_t seen         = results_done_ns.load();
+                            while (seen < now_ns && !results_done_ns.compare_exchange_weak(seen, now_ns)) {}
                         }
                     }
                     arrive();
@@ -459,7 +478,12 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
     for (hipEvent_t e : class_done)
         if (e) (void)hipEventDestroy(e);
     out.seconds      = std::chrono::duration<double>(t_end - t_begin).count();
-    if (compute_seconds) *compute_seconds = std::chrono::duration<double>(t_end - compute_begin).count();
+    if (compute_seconds)
+    {
+        const auto t_results = t_begin + std::chrono::nanoseconds(results_done_ns.load());
+        *compute_seconds     = results_done_ns.load() > 0 ? std::chrono::duration<double>(t_results - compute_begin).count()
+                                                          : std::chrono::duration<double>(t_end - compute_begin).count();
+    }
     out.launches = launches.load();
     for (const std::exception_ptr& e : errors)
         if (e) std::rethrow_exception(e);

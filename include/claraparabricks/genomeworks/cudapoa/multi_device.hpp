@@ -72,8 +72,9 @@ void plan_size_classes(SizeClassPlan& plan, const std::vector<int32_t>& longest,
 /// One worker (host thread, stream, allocator slice, Batch) per class of the plan on `device`, all at once; a class whose
 /// windows do not fit its slice takes several fills. memory_budget: device bytes for all classes together (each class gets
 /// its share of the plan's total, scaled down if the total exceeds the budget). out.seconds = wall time of the workers
-/// including batch creation and filling; *compute_seconds (optional) = from the moment every worker has filled its first
-/// batch to the last worker's end (generate_poa + get_consensus / get_msa and any further fills).
+/// including batch creation, filling and the release of the slabs; *compute_seconds (optional) = from the moment every worker
+/// has filled its first batch to the moment the last worker has handed over its last results (generate_poa + get_consensus /
+/// get_msa and any further fills; not the destruction of the batches).
 void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std::vector<std::string>>& windows,
                                   const SizeClassPlan& plan, int32_t device, int64_t memory_budget, int8_t output_mask,
                                   int16_t gap_score = -8, int16_t mismatch_score = -6, int16_t match_score = 8,
