@@ -43,11 +43,10 @@ static_assert(kReadLds + kCodeTileLds >= 3072 * 2, "the incremental topsort keep
 // Graphs that do not fit the LDS tables (long reads: HBM row table, 32-bit cells, bands up to 1536 columns) spend their
 // LDS on the forward pass instead: a ring of the most recent score rows wide enough for 5 rows of the widest band,
 // the band starts of those rows, and a sliding window of the read. 4 blocks per CU still fit (4 x 35 KB).
-constexpr int kWideRingBytes = 57344; // 9 rows of the widest band (1544 x 4 B); two blocks per CU
 constexpr int kBsRingBytes   = 2048; // band starts of the ring rows (64 x 4 B) + 64 staged rows of the HBM row table (64 x 24 B)
 constexpr int kReadWinBytes  = 4096;
-constexpr int kMwLds         = 512;
-constexpr size_t kReservedCuLds = 128 * 1024; // 160 KB per CU: nothing else of this kernel family (>= 35 KB per block) fits beside it  // arguments and carry words of the multi-wave forward pass (poa_device.h)
+constexpr int kMwLds         = 512;  // arguments, progress and carry words of the multi-wave forward pass (poa_device.h)
+constexpr size_t kReservedCuLds = 128 * 1024; // LDS of a multi-wave block (160 KB per CU: nothing else of this kernel family, >= 35 KB per block, fits beside it)
 
 struct KernelArgs
 {
@@ -105,8 +104,8 @@ __device__ GraphView<IdT> carve_graph(uint8_t* slab, const PoaLayout& L)
 // flag (not a runtime select) so every pointer has one address space and the row loop issues ds_* ops only:
 // a flat/global load in that loop would wait on the previous row's score store (shared in-order vmcnt).
 // NW: wavefronts per window. 1 everywhere but for graphs beyond the LDS tables in the adaptive band mode (long reads),
-// where the wide bands' forward pass runs one wavefront per 256-column pass (generic_forward_mw); every other phase is
-// wave 0's, the helper wavefronts wait at a barrier in between.
+// where the wide bands' forward pass is a pipeline of wavefronts over 256-column blocks (generic_forward_skew); every other
+// phase is wave 0's, the helper wavefronts wait at a barrier in between.
 template <typename ScoreT, typename IdT, typename TraceT, int BM, bool MSA, bool LDS_TABLES, int NW>
 __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
 {
@@ -561,27 +560,19 @@ static hipError_t launch_window_kernel(const KernelArgs& ka_in, hipStream_t stre
 {
     KernelArgs ka = ka_in;
     constexpr size_t wide_rest = (size_t)kBsRingBytes + kReadWinBytes + kMwLds;
-    // multi-wave blocks of long reads (16 kbp and more): 9 ring rows of the widest band, two blocks per CU; shorter reads
-    // keep four blocks per CU (their bands are mostly narrow: 14 rows of a 512-column band, 5 of the widest)
-    ka.wide_ring_bytes = ka.cfg.max_sequence_size >= 16384 ? kWideRingBytes : 5 * (kMaxAdaptiveBand + kRightPad) * 4;
-    size_t lds = LDS_TABLES ? (size_t)kRingBytes + kRowInfoBytes + kReadLds + kCodeTileLds : (size_t)ka.wide_ring_bytes + wide_rest;
+    // HBM-table layout, single-wave kernels: a ring of five rows of the widest band, four blocks per CU
+    ka.wide_ring_bytes = 5 * (kMaxAdaptiveBand + kRightPad) * 4;
+    const size_t lds   = LDS_TABLES ? (size_t)kRingBytes + kRowInfoBytes + kReadLds + kCodeTileLds : (size_t)ka.wide_ring_bytes + wide_rest;
     dim3 grid(ka.total_windows);
-    // A launch of few, heavy windows (long reads: at most one per CU, reads of 16 kbp and more) asks for more LDS than a
-    // block uses, so that no block of a concurrently running launch of lighter windows fits beside it: the heavy window
-    // is the critical path of the whole set (one chain of dependent steps) and keeps its CU's issue slots to itself.
 #define GW_LAUNCH(BM)                                                                                              \
     {                                                                                                              \
         constexpr int NW = (!LDS_TABLES && BM == GWHIP_ADAPTIVE_BAND) ? kSkWaves : 1;                              \
         size_t lds_req = lds;                                                                                      \
-        if (!LDS_TABLES && NW == 1) /* single-wave HBM-table kernels: five rows of the widest band, four blocks per CU */ \
-        {                                                                                                          \
-            ka.wide_ring_bytes = 5 * (kMaxAdaptiveBand + kRightPad) * 4;                                           \
-            lds_req            = (size_t)ka.wide_ring_bytes + wide_rest;                                           \
-        }                                                                                                          \
-        if (NW > 1) /* multi-wave blocks: the register count allows one 8-wave block per CU, which then owns its LDS */ \
+        if (NW > 1) /* multi-wave blocks (long reads): the register count allows one 8-wave block per CU anyway; it   \
+                       owns the CU's LDS and puts it to use as a ring of 20 rows of the widest band */             \
         {                                                                                                          \
             lds_req            = kReservedCuLds;                                                                   \
-            ka.wide_ring_bytes = (int32_t)(kReservedCuLds - wide_rest); /* the whole reservation is put to use */  \
+            ka.wide_ring_bytes = (int32_t)(kReservedCuLds - wide_rest);                                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReservedCuLds);             \
         }                                                                                                          \

@@ -129,7 +129,7 @@ struct PhaseClock
 // ---- wave-level helpers ----
 // Ordering point of ONE wavefront with itself: everything the wave wrote (LDS, global) is complete and visible to
 // every lane of the same wave afterwards. A window is worked on by one wavefront in all phases but the multi-wave
-// forward pass (generic_forward_mw below), so this is what the single-wave code needs where a block-wide kernel
+// forward pass (generic_forward_skew below), so this is what the single-wave code needs where a block-wide kernel
 // would write __syncthreads() -- and it contains no s_barrier, which the helper wavefronts of a multi-wave block
 // (parked at their own barrier) must not be released by.
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
@@ -139,12 +139,6 @@ __device__ __forceinline__ void block_barrier()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-// barrier that orders LDS traffic only: outstanding global stores keep draining behind it (a full block_barrier()
-// would make every row of the multi-wave forward pass wait for the acknowledgement of its own score stores)
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ __forceinline__ int32_t wave_bcast(int32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int32_t wave_first(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
