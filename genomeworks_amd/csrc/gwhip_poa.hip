@@ -468,9 +468,12 @@ __global__ __launch_bounds__(kWave) void poa_consensus_lds_kernel(KernelArgs a)
 
 // MSA kernel: lane 0 does the racon topsort + column assignment, then one lane per sequence
 // (loops when num_seqs > 64; the reference launches max_sequences_per_poa threads, cudapoa_kernels.cuh:1025-1026).
+constexpr int kMsaStackEntries = 4096; // LDS stack of the wave-wide racon order (its depth is a few dozen on real graphs)
+
 template <typename IdT>
 __global__ __launch_bounds__(kWave) void poa_msa_kernel(KernelArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t msa_smem[]; // [stack | one state byte per node], or nothing
     __shared__ int32_t msa_length;
     const int32_t w    = blockIdx.x;
     const gwhip_poa_config& c = a.cfg;
@@ -480,16 +483,30 @@ __global__ __launch_bounds__(kWave) void poa_msa_kernel(KernelArgs a)
     GraphView<IdT> g   = carve_graph<IdT>(slab, a.L);
     const gwhip_window_details wd = a.window_details[w];
     const int32_t n    = a.sequence_lengths[wd.seq_len_buffer_offset];
-    if (threadIdx.x == 0)
+    const int lane     = threadIdx.x & (kWave - 1);
+    bool done          = false;
+    if (a.cons_lds_nodes >= n && n > 0) // the launch gave this kernel LDS for graphs of up to cons_lds_nodes nodes
+    {
+        uint32_t* stack = reinterpret_cast<uint32_t*>(msa_smem);
+        uint8_t* state  = msa_smem + (size_t)kMsaStackEntries * 4;
+        if (topsort_racon_wave<IdT>(g, n, state, stack, kMsaStackEntries, lane))
+        {
+            const int32_t len = node_id_to_msa_pos_wave<IdT>(g, n, state, lane);
+            if (lane == 0) msa_length = len;
+            done = true;
+        }
+    }
+    if (!done && threadIdx.x == 0)
     {
         // static_cast<SizeT>(max_nodes_per_graph), cudapoa_generate_msa.cuh:196
         topsort_racon<IdT>(g, n, (int32_t)(IdT)c.max_nodes_per_graph);
         msa_length = node_id_to_msa_pos<IdT>(g, n);
-        if ((uint32_t)msa_length >= (uint32_t)c.max_consensus_size)
-        {
-            consensus[0] = kKernelError;
-            consensus[1] = kExceededMaximumSequenceSize;
-        }
+    }
+    wave_sync();
+    if (threadIdx.x == 0 && (uint32_t)msa_length >= (uint32_t)c.max_consensus_size)
+    {
+        consensus[0] = kKernelError;
+        consensus[1] = kExceededMaximumSequenceSize;
     }
     wave_sync();
     if (consensus[0] == kKernelError) return;
@@ -719,8 +736,21 @@ int gwhip_poa_generate(const gwhip_poa_args* args, gwhip_stream_t stream_)
     dim3 grid(args->total_windows), block(kWave);
     if (msa)
     {
-        if (args->cfg.size32) hipLaunchKernelGGL(poa_msa_kernel<int32_t>, grid, block, 0, stream, ka);
-        else hipLaunchKernelGGL(poa_msa_kernel<int16_t>, grid, block, 0, stream, ka);
+        // wave-wide racon order with its marks in LDS when a byte per node fits (long-read graphs: one block per CU)
+        const size_t msa_lds = (size_t)kMsaStackEntries * 4 + (((size_t)args->cfg.max_nodes_per_graph + 15) & ~size_t(15));
+        const char* msa_dbg  = std::getenv("GWHIP_MSA_SERIAL"); // debugging: the serial HBM routine
+        const bool msa_wave  = msa_lds <= 150 * 1024 && !(msa_dbg && msa_dbg[0] == '1');
+        ka.cons_lds_nodes    = msa_wave ? args->cfg.max_nodes_per_graph : 0;
+        if (args->cfg.size32)
+        {
+            if (msa_wave) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poa_msa_kernel<int32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msa_lds);
+            hipLaunchKernelGGL(poa_msa_kernel<int32_t>, grid, block, msa_wave ? msa_lds : 0, stream, ka);
+        }
+        else
+        {
+            if (msa_wave) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poa_msa_kernel<int16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msa_lds);
+            hipLaunchKernelGGL(poa_msa_kernel<int16_t>, grid, block, msa_wave ? msa_lds : 0, stream, ka);
+        }
     }
     else
     {

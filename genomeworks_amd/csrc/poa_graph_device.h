@@ -1078,6 +1078,102 @@ __device__ void topsort_racon(const GraphView<IdT>& g, int32_t node_count, int32
     }
 }
 
+// The same order, for the MSA kernel, by the whole wavefront: the depth-first walk stays serial (the order is defined by
+// it) but a visit is one memory round trip instead of eight dependent ones -- all lanes load the node's in-edges and aligned
+// nodes at once (lane e: edge / alignment e; the two counts ride along), the per-node marks and "check" flags live in LDS
+// (one byte per node: marks [0:2), check [2]), the nodes to push are found with a ballot and written in slot order by prefix
+// popcount, and the stack is in LDS. Returns false when the stack outgrows its LDS (the caller then runs topsort_racon).
+// ------------------------------------------------------------------------------------------------
+template <typename IdT>
+__device__ __forceinline__ bool topsort_racon_wave(const GraphView<IdT>& g, int32_t node_count, uint8_t* state, uint32_t* stack,
+                                                   int32_t stack_cap, int lane)
+{
+    static_assert(kEdges <= kWave && kAligns <= kWave, "one lane per edge / alignment slot");
+    for (int32_t i = lane; i < node_count; i += kWave) state[i] = 4; // marks 0, check 1
+    wave_sync();
+    int32_t top = -1, sorted_idx = 0;
+    for (int32_t i = 0; i < node_count; i++)
+    {
+        if ((wave_first((int32_t)state[i]) & 3) != 0) continue;
+        top = 0;
+        if (lane == 0) stack[0] = (uint32_t)i;
+        while (top >= 0)
+        {
+            const int32_t node = wave_first((int32_t)stack[top]);
+            const uint32_t st  = (uint32_t)wave_first((int32_t)state[node]);
+            bool valid         = true;
+            if ((st & 3) != 2)
+            {
+                // one round trip: both counts, every in-edge slot, every alignment slot
+                const int32_t ic  = wave_first((int32_t)g.incoming_edge_count[node]);
+                const int32_t ac  = wave_first((int32_t)g.node_alignment_count[node]);
+                const int32_t ed  = lane < kEdges ? (int32_t)g.incoming_edges[(int64_t)node * kEdges + lane] : 0;
+                const int32_t al  = lane < kAligns ? (int32_t)g.node_alignments[(int64_t)node * kAligns + lane] : 0;
+                const bool check  = (st & 4) != 0;
+                const bool push_e = lane < ic && (state[max(ed, 0)] & 3) != 2;
+                const bool push_a = check && lane < ac && (state[max(al, 0)] & 3) != 2;
+                const unsigned long long me = __ballot(push_e), ma = __ballot(push_a);
+                const int32_t ne = __popcll(me), na = __popcll(ma);
+                if (top + ne + na >= stack_cap) return false;
+                const unsigned long long below = (1ull << lane) - 1;
+                if (push_e) stack[top + 1 + __popcll(me & below)] = (uint32_t)ed;
+                if (push_a)
+                {
+                    stack[top + 1 + ne + __popcll(ma & below)] = (uint32_t)al;
+                    state[al] &= (uint8_t)~4u; // check[aid] = 0 (two slots never name the same node)
+                }
+                valid = ne + na == 0;
+                top += ne + na;
+                if (valid)
+                {
+                    if (lane == 0) state[node] = (uint8_t)((st & ~3u) | 2u);
+                    if (check)
+                    {
+                        if (lane == 0)
+                        {
+                            g.sorted_poa[sorted_idx]  = (IdT)node;
+                            g.node_id_to_pos[node]    = (IdT)sorted_idx;
+                        }
+                        if (lane < ac)
+                        {
+                            g.sorted_poa[sorted_idx + 1 + lane] = (IdT)al;
+                            g.node_id_to_pos[al]                = (IdT)(sorted_idx + 1 + lane);
+                        }
+                        sorted_idx += 1 + ac;
+                    }
+                }
+                else if (lane == 0)
+                    state[node] = (uint8_t)((st & ~3u) | 1u);
+                // (LDS only: one wavefront's LDS operations execute in order; the order's global stores are not read before
+                // the end and must not be waited for in every visit)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (valid) top--;
+        }
+    }
+    wave_sync();
+    return true;
+}
+
+// MSA column of every node from the racon order and the check flags topsort_racon_wave left in `state`: a node with its
+// flag set opens a column, the aligned nodes behind it share it (node_id_to_msa_pos below, all lanes). Returns the MSA length.
+template <typename IdT>
+__device__ __forceinline__ int32_t node_id_to_msa_pos_wave(const GraphView<IdT>& g, int32_t node_count, const uint8_t* state, int lane)
+{
+    int32_t columns = 0;
+    for (int32_t base = 0; base < node_count; base += kWave)
+    {
+        const int32_t rank  = base + lane;
+        const int32_t node  = rank < node_count ? (int32_t)g.sorted_poa[rank] : 0;
+        const bool opens    = rank < node_count && (state[node] & 4) != 0;
+        const unsigned long long m = __ballot(opens);
+        if (rank < node_count) g.msa_pos[node] = (IdT)(columns + __popcll(m & ((2ull << lane) - 1)) - 1);
+        columns += __popcll(m);
+    }
+    wave_sync();
+    return columns;
+}
+
 // heaviest bundle + branch completion. `scores` has a guard element at index -1.
 template <typename IdT>
 __device__ int32_t branch_completion(int32_t max_score_id_pos, const GraphView<IdT>& g, int32_t node_count,
@@ -1361,6 +1457,10 @@ __device__ int32_t node_id_to_msa_pos(const GraphView<IdT>& g, int32_t node_coun
     return msa_pos;
 }
 
+// One lane per sequence: the walk along the sequence's path is a chain of dependent loads, so what counts is round trips per
+// node. The node's column, base, out-degree and its first two out-edges with their coverage counts are one round trip; an
+// edge's coverage list (the sequences that use the edge, up to max_sequences_per_poa) is searched eight entries per round
+// trip -- entry by entry the last sequences of a 32-read window paid up to 31 dependent loads per backbone node.
 template <typename IdT>
 __device__ void generate_msa_row(const GraphView<IdT>& g, uint16_t s, uint8_t* msa, int32_t msa_length,
                                  uint32_t max_sequences_per_poa, uint32_t max_limit_consensus_size)
@@ -1370,25 +1470,31 @@ __device__ void generate_msa_row(const GraphView<IdT>& g, uint16_t s, uint8_t* m
     uint8_t* row         = msa + (size_t)s * max_limit_consensus_size;
     for (;;)
     {
-        int32_t msa_pos = g.msa_pos[node_id];
-        row[msa_pos]    = g.nodes[node_id];
+        const int64_t eb      = (int64_t)node_id * kEdges;
+        const int32_t msa_pos = g.msa_pos[node_id];
+        const uint8_t base    = g.nodes[node_id];
+        const int32_t oc      = g.outgoing_edge_count[node_id];
+        const int32_t e0 = (int32_t)g.outgoing_edges[eb], e1 = (int32_t)g.outgoing_edges[eb + 1];
+        const int32_t c0 = (int32_t)g.out_cov_cnt[eb], c1 = (int32_t)g.out_cov_cnt[eb + 1];
+        row[msa_pos] = base;
         for (int32_t i = filled_until; i < msa_pos; i++) row[i] = '-';
         filled_until  = msa_pos + 1;
         bool end_node = true;
-        for (int32_t n = 0; n < g.outgoing_edge_count[node_id]; n++)
+        for (int32_t n = 0; n < oc && end_node; n++)
         {
-            int32_t to_node = g.outgoing_edges[(int64_t)node_id * kEdges + n];
-            uint16_t cc     = g.out_cov_cnt[(int64_t)node_id * kEdges + n];
-            for (int32_t m = 0; m < cc; m++)
+            const int32_t to_node = n == 0 ? e0 : (n == 1 ? e1 : (int32_t)g.outgoing_edges[eb + n]);
+            const int32_t cc      = n == 0 ? c0 : (n == 1 ? c1 : (int32_t)g.out_cov_cnt[eb + n]);
+            const uint16_t* list  = g.out_cov + (eb + n) * max_sequences_per_poa;
+            for (int32_t m0 = 0; m0 < cc && end_node; m0 += 8)
             {
-                if (g.out_cov[((int64_t)node_id * kEdges + n) * max_sequences_per_poa + m] == s)
-                {
-                    end_node = false;
-                    node_id  = to_node;
-                    break;
-                }
+                uint16_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = list[min(m0 + u, cc - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (m0 + u < cc && v[u] == s) end_node = false;
             }
-            if (!end_node) break;
+            if (!end_node) node_id = to_node;
         }
         if (end_node)
         {
