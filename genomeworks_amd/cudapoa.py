@@ -407,6 +407,14 @@ class SizeClassPlan:
             self.bytes_per_window.append(b.value)
         self.total_bytes = L.gw_poa_size_plan_total_bytes(self._h)
 
+    def admission_gates(self, compute_units=256):
+        """cudapoa::size_class_admission_gates: per class, the class whose end it waits for on the device (-1: none)."""
+        out = (C.c_int32 * max(len(self.groups), 1))()
+        self._L.gw_poa_size_plan_admission_gates.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        if self._L.gw_poa_size_plan_admission_gates(self._h, compute_units, out) != 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        return [out[k] for k in range(len(self.groups))]
+
     def keep(self, window_ids):
         """Restrict the plan to these windows (a rank's share of a multi-GPU job); the configs stay those of the whole set."""
         n = max(max((max(g) for g in self.groups if g), default=-1), max(window_ids, default=-1)) + 1

@@ -642,6 +642,15 @@ int gw_poa_size_plan_keep(gw_poa_size_plan* p, const uint8_t* keep, int32_t n_wi
     GW_CATCH(-1)
 }
 
+int gw_poa_size_plan_admission_gates(gw_poa_size_plan* p, int32_t compute_units, int32_t* gates)
+{
+    GW_TRY
+    const std::vector<int32_t> g = poa::size_class_admission_gates(p->plan, compute_units);
+    for (size_t k = 0; k < g.size(); ++k) gates[k] = g[k];
+    return 0;
+    GW_CATCH(-1)
+}
+
 gw_poa_multi* gw_poa_size_classes_run(int32_t n_windows, const int32_t* reads_per_window, const char* const* seqs, const int32_t* lengths,
                                       gw_poa_size_plan* plan, int32_t device, int64_t memory_budget, int8_t output_mask, int16_t gap_score,
                                       int16_t mismatch_score, int16_t match_score, double* compute_seconds)

@@ -244,6 +244,30 @@ void plan_size_classes(SizeClassPlan& plan, const std::vector<int32_t>& longest,
     }
 }
 
+std::vector<int32_t> size_class_admission_gates(const SizeClassPlan& plan, int32_t compute_units)
+{
+    const size_t classes = plan.groups.size();
+    std::vector<int32_t> gate_on(classes, -1);
+    const int64_t cus  = compute_units > 0 ? compute_units : 256;
+    const int64_t room = cus + cus / 4;
+    int64_t in_group   = 0;
+    int32_t prev_last = -1, last = -1;
+    for (size_t k = 0; k < classes; ++k)
+    {
+        if (plan.groups[k].empty()) continue;
+        const int64_t w = static_cast<int64_t>(plan.groups[k].size());
+        if (last >= 0 && in_group + w > room)
+        {
+            prev_last = last;
+            in_group  = 0;
+        }
+        gate_on[k] = prev_last;
+        in_group += w;
+        last = static_cast<int32_t>(k);
+    }
+    return gate_on;
+}
+
 void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std::vector<std::string>>& windows,
                                   const SizeClassPlan& plan, int32_t device, int64_t memory_budget, int8_t output_mask,
                                   int16_t gap_score, int16_t mismatch_score, int16_t match_score, double* compute_seconds)
@@ -301,27 +325,9 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
     // finish make room at once) fit; the next group of classes is gated, on the device, on the end of the lightest class
     // of the group before it. Admitting everything at once only makes the long chains of the heavy classes queue for CUs
     // behind light windows -- and those chains are what the set waits for at the end.
-    std::vector<int32_t> gate_on(classes, -1);
-    {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-        const int64_t room = static_cast<int64_t>(cus) + cus / 4;
-        int64_t in_group   = 0;
-        int32_t prev_last = -1, last = -1;
-        for (size_t k = 0; k < classes; ++k)
-        {
-            if (plan.groups[k].empty()) continue;
-            const int64_t w = static_cast<int64_t>(plan.groups[k].size());
-            if (last >= 0 && in_group + w > room)
-            {
-                prev_last = last;
-                in_group  = 0;
-            }
-            gate_on[k] = prev_last;
-            in_group += w;
-            last = static_cast<int32_t>(k);
-        }
-    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    const std::vector<int32_t> gate_on = size_class_admission_gates(plan, cus);
     std::vector<hipEvent_t> class_done(classes, nullptr);
     for (size_t k = 0; k < classes; ++k) GW_CU_CHECK_ERR(hipEventCreateWithFlags(&class_done[k], hipEventDisableTiming));
     std::mutex start_mutex;

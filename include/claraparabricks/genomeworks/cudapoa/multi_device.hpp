@@ -69,6 +69,12 @@ void plan_size_classes(SizeClassPlan& plan, const std::vector<int32_t>& longest,
                        float graph_length_factor = 3.0f, int32_t max_pred_distance = 0, int32_t mismatch_score = -6,
                        int32_t gap_score = -8, int32_t match_score = 8);
 
+/// Admission by residency (process_windows_size_classes): a long-read window occupies a compute unit for its whole life, so the
+/// device holds about one window per unit at a time. Classes are admitted in plan order while their windows (a quarter more than
+/// there are units: the first to finish make room at once) fit; the classes of the next group wait, on the device, for the end
+/// of the last class of the group before them. Returns, per class, the class it waits for (-1: admitted at once; empty classes: -1).
+std::vector<int32_t> size_class_admission_gates(const SizeClassPlan& plan, int32_t compute_units);
+
 /// One worker (host thread, stream, allocator slice, Batch) per class of the plan on `device`, all at once; a class whose
 /// windows do not fit its slice takes several fills. memory_budget: device bytes for all classes together (each class gets
 /// its share of the plan's total, scaled down if the total exceeds the budget). out.seconds = wall time of the workers

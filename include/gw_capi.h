@@ -151,6 +151,8 @@ int gw_poa_size_plan_class(gw_poa_size_plan* p, int32_t k, gw_poa_batch_config* 
 int gw_poa_size_plan_windows(gw_poa_size_plan* p, int32_t k, int32_t* window_ids);
 /* keep[w] != 0: window w stays in the plan (a rank of a multi-GPU job keeps its share; configs stay those of the whole set) */
 int gw_poa_size_plan_keep(gw_poa_size_plan* p, const uint8_t* keep, int32_t n_windows);
+/* cudapoa::size_class_admission_gates: gates[k] = class that class k waits for on a device of `compute_units` units, -1 = none */
+int gw_poa_size_plan_admission_gates(gw_poa_size_plan* p, int32_t compute_units, int32_t* gates);
 gw_poa_multi* gw_poa_size_classes_run(int32_t n_windows, const int32_t* reads_per_window, const char* const* seqs, const int32_t* lengths,
                                       gw_poa_size_plan* plan, int32_t device, int64_t memory_budget, int8_t output_mask, int16_t gap_score,
                                       int16_t mismatch_score, int16_t match_score, double* compute_seconds);

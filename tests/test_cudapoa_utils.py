@@ -170,3 +170,26 @@ def test_size_class_plan_is_a_partition_with_geometric_shapes():
     plan.keep([1, 6, 10])
     assert plan.groups == [[1], [], [6], [], [10]] and plan.total_bytes == sizes[0] + sizes[2] + sizes[4]
     assert cudapoa.SizeClassPlan([], msa_flag=False).configs == []
+
+
+def test_size_class_admission_gates():
+    """cudapoa::size_class_admission_gates (host-only): classes are admitted in plan order while their windows fit 1.25 x the
+    compute units; the classes of the next group wait for the last class of the group before. The long-read set of
+    BASELINE configs[3] has 157 / 151 / 160 / 130 windows per class: on 256 units the two heavy classes start at once and
+    the two light ones wait for the second."""
+    from genomeworks_amd import cudapoa
+    def plan_of(counts):
+        lengths = []
+        for k, c in enumerate(counts):
+            lengths += [30000 >> k] * c
+        return cudapoa.SizeClassPlan([["A" * n, "C" * (n - 1)] for n in lengths], msa_flag=True, adaptive_storage_factor=4.0)
+    plan = plan_of([157, 151, 160, 130])
+    assert [len(g) for g in plan.groups] == [157, 151, 160, 130]
+    assert plan.admission_gates(256) == [-1, -1, 1, 1]
+    assert plan.admission_gates(1024) == [-1, -1, -1, -1]
+    assert plan.admission_gates(64) == [-1, 0, 1, 2]      # nothing fits beside anything: a chain
+    plan.keep(list(range(157)) + list(range(157 + 151, 157 + 151 + 160)))
+    assert [len(g) for g in plan.groups] == [157, 0, 160, 0]
+    assert plan.admission_gates(256) == [-1, -1, -1, -1]  # 317 windows fit 320; empty classes gate nothing
+    assert plan.admission_gates(200) == [-1, -1, 0, -1]
+
