@@ -384,8 +384,19 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
         bool sorted_here = false;
         if constexpr (kCachedSort)
         {
-            if (status_and_count >= 0 && !c.spoa_accurate && !(a.debug_flags & (1 << 21)) &&
-                (int64_t)a.L.scores_elems * (int64_t)sizeof(ScoreT) >= (int64_t)(2 * ((node_count + 63) & ~63)) * 4)
+            // incremental order (replay of the previous run in blocks) when the ids fit its 17-bit fields and the score
+            // matrix holds its working set (24 bytes per node); GWHIP_DEBUG bit 17 selects the cached full re-sort instead
+            // (A/B: the choice must be the same for every read of a window, the two keep different things in local_cnt)
+            const bool incr_ok = c.max_nodes_per_graph <= 131071 && !(a.debug_flags & (1 << 17)) &&
+                                 (int64_t)a.L.scores_elems * (int64_t)sizeof(ScoreT) >= (int64_t)c.max_nodes_per_graph * 24 + 2048;
+            if (status_and_count >= 0 && !c.spoa_accurate && !(a.debug_flags & (1 << 21)) && incr_ok)
+            {
+                wave_sync();
+                topsort_kahn_incr_hbm<IdT>(g, node_count, status_and_count, reinterpret_cast<int32_t*>(scores), lane);
+                sorted_here = true;
+            }
+            else if (status_and_count >= 0 && !c.spoa_accurate && !(a.debug_flags & (1 << 21)) &&
+                     (int64_t)a.L.scores_elems * (int64_t)sizeof(ScoreT) >= (int64_t)(2 * ((node_count + 63) & ~63)) * 4)
             {
                 wave_sync();
                 topsort_kahn_cached<IdT>(g, node_count, status_and_count, smem, reinterpret_cast<int32_t*>(scores), lane);

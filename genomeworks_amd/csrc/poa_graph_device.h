@@ -1007,6 +1007,167 @@ __device__ __forceinline__ void topsort_kahn_incr_lds(const GraphView<IdT>& g, i
     if (tsel && lane == 0) *prof_acc += tacc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The incremental Kahn order (topsort_kahn_incr_lds above: replay of the previous run, 64 positions at a time, wherever
+// the state is in sync with it) for graphs beyond the LDS tables: same algorithm, its working set in HBM scratch (the
+// score matrix, dead between the merge and the next forward pass) with ids of up to 17 bits:
+//   ent[n] (uint4): x, y, z = out-edges 0..2;  w = unvisited in-edges [0:6) | new in-edge or new node [6] | new out-edge or
+//                   new node [7] | min(out-degree, 4) [8:11) | previous queue length [11:15) | previous position [15:32)
+//   queue[] = the new order: a pushed entry is the node id, a popped one node | queue length at the pop << 28
+//   sold[]  = the previous order
+// The w words are the in-edge counters: they are only touched with device-scope atomics after the build pass (block replay
+// decrements them from many lanes; a plain load could be served from a stale L1 line), everything else with plain loads and
+// stores of this one wavefront. Nodes with more than three out-edges always take an ordinary step (1.6 % of the nodes).
+// At long-read divergence the scalar model replays 86-88 % of a re-sort in blocks of 16-18 (tools/topsort_replay_stats.py).
+// Per node carried from read to read in GraphView::local_cnt as in the LDS version (queue length | out-degree << 4 |
+// in-degree << 10), so a window must use this routine for every read or for none.
+// ------------------------------------------------------------------------------------------------
+template <typename IdT>
+__device__ __forceinline__ void topsort_kahn_incr_hbm(const GraphView<IdT>& g, int32_t n_old, int32_t node_count, int32_t* scratch, int lane)
+{
+    constexpr int32_t kQClip = 15;
+    constexpr uint32_t kIdMask = 0x0fffffffu;
+    const int32_t n_pad = (node_count + 63) & ~63;
+    uint4* ent     = reinterpret_cast<uint4*>(scratch);
+    uint32_t* entw = reinterpret_cast<uint32_t*>(scratch);
+    int32_t* queue = scratch + 4 * n_pad;
+    int32_t* sold  = queue + n_pad + 64;
+    auto load_w = [&](int32_t n) -> uint32_t { return __hip_atomic_load(entw + 4 * (size_t)n + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto dec_w  = [&](int32_t n) -> uint32_t { return __hip_atomic_fetch_sub(entw + 4 * (size_t)n + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto w_inleft = [](uint32_t w) -> uint32_t { return w & 0x3fu; };
+    auto w_din    = [](uint32_t w) -> uint32_t { return (w >> 6) & 1u; };
+    auto w_dout   = [](uint32_t w) -> uint32_t { return (w >> 7) & 1u; };
+    auto w_ocq    = [](uint32_t w) -> int32_t { return (int32_t)((w >> 8) & 7u); };
+    auto w_qlen   = [](uint32_t w) -> int32_t { return (int32_t)((w >> 11) & 15u); };
+    auto w_pos    = [](uint32_t w) -> int32_t { return (int32_t)(w >> 15); };
+
+    // phase 1 (all lanes): node words with change flags, previous order, sources in ascending node id
+    int32_t tail = 0;
+    for (int32_t base = 0; base < node_count; base += kWave)
+    {
+        const int32_t n  = base + lane;
+        const int32_t nc = min(n, node_count - 1);
+        const int32_t nn = nc >= n_old ? 0 : nc;
+        const uint32_t ic = g.incoming_edge_count[nc], oc = g.outgoing_edge_count[nc];
+        const uint32_t e0 = (uint32_t)(int32_t)g.outgoing_edges[(int64_t)nc * kEdges];
+        const uint32_t e1 = (uint32_t)(int32_t)g.outgoing_edges[(int64_t)nc * kEdges + 1];
+        const uint32_t e2 = (uint32_t)(int32_t)g.outgoing_edges[(int64_t)nc * kEdges + 2];
+        const uint32_t m  = g.local_cnt[nn];
+        const uint32_t po = (uint32_t)(int32_t)g.node_id_to_pos[nn];
+        const int32_t so  = (int32_t)g.sorted_poa[nn];
+        bool is_src = false;
+        if (n < node_count)
+        {
+            const bool is_new = n >= n_old;
+            if (!is_new) sold[n] = so;
+            const uint32_t din  = (is_new || ((m >> 10) & 63u) != ic) ? 1u : 0u;
+            const uint32_t dout = (is_new || ((m >> 4) & 63u) != oc) ? 1u : 0u;
+            const uint32_t w    = (ic & 0x3fu) | (din << 6) | (dout << 7) | (min(oc, 4u) << 8) | (is_new ? 0u : (m & 15u) << 11) | (is_new ? 0u : po << 15);
+            ent[n] = make_uint4(oc > 0 ? e0 : 0u, oc > 1 ? e1 : 0u, oc > 2 ? e2 : 0u, w);
+            is_src = ic == 0;
+        }
+        const unsigned long long ms = __ballot(is_src);
+        if (is_src) queue[tail + __popcll(ms & ((1ull << lane) - 1))] = n;
+        tail += __popcll(ms);
+    }
+    wave_sync();
+    auto lane0_dec = [&](int32_t n) -> uint32_t { // one decrement, its old value to every lane
+        uint32_t old = 0;
+        if (lane == 0) old = dec_w(n);
+        return (uint32_t)wave_first((int32_t)old);
+    };
+    // phase 2: wave-uniform control; k = new nodes output so far, M = highest previous position output so far
+    int32_t head = 0, k = 0, M = -1;
+    while (head < tail)
+    {
+        const int32_t u   = (int32_t)((uint32_t)wave_first(queue[head]) & kIdMask);
+        const uint4 eu    = ent[u];
+        const uint32_t hi = (uint32_t)wave_first((int32_t)load_w(u));
+        const int32_t ocq = w_ocq(hi);
+        const int32_t c0 = wave_first((int32_t)eu.x), c1 = wave_first((int32_t)eu.y), c2 = wave_first((int32_t)eu.z);
+        const uint32_t h0 = ocq > 0 ? (uint32_t)wave_first((int32_t)load_w(c0)) : 0u;
+        const uint32_t h1 = ocq > 1 ? (uint32_t)wave_first((int32_t)load_w(c1)) : 0u;
+        const uint32_t h2 = ocq > 2 ? (uint32_t)wave_first((int32_t)load_w(c2)) : 0u;
+        const int32_t len = tail - head;
+        const int32_t p = w_pos(hi), qo = w_qlen(hi);
+        const bool is_new = u >= n_old;
+        // an ordinary step is needed when the node has a new out-edge, a child has a new in-edge, or it has more than three children
+        const bool need_real = is_new | (w_dout(hi) != 0) | (ocq > 3) | ((ocq > 0) & (w_din(h0) != 0)) | ((ocq > 1) & (w_din(h1) != 0)) |
+                               ((ocq > 2) & (w_din(h2) != 0));
+        bool block = !need_real && (head - k == p) && (M == p - 1) && (len == qo) && (qo < kQClip);
+        if (block && len > 1) // the queue must be the previous run's queue at p, element by element
+        {
+            const int32_t qi  = lane < len ? (int32_t)((uint32_t)queue[head + lane] & kIdMask) : u;
+            const uint32_t qh = load_w(qi);
+            const bool ok     = lane >= len || (qi < n_old && w_pos(qh) == p + lane);
+            block             = __ballot(!ok) == 0;
+        }
+        if (block)
+        {
+            // lane l replays the pop of position p + l of the previous order
+            const int32_t posl = p + lane;
+            const bool valid   = posl < n_old;
+            const int32_t node = valid ? sold[posl] : u;
+            const uint4 en     = ent[node];
+            const uint32_t nhi = load_w(node);
+            const int32_t noc  = w_ocq(nhi);
+            const int32_t ch0  = noc > 0 ? (int32_t)en.x : node;
+            const int32_t ch1  = noc > 1 ? (int32_t)en.y : node;
+            const int32_t ch2  = noc > 2 ? (int32_t)en.z : node;
+            const uint32_t g0 = load_w(ch0), g1 = load_w(ch1), g2 = load_w(ch2);
+            const bool bad = !valid | (w_dout(nhi) != 0) | (noc > 3) | ((lane > 0) & (w_din(nhi) != 0)) | ((noc > 0) & (w_din(g0) != 0)) |
+                             ((noc > 1) & (w_din(g1) != 0)) | ((noc > 2) & (w_din(g2) != 0));
+            const unsigned long long mb = __ballot(bad);
+            const int32_t b = mb ? __ffsll((unsigned long long)mb) - 1 : kWave; // >= 1: lane 0 passed the test above
+            // all decrements in flight together; a child whose counter reaches 0 was pushed by the previous run here
+            const bool do0 = lane < b && noc > 0, do1 = lane < b && noc > 1, do2 = lane < b && noc > 2;
+            uint32_t r0 = 0, r1 = 0, r2 = 0;
+            if (do0) r0 = dec_w(ch0);
+            if (do1) r1 = dec_w(ch1);
+            if (do2) r2 = dec_w(ch2);
+            const int32_t npush = __popcll(__ballot(do0 && w_inleft(r0) == 1u)) + __popcll(__ballot(do1 && w_inleft(r1) == 1u)) +
+                                  __popcll(__ballot(do2 && w_inleft(r2) == 1u));
+            // pushed entries continue the previous order; slots popped inside this same block are written by the popping lane
+            // (with their queue length), the others here: disjoint slots
+            for (int32_t j = lane; j < npush; j += kWave)
+                if (tail + j >= head + b) queue[tail + j] = sold[p + len + j];
+            if (lane < b) queue[head + lane] = (int32_t)((uint32_t)node | ((uint32_t)w_qlen(nhi) << 28));
+            head += b;
+            tail += npush;
+            M = p + b - 1;
+            continue;
+        }
+        // ordinary Kahn step
+        if (lane == 0) queue[head] = (int32_t)((uint32_t)u | ((uint32_t)min(len, kQClip) << 28));
+        head++;
+        k += is_new ? 1 : 0;
+        M = is_new ? M : max(M, p);
+        const int32_t oc = ocq > 3 ? wave_first((int32_t)g.outgoing_edge_count[u]) : ocq;
+        for (int32_t e = 0; e < oc; e++)
+        {
+            const int32_t child = e == 0 ? c0 : (e == 1 ? c1 : (e == 2 ? c2 : wave_first((int32_t)g.outgoing_edges[(int64_t)u * kEdges + e])));
+            const uint32_t old  = lane0_dec(child);
+            if (w_inleft(old) == 1u)
+            {
+                if (lane == 0) queue[tail] = child;
+                tail++;
+            }
+        }
+    }
+    wave_sync();
+    // phase 3 (all lanes): publish order, inverse map and the per-node record for the next read
+    for (int32_t i = lane; i < node_count; i += kWave)
+    {
+        const uint32_t e   = (uint32_t)queue[i];
+        const int32_t node = (int32_t)(e & kIdMask);
+        const uint32_t oc = g.outgoing_edge_count[node], ic = g.incoming_edge_count[node];
+        g.sorted_poa[i]        = (IdT)node;
+        g.node_id_to_pos[node] = (IdT)i;
+        g.local_cnt[node]      = (uint16_t)((e >> 28) | (oc << 4) | (ic << 10));
+    }
+    wave_sync();
+}
+
 // racon/spoa DFS order (aligned nodes adjacent)
 template <typename IdT>
 __device__ void topsort_racon(const GraphView<IdT>& g, int32_t node_count, int32_t max_nodes_per_graph)

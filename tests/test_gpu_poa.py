@@ -222,7 +222,8 @@ def test_long_read_adaptive_msa_32bit_path():
 def test_long_read_forward_and_traceback_variants_agree(monkeypatch):
     """A/B inside the long-read kernel (graphs beyond the LDS tables, adaptive band): the pipelined multi-wave forward
     pass with trace codes and the table-lookup traceback (default) against the table-lookup traceback switched off
-    (GWHIP_DEBUG bit 6: recomputation from the score matrix) and against the single-wave forward pass (bit 18), on
+    (GWHIP_DEBUG bit 6: recomputation from the score matrix), against the single-wave forward pass (bit 18) and against the
+    full topological re-sorts (bit 17: cached Kahn order, bit 21: serial; default: incremental order with block replay), on
     divergent long reads whose bands widen to 512 .. 1536 columns: identical MSA, status and cell counts, and equal to
     the oracle."""
     from genomeworks_amd import synthetic
@@ -230,7 +231,8 @@ def test_long_read_forward_and_traceback_variants_agree(monkeypatch):
     windows.append([r.decode() for r in synthetic.generate_window(9200, 6000, 10, 900, 40, 40)])   # four predecessors and more
     windows.append([r.decode() for r in synthetic.generate_window(9201, 3000, 5, 20, 900, 20)])    # reads much longer than the backbone
     out = {}
-    for name, flag in (("default", None), ("recomputed_traceback", str(1 << 6)), ("single_wave", str(1 << 18))):
+    for name, flag in (("default", None), ("recomputed_traceback", str(1 << 6)), ("single_wave", str(1 << 18)),
+                       ("cached_full_resort", str(1 << 17)), ("serial_full_resort", str(1 << 21))):
         if flag is None:
             monkeypatch.delenv("GWHIP_DEBUG", raising=False)
         else:
@@ -239,6 +241,8 @@ def test_long_read_forward_and_traceback_variants_agree(monkeypatch):
         out[name] = (b.get_msa(), b.total_cells())
     assert out["default"] == out["recomputed_traceback"]
     assert out["default"] == out["single_wave"]
+    assert out["default"] == out["cached_full_resort"]   # incremental Kahn order in HBM (default) vs the cached full re-sort
+    assert out["default"] == out["serial_full_resort"]   # ... vs the reference's schedule on one lane
     (msa, status), _ = out["default"]
     cfg = oracle_cfg("adaptive_band", 8192, 12, output_mask=2, nodes=4 * 8192)
     with O.Workspace(cfg) as ws:
