@@ -1,5 +1,7 @@
 #!/bin/bash
-# A/B on one box: the kernel library of the previous commit (genomeworks_amd/lib_old) against the current one
+# A/B on one box: the kernel library of another commit against the current one. genomeworks_amd/lib_old/libgwhip.so is not
+# kept in the tree: build it from a worktree of that commit (`git worktree add /tmp/old <commit>`, then
+# `python -c "from genomeworks_amd import build; build.build_kernels()"` there) and copy it in before the gpurun call.
 set -u
 TAG=${1:-r02ab}
 mkdir -p gpurun_out/${TAG}
