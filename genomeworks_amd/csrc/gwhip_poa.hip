@@ -106,9 +106,12 @@ __device__ GraphView<IdT> carve_graph(uint8_t* slab, const PoaLayout& L)
 // NW: wavefronts per window. 1 everywhere but for graphs beyond the LDS tables in the adaptive band mode (long reads),
 // where the wide bands' forward pass is a pipeline of wavefronts over 256-column blocks (generic_forward_skew); every other
 // phase is wave 0's, the helper wavefronts wait at a barrier in between.
-template <typename ScoreT, typename IdT, typename TraceT, int BM, bool MSA, bool LDS_TABLES, int NW>
+// DBG: the instantiation that honours GWHIP_DEBUG selectors and the per-phase cycle accounting. Production launches
+// (no selector, no phase buffer) run DBG = false, in which every selector test and profiling hook folds away.
+template <typename ScoreT, typename IdT, typename TraceT, int BM, bool MSA, bool LDS_TABLES, int NW, bool DBG>
 __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
 {
+    const int32_t debug_flags = DBG ? a.debug_flags : 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane       = threadIdx.x & (kWave - 1);
     const int wave       = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
     uint64_t cells = 0;
     int32_t node_count = len0;
     uint64_t phase_acc[kPhCount] = {0, 0, 0, 0, 0, 0};
-    PhaseClock pc{a.phase_cycles ? phase_acc : nullptr, 0};
+    PhaseClock pc{(DBG && a.phase_cycles) ? phase_acc : nullptr, 0};
     wave_sync();
     pc.start();
 
@@ -276,20 +279,20 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
         {
             alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                 banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
-                                                c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring,
+                                                c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring,
                                                 mw_args, mw_shared);
             if (alen == kShiftLeft || alen == kShiftRight)
                 alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                     banded_buffer_size, alignment_graph, alignment_read,
                                                     c.alignment_band_width, c.gap_score, c.mismatch_score, c.match_score,
-                                                    alen, cells, pc, a.debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring,
+                                                    alen, cells, pc, debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring,
                                                     mw_args, mw_shared);
         }
         else if (BM == GWHIP_STATIC_BAND || BM == GWHIP_ADAPTIVE_BAND)
         {
             alen = nw_banded<ScoreT, IdT, RowT, false, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                  banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
-                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, a.debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring);
+                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring);
         }
         else
         {
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
                                                                (uint16_t)s, (uint32_t)c.max_sequences_per_poa,
                                                                c.max_nodes_per_graph, scratch, scratch + lpad,
                                                                reinterpret_cast<uint32_t*>(scratch + 2 * lpad), lane,
-                                                               a.debug_flags, pc.acc ? &pc.acc[kPhOther] : nullptr);
+                                                               debug_flags, pc.acc ? &pc.acc[kPhOther] : nullptr);
             if (par_rc == 0)
             {
                 if (lane == 0) seq_lens[0] = new_count; // :506
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
                                                       (uint16_t)s, (uint32_t)c.max_sequences_per_poa,
                                                       c.max_nodes_per_graph, reinterpret_cast<int16_t*>(smem),
                                                       reinterpret_cast<int16_t*>(smem) + 2048,
-                                                      reinterpret_cast<uint32_t*>(lds_rowinfo_region), lane, a.debug_flags,
+                                                      reinterpret_cast<uint32_t*>(lds_rowinfo_region), lane, debug_flags,
                                                       pc.acc ? &pc.acc[kPhOther] : nullptr);
             if (par_rc == 0)
             {
@@ -387,15 +390,15 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
             // incremental order (replay of the previous run in blocks) when the ids fit its 17-bit fields and the score
             // matrix holds its working set (24 bytes per node); GWHIP_DEBUG bit 17 selects the cached full re-sort instead
             // (A/B: the choice must be the same for every read of a window, the two keep different things in local_cnt)
-            const bool incr_ok = c.max_nodes_per_graph <= 131071 && !(a.debug_flags & (1 << 17)) &&
+            const bool incr_ok = c.max_nodes_per_graph <= 131071 && !(debug_flags & (1 << 17)) &&
                                  (int64_t)a.L.scores_elems * (int64_t)sizeof(ScoreT) >= (int64_t)c.max_nodes_per_graph * 24 + 2048;
-            if (status_and_count >= 0 && !c.spoa_accurate && !(a.debug_flags & (1 << 21)) && incr_ok)
+            if (status_and_count >= 0 && !c.spoa_accurate && !(debug_flags & (1 << 21)) && incr_ok)
             {
                 wave_sync();
                 topsort_kahn_incr_hbm<IdT>(g, node_count, status_and_count, reinterpret_cast<int32_t*>(scores), lane);
                 sorted_here = true;
             }
-            else if (status_and_count >= 0 && !c.spoa_accurate && !(a.debug_flags & (1 << 21)) &&
+            else if (status_and_count >= 0 && !c.spoa_accurate && !(debug_flags & (1 << 21)) &&
                      (int64_t)a.L.scores_elems * (int64_t)sizeof(ScoreT) >= (int64_t)(2 * ((node_count + 63) & ~63)) * 4)
             {
                 wave_sync();
@@ -417,11 +420,11 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
         {
             if constexpr (LDS_TABLES)
             {
-                if (!(a.debug_flags & (1 << 21))) // GWHIP_DEBUG bit 21: full re-sort after every read (A/B switch)
+                if (!(debug_flags & (1 << 21))) // GWHIP_DEBUG bit 21: full re-sort after every read (A/B switch)
                     topsort_kahn_incr_lds<IdT>(g, node_count, status_and_count, lds_rowinfo_region, smem, lds_read_buf, lane,
-                                               a.debug_flags, pc.acc ? &pc.acc[kPhOther] : nullptr);
+                                               debug_flags, pc.acc ? &pc.acc[kPhOther] : nullptr);
                 else
-                    topsort_kahn_lds<IdT>(g, status_and_count, lds_rowinfo_region, smem, lane, a.debug_flags, pc.acc ? &pc.acc[kPhOther] : nullptr);
+                    topsort_kahn_lds<IdT>(g, status_and_count, lds_rowinfo_region, smem, lane, debug_flags, pc.acc ? &pc.acc[kPhOther] : nullptr);
             }
         }
         pc.tick(kPhTopsort);
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
         node_count = status_and_count;
     }
     if (lane == 0 && a.cells) a.cells[w] = cells;
-    if (lane == 0 && a.phase_cycles)
+    if (DBG && lane == 0 && a.phase_cycles)
         for (int k = 0; k < kPhCount; k++) a.phase_cycles[(size_t)w * kPhCount + k] = phase_acc[k];
     if constexpr (NW > 1)
     {
@@ -601,10 +604,15 @@ static hipError_t launch_window_kernel(const KernelArgs& ka_in, hipStream_t stre
         {                                                                                                          \
             lds_req            = kReservedCuLds;                                                                   \
             ka.wide_ring_bytes = (int32_t)(kReservedCuLds - wide_rest);                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW>), \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, false>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReservedCuLds);             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, true>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReservedCuLds);             \
         }                                                                                                          \
-        hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW>), grid, dim3(kWave * NW), lds_req, stream, ka); \
+        if (ka.debug_flags != 0 || ka.phase_cycles != nullptr)                                                     \
+            hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, true>), grid, dim3(kWave * NW), lds_req, stream, ka); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, false>), grid, dim3(kWave * NW), lds_req, stream, ka); \
     }                                                                                                              \
     break;
     switch (ka.cfg.band_mode)

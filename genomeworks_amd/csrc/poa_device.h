@@ -1482,6 +1482,8 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
 
 } // namespace gwhip
 #include "poa_forward_packed.h"
+#include "poa_forward_moves.h"
+#include "poa_traceback_moves.h"
 namespace gwhip
 {
 
@@ -2472,14 +2474,23 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     };
 
     constexpr bool kFastOk = std::is_same<RowT, RowInfo<true>>::value && LDS_READ;
-    bool fast_done = false, codes_valid = false;
+    bool fast_done = false, codes_valid = false, moves_valid = false;
     if constexpr (kFastOk && std::is_same<ScoreT, int16_t>::value)
     {
         // packed 16-bit pass for the 256-column band (preconditions: poa_forward_packed.h)
         const bool packed_ok = band_width == 256 && max_column >= band_width && ring_bytes >= kPkSlots * kPkSlotBytes &&
                                abs(gap_score) <= 30 && abs(match_score) <= 100 && abs(mismatch_score) <= 100 &&
-                               codes != nullptr && !(dbg & 256);
-        if (packed_ok)
+                               codes != nullptr && !(dbg & 256) && ring_bytes >= kMtBytes;
+        if (packed_ok && !(dbg & (1 << 25)))
+        {
+            // round 3: move bytes, row kinds, descriptors in registers (poa_forward_moves.h); GWHIP_DEBUG bit 25 selects the
+            // round-2 pass with its code-table traceback instead (A/B)
+            banded_forward_moves<IdT>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
+                                      reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score);
+            fast_done   = true;
+            moves_valid = true;
+        }
+        else if (packed_ok)
         {
             classify_rows(rowinfo, graph_count, lane, reinterpret_cast<const uint64_t*>(code_tile), dbg, pc.acc ? &pc.acc[kPhOther] : nullptr);
             wave_sync();
@@ -2784,9 +2795,19 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     const bool tile_fits = (int32_t)(64 * 64 * sizeof(ScoreT) + 64 * sizeof(int32_t)) <= ring_bytes; // also covers the 60 x 68 + 64-word layout
     constexpr bool kLanesOk = std::is_same<RowT, RowInfo<true>>::value && LDS_READ;
     bool tb_done = false;
+    if constexpr (kLanesOk && std::is_same<ScoreT, int16_t>::value)
+    {
+        if (moves_valid)
+        {
+            aligned_nodes = traceback_moves<IdT, ADAPTIVE>(b, g, rowinfo, graph_count, lds_read, read_length, wave_first(best_i),
+                                                           alignment_graph, alignment_read, gap_score, mismatch_score, match_score,
+                                                           rerun, reinterpret_cast<uint8_t*>(ring_base), codes);
+            tb_done = true;
+        }
+    }
     if constexpr (kLanesOk)
     {
-        if (tile_fits && b.stride >= 64 && !(dbg & 32))
+        if (!tb_done && tile_fits && b.stride >= 64 && !(dbg & 32))
         {
             aligned_nodes = traceback_banded_lanes<ScoreT, IdT, ADAPTIVE>(b, g, rowinfo, graph_count, lds_read, read_length,
                                                                           wave_first(best_i), alignment_graph, alignment_read, gap_score,

@@ -28,6 +28,10 @@ int32_t poa_band_start_for_row(int32_t row, float gradient, int32_t band_width, 
 #define SCORE_T int16_t
 #define SCORE_MIN INT16_MIN
 #define SFX(n) n##_s16
+/* Optional observer of the banded traceback (one call per step: the cell left and the cell entered). NULL unless an
+ * analysis tool installs one; it never changes a result. */
+void (*poa_oracle_step_hook)(int32_t i, int32_t j, int32_t prev_i, int32_t prev_j) = 0;
+
 #include "poa_nw.inc"
 #include "poa_nw_tb.inc"
 #undef SCORE_T
