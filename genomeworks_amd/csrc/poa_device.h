@@ -2486,7 +2486,8 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             // round 3: move bytes, row kinds, descriptors in registers (poa_forward_moves.h); GWHIP_DEBUG bit 25 selects the
             // round-2 pass with its code-table traceback instead (A/B)
             banded_forward_moves<IdT>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
-                                      reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score);
+                                      reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score, dbg,
+                                      pc.acc ? &pc.acc[kPhOther] : nullptr);
             fast_done   = true;
             moves_valid = true;
         }

@@ -22,7 +22,7 @@
 //   * TWO PHASES: rows whose band starts at column 0 (the first ~band/2 rows of a read: their left boundary is a
 //     real cell) and the rest (left boundary = min_score by construction) run in separate instantiations, so the
 //     bulk of the rows carries no boundary code at all.
-//   * Stores address HBM as scalar base + per-lane 32-bit offset (no 64-bit vector address arithmetic per row).
+//   * Stores go through per-lane running pointers (one 64-bit add per row and stream).
 //
 // Preconditions are those of poa_forward_packed.h (checked by nw_banded).
 #pragma once
@@ -45,21 +45,12 @@ __device__ __forceinline__ uint32_t pk_mad_u16_vvs(uint32_t a, uint32_t b, uint3
     asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(s));
     return d;
 }
-// stores through scalar base + per-lane byte offset
-__device__ __forceinline__ void gstore_u64(const void* sbase, uint32_t voff, uint32_t lo, uint32_t hi)
+// lane 0 only: the 2 bytes just below the lane's own pointer (the left-boundary slot of a score row). The address is a
+// per-lane VGPR pair: an inline-asm VMEM instruction must not take a scalar base the compiler may just have reloaded with
+// v_readlane (the VALU-writes-SGPR -> VMEM hazard is not tracked across inline asm).
+__device__ __forceinline__ void gstore_u16_lane0_below(const void* vptr, uint32_t v)
 {
-    const uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
-    asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ void gstore_u32(const void* sbase, uint32_t voff, uint32_t v)
-{
-    asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
-}
-// lane 0 only: the 2 bytes just below the lane's own offset (the left-boundary slot of a score row)
-__device__ __forceinline__ void gstore_u16_lane0_below(const void* sbase, uint32_t voff, uint32_t v)
-{
-    asm volatile("s_mov_b64 exec, 1\n\tglobal_store_short %0, %1, %2 offset:-2\n\ts_mov_b64 exec, -1" ::"v"(voff), "v"(v), "s"(sbase)
-                 : "memory");
+    asm volatile("s_mov_b64 exec, 1\n\tglobal_store_short %0, %1, off offset:-2\n\ts_mov_b64 exec, -1" ::"v"(vptr), "v"(v) : "memory");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -108,8 +99,21 @@ template <typename IdT>
 __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, RowInfo<true>* rowinfo, int32_t graph_count,
                                                      const uint8_t* lds_read, int16_t* scores, uint8_t* moves, uint8_t* ring,
                                                      const uint64_t* xpred, int32_t max_column, int32_t gap_score,
-                                                     int32_t mismatch_score, int32_t match_score)
+                                                     int32_t mismatch_score, int32_t match_score, int32_t dbg,
+                                                     uint64_t* prof_acc)
 {
+    // timing ablations (GWHIP_DEBUG, debug instantiation only; results are only meaningful on a relaunch over the
+    // buffers of an unablated launch of the same batch): bit 26 no score-row stores, bit 27 no move-row stores
+    // (tools/microbench_rows.hip only, results are garbage: bit 20 no ring write, 19 no guard write, 18 no cross-lane scan,
+    // 17 no move bytes, 16 no rows at all)
+    const bool st_scores = !(dbg & (1 << 26)), st_moves = !(dbg & (1 << 27));
+    const bool ab_ring = !(dbg & (1 << 20)), ab_guard = !(dbg & (1 << 19)), ab_scan = !(dbg & (1 << 18)), ab_moves = !(dbg & (1 << 17)),
+               ab_rows = !(dbg & (1 << 16));
+    // profiling (GWHIP_DEBUG bits 28-30 = row kind + 1): cycles spent in rows of that kind, or with bit 12 their number;
+    // arrives in the "other" phase accumulator
+    const int32_t ksel = prof_acc ? ((dbg >> 28) & 7) - 1 : -1;
+    const bool kcount  = (dbg & (1 << 12)) != 0;
+    uint64_t kacc      = 0;
     constexpr int32_t band_width = 256;
     constexpr int32_t stride     = band_width + kRightPad;
     const int lane               = threadIdx.x & (kWave - 1);
@@ -152,9 +156,9 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
     uint32_t rd4n = lds_load_u32(read_base + lane4 + 4);
     uint32_t a1   = (uint32_t)lane8;
     uint32_t ga   = (a1 + guard_off) & (kPkSlotBytes - 1);
-    // per-lane byte offsets of the lane's quad in the HBM score row / of its four bytes in the move row of the CURRENT row
-    uint32_t score_off = (uint32_t)lane8 + 2u * (1 + kRelShift);
-    uint32_t move_off  = (uint32_t)lane4 + (1 + kRelShift);
+    // per-lane pointers to the lane's quad in the HBM score row / to its four bytes in the move row of the CURRENT row
+    uint8_t* score_ptr = reinterpret_cast<uint8_t*>(scores) + lane8 + 2 * (1 + kRelShift);
+    uint8_t* move_ptr  = moves + lane4 + (1 + kRelShift);
 
     // row 0 into ring slot 0
     lds_store_u64(ring_base + a1, P01, P23);
@@ -166,7 +170,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
         const uint32_t pm01 = pk_max(u01, (u01 << 16) | 0x8000u);
         const uint32_t pm23 = pk_max(u23, (u23 << 16) | 0x8000u);
         const int32_t m3    = (int32_t)pk_max(pm01, pm23) >> 16; // max(u0..u3)
-        const int32_t incl  = wave_inclusive_max(m3);
+        const int32_t incl  = ab_scan ? wave_inclusive_max(m3) : m3;
         const int32_t excl  = max(wave_shr1(incl, cu), cu); // lane 0: the carry-in alone
         const uint32_t ex2  = __builtin_amdgcn_perm((uint32_t)excl, (uint32_t)excl, 0x01000100u);
         const uint32_t m1b  = __builtin_amdgcn_perm(pm01, pm01, 0x03020302u); // max(u0,u1) in both halves
@@ -195,21 +199,21 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
     // the finished row (P01/P23) of row r: HBM score row, ring slot r & 7 with its guard quad, and its move bytes
     auto store_row = [&](auto bs0_tag, int32_t r, int32_t rel0_val, uint32_t mv4) {
         constexpr bool BS0 = decltype(bs0_tag)::value;
-        score_off += stride * 2;
-        move_off += stride;
+        score_ptr += stride * 2;
+        move_ptr += stride;
         const uint32_t sbase = ring_base + (((uint32_t)r & (kPkSlots - 1)) * kPkSlotBytes);
-        gstore_u64(scores, score_off, P01, P23);
-        lds_store_u64(sbase + a1, P01, P23);
+        if (st_scores) *reinterpret_cast<uint2*>(score_ptr) = make_uint2(P01, P23);
+        if (ab_ring) lds_store_u64(sbase + a1, P01, P23);
         if constexpr (BS0)
         {
             const uint32_t rel0pk = ((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)rel0_val << 16);
-            lds_store_u64_lanes17(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
-            gstore_u16_lane0_below(scores, score_off, (uint32_t)rel0_val); // a real left-boundary value
+            if (ab_guard) lds_store_u64_lanes17(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
+            gstore_u16_lane0_below(score_ptr, (uint32_t)rel0_val); // a real left-boundary value
             prev_rel0 = rel0_val;
         }
-        else
+        else if (ab_guard)
             lds_store_u64_lanes17(sbase + ga, SENT2, GUARD_HI_MIN);
-        gstore_u32(moves, move_off, mv4);
+        if (st_moves) *reinterpret_cast<uint32_t*>(move_ptr) = mv4;
     };
     // four move bytes from two registers of 16-bit moves
     auto pack_moves = [&](uint32_t m01, uint32_t m23) -> uint32_t {
@@ -308,15 +312,15 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
         }
         scan_row(pk_make(s0, s1), pk_make(s2, s3), fe + gap_score);
         // stores (either flavour of left boundary)
-        score_off += stride * 2;
-        move_off += stride;
+        score_ptr += stride * 2;
+        move_ptr += stride;
         const uint32_t sbase  = ring_base + (((uint32_t)r & (kPkSlots - 1)) * kPkSlotBytes);
         const uint32_t rel0pk = ((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)rel0_val << 16);
-        gstore_u64(scores, score_off, P01, P23);
+        *reinterpret_cast<uint2*>(score_ptr) = make_uint2(P01, P23);
         lds_store_u64(sbase + a1, P01, P23);
         lds_store_u64_lanes17(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
-        if (bs == 0) gstore_u16_lane0_below(scores, score_off, (uint32_t)rel0_val);
-        gstore_u32(moves, move_off, 0u);
+        if (bs == 0) gstore_u16_lane0_below(score_ptr, (uint32_t)rel0_val);
+        *reinterpret_cast<uint32_t*>(move_ptr) = 0u;
         prev_rel0_io = rel0_val;
     };
 
@@ -360,7 +364,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
         // move = H == D ? 3 : H == V ? 2 : 1   ==  3 + [H != D] * (-1 - [H != V])
         const uint32_t m01 = pk_mad_u16(nz(P01, D01), pk_mad_u16(nz(P01, V01), NEG1, NEG1), THREE2);
         const uint32_t m23 = pk_mad_u16(nz(P23, D23), pk_mad_u16(nz(P23, V23), NEG1, NEG1), THREE2);
-        uint32_t mv4 = pack_moves(m01, m23);
+        uint32_t mv4 = ab_moves ? pack_moves(m01, m23) : 0u;
         if constexpr (MOVED) mv4 = is_lane63 ? 0u : mv4;
         store_row(bs0_tag, r, rel0_val, mv4);
     };
@@ -403,12 +407,17 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
             for (;;)
             {
                 // streak of rows whose predecessor is the previous row and whose band did not move
+                const uint64_t t_k0 = ksel == 0 ? clock64() : 0;
+                const int32_t r_k0  = r;
                 while (kind == 0)
                 {
                     reg_row(bs0_tag, std::false_type{}, r, d0, base4);
                     advance();
                 }
+                if (ksel == 0) kacc += kcount ? (uint64_t)(r - r_k0) : clock64() - t_k0;
                 if (kind == 7u) break;
+                const int32_t kind_now = (int32_t)min(kind, 4u);
+                const uint64_t t_kx    = ksel == kind_now ? clock64() : 0;
                 if (kind == 1)
                     reg_row(bs0_tag, std::true_type{}, r, d0, base4);
                 else if (kind <= 3)
@@ -558,16 +567,19 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
                     general_row(r, prev_rel0);
                     if constexpr (!BS0) prev_rel0 = min_score;
                 }
+                if (ksel == kind_now) kacc += kcount ? 1 : clock64() - t_kx;
                 advance();
             }
         }
     };
 
     const int32_t bs0_end = min(first_moved - 1, graph_count); // last row whose band starts at column 0
+    if (!ab_rows) return;
     run_rows(std::true_type{}, 1, bs0_end);
     // from here on every row's left boundary is min_score by construction; the first such row sees the previous row's
     // real boundary through the general routine (band-start transition rows are kind 4)
     run_rows(std::false_type{}, bs0_end + 1, graph_count);
+    if (ksel >= 0 && lane == 0) *prof_acc += kacc;
 }
 
 } // namespace gwhip

@@ -160,7 +160,6 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<int16_t>& b, 
     const bool is_diag    = kind == 0, is_vert = kind == 1, is_horiz = kind == 2, is_self = kind == 3;
     const int32_t col_dec = (is_vert | is_self) ? 0 : 1; // candidate column = j - col_dec
     const uint32_t lane_step = (uint32_t)lane * kMtStride;  // byte distance of the cell `lane` steps (1 up, 1 left) ahead
-    const uint32_t lane4     = (uint32_t)lane * 4;
 
     while (!(i == 0 && j == 0) && n < bound)
     {
@@ -193,9 +192,8 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<int16_t>& b, 
                 }
                 if (lane < take)
                 {
-                    const uint32_t off = (uint32_t)n * 4u + lane4;
-                    gstore_u32(alignment_graph, off, (uint32_t)og);
-                    gstore_u32(alignment_read, off, (uint32_t)orr);
+                    alignment_graph[n + lane] = og;
+                    alignment_read[n + lane]  = orr;
                 }
                 n += take;
                 i -= nrun + drow;
@@ -286,15 +284,14 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<int16_t>& b, 
         }
         if (lane == 0)
         {
-            gstore_u32(alignment_graph, (uint32_t)n * 4u, (uint32_t)(i == next_i ? -1 : i - 1)); // sorted position; node ids are filled in below
-            gstore_u32(alignment_read, (uint32_t)n * 4u, (uint32_t)(j == next_j ? -1 : j - 1));
+            alignment_graph[n] = i == next_i ? -1 : i - 1; // sorted position; node ids are filled in below
+            alignment_read[n]  = j == next_j ? -1 : j - 1;
         }
         n++;
         i = next_i;
         j = next_j;
     }
     if (n >= bound) n = kNwLoopFailed;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the entries above were stored behind the compiler's back
     wave_sync();
     for (int32_t k0 = lane; k0 < n; k0 += 4 * kWave) // 4 independent load chains per lane in flight
     {
