@@ -45,7 +45,6 @@ static_assert(kReadLds + kCodeTileLds >= 3072 * 2, "the incremental topsort keep
 // the band starts of those rows, and a sliding window of the read. 4 blocks per CU still fit (4 x 35 KB).
 constexpr int kBsRingBytes   = 2048; // band starts of the ring rows (64 x 4 B) + 64 staged rows of the HBM row table (64 x 24 B)
 constexpr int kReadWinBytes  = 4096;
-constexpr int kDuoLds        = 32;   // progress words of the two-wavefront forward pass (DuoShared, poa_forward_moves.h)
 constexpr int kMwLds         = 512;  // arguments, progress and carry words of the multi-wave forward pass (poa_device.h)
 constexpr size_t kReservedCuLds = 128 * 1024; // LDS of a multi-wave block (160 KB per CU: nothing else of this kernel family, >= 35 KB per block, fits beside it)
 
@@ -155,32 +154,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
     const float banded_buffer_size = __fmul_rn((float)c.max_nodes_per_graph, (float)c.matrix_sequence_dimension);
     MwArgs<ScoreT>* mw_args = nullptr;
     MwShared* mw_shared     = nullptr;
-    DuoShared* duo          = nullptr;
-    if constexpr (NW > 1 && LDS_TABLES)
-    {
-        // two wavefronts per window (short reads): wave 1 is the trail of the forward pass, parked at the barrier in between
-        static_assert(sizeof(DuoShared) <= kDuoLds, "DuoShared");
-        duo = reinterpret_cast<DuoShared*>(smem + kRingBytes + kRowInfoBytes + kReadLds + kCodeTileLds);
-        if (wave != 0)
-        {
-            if constexpr (std::is_same<ScoreT, int16_t>::value)
-            {
-                uint8_t* moves = a.L.codes ? slab + a.L.codes : nullptr;
-                for (;;)
-                {
-                    block_barrier();
-                    if (wave_first(duo->op) != 1) return;
-                    forward_trail(reinterpret_cast<const RowInfo<true>*>(smem + kRingBytes), smem + kRingBytes + kRowInfoBytes,
-                                  reinterpret_cast<int16_t*>(slab + a.L.scores), moves, smem,
-                                  reinterpret_cast<const uint64_t*>(smem + kRingBytes + kRowInfoBytes + kReadLds), c.gap_score,
-                                  c.mismatch_score, c.match_score, duo);
-                    block_barrier();
-                }
-            }
-            return;
-        }
-    }
-    if constexpr (NW > 1 && !LDS_TABLES)
+    if constexpr (NW > 1)
     {
         // Issue priority by the window's weight (its bases: 2^16 .. 2^19 and more -> 0 .. 3). A launch -- or several
         // concurrent launches of different size classes -- lasts as long as its heaviest window, one chain of dependent
@@ -194,6 +168,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
             else if (level == 2) __builtin_amdgcn_s_setprio(2);
             else if (level == 1) __builtin_amdgcn_s_setprio(1);
         }
+        static_assert(!LDS_TABLES, "the multi-wave forward pass belongs to the HBM-table layout");
         mw_args   = reinterpret_cast<MwArgs<ScoreT>*>(smem + ring_bytes + kBsRingBytes + kReadWinBytes);
         mw_shared = reinterpret_cast<MwShared*>(smem + ring_bytes + kBsRingBytes + kReadWinBytes + 128);
         if (wave != 0)
@@ -305,20 +280,19 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
             alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                 banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring,
-                                                mw_args, mw_shared, duo);
+                                                mw_args, mw_shared);
             if (alen == kShiftLeft || alen == kShiftRight)
                 alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                     banded_buffer_size, alignment_graph, alignment_read,
                                                     c.alignment_band_width, c.gap_score, c.mismatch_score, c.match_score,
                                                     alen, cells, pc, debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring,
-                                                    mw_args, mw_shared, duo);
+                                                    mw_args, mw_shared);
         }
         else if (BM == GWHIP_STATIC_BAND || BM == GWHIP_ADAPTIVE_BAND)
         {
             alen = nw_banded<ScoreT, IdT, RowT, false, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                  banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
-                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring,
-                                                 nullptr, nullptr, duo);
+                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring);
         }
         else
         {
@@ -332,7 +306,6 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
         if (alen == kNwLoopFailed) err = kLoopCountExceeded;
         else if (alen == kNwAdaptiveStorageFailed) err = kExceededAdaptiveBandedMatrixSize;
         else if (TB && alen == kNwTracebackBufferFailed) err = kExceededMaximumPredecessorDistance;
-        else if (alen == kNwDuoFailed) err = kGenericError;
         if (err)
         {
             if (lane == 0) { consensus[0] = kKernelError; consensus[1] = err; }
@@ -461,12 +434,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
     if (lane == 0 && a.cells) a.cells[w] = cells;
     if (DBG && lane == 0 && a.phase_cycles)
         for (int k = 0; k < kPhCount; k++) a.phase_cycles[(size_t)w * kPhCount + k] = phase_acc[k];
-    if constexpr (NW > 1 && LDS_TABLES)
-    {
-        if (lane == 0) duo->op = 2; // the trail wavefront leaves
-        block_barrier();
-    }
-    if constexpr (NW > 1 && !LDS_TABLES)
+    if constexpr (NW > 1)
     {
         if (lane == 0) mw_args->op = 2; // the helper wavefronts leave
         block_barrier();
@@ -629,11 +597,9 @@ static hipError_t launch_window_kernel(const KernelArgs& ka_in, hipStream_t stre
     dim3 grid(ka.total_windows);
 #define GW_LAUNCH(BM)                                                                                              \
     {                                                                                                              \
-        constexpr bool kDuo = LDS_TABLES && std::is_same<ScoreT, int16_t>::value &&                                \
-                              (BM == GWHIP_STATIC_BAND || BM == GWHIP_ADAPTIVE_BAND);                              \
-        constexpr int NW = kDuo ? 2 : ((!LDS_TABLES && BM == GWHIP_ADAPTIVE_BAND) ? kSkWaves : 1);                 \
-        size_t lds_req = lds + (kDuo ? kDuoLds : 0);                                                               \
-        if (NW > 1 && !LDS_TABLES) /* multi-wave blocks (long reads): the register count allows one 8-wave block per CU anyway; it   \
+        constexpr int NW = (!LDS_TABLES && BM == GWHIP_ADAPTIVE_BAND) ? kSkWaves : 1;                              \
+        size_t lds_req = lds;                                                                                      \
+        if (NW > 1) /* multi-wave blocks (long reads): the register count allows one 8-wave block per CU anyway; it   \
                        owns the CU's LDS and puts it to use as a ring of 20 rows of the widest band */             \
         {                                                                                                          \
             lds_req            = kReservedCuLds;                                                                   \

@@ -140,12 +140,6 @@ __device__ __forceinline__ void block_barrier()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-// one look at a progress word another wavefront of the block writes (LDS)
-__device__ __forceinline__ int32_t lds_poll(const int32_t* p)
-{
-    const int32_t v = *(const volatile __attribute__((address_space(3))) int32_t*)p;
-    return __builtin_amdgcn_readfirstlane(v);
-}
 __device__ __forceinline__ int32_t wave_bcast(int32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ int32_t wave_first(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -1552,6 +1546,11 @@ struct MwShared // in LDS, behind the regions of the single-wave layout
     unsigned long long prof;    // profiling: the selected counter, summed over the waves
 };
 
+__device__ __forceinline__ int32_t lds_poll(const int32_t* p)
+{
+    const int32_t v = *(const volatile __attribute__((address_space(3))) int32_t*)p;
+    return __builtin_amdgcn_readfirstlane(v);
+}
 
 template <typename ScoreT, typename IdT, typename RowT>
 __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, const GraphView<IdT>& g, const RowT* rowinfo, ScoreT* ring,
@@ -2373,7 +2372,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                              int32_t band_width, int32_t gap_score, int32_t mismatch_score, int32_t match_score,
                              int32_t rerun, uint64_t& cells, PhaseClock& pc, int32_t dbg = 0, uint8_t* codes = nullptr,
                              uint8_t* code_tile = nullptr, uint8_t* read_window = nullptr, int32_t* bs_ring = nullptr,
-                             MwArgs<ScoreT>* mw_args = nullptr, MwShared* mw_shared = nullptr, DuoShared* duo = nullptr)
+                             MwArgs<ScoreT>* mw_args = nullptr, MwShared* mw_shared = nullptr)
 {
     const int lane              = threadIdx.x & (kWave - 1);
     const int32_t min_score     = Limits<ScoreT>::min / 2;
@@ -2486,19 +2485,9 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
         {
             // round 3: move bytes, row kinds, descriptors in registers (poa_forward_moves.h); GWHIP_DEBUG bit 25 selects the
             // round-2 pass with its code-table traceback instead (A/B)
-            // two wavefronts per window when the block has a second one (GWHIP_DEBUG bit 24: the lead does everything, A/B)
-            if (duo != nullptr && !(dbg & (1 << 24)))
-            {
-                banded_forward_moves<IdT, 1>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
-                                             reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score,
-                                             0, nullptr, duo);
-                block_barrier(); // the trail wavefront has stored its last row
-                if (wave_first(duo->fail) != 0) return kNwDuoFailed; // a bounded hand-over wait ran out: never a silent result
-            }
-            else
-                banded_forward_moves<IdT, 0>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
-                                             reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score, dbg,
-                                             pc.acc ? &pc.acc[kPhOther] : nullptr);
+            banded_forward_moves<IdT>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
+                                      reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score, dbg,
+                                      pc.acc ? &pc.acc[kPhOther] : nullptr);
             fast_done   = true;
             moves_valid = true;
         }

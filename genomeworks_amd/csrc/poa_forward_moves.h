@@ -57,7 +57,6 @@ __device__ __forceinline__ void gstore_u16_lane0_below(const void* vptr, uint32_
 // Row kinds, all lanes in parallel. Needs the band starts in the table already. Returns the first row whose band
 // starts past column 0 (graph_count + 1 if there is none); band starts never decrease from row to row.
 // ------------------------------------------------------------------------------------------------
-template <int MAXD>
 __device__ __forceinline__ int32_t classify_kinds(RowInfo<true>* rowinfo, int32_t graph_count, int lane, const uint64_t* xpred)
 {
     int32_t first_moved = graph_count + 1;
@@ -78,7 +77,7 @@ __device__ __forceinline__ int32_t classify_kinds(RowInfo<true>* rowinfo, int32_
                 const int32_t p   = k < 3 ? ri.pred(k) : xpred_row(xe, k);
                 const int32_t d   = r - p;
                 const int32_t pbs = rowinfo[p].bs(); // row 0 holds band start 0
-                ok                = ok && d >= 1 && d <= MAXD && (bs - pbs) <= kPkGuardCols && (bs == 0 || pbs > 0);
+                ok                = ok && d >= 1 && d <= kPkMaxDist && (bs - pbs) <= kPkGuardCols && (bs == 0 || pbs > 0);
                 if (k == 0) { d0 = d; pbs0 = pbs; }
             }
             if (ok) kind = cnt > 1 ? 3 : ((d0 == 1 && pbs0 == bs) ? 0 : ((d0 == 1 && bs - pbs0 == kCellsPerLane) ? 1 : 2));
@@ -92,45 +91,17 @@ __device__ __forceinline__ int32_t classify_kinds(RowInfo<true>* rowinfo, int32_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Two wavefronts per window (ROLE 1 = lead, ROLE 2 = trail, forward_trail below; ROLE 0 = one wavefront does everything).
-// A lone wavefront issues one instruction per ~5 cycles whatever the rest of its SIMD does, an LDS write costs it ~50
-// cycles and an HBM store ~20 (tools/microbench_rows.hip, profiles/r03_microbench_rows_*.json), so a row's time is the
-// length of its instruction stream -- and a second wavefront of the same window on another issue slot is worth exactly
-// the instructions it takes off the first. The recurrence itself cannot be split (every row needs the previous one),
-// but what hangs off it can: the LEAD wavefront computes the rows and writes them to the LDS ring (its successors read
-// them there anyway); the TRAIL wavefront follows one or two rows behind, reads each finished row and its predecessors
-// from the ring, re-derives the candidates, and produces everything the lead's critical path does not need -- the move
-// bytes and the HBM stores of both matrices (about a third of a row's instructions).
-// Hand-over through three LDS words, no barrier in the row loop:
-//   lead_row   last row the lead has written to the ring (the trail polls it before it touches a row);
-//   trail_row  last row whose ring operands the trail has read (the lead may overwrite ring slot r & 7, i.e. row r - 8,
-//              once trail_row >= r - 2: ring predecessors are at most 6 rows up in this mode);
-//   trail_hbm  last row up to which the trail's HBM stores are complete (published before every general row, which the
-//              lead computes and stores itself and whose far predecessors it reads back from HBM, and at the end).
-// ------------------------------------------------------------------------------------------------
-struct DuoShared
-{
-    int32_t op;          // 1 = a forward pass follows the barrier, 2 = leave the kernel
-    int32_t graph_count, first_moved, max_column;
-    int32_t lead_row, trail_row, trail_hbm;
-    int32_t fail;        // a bounded wait ran out (protocol error): the window reports a failure status, never a result
-};
-constexpr int32_t kDuoSpinLimit = 1 << 22; // polls (~100 cycles each) before a wait gives up
-constexpr int kDuoMaxDist = 6;
-
-// ------------------------------------------------------------------------------------------------
 // The forward pass. `ring` is kPkSlots * kPkSlotBytes of LDS at LDS address 0 .. (the launcher's carve puts the ring
 // first); `scores` the HBM score matrix and `moves` the HBM move-byte matrix (row stride 264 elements / bytes);
 // lds_read the LDS copy of the read.
 // ------------------------------------------------------------------------------------------------
-template <typename IdT, int ROLE>
+template <typename IdT>
 __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, RowInfo<true>* rowinfo, int32_t graph_count,
                                                      const uint8_t* lds_read, int16_t* scores, uint8_t* moves, uint8_t* ring,
                                                      const uint64_t* xpred, int32_t max_column, int32_t gap_score,
                                                      int32_t mismatch_score, int32_t match_score, int32_t dbg,
-                                                     uint64_t* prof_acc, DuoShared* duo = nullptr)
+                                                     uint64_t* prof_acc)
 {
-    constexpr bool LEAD = ROLE == 1;
     // timing ablations (GWHIP_DEBUG, debug instantiation only; results are only meaningful on a relaunch over the
     // buffers of an unablated launch of the same batch): bit 26 no score-row stores, bit 27 no move-row stores
     // (tools/microbench_rows.hip only, results are garbage: bit 20 no ring write, 19 no guard write, 18 no cross-lane scan,
@@ -149,23 +120,8 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
     const int32_t lane4 = lane * 4, lane8 = lane * 8;
     const int32_t min_score = Limits<int16_t>::min / 2;
 
-    const int32_t first_moved = classify_kinds<LEAD ? kDuoMaxDist : kPkMaxDist>(rowinfo, graph_count, lane, xpred);
+    const int32_t first_moved = classify_kinds(rowinfo, graph_count, lane, xpred);
     wave_sync();
-    if constexpr (LEAD)
-    {
-        if (lane == 0)
-        {
-            duo->op          = 1;
-            duo->graph_count = graph_count;
-            duo->first_moved = first_moved;
-            duo->max_column  = max_column;
-            duo->lead_row    = 0;
-            duo->trail_row   = 0;
-            duo->trail_hbm   = 0;
-            duo->fail        = 0;
-        }
-        block_barrier(); // the trail wavefront waits here for a pass
-    }
 
     const uint32_t MIN2   = pin_vgpr(pk_dup(min_score));
     const uint32_t SENT2  = pin_vgpr(pk_dup(kPkSentinel));
@@ -241,44 +197,23 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
         V23 = pk_add(q23, GAP2);
     };
     // the finished row (P01/P23) of row r: HBM score row, ring slot r & 7 with its guard quad, and its move bytes
-    // lead: the trail's progress, requested at the start of a row and looked at before the row's ring slot is overwritten
-    uint32_t trail_seen_v = 0;
-    auto request_trail = [&]() {
-        if constexpr (LEAD) trail_seen_v = (uint32_t)*(const volatile __attribute__((address_space(3))) int32_t*)&duo->trail_row;
-    };
     auto store_row = [&](auto bs0_tag, int32_t r, int32_t rel0_val, uint32_t mv4) {
         constexpr bool BS0 = decltype(bs0_tag)::value;
+        score_ptr += stride * 2;
+        move_ptr += stride;
         const uint32_t sbase = ring_base + (((uint32_t)r & (kPkSlots - 1)) * kPkSlotBytes);
-        if constexpr (LEAD)
-        {
-            // ring slot r & 7 still holds row r - 8: the trail needs it until it has read the operands of row r - 2
-            int32_t seen = wave_first((int32_t)trail_seen_v);
-            for (int32_t spin = 0; seen < r - 2; spin++)
-            {
-                seen = lds_poll(&duo->trail_row);
-                if (spin > kDuoSpinLimit) { lane0_store_u32(&duo->fail, 1u); break; }
-            }
-        }
-        else
-        {
-            score_ptr += stride * 2;
-            move_ptr += stride;
-            if (st_scores) *reinterpret_cast<uint2*>(score_ptr) = make_uint2(P01, P23);
-        }
+        if (st_scores) *reinterpret_cast<uint2*>(score_ptr) = make_uint2(P01, P23);
         if (ab_ring) lds_store_u64(sbase + a1, P01, P23);
         if constexpr (BS0)
         {
             const uint32_t rel0pk = ((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)rel0_val << 16);
             if (ab_guard) lds_store_u64_lanes17(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
-            if constexpr (!LEAD) gstore_u16_lane0_below(score_ptr, (uint32_t)rel0_val); // a real left-boundary value
+            gstore_u16_lane0_below(score_ptr, (uint32_t)rel0_val); // a real left-boundary value
             prev_rel0 = rel0_val;
         }
         else if (ab_guard)
             lds_store_u64_lanes17(sbase + ga, SENT2, GUARD_HI_MIN);
-        if constexpr (LEAD)
-            lane0_store_u32(&duo->lead_row, (uint32_t)r); // behind the row's ring stores (one wavefront's LDS operations execute in order)
-        else if (st_moves)
-            *reinterpret_cast<uint32_t*>(move_ptr) = mv4;
+        if (st_moves) *reinterpret_cast<uint32_t*>(move_ptr) = mv4;
     };
     // four move bytes from two registers of 16-bit moves
     auto pack_moves = [&](uint32_t m01, uint32_t m23) -> uint32_t {
@@ -287,14 +222,6 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
 
     // ---------------- general row (kind 4): 32-bit arithmetic, previous row from registers, others from HBM ----------------
     auto general_row = [&](int32_t r, int32_t& prev_rel0_io) {
-        if constexpr (LEAD)
-        {
-            // every earlier row must be in HBM (the trail stores them) before this row may read them back
-            for (int32_t spin = 0; lds_poll(&duo->trail_hbm) < r - 1; spin++)
-                if (spin > kDuoSpinLimit) { lane0_store_u32(&duo->fail, 1u); break; }
-            score_ptr = reinterpret_cast<uint8_t*>(scores) + lane8 + 2 * (1 + kRelShift) + (int64_t)(r - 1) * (stride * 2);
-            move_ptr  = moves + lane4 + (1 + kRelShift) + (int64_t)(r - 1) * stride;
-        }
         const RowInfo<true> ri = uniform_row(rowinfo[r]);
         const int32_t bs       = ri.bs();
         const uint32_t base    = (uint32_t)ri.base();
@@ -395,17 +322,12 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
         if (bs == 0) gstore_u16_lane0_below(score_ptr, (uint32_t)rel0_val);
         *reinterpret_cast<uint32_t*>(move_ptr) = 0u;
         prev_rel0_io = rel0_val;
-        if constexpr (LEAD)
-        {
-            lane0_store_u32(&duo->lead_row, (uint32_t)r); // the trail skips this row
-        }
     };
 
     // ---------------- kinds 0 / 1: one predecessor, the previous row, in registers ----------------
     auto reg_row = [&](auto bs0_tag, auto moved_tag, int32_t r, uint32_t d0, uint32_t base4) {
         constexpr bool BS0   = decltype(bs0_tag)::value;
         constexpr bool MOVED = decltype(moved_tag)::value;
-        request_trail();
         uint32_t s0x, q01, q23;
         if constexpr (!MOVED)
         {
@@ -439,15 +361,11 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
             s23 = is_lane63 ? MIN2 : s23;
         }
         scan_row(s01, s23, cu);
-        uint32_t mv4 = 0u;
-        if constexpr (!LEAD)
-        {
-            // move = H == D ? 3 : H == V ? 2 : 1   ==  3 + [H != D] * (-1 - [H != V])
-            const uint32_t m01 = pk_mad_u16(nz(P01, D01), pk_mad_u16(nz(P01, V01), NEG1, NEG1), THREE2);
-            const uint32_t m23 = pk_mad_u16(nz(P23, D23), pk_mad_u16(nz(P23, V23), NEG1, NEG1), THREE2);
-            mv4 = ab_moves ? pack_moves(m01, m23) : 0u;
-            if constexpr (MOVED) mv4 = is_lane63 ? 0u : mv4;
-        }
+        // move = H == D ? 3 : H == V ? 2 : 1   ==  3 + [H != D] * (-1 - [H != V])
+        const uint32_t m01 = pk_mad_u16(nz(P01, D01), pk_mad_u16(nz(P01, V01), NEG1, NEG1), THREE2);
+        const uint32_t m23 = pk_mad_u16(nz(P23, D23), pk_mad_u16(nz(P23, V23), NEG1, NEG1), THREE2);
+        uint32_t mv4 = ab_moves ? pack_moves(m01, m23) : 0u;
+        if constexpr (MOVED) mv4 = is_lane63 ? 0u : mv4;
         store_row(bs0_tag, r, rel0_val, mv4);
     };
 
@@ -505,7 +423,6 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
                 else if (kind <= 3)
                 {
                     // ===== predecessors from the LDS ring =====
-                    request_trail();
                     const uint32_t bs = ((d0 >> 3) & 0x1ffu) << 2;
                     a1 = (2u * bs + (uint32_t)lane8) & (kPkSlotBytes - 1);
                     ga = (a1 + guard_off) & (kPkSlotBytes - 1);
@@ -532,15 +449,11 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
                         const bool outside = (q0.x & 0xffffu) == sent16; // chunk beyond the predecessor's band
                         const uint32_t s01 = pk_max(D01, V01), s23 = pk_max(D23, V23);
                         scan_row(outside ? MIN2 : s01, outside ? MIN2 : s23, cu);
-                        uint32_t mv4 = 0u;
-                        if constexpr (!LEAD)
-                        {
-                            // move = H == D ? 2 d + 1 : H == V ? 2 d : 1  ==  (2 d + 1) + [H != D] * (-1 + [H != V] * (1 - 2 d))
-                            const uint32_t cD = pk_dup((int32_t)(2u * dd0 + 1u)), cV = pk_dup(1 - (int32_t)(2u * dd0));
-                            const uint32_t m01 = pk_mad_u16_vvs(nz(P01, D01), pk_mad_u16_vsv(nz(P01, V01), cV, NEG1), cD);
-                            const uint32_t m23 = pk_mad_u16_vvs(nz(P23, D23), pk_mad_u16_vsv(nz(P23, V23), cV, NEG1), cD);
-                            mv4 = outside ? 0u : pack_moves(m01, m23);
-                        }
+                        // move = H == D ? 2 d + 1 : H == V ? 2 d : 1  ==  (2 d + 1) + [H != D] * (-1 + [H != V] * (1 - 2 d))
+                        const uint32_t cD = pk_dup((int32_t)(2u * dd0 + 1u)), cV = pk_dup(1 - (int32_t)(2u * dd0));
+                        const uint32_t m01 = pk_mad_u16_vvs(nz(P01, D01), pk_mad_u16_vsv(nz(P01, V01), cV, NEG1), cD);
+                        const uint32_t m23 = pk_mad_u16_vvs(nz(P23, D23), pk_mad_u16_vsv(nz(P23, V23), cV, NEG1), cD);
+                        const uint32_t mv4 = outside ? 0u : pack_moves(m01, m23);
                         store_row(bs0_tag, r, rel0_val, mv4);
                     }
                     else
@@ -667,244 +580,6 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
     // real boundary through the general routine (band-start transition rows are kind 4)
     run_rows(std::false_type{}, bs0_end + 1, graph_count);
     if (ksel >= 0 && lane == 0) *prof_acc += kacc;
-}
-
-// ------------------------------------------------------------------------------------------------
-// The trail wavefront of a two-wavefront pass (see DuoShared): for every row the lead has finished it reads the row and
-// its ring predecessors, re-derives the candidates exactly as the lead did (same operands, same packed arithmetic) and
-// stores the score row, the left-boundary value and the move bytes. General rows (kind 4) are the lead's.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void forward_trail(const RowInfo<true>* rowinfo, const uint8_t* lds_read, int16_t* scores, uint8_t* moves,
-                                              uint8_t* ring, const uint64_t* xpred, int32_t gap_score, int32_t mismatch_score,
-                                              int32_t match_score, DuoShared* duo, int32_t ablate = 0)
-{
-    // ablate (tools/microbench_rows.hip only): 1 hand-over only, 2 + ring loads, 3 + arithmetic (no HBM stores)
-    constexpr int32_t band_width = 256;
-    constexpr int32_t stride     = band_width + kRightPad;
-    const int lane               = threadIdx.x & (kWave - 1);
-    const int32_t lane4 = lane * 4, lane8 = lane * 8;
-    const int32_t min_score   = Limits<int16_t>::min / 2;
-    const int32_t graph_count = wave_first(duo->graph_count);
-    const int32_t first_moved = wave_first(duo->first_moved);
-
-    const uint32_t MIN2   = pin_vgpr(pk_dup(min_score));
-    const uint32_t GAP2   = pin_vgpr(pk_dup(gap_score));
-    const uint32_t MAT2   = pin_vgpr(pk_dup(match_score));
-    const uint32_t DIF2   = pin_vgpr(pk_dup(mismatch_score - match_score));
-    const uint32_t ONE2   = pin_vgpr(0x00010001u);
-    const uint32_t NEG1   = pin_vgpr(0xffffffffu);
-    const uint32_t ring_base = lds_addr(ring);
-    const uint32_t read_base = lds_addr(lds_read);
-    const uint32_t move_keep = lane == 0 ? 0xffffff00u : 0xffffffffu; // the band's first cell stays undecided
-    const uint32_t sent16    = (uint32_t)kPkSentinel & 0xffffu;
-
-    uint32_t rd4 = lds_load_u32(read_base + lane4);
-    uint32_t a1  = (uint32_t)lane8;
-    uint32_t cur_bs = 0;
-    uint8_t* score_row0 = reinterpret_cast<uint8_t*>(scores) + lane8 + 2 * (1 + kRelShift); // the lane's quad in row 0
-    uint8_t* move_row0  = moves + lane4 + (1 + kRelShift);
-    int32_t lead_seen   = 0;
-
-    auto nz = [&](uint32_t a, uint32_t b) -> uint32_t { return pk_min_u16(pk_sub(a, b), ONE2); };
-    auto costs = [&](uint32_t base4, uint32_t& c01, uint32_t& c23) {
-        const uint32_t x   = rd4 ^ base4;
-        const uint32_t x01 = __builtin_amdgcn_perm(0u, x, 0x0c010c00u);
-        const uint32_t x23 = __builtin_amdgcn_perm(0u, x, 0x0c030c02u);
-        c01 = pk_mad_u16(pk_min_u16(x01, ONE2), DIF2, MAT2);
-        c23 = pk_mad_u16(pk_min_u16(x23, ONE2), DIF2, MAT2);
-    };
-    auto from_pred = [&](uint32_t s0x, uint32_t q01, uint32_t q23, uint32_t c01, uint32_t c23, uint32_t& D01, uint32_t& D23,
-                         uint32_t& V01, uint32_t& V23) {
-        D01 = pk_add(__builtin_amdgcn_alignbit(q01, s0x, 16), c01);
-        D23 = pk_add(__builtin_amdgcn_alignbit(q23, q01, 16), c23);
-        V01 = pk_add(q01, GAP2);
-        V23 = pk_add(q23, GAP2);
-    };
-    auto pack_moves = [&](uint32_t m01, uint32_t m23) -> uint32_t { return __builtin_amdgcn_perm(m23, m01, 0x06040200u) & move_keep; };
-    bool gave_up   = false;
-    auto wait_lead = [&](int32_t r) {
-        for (int32_t spin = 0; lead_seen < r; spin++)
-        {
-            lead_seen = lds_poll(&duo->lead_row);
-            if (spin > kDuoSpinLimit) { lane0_store_u32(&duo->fail, 1u); gave_up = true; break; }
-        }
-    };
-
-    int32_t r = 1;
-    while (r <= graph_count && !gave_up)
-    {
-        const int32_t r0 = r;
-        uint32_t D0v, D1v;
-        {
-            const int32_t rr    = min(r0 + lane, graph_count);
-            const uint64_t w    = rowinfo[rr].w;
-            const uint32_t kind = (uint32_t)(w >> kKindShift) & 7u;
-            const uint32_t cnt  = (uint32_t)(w >> 8) & 0x3fu;
-            const uint32_t bs4  = (uint32_t)(w >> 15) & 0x1ffu;
-            const uint32_t p0 = (uint32_t)(w >> 24) & 0xfffu, p1 = (uint32_t)(w >> 36) & 0xfffu, p2 = (uint32_t)(w >> 48) & 0xfffu;
-            const uint32_t slots = (p0 & 7u) | ((p1 & 7u) << 3) | ((p2 & 7u) << 6);
-            const uint32_t dists = (((uint32_t)rr - p0) & 7u) | ((((uint32_t)rr - p1) & 7u) << 3) | ((((uint32_t)rr - p2) & 7u) << 6);
-            D0v = kind | (bs4 << 3) | (slots << 12) | (dists << 21) | ((cnt <= 3 ? cnt : 0u) << 30);
-            D1v = ((uint32_t)w & 0xffu) * 0x01010101u;
-            D0v = (r0 + lane <= graph_count) ? D0v : 7u;
-        }
-        for (int32_t k = 0; k < kWave; k++, r++)
-        {
-            const uint32_t d0    = (uint32_t)__builtin_amdgcn_readlane((int32_t)D0v, k);
-            const uint32_t base4 = (uint32_t)__builtin_amdgcn_readlane((int32_t)D1v, k);
-            const uint32_t kind  = d0 & 7u;
-            if (kind == 7u || gave_up) break;
-            if (kind == 4u)
-            {
-                // the lead computes and stores this row itself and may read any earlier row back from HBM
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                lane0_store_u32(&duo->trail_hbm, (uint32_t)(r - 1));
-                wait_lead(r);
-                lane0_store_u32(&duo->trail_row, (uint32_t)r);
-                continue;
-            }
-            const bool bs0    = r < first_moved;
-            const uint32_t bs = ((d0 >> 3) & 0x1ffu) << 2;
-            if (bs != cur_bs)
-            {
-                cur_bs = bs;
-                a1     = (2u * bs + (uint32_t)lane8) & (kPkSlotBytes - 1);
-                rd4    = lds_load_u32(read_base + bs + lane4);
-            }
-            const uint32_t a0    = (a1 - 4) & (kPkSlotBytes - 1);
-            const uint32_t sbase = ring_base + (((uint32_t)r & (kPkSlots - 1)) * kPkSlotBytes);
-            const uint32_t b0    = ring_base + (((d0 >> 12) & 7u) * kPkSlotBytes);
-            const uint32_t dd0   = (d0 >> 21) & 7u;
-            const uint32_t cnt3  = d0 >> 30; // 1, 2, 3, or 0 = more than three
-            wait_lead(r);
-            if (ablate == 1)
-            {
-                lane0_store_u32(&duo->trail_row, (uint32_t)r);
-                continue;
-            }
-            uint32_t mv4;
-            uint2 H;
-            uint32_t rel0w = 0;
-            if (cnt3 == 1)
-            {
-                H = lds_load_u64(sbase + a1);
-                const uint32_t x0 = lds_load_u32(b0 + a0);
-                const uint2 q0    = lds_load_u64(b0 + a1);
-                if (bs0) rel0w = lds_load_u32(sbase + kPkSlotBytes - 4);
-                lane0_store_u32(&duo->trail_row, (uint32_t)r); // behind the loads: LDS operations of a wavefront execute in order
-                uint32_t c01, c23, D01, D23, V01, V23;
-                costs(base4, c01, c23);
-                from_pred(x0, q0.x, q0.y, c01, c23, D01, D23, V01, V23);
-                const bool outside = (q0.x & 0xffffu) == sent16;
-                const uint32_t cD = pk_dup((int32_t)(2u * dd0 + 1u)), cV = pk_dup(1 - (int32_t)(2u * dd0));
-                const uint32_t m01 = pk_mad_u16_vvs(nz(H.x, D01), pk_mad_u16_vsv(nz(H.x, V01), cV, NEG1), cD);
-                const uint32_t m23 = pk_mad_u16_vvs(nz(H.y, D23), pk_mad_u16_vsv(nz(H.y, V23), cV, NEG1), cD);
-                mv4 = outside ? 0u : pack_moves(m01, m23);
-            }
-            else
-            {
-                const int32_t cnt = cnt3 == 2 ? 2 : 3;
-                const uint32_t b1 = ring_base + (((d0 >> 15) & 7u) * kPkSlotBytes);
-                const uint32_t b2 = cnt > 2 ? ring_base + (((d0 >> 18) & 7u) * kPkSlotBytes) : b0;
-                const uint32_t dd1 = (d0 >> 24) & 7u, dd2 = (d0 >> 27) & 7u;
-                H = lds_load_u64(sbase + a1);
-                const uint32_t x0 = lds_load_u32(b0 + a0);
-                const uint2 q0    = lds_load_u64(b0 + a1);
-                const uint32_t x1 = lds_load_u32(b1 + a0);
-                const uint2 q1    = lds_load_u64(b1 + a1);
-                uint32_t x2 = 0;
-                uint2 q2 = make_uint2(0, 0);
-                if (cnt > 2)
-                {
-                    x2 = lds_load_u32(b2 + a0);
-                    q2 = lds_load_u64(b2 + a1);
-                }
-                if (bs0) rel0w = lds_load_u32(sbase + kPkSlotBytes - 4);
-                uint64_t xe = 0;
-                if (cnt3 == 0) xe = wave_first64(xpred[r & 255]);
-                const int32_t cnt_all = cnt3 == 0 ? (int32_t)((xe >> 13) & 63u) : cnt;
-                uint32_t c01, c23;
-                costs(base4, c01, c23);
-                uint32_t xD01 = MIN2, xD23 = MIN2, xV01 = MIN2, xV23 = MIN2;
-                bool undecided = false;
-                for (int32_t kk = 3; kk < cnt_all; kk++) // predecessors 3..5: their loads too before the progress word
-                {
-                    const uint32_t bk = ring_base + (((uint32_t)xpred_row(xe, kk) & 7u) * kPkSlotBytes);
-                    const uint32_t xk = lds_load_u32(bk + a0);
-                    const uint2 qk    = lds_load_u64(bk + a1);
-                    uint32_t Da, Db, Va, Vb;
-                    from_pred(xk, qk.x, qk.y, c01, c23, Da, Db, Va, Vb);
-                    const bool outk = (qk.x & 0xffffu) == sent16;
-                    undecided       = undecided | outk;
-                    xD01 = pk_max(xD01, outk ? MIN2 : Da); xD23 = pk_max(xD23, outk ? MIN2 : Db);
-                    xV01 = pk_max(xV01, outk ? MIN2 : Va); xV23 = pk_max(xV23, outk ? MIN2 : Vb);
-                }
-                lane0_store_u32(&duo->trail_row, (uint32_t)r);
-                uint32_t D0a, D0b, V0a, V0b, D1a, D1b, V1a, V1b;
-                from_pred(x0, q0.x, q0.y, c01, c23, D0a, D0b, V0a, V0b);
-                from_pred(x1, q1.x, q1.y, c01, c23, D1a, D1b, V1a, V1b);
-                const bool out0 = (q0.x & 0xffffu) == sent16, out1 = (q1.x & 0xffffu) == sent16;
-                undecided = undecided | out0 | out1;
-                D0a = out0 ? MIN2 : D0a; D0b = out0 ? MIN2 : D0b; V0a = out0 ? MIN2 : V0a; V0b = out0 ? MIN2 : V0b;
-                D1a = out1 ? MIN2 : D1a; D1b = out1 ? MIN2 : D1b; V1a = out1 ? MIN2 : V1a; V1b = out1 ? MIN2 : V1b;
-                uint32_t bD01 = pk_max(D0a, D1a), bD23 = pk_max(D0b, D1b), bV01 = pk_max(V0a, V1a), bV23 = pk_max(V0b, V1b);
-                const uint32_t mD0 = pk_dup((int32_t)(2u * dd0 + 1u)), mV0 = pk_dup((int32_t)(2u * dd0));
-                const uint32_t E1v = pin_vgpr(pk_dup(2 * ((int32_t)dd1 - (int32_t)dd0)));
-                uint32_t A01, A23, B01, B23;
-                if (cnt > 2)
-                {
-                    uint32_t D2a, D2b, V2a, V2b;
-                    from_pred(x2, q2.x, q2.y, c01, c23, D2a, D2b, V2a, V2b);
-                    const bool out2 = (q2.x & 0xffffu) == sent16;
-                    undecided       = undecided | out2;
-                    D2a = out2 ? MIN2 : D2a; D2b = out2 ? MIN2 : D2b; V2a = out2 ? MIN2 : V2a; V2b = out2 ? MIN2 : V2b;
-                    bD01 = pk_max(bD01, D2a); bD23 = pk_max(bD23, D2b); bV01 = pk_max(bV01, V2a); bV23 = pk_max(bV23, V2b);
-                    const uint32_t E2 = pin_vgpr(pk_dup(2 * ((int32_t)dd2 - (int32_t)dd1)));
-                    A01 = pk_mad_u16_vvs(nz(bD01, D0a), pk_mad_u16(nz(bD01, D1a), E2, E1v), mD0);
-                    A23 = pk_mad_u16_vvs(nz(bD23, D0b), pk_mad_u16(nz(bD23, D1b), E2, E1v), mD0);
-                    B01 = pk_mad_u16_vvs(nz(bV01, V0a), pk_mad_u16(nz(bV01, V1a), E2, E1v), mV0);
-                    B23 = pk_mad_u16_vvs(nz(bV23, V0b), pk_mad_u16(nz(bV23, V1b), E2, E1v), mV0);
-                }
-                else
-                {
-                    A01 = pk_mad_u16_vvs(nz(bD01, D0a), E1v, mD0); A23 = pk_mad_u16_vvs(nz(bD23, D0b), E1v, mD0);
-                    B01 = pk_mad_u16_vvs(nz(bV01, V0a), E1v, mV0); B23 = pk_mad_u16_vvs(nz(bV23, V0b), E1v, mV0);
-                }
-                if (cnt3 == 0)
-                {
-                    const uint32_t fD01 = pk_max(bD01, xD01), fD23 = pk_max(bD23, xD23), fV01 = pk_max(bV01, xV01), fV23 = pk_max(bV23, xV23);
-                    // A *= [max of the first three == overall max]
-                    A01 = pk_mad_u16(nz(bD01, fD01), pk_sub(0u, A01), A01); A23 = pk_mad_u16(nz(bD23, fD23), pk_sub(0u, A23), A23);
-                    B01 = pk_mad_u16(nz(bV01, fV01), pk_sub(0u, B01), B01); B23 = pk_mad_u16(nz(bV23, fV23), pk_sub(0u, B23), B23);
-                    bD01 = fD01; bD23 = fD23; bV01 = fV01; bV23 = fV23;
-                }
-                auto move_of = [&](uint32_t Hh, uint32_t bD, uint32_t bV, uint32_t A, uint32_t B) -> uint32_t {
-                    const uint32_t t1 = pk_mad_u16(nz(Hh, bV), pk_sub(ONE2, B), B);
-                    return pk_mad_u16(nz(Hh, bD), pk_sub(t1, A), A);
-                };
-                const uint32_t m01 = move_of(H.x, bD01, bV01, A01, B01);
-                const uint32_t m23 = move_of(H.y, bD23, bV23, A23, B23);
-                mv4 = undecided ? 0u : pack_moves(m01, m23);
-            }
-            if (ablate == 2)
-            {
-                if (((H.x ^ mv4) == 0x12345u) | (ablate == 3 && mv4 == 0x7654321u)) *reinterpret_cast<uint32_t*>(move_row0) = mv4; // keeps the loads alive
-                continue;
-            }
-            if (ablate == 3)
-            {
-                if (mv4 == 0x7654321u) *reinterpret_cast<uint32_t*>(move_row0) = mv4 ^ H.x; // keeps the arithmetic alive
-                continue;
-            }
-            uint8_t* sp = score_row0 + (int64_t)r * (stride * 2);
-            *reinterpret_cast<uint2*>(sp)                                   = H;
-            *reinterpret_cast<uint32_t*>(move_row0 + (int64_t)r * stride) = mv4;
-            if (bs0) gstore_u16_lane0_below(sp, rel0w >> 16);
-        }
-    }
-    // everything in HBM before the lead goes on to the sink selection and the traceback
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lane0_store_u32(&duo->trail_hbm, (uint32_t)graph_count);
 }
 
 } // namespace gwhip

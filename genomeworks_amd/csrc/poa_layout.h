@@ -24,7 +24,6 @@ constexpr int kRightPad = 8;       // CUDAPOA_BANDED_MATRIX_RIGHT_PADDING: obser
 constexpr int kMaxAdaptiveBand = 1536;
 constexpr int kShiftLeft = -10, kShiftRight = -11;
 constexpr int kNwLoopFailed = -1, kNwAdaptiveStorageFailed = -2, kNwTracebackBufferFailed = -3;
-constexpr int kNwDuoFailed = -4; // the two-wavefront forward pass gave up on a hand-over wait (protocol error, never expected)
 constexpr uint8_t kKernelError = 0xFF;
 
 // StatusType values written to consensus[1] (cudapoa.hpp:34-49)
@@ -35,8 +34,7 @@ enum : uint8_t
     kExceededAdaptiveBandedMatrixSize = 6,
     kExceededMaximumPredecessorDistance = 7,
     kLoopCountExceeded = 8,
-    kExceededMaximumSequenceSize = 2,
-    kGenericError = 12
+    kExceededMaximumSequenceSize = 2
 };
 
 struct PoaLayout

@@ -19,7 +19,7 @@ constexpr size_t kLdsBytes = kRingBytesMb + kRowInfoRows * 8 + kReadBytes + kTil
 
 struct MbArgs
 {
-    int32_t pattern, graph_count, read_length, reps, dbg, duo;
+    int32_t pattern, graph_count, read_length, reps, dbg;
     uint8_t* slabs;
     size_t per_block;
     unsigned long long* cycles;
@@ -35,11 +35,10 @@ __device__ int32_t mb_band_start(int32_t pattern, int32_t r, int32_t max_column)
     return min(bs, ((max_column - 252) / 4) * 4);
 }
 
-__global__ __launch_bounds__(2 * kWave) void rows_kernel(MbArgs a)
+__global__ __launch_bounds__(kWave) void rows_kernel(MbArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane            = threadIdx.x & (kWave - 1);
-    const int wave            = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane            = threadIdx.x;
     uint8_t* ring             = smem;
     RowInfo<true>* rowinfo    = reinterpret_cast<RowInfo<true>*>(smem + kRingBytesMb);
     uint8_t* lds_read         = smem + kRingBytesMb + kRowInfoRows * 8;
@@ -48,17 +47,6 @@ __global__ __launch_bounds__(2 * kWave) void rows_kernel(MbArgs a)
     int16_t* scores           = reinterpret_cast<int16_t*>(slab);
     uint8_t* moves            = slab + (size_t)3072 * 264 * 2;
     const int32_t max_column  = a.read_length + 1;
-    DuoShared* duo            = reinterpret_cast<DuoShared*>(smem + kLdsBytes);
-    if (wave == 1) // the trail wavefront of the two-wavefront mode
-    {
-        for (int32_t rep = 0; rep < a.reps; rep++)
-        {
-            block_barrier();
-            forward_trail(rowinfo, lds_read, scores, moves, ring, xpred, -8, -6, 8, duo, a.dbg);
-            block_barrier();
-        }
-        return;
-    }
     for (int32_t i = lane; i < kReadBytes; i += kWave) lds_read[i] = "ACGT"[(i * 7 + (i >> 3)) & 3];
     for (int32_t i = lane; i < 256; i += kWave) xpred[i] = 0;
     if (lane == 0) rowinfo[0].set(0, 0, false, 0, 0, 0);
@@ -87,13 +75,7 @@ __global__ __launch_bounds__(2 * kWave) void rows_kernel(MbArgs a)
     const unsigned long long t0 = clock64();
     for (int32_t rep = 0; rep < a.reps; rep++)
     {
-        if (a.duo)
-        {
-            banded_forward_moves<int16_t, 1>(g, rowinfo, a.graph_count, lds_read, scores, moves, ring, xpred, max_column, -8, -6, 8, 0, nullptr, duo);
-            block_barrier();
-        }
-        else
-            banded_forward_moves<int16_t, 0>(g, rowinfo, a.graph_count, lds_read, scores, moves, ring, xpred, max_column, -8, -6, 8, a.dbg, nullptr);
+        banded_forward_moves<int16_t>(g, rowinfo, a.graph_count, lds_read, scores, moves, ring, xpred, max_column, -8, -6, 8, a.dbg, nullptr);
         wave_sync();
     }
     const unsigned long long t1 = clock64();
@@ -115,7 +97,7 @@ int main(int argc, char** argv)
         return 1;
     }
     hipMemset(a.slabs, 0, a.per_block * blocks);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes + 64);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     const char* pattern_name[] = {"kind 0 (previous row, band fixed)", "kind 3 (rows r-1 and r-2 from the ring)", "kind 2 (row r-2 from the ring)",
                                   "kind 1 (previous row, band moves every row)", "kinds 0+1 (band moves every 5th row)",
                                   "mix 7/16 kinds 0-1, 3/16 kind 2, 6/16 kind 3"};
@@ -138,24 +120,17 @@ int main(int argc, char** argv)
     hipEventCreate(&e1);
     printf("{\"blocks\": %d, \"rows_per_pass\": %d, \"passes\": %d, \"results\": [\n", blocks, a.graph_count, reps);
     bool first = true;
-    const bool quick = argc > 3 && atoi(argv[3]) != 0; // only the full rows, one and two wavefronts
-    const Abl trail_abl[] = {{"full row", 0}, {"trail: hand-over only", 1}, {"trail: hand-over + ring loads", 2}, {"trail: everything but the HBM stores", 3}};
-    for (int duo = 0; duo < 2; duo++)
     for (int p = 0; p < 6; p++)
-        for (int ai = 0; ai < (duo ? 4 : (int)(sizeof(abl) / sizeof(abl[0]))); ai++)
+        for (const Abl& ab : abl)
         {
-            const Abl& ab = duo ? trail_abl[ai] : abl[ai];
-            if (!duo && p != 0 && p != 5 && ab.bits != 0 && ab.bits != ((1 << 26) | (1 << 27)) && ab.bits != (1 << 16)) continue; // full ablation table for kind 0 and the mix
-            if (!duo && quick && ab.bits != 0) continue;
-            if (duo && p != 0 && p != 1 && p != 5 && ab.bits != 0) continue;
+            if (p != 0 && p != 5 && ab.bits != 0 && ab.bits != ((1 << 26) | (1 << 27)) && ab.bits != (1 << 16)) continue; // full ablation table for kind 0 and the mix
             a.pattern = p;
             a.dbg     = ab.bits;
-            a.duo     = duo;
             double best_ms = 1e30, cyc = 0;
             for (int it = 0; it < 3; it++)
             {
                 hipEventRecord(e0, 0);
-                hipLaunchKernelGGL(rows_kernel, dim3(blocks), dim3(duo ? 2 * kWave : kWave), kLdsBytes + 64, 0, a);
+                hipLaunchKernelGGL(rows_kernel, dim3(blocks), dim3(kWave), kLdsBytes, 0, a);
                 hipEventRecord(e1, 0);
                 if (hipEventSynchronize(e1) != hipSuccess) { fprintf(stderr, "launch failed: %s\n", hipGetErrorString(hipGetLastError())); return 2; }
                 float ms = 0;
@@ -169,7 +144,7 @@ int main(int argc, char** argv)
                     cyc = s / blocks / ((double)reps * a.graph_count);
                 }
             }
-            printf("%s {\"wavefronts_per_window\": %d, \"rows\": \"%s\", \"variant\": \"%s\", \"cycles_per_row\": %.1f, \"kernel_ms\": %.3f}", first ? " " : ",\n ", duo + 1, pattern_name[p], ab.name, cyc, best_ms);
+            printf("%s {\"rows\": \"%s\", \"variant\": \"%s\", \"cycles_per_row\": %.1f, \"kernel_ms\": %.3f}", first ? " " : ",\n ", pattern_name[p], ab.name, cyc, best_ms);
             first = false;
         }
     printf("\n]}\n");
