@@ -17,7 +17,8 @@ and, with more than one GPU, a strong-scaling record of the metric config (the s
 by estimated cost, consensus gathered by global index and hashed against the committed oracle golden).
 
 Multi-GPU (torchrun, one rank per GPU): windows and pairs are independent, so there is no data-path collective. The
-headline is weak scaling -- each rank runs its own 1024-window batch (seeds 1000 + rank * 1024 + w) -- because one
+headline is weak scaling -- each rank runs the SAME 1024 windows (seeds 1000 + w: the batch the oracle golden covers, so
+every rank's output is checked inside the run) -- because one
 window is one chain of 31 dependent alignments: 1024 windows already leave a single MI355X at one wavefront per SIMD,
 and splitting them further only idles SIMDs (the strong-scaling record shows exactly that). RCCL carries the barrier
 and the max / sum reductions of the timing scalars only.
@@ -115,10 +116,23 @@ def cpu_baseline_pairs(pairs, max_bandwidth, budget_s):
                 else "C port of the banded Myers kernel (band cells)")}
 
 
+def config3_golden_digest():
+    """sha256 of the oracle's consensus strings of the 1024 config-3 windows, joined by newlines (tests/golden)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "config_goldens.json")))["config3"]["consensus_sha256"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def consensus_digest(consensus_strings):
+    return hashlib.sha256("\n".join(consensus_strings).encode()).hexdigest()
+
+
 def reduce_scalars(dist, torch, values, op):
     if dist is None:
         return list(values)
-    t = torch.tensor(list(values), device="cuda", dtype=torch.float64)
+    # RCCL reduces device tensors; the gloo group of the single-device test mode takes host tensors
+    t = torch.tensor(list(values), device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
     dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
     return [float(x) for x in t.tolist()]
 
@@ -337,7 +351,7 @@ def main():
         local_rank = local_rank // ranks_per_device
 
     from genomeworks_amd import synthetic
-    first_seed = 1000 + rank * args.windows
+    first_seed = 1000 # every rank the same batch: the one tests/golden/config3_windows.txt.gz holds the oracle's output for
     windows = [[r.decode() for r in synthetic.generate_window(first_seed + w)] for w in range(args.windows)]
     # the CPU baseline forks one worker per core: before this process makes its first device call
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
@@ -357,8 +371,8 @@ def main():
     from genomeworks_amd.cuda import cuda_set_device
     cuda_set_device(local_rank)
 
-    def new_batch():
-        return cudapoa.CudaPoaBatch(32, 1024, 8 << 30, output_type="consensus", band_mode="static_band",
+    def new_batch(max_mem=8 << 30):
+        return cudapoa.CudaPoaBatch(32, 1024, max_mem, output_type="consensus", band_mode="static_band",
                                     alignment_band_width=256, max_nodes_per_graph=3072, device_id=local_rank)
 
     batch = new_batch()
@@ -394,6 +408,14 @@ def main():
     elapsed = time.perf_counter() - t0
     (elapsed,) = reduce_scalars(dist, torch, [elapsed], "MAX")
     (total_cells,) = reduce_scalars(dist, torch, [float(cells)], "SUM")
+    # the line certifies itself: the consensus of the LAST timed step of every rank against the oracle golden (outside the clock)
+    cons_last, _cov_last, status_last = batch.get_consensus()
+    my_digest = consensus_digest(cons_last)
+    golden = config3_golden_digest()
+    checkable = golden is not None and args.windows == WINDOWS
+    ok_here = 1.0 if (checkable and my_digest == golden and all(int(x) == 0 for x in status_last)) else 0.0
+    (ok_all,) = reduce_scalars(dist, torch, [ok_here], "MIN")
+    equals_golden = (ok_all == 1.0) if checkable else None
 
     # ---- the same kernels on inputs resident in HBM (no H2D) ----
     batch.relaunch()
@@ -416,47 +438,52 @@ def main():
     k_ms = sum(kms) / len(kms)
     o_ms = sum(oms) / len(oms)
 
-    # ---- strong scaling of the metric config: the SAME 1024 windows over the ranks ----
-    strong = None
+    # ---- strong scaling of the metric config: the SAME windows over the ranks, at 1024 windows (one wavefront per SIMD of ONE
+    # device already: splitting them further idles SIMDs) and at 8 x 1024 windows (the size at which an index split can scale:
+    # the 1024 golden windows eight times over, so every block of 1024 results is checked against the same golden) ----
+    strong = strong8 = None
     if world > 1:
-        all_windows = [[r.decode() for r in synthetic.generate_window(1000 + w)] for w in range(args.windows)]
-        cost = [multi_gpu.poa_window_cost(w, 256) for w in all_windows]
-        timing = {}
+        base_windows = [[r.decode() for r in synthetic.generate_window(1000 + w)] for w in range(args.windows)]
 
-        def process(units, idx):
-            sb = new_batch()
-            for w in units:
-                st, _ = sb.add_poa_group(w)
-                assert st == 0, st
-            sb.generate_poa()
-            sb.get_consensus_native()
-            sync()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
+        def strong_record(copies):
+            all_windows = base_windows * copies
+            cost = [multi_gpu.poa_window_cost(w, 256) for w in all_windows]
+            timing = {}
+
+            def process(units, idx):
+                sb = new_batch(max(8 << 30, len(units) * (5 << 20)))
+                for w in units:
+                    st, _ = sb.add_poa_group(w)
+                    assert st == 0, st
                 sb.generate_poa()
                 sb.get_consensus_native()
-            sync()
-            timing["s"] = time.perf_counter() - t1
-            cons, _cov, status = sb.get_consensus()
-            timing["cells"] = sb.total_cells()
-            return [(c, st) for c, st in zip(cons, status)]
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    sb.generate_poa()
+                    sb.get_consensus_native()
+                sync()
+                timing["s"] = time.perf_counter() - t1
+                cons, _cov, status = sb.get_consensus()
+                timing["cells"] = sb.total_cells()
+                return [(c, st) for c, st in zip(cons, status)]
 
-        gathered = multi_gpu.run_sharded(all_windows, process, gather=True, costs=cost)
-        s_elapsed, = reduce_scalars(dist, torch, [timing["s"]], "MAX")
-        s_cells, = reduce_scalars(dist, torch, [float(timing["cells"])], "SUM")
-        if rank == 0:
-            digest = hashlib.sha256("\n".join(c for c, _ in gathered).encode()).hexdigest()
-            golden = None
-            try:
-                golden = json.load(open(os.path.join(ROOT, "tests", "golden", "config_goldens.json")))["config3"]["consensus_sha256"]
-            except (OSError, ValueError, KeyError):
-                pass
-            strong = {"scaling": "strong", "windows": args.windows, "ms_per_step": round(s_elapsed / args.steps * 1e3, 3),
-                      "gcups": round(s_cells * args.steps / s_elapsed / 1e9, 3),
-                      "windows_per_s": round(args.windows * args.steps / s_elapsed, 1),
-                      "consensus_sha256": digest,
-                      "equals_oracle_golden": (digest == golden) if (golden and args.windows == WINDOWS) else None,
-                      "split": "balanced_partition by estimated cells, results gathered by global window index"}
+            gathered = multi_gpu.run_sharded(all_windows, process, gather=True, costs=cost)
+            s_elapsed, = reduce_scalars(dist, torch, [timing["s"]], "MAX")
+            s_cells, = reduce_scalars(dist, torch, [float(timing["cells"])], "SUM")
+            if rank != 0:
+                return None
+            n = args.windows
+            digests = [consensus_digest([c for c, _ in gathered[k * n:(k + 1) * n]]) for k in range(copies)]
+            return {"scaling": "strong", "windows": len(all_windows), "ms_per_step": round(s_elapsed / args.steps * 1e3, 3),
+                    "gcups": round(s_cells * args.steps / s_elapsed / 1e9, 3),
+                    "windows_per_s": round(len(all_windows) * args.steps / s_elapsed, 1),
+                    "consensus_sha256": digests[0],
+                    "equals_oracle_golden": all(d == golden for d in digests) if checkable else None,
+                    "split": "balanced_partition by estimated cells, results gathered by global window index"}
+
+        strong = strong_record(1)
+        strong8 = strong_record(8)
 
     # ---- sub-records: the other BASELINE configs ----
     sub = {}
@@ -480,7 +507,7 @@ def main():
         # HBM bytes per launch from the committed PMC pass of this same workload (rocprofv3 cannot run inside the
         # timed region; tools/pmc_passes.sh collects FETCH_SIZE / WRITE_SIZE in their own runs)
         traffic = None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pmc.get("windows") == args.windows:
@@ -493,6 +520,7 @@ def main():
             "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
+            "equals_oracle_golden": equals_golden, "consensus_sha256": my_digest,
             "windows_per_s": round(world * args.windows * args.steps / elapsed, 1),
             "timed_region": "generate_poa() [H2D from pinned host + graph-build kernel + consensus kernel] + get_consensus() "
                             "[D2H + host un-reversal], steady state on one Batch (cudapoa/benchmarks/single_batch.hpp:86-93)",
@@ -516,6 +544,8 @@ def main():
             out["cpu_baseline"] = cpu
         if strong is not None:
             out["strong_scaling"] = strong
+        if strong8 is not None:
+            out["strong_scaling_8x"] = strong8
         if sub:
             out["sub_records"] = sub
         print(json.dumps(out))

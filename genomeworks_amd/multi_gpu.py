@@ -60,6 +60,24 @@ def dist_info():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+_HOST_GROUP = None
+
+
+def host_group():
+    """Process group for HOST objects (pickled result lists): gloo. With the RCCL ("nccl") default group an object
+    collective would stage its pickles through device tensors; RCCL only ever carries the barrier and the timing scalars.
+    None when the default group is gloo already (or no group is initialised). Collective: every rank must call it."""
+    global _HOST_GROUP
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_backend() == "gloo":
+        return None
+    if _HOST_GROUP is None:
+        _HOST_GROUP = dist.new_group(backend="gloo")
+    return _HOST_GROUP
+
+
 def run_sharded(units, process_fn, gather=True, costs=None):
     """Process `units` (a list) with process_fn(list_of_units, lo) -> list of per-unit results on every rank's
     own slice. Returns the full result list in global order on rank 0 (None elsewhere) when gather is True and a
@@ -79,7 +97,7 @@ def run_sharded(units, process_fn, gather=True, costs=None):
         if not (active and gather):
             return local
         parts = [None] * world if rank == 0 else None
-        dist.gather_object((mine, local), parts, dst=0)
+        dist.gather_object((mine, local), parts, dst=0, group=host_group())
         if rank != 0:
             return None
         out = [None] * len(units)
@@ -94,7 +112,7 @@ def run_sharded(units, process_fn, gather=True, costs=None):
     if not (active and gather):
         return local
     parts = [None] * world if rank == 0 else None
-    dist.gather_object((lo, local), parts, dst=0)
+    dist.gather_object((lo, local), parts, dst=0, group=host_group())
     if rank != 0:
         return None
     out = [None] * len(units)
