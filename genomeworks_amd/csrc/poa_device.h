@@ -1544,6 +1544,7 @@ struct MwShared // in LDS, behind the regions of the single-wave layout
     int32_t done[kSkWaves];     // per wave: last row finished or skipped
     int32_t carry[kSkWaves][8]; // per wave: the last cell of its block in row r at [r & 7] (a wave is never more than kSkLead + 1 rows ahead of its reader)
     unsigned long long prof;    // profiling: the selected counter, summed over the waves
+    int32_t fail;               // a wavefront gave up on a bounded wait (protocol error): the window reports a failure status
 };
 
 __device__ __forceinline__ int32_t lds_poll(const int32_t* p)
@@ -1656,8 +1657,9 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                      : "memory");
     };
     int32_t left_done = 0, right_done = 0; // cached copies
-    // Waits are bounded: a protocol error must end as a wrong result the parity tests catch, not as a wavefront spinning
-    // forever (after the first timeout the waves stop waiting altogether).
+    // Waits are bounded: a protocol error must not end as a wavefront spinning forever. After the first timeout a wave
+    // stops waiting altogether and raises MwShared::fail; wave 0 turns that into a failure status of the window (nw_banded
+    // returns kNwPipelineFailed -> StatusType::generic_error): never a silent result.
     bool gave_up = false;
     auto wait_left = [&](int32_t row) {
         const uint64_t t_w = sksel == 5 ? clock64() : 0;
@@ -2137,6 +2139,7 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
     }
     if (sksel == 4) skacc += clock64() - t_pass;
     if (sksel && lane == 0) __hip_atomic_fetch_add(&shared->prof, (unsigned long long)skacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (gave_up && lane == 0) shared->fail = 1;
     block_barrier(); // the score and code matrices are complete in HBM (wave 0's traceback reads them)
     if (sksel && prof_out && lane == 0) *prof_out += shared->prof;
 }
@@ -2529,9 +2532,10 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             if (lane == 0) *mw_args = A;
             if (lane < kSkWaves) mw_shared->done[lane] = 0;
             if (lane < kSkWaves * 8) (&mw_shared->carry[0][0])[lane] = 0;
-            if (lane == 0) mw_shared->prof = 0;
+            if (lane == 0) { mw_shared->prof = 0; mw_shared->fail = 0; }
             block_barrier(); // the helper wavefronts wait here for their arguments
             generic_forward_skew<ScoreT, IdT, RowT>(A, g, rowinfo, b.ring, mw_shared, 0, lane, pc.acc ? &pc.acc[kPhOther] : nullptr);
+            if (wave_first(mw_shared->fail) != 0) return kNwPipelineFailed; // a bounded hand-over wait ran out
             fast_done   = true;
             codes_valid = codes != nullptr;
         }

@@ -24,6 +24,7 @@ constexpr int kRightPad = 8;       // CUDAPOA_BANDED_MATRIX_RIGHT_PADDING: obser
 constexpr int kMaxAdaptiveBand = 1536;
 constexpr int kShiftLeft = -10, kShiftRight = -11;
 constexpr int kNwLoopFailed = -1, kNwAdaptiveStorageFailed = -2, kNwTracebackBufferFailed = -3;
+constexpr int kNwPipelineFailed = -4; // the multi-wave forward pass gave up on a bounded hand-over wait (protocol error, never expected)
 constexpr uint8_t kKernelError = 0xFF;
 
 // StatusType values written to consensus[1] (cudapoa.hpp:34-49)
@@ -34,7 +35,8 @@ enum : uint8_t
     kExceededAdaptiveBandedMatrixSize = 6,
     kExceededMaximumPredecessorDistance = 7,
     kLoopCountExceeded = 8,
-    kExceededMaximumSequenceSize = 2
+    kExceededMaximumSequenceSize = 2,
+    kGenericError = 12 // StatusType::generic_error
 };
 
 struct PoaLayout

@@ -555,26 +555,49 @@ gw_poa_multi* gw_poa_multi_device_run(int32_t n_windows, const int32_t* reads_pe
 void gw_poa_multi_destroy(gw_poa_multi* h) { delete h; }
 int32_t gw_poa_multi_launches(gw_poa_multi* h) { return h->out.launches; }
 double gw_poa_multi_seconds(gw_poa_multi* h) { return h->out.seconds; }
-int32_t gw_poa_multi_status(gw_poa_multi* h, int32_t w) { return static_cast<int32_t>(h->out.status.at(static_cast<size_t>(w))); }
-int32_t gw_poa_multi_worker(gw_poa_multi* h, int32_t w) { return h->out.worker_of_window.at(static_cast<size_t>(w)); }
+// Accessors by window index: an index out of range, or asking for an output the run did not produce (consensus of an
+// MSA-only run and vice versa), is an error return with gw_last_error() set -- never an exception across the C ABI.
+int32_t gw_poa_multi_status(gw_poa_multi* h, int32_t w)
+{
+    GW_TRY
+    return static_cast<int32_t>(h->out.status.at(static_cast<size_t>(w)));
+    GW_CATCH(-1)
+}
+int32_t gw_poa_multi_worker(gw_poa_multi* h, int32_t w)
+{
+    GW_TRY
+    return h->out.worker_of_window.at(static_cast<size_t>(w));
+    GW_CATCH(-1)
+}
 const char* gw_poa_multi_consensus(gw_poa_multi* h, int32_t w, int32_t* length)
 {
+    GW_TRY
     const std::string& s = h->out.consensus.at(static_cast<size_t>(w));
     if (length) *length = static_cast<int32_t>(s.size());
     return s.c_str();
+    GW_CATCH(nullptr)
 }
 const uint16_t* gw_poa_multi_coverage(gw_poa_multi* h, int32_t w, int32_t* length)
 {
+    GW_TRY
     const auto& v = h->out.coverage.at(static_cast<size_t>(w));
     if (length) *length = static_cast<int32_t>(v.size());
     return v.data();
+    GW_CATCH(nullptr)
 }
-int32_t gw_poa_multi_msa_rows(gw_poa_multi* h, int32_t w) { return static_cast<int32_t>(h->out.msa.at(static_cast<size_t>(w)).size()); }
+int32_t gw_poa_multi_msa_rows(gw_poa_multi* h, int32_t w)
+{
+    GW_TRY
+    return static_cast<int32_t>(h->out.msa.at(static_cast<size_t>(w)).size());
+    GW_CATCH(-1)
+}
 const char* gw_poa_multi_msa_row(gw_poa_multi* h, int32_t w, int32_t row, int32_t* length)
 {
+    GW_TRY
     const std::string& s = h->out.msa.at(static_cast<size_t>(w)).at(static_cast<size_t>(row));
     if (length) *length = static_cast<int32_t>(s.size());
     return s.c_str();
+    GW_CATCH(nullptr)
 }
 
 struct gw_poa_size_plan

@@ -243,6 +243,8 @@ StatusType BandedAligner::align_all()
     d_metadata_         = reinterpret_cast<uint32_t*>(device_block_ + o_meta);
     d_cells_            = reinterpret_cast<uint64_t*>(device_block_ + o_cells);
     d_workspace_        = device_block_ + o_ws;
+    // a previous align_all() without a sync in between may still be uploading from the buffer this replaces
+    if (uploads_in_flight_) GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
     order_h_            = std::move(order);
 
     GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq_, seq_h_.data(), static_cast<size_t>(total_len), hipMemcpyHostToDevice, stream_));
@@ -362,6 +364,11 @@ StatusType BandedAligner::sync_alignments()
         GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned, d_results_, total, hipMemcpyDeviceToHost, stream_));
         GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned + counts_at, d_result_counts_, total * 4, hipMemcpyDeviceToHost, stream_));
     }
+    // From here on copies into the block's pinned memory are in flight and the batch's sequence arrays move into the block:
+    // any exception below (bad_alloc, a HIP error) must first drain the stream -- the block's destructor hands the pinned
+    // buffers back to the process-wide cache -- and leave the aligner in its empty, consistent state.
+    try
+    {
     // while the runs are in flight: hand the batch's (pinned) sequence arrays to the block and lay out the views
     block->sequences_buffer  = seq_h_.detach(&block->sequences_bytes);
     block->sequences         = block->sequences_buffer;
@@ -406,6 +413,14 @@ StatusType BandedAligner::sync_alignments()
     }
     block->n_alignments = un;
     GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+    }
+    catch (...)
+    {
+        (void)hipStreamSynchronize(stream_);
+        alignments_.clear();
+        reset_data();
+        throw;
+    }
     total_length_h_ = static_cast<int64_t>(total);
     // keep the device block (device-resident results stay valid until reset()); host queues are cleared like the reference
     n_last_ = n;

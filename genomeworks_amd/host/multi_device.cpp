@@ -26,6 +26,63 @@ namespace cudapoa
 
 namespace
 {
+// Streams / events owned for the length of a driver call, released on every exit path (device switched per resource).
+struct OwnedStreams
+{
+    std::vector<std::pair<int32_t, cudaStream_t>> items;
+    OwnedStreams()                               = default;
+    OwnedStreams(const OwnedStreams&)            = delete;
+    OwnedStreams& operator=(const OwnedStreams&) = delete;
+    cudaStream_t create(int32_t device, bool with_priority = false, int priority = 0)
+    {
+        scoped_device_switch dev(device);
+        cudaStream_t s = nullptr;
+        if (with_priority) GW_CU_CHECK_ERR(hipStreamCreateWithPriority(&s, hipStreamDefault, priority));
+        else GW_CU_CHECK_ERR(hipStreamCreate(&s));
+        items.emplace_back(device, s);
+        return s;
+    }
+    ~OwnedStreams()
+    {
+        for (auto& it : items)
+        {
+            scoped_device_switch dev(it.first);
+            (void)hipStreamDestroy(it.second);
+        }
+    }
+};
+struct OwnedEvents
+{
+    std::vector<hipEvent_t> items;
+    OwnedEvents()                              = default;
+    OwnedEvents(const OwnedEvents&)            = delete;
+    OwnedEvents& operator=(const OwnedEvents&) = delete;
+    hipEvent_t create()
+    {
+        hipEvent_t e = nullptr;
+        GW_CU_CHECK_ERR(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        items.push_back(e);
+        return e;
+    }
+    ~OwnedEvents()
+    {
+        for (hipEvent_t e : items) (void)hipEventDestroy(e);
+    }
+};
+// joins whatever was started, also when spawning the next thread throws
+struct JoinAll
+{
+    std::vector<std::thread>& threads;
+    ~JoinAll()
+    {
+        for (std::thread& t : threads)
+            if (t.joinable()) t.join();
+    }
+};
+} // namespace
+
+namespace
+{
 struct SharedCursor
 {
     std::mutex mutex;
@@ -168,36 +225,33 @@ void process_windows_multi_device(MultiDeviceOutput& out, const std::vector<std:
     SharedCursor cursor;
     std::atomic<int32_t> launches{0};
     const auto t_begin = std::chrono::steady_clock::now();
-    std::vector<std::thread> threads;
-    std::vector<cudaStream_t> streams;
-    std::vector<std::exception_ptr> errors(groups.size() * static_cast<size_t>(config.batches_per_device));
-    int32_t worker = 0;
+    // every stream exists before the first worker starts (a failing hipStreamCreate must not leave joinable threads behind)
+    OwnedStreams streams;
     for (Group& g : groups)
-        for (int32_t b = 0; b < config.batches_per_device; b++, worker++)
-        {
-            scoped_device_switch dev(g.device);
-            cudaStream_t stream = nullptr;
-            GW_CU_CHECK_ERR(hipStreamCreate(&stream));
-            streams.push_back(stream);
-            const int64_t memory = g.memory / config.batches_per_device;
-            threads.emplace_back([&, worker, stream, memory, device = g.device, allocator = g.allocator]() {
-                try
-                {
-                    worker_loop(worker, device, stream, allocator, memory, batch_size, config, windows, cursor, out, launches);
-                }
-                catch (...)
-                {
-                    errors[static_cast<size_t>(worker)] = std::current_exception();
-                }
-            });
-        }
-    for (std::thread& t : threads) t.join();
-    out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-    for (size_t k = 0; k < streams.size(); k++)
+        for (int32_t b = 0; b < config.batches_per_device; b++) streams.create(g.device);
+    std::vector<std::exception_ptr> errors(groups.size() * static_cast<size_t>(config.batches_per_device));
+    std::vector<std::thread> threads;
     {
-        scoped_device_switch dev(groups[k / static_cast<size_t>(config.batches_per_device)].device);
-        (void)hipStreamDestroy(streams[k]);
+        JoinAll join{threads};
+        int32_t worker = 0;
+        for (Group& g : groups)
+            for (int32_t b = 0; b < config.batches_per_device; b++, worker++)
+            {
+                cudaStream_t stream  = streams.items[static_cast<size_t>(worker)].second;
+                const int64_t memory = g.memory / config.batches_per_device;
+                threads.emplace_back([&, worker, stream, memory, device = g.device, allocator = g.allocator]() {
+                    try
+                    {
+                        worker_loop(worker, device, stream, allocator, memory, batch_size, config, windows, cursor, out, launches);
+                    }
+                    catch (...)
+                    {
+                        errors[static_cast<size_t>(worker)] = std::current_exception();
+                    }
+                });
+            }
     }
+    out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     out.launches = launches.load();
     for (const std::exception_ptr& e : errors)
         if (e) std::rethrow_exception(e);
@@ -328,12 +382,21 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
     const std::vector<int32_t> gate_on = size_class_admission_gates(plan, cus);
-    std::vector<hipEvent_t> class_done(classes, nullptr);
-    for (size_t k = 0; k < classes; ++k) GW_CU_CHECK_ERR(hipEventCreateWithFlags(&class_done[k], hipEventDisableTiming));
+    OwnedEvents class_events; // released on every exit path
+    for (size_t k = 0; k < classes; ++k) class_events.create();
+    const std::vector<hipEvent_t>& class_done = class_events.items;
+    // streams of the class workers, created up front for the same reason
+    OwnedStreams class_streams;
+    std::vector<cudaStream_t> stream_of(classes, nullptr);
+    for (size_t k = 0; k < classes; ++k)
+        if (!plan.groups[k].empty())
+            // numerically lower = more urgent; the range is narrow (three levels on this hardware), later classes share the last
+            stream_of[k] = class_streams.create(device, true, std::min(priority_least, priority_greatest + launch_rank[k]));
     std::mutex start_mutex;
     std::chrono::steady_clock::time_point compute_begin{};
     std::vector<std::exception_ptr> errors(classes);
     std::vector<std::thread> threads;
+    JoinAll join_on_exit{threads};
     const auto t_begin = std::chrono::steady_clock::now();
     for (size_t k = 0; k < classes; ++k)
     {
@@ -353,10 +416,7 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
             try
             {
                 scoped_device_switch d(device);
-                cudaStream_t stream = nullptr;
-                // numerically lower = more urgent; the range is narrow (three levels on this hardware), later classes share the last
-                const int priority = std::min(priority_least, priority_greatest + launch_rank[k]);
-                GW_CU_CHECK_ERR(hipStreamCreateWithPriority(&stream, hipStreamDefault, priority));
+                cudaStream_t stream = stream_of[k];
                 {
                     DefaultDeviceAllocator allocator(static_cast<size_t>(share[k]), stream);
                     std::unique_ptr<Batch> batch = create_batch(device, stream, allocator, share[k], output_mask, plan.configs[k], gap_score,
@@ -417,10 +477,12 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                         if (trace) std::fprintf(stderr, "[size classes] class %zu: generate_poa() called at %.1f ms\n", k, since());
                         if (batch->get_total_poas() > 0) batch->generate_poa();
                         if (trace) std::fprintf(stderr, "[size classes] class %zu: generate_poa() returned at %.1f ms\n", k, since());
+                        // the gate of later class groups: (re-)recorded behind EVERY launch of this class, so a waiter that
+                        // arrives late waits for the class's last submitted launch, not only for its first
+                        GW_CU_CHECK_ERR(hipEventRecord(class_done[k], stream));
                         if (first_launch)
                         {
                             first_launch = false;
-                            GW_CU_CHECK_ERR(hipEventRecord(class_done[k], stream));
                             launch_turn.fetch_add(1);
                         }
                         if (batch->get_total_poas() == 0) continue;
@@ -466,7 +528,6 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                     }
                     arrive();
                 }
-                (void)hipStreamDestroy(stream);
             }
             catch (...)
             {
@@ -481,8 +542,6 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
     }
     for (std::thread& t : threads) t.join();
     const auto t_end = std::chrono::steady_clock::now();
-    for (hipEvent_t e : class_done)
-        if (e) (void)hipEventDestroy(e);
     out.seconds      = std::chrono::duration<double>(t_end - t_begin).count();
     if (compute_seconds)
     {

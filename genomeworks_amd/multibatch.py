@@ -32,9 +32,11 @@ def run_plan(windows, cfgs, groups, max_gpu_mem, output_type="msa", band_mode="a
             pending.sort(key=lambda g: (-sum(len(r) for r in windows[g]) * max((len(r) for r in windows[g]), default=0), g))
         while pending:
             taken = []
+            batch_full = False
             while pending:
                 st, seq_st = batch.add_poa_group(windows[pending[0]])
                 if st == cudapoa.exceeded_maximum_poas:
+                    batch_full = True
                     break
                 g = pending.pop(0)
                 if st == cudapoa.success:
@@ -46,8 +48,15 @@ def run_plan(windows, cfgs, groups, max_gpu_mem, output_type="msa", band_mode="a
                     # every read was rejected AFTER the batch opened a POA for the group: as in the reference
                     # (cudapoa_batch.cuh:122-150) that empty POA stays in the batch and owns an output slot
                     taken.append(None)
-            if not any(g is not None for g in taken):
-                raise RuntimeError("a batch of this plan cannot hold a single window")
+                    results[g] = (None, st)
+                else:
+                    # rejected by the batch (e.g. its longest read exceeds the bin's BatchConfig): recorded with its
+                    # status like the C++ drivers do (out.status[w]), never dropped
+                    results[g] = (None, st)
+            if not taken:
+                if batch_full:  # the batch was full before it held one window
+                    raise RuntimeError("a batch of this plan cannot hold a single window")
+                continue  # every window of this fill was rejected: nothing to launch
             t0 = time.perf_counter()
             batch.generate_poa()
             n_out = batch.get_msa_native() if output_type == "msa" else batch.get_consensus_native()
