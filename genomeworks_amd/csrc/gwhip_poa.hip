@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
         if (alen == kNwLoopFailed) err = kLoopCountExceeded;
         else if (alen == kNwAdaptiveStorageFailed) err = kExceededAdaptiveBandedMatrixSize;
         else if (TB && alen == kNwTracebackBufferFailed) err = kExceededMaximumPredecessorDistance;
-        else if (alen == kNwPipelineFailed) err = kGenericError;
+        else if (alen == kNwPipelineFailed || alen == kNwScoreWrapped) err = kGenericError;
         if (err)
         {
             if (lane == 0) { consensus[0] = kKernelError; consensus[1] = err; }

@@ -30,6 +30,17 @@ template <> struct Limits<int32_t> { static constexpr int32_t min = INT32_MIN; }
 
 template <typename ScoreT> struct alignas(sizeof(ScoreT) * 4) Quad { ScoreT v[4]; };
 
+// Narrowing of a score to the matrix type with a sticky "did not fit" flag. The kernels agree with the reference only while
+// no int16 store wraps (with a wrap the reference's result depends on its relaxation order): the
+// general forward passes raise the flag and the window then ends with StatusType::generic_error instead of a silent
+// divergence; the packed pass of the 256-column band is only taken when bounds on the scores exclude a wrap (nw_banded).
+template <typename ScoreT> __device__ __forceinline__ int32_t narrow_chk(int32_t v, bool& wrapped)
+{
+    const int32_t n = (int32_t)(ScoreT)v;
+    if constexpr (sizeof(ScoreT) == 2) wrapped |= n != v;
+    return n;
+}
+
 // Per-row table entry: node base, predecessor count, sink flag, the row's band start and the score-matrix rows
 // (node_id_to_pos + 1) of the first 3 predecessor slots. The LDS-resident flavour (PACKED) is bit-packed into one 64-bit
 // word (one ds_read_b64, decoded on the scalar unit): rows <= 4095, band starts <= 2044.
@@ -387,164 +398,6 @@ __device__ __forceinline__ int32_t traceback_banded(const BandedCtx<ScoreT>& b, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Traceback by recomputation with the score matrix served from an LDS tile.
-// Same decision sequence as traceback_banded (cudapoa_nw_banded.cuh:428-549). The walk is executed
-// wave-uniformly (every lane follows the same (i, j)); all 64 lanes stage a tile of 64 rows x 64 columns of
-// the HBM score matrix around the current position, so a step costs LDS latency instead of HBM round trips.
-// Cells outside the tile (far predecessors) fall back to the HBM copy; the tile is re-anchored when the walk
-// approaches its edge.  tile layout in LDS: int16/int32 tile[64][64], then per tile row {band start, first column}.
-// ------------------------------------------------------------------------------------------------
-template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE>
-__device__ __forceinline__ int32_t traceback_banded_tiled(const BandedCtx<ScoreT>& b, const GraphView<IdT>& g,
-                                                          const RowT* rowinfo, int32_t graph_count,
-                                                          const uint8_t* read, int32_t read_length, int32_t start_i,
-                                                          int32_t* alignment_graph, int32_t* alignment_read,
-                                                          int32_t gap_score, int32_t mismatch_score,
-                                                          int32_t match_score, int32_t rerun, ScoreT* tile,
-                                                          int32_t* tile_meta)
-{
-    constexpr int kTileRows = 64, kTileCols = 64, kReanchor = 44;
-    const int lane      = threadIdx.x & (kWave - 1);
-    const int32_t bound = read_length + graph_count + 2;
-    int32_t aligned_nodes = 0, loop_count = 0;
-    int32_t i = start_i, j = read_length, prev_i = 0, prev_j = 0;
-    int32_t tile_top = -1; // matrix row held in tile row 0 (-1: no tile)
-
-    auto load_tile = [&](int32_t top, int32_t col) {
-        wave_sync();
-        // lane = tile row: row = top - lane; window of 64 stored elements around column (col - lane) - 40
-        const int32_t row = top - lane;
-        int32_t bs = 0, e0 = 0;
-        if (row >= 0)
-        {
-            bs = band_start_for_row(row, b.gradient, b.band_width, b.band_shift, b.max_column);
-            e0 = (col - lane - 40) - bs + kRelShift; // stored element index of the window start
-            e0 = min(max(e0 & ~3, 0), b.stride - kTileCols);
-            const ScoreT* src = b.scores + (int64_t)row * b.stride + e0;
-            ScoreT* dst       = tile + lane * kTileCols;
-#pragma unroll
-            for (int k = 0; k < kTileCols; k += 4)
-                *reinterpret_cast<Quad<ScoreT>*>(dst + k) = *reinterpret_cast<const Quad<ScoreT>*>(src + k);
-        }
-        tile_meta[lane] = (row >= 0) ? ((bs & 0xffff) | ((e0 - kRelShift + bs) << 16)) : 0x7fff0000;
-        wave_sync();
-    };
-    // get_score() of cudapoa_nw_banded.cuh:80-102, tile first
-    auto score_at = [&](int32_t row, int32_t column) -> int32_t {
-        const int32_t rr = tile_top - row;
-        if (tile_top >= 0 && rr >= 0 && rr < kTileRows)
-        {
-            const int32_t meta = tile_meta[rr];
-            const int32_t bs   = meta & 0xffff;
-            const int32_t lo   = meta >> 16; // column stored in tile element 0
-            const int32_t bend = min(bs + b.band_width, b.max_column);
-            if ((column > bend || column < bs) && column != -1) return b.min_score;
-            const int32_t col = column == -1 ? bs : column;
-            if (col == bs && bs > 0 && row > 0) return b.min_score; // relative-0 slot, see get_score
-            const int32_t off = col - lo;
-            if (off >= 0 && off < kTileCols) return tile[rr * kTileCols + off];
-        }
-        return get_score(b, row, column);
-    };
-
-    while (!(i == 0 && j == 0) && loop_count < bound)
-    {
-        // keep the current cell and its near predecessors inside the tile
-        {
-            const int32_t rr = tile_top - i;
-            bool reload      = tile_top < 0 || rr < 0 || rr >= kReanchor;
-            if (!reload)
-            {
-                const int32_t meta = tile_meta[rr];
-                const int32_t off  = j - (meta >> 16);
-                reload             = (off < 2 || off >= kTileCols);
-            }
-            if (reload && i > 0)
-            {
-                tile_top = i;
-                load_tile(i, j);
-            }
-        }
-        loop_count++;
-        const int32_t scores_ij = score_at(i, j);
-        bool pred_found         = false;
-        RowT ri{};
-        int32_t pred_count = 0, node_id = 0;
-        if (i != 0)
-        {
-            ri         = rowinfo[i];
-            pred_count = ri.cnt();
-        }
-        auto pred_row = [&](int32_t p) -> int32_t {
-            if (pred_count == 0) return 0;
-            if (p < 3) return ri.pred(p);
-            return (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1;
-        };
-        if (i != 0 && pred_count > 3) node_id = g.sorted_poa[i - 1];
-        bool rerun_break = false;
-        if (i != 0 && j != 0)
-        {
-            if (ADAPTIVE)
-            {
-                if (rerun == 0 && b.band_width < kMaxAdaptiveBand)
-                {
-                    int32_t threshold = max(1, b.max_column / 1024);
-                    if (j > threshold && j < b.max_column - threshold)
-                    {
-                        int32_t bs = band_start_for_row(i, b.gradient, b.band_width, b.band_shift, b.max_column);
-                        if (j <= bs + threshold) { aligned_nodes = kShiftLeft; rerun_break = true; }
-                        else if (j >= (bs + b.band_width - threshold)) { aligned_nodes = kShiftRight; rerun_break = true; }
-                    }
-                }
-            }
-            if (!rerun_break)
-            {
-                int32_t match_cost = ((uint32_t)ri.base() == read[j - 1] ? match_score : mismatch_score);
-                int32_t np         = max(pred_count, 1);
-                for (int32_t p = 0; p < np; p++)
-                {
-                    int32_t pi = pred_row(p);
-                    if (scores_ij == score_at(pi, j - 1) + match_cost)
-                    {
-                        prev_i = pi; prev_j = j - 1; pred_found = true;
-                        break;
-                    }
-                }
-            }
-        }
-        if (rerun_break) break;
-        if (!pred_found && i != 0)
-        {
-            int32_t np = max(pred_count, 1);
-            for (int32_t p = 0; p < np; p++)
-            {
-                int32_t pi = pred_row(p);
-                if (scores_ij == score_at(pi, j) + gap_score)
-                {
-                    prev_i = pi; prev_j = j; pred_found = true;
-                    break;
-                }
-            }
-        }
-        if (!pred_found && scores_ij == score_at(i, j - 1) + gap_score)
-        {
-            prev_i = i; prev_j = j - 1; pred_found = true;
-        }
-        if (lane == 0)
-        {
-            alignment_graph[aligned_nodes] = (i == prev_i ? -1 : (int32_t)g.sorted_poa[i - 1]);
-            alignment_read[aligned_nodes]  = (j == prev_j ? -1 : j - 1);
-        }
-        aligned_nodes++;
-        i = prev_i;
-        j = prev_j;
-    }
-    if (loop_count >= bound) aligned_nodes = kNwLoopFailed;
-    wave_sync();
-    return aligned_nodes;
-}
-
-// ------------------------------------------------------------------------------------------------
 // Tiled traceback for graphs whose row table lives in HBM (long reads). traceback_banded_tiled keeps the score matrix
 // around the path in LDS, but with the row table, the read and the output arrays in HBM every step still paid global
 // round trips behind its own stores (about 1 450 cycles per step). Here everything a step touches is staged with the
@@ -766,12 +619,10 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
                                                           const uint8_t* read, int32_t read_length, int32_t start_i,
                                                           int32_t* alignment_graph, int32_t* alignment_read,
                                                           int32_t gap_score, int32_t mismatch_score,
-                                                          int32_t match_score, int32_t rerun, ScoreT* tile,
-                                                          const uint8_t* codes, uint8_t* ctile, int32_t dbg = 0,
+                                                          int32_t match_score, int32_t rerun, ScoreT* tile, int32_t dbg = 0,
                                                           uint64_t* prof_acc = nullptr)
 {
     constexpr int kTileRows = 60, kTileCols = 64, kTileStride = 68, kReanchor = 44, kLead = 40, kHalf = 31;
-    constexpr int kCodeRows = 64, kCodeCols = 64, kCodeReanchor = 60; // LDS tile of trace codes (poa_forward_packed.h)
     constexpr int kStage = 64;
     const int lane      = threadIdx.x & (kWave - 1);
     const int32_t bound = read_length + graph_count + 2;
@@ -779,9 +630,8 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     int32_t i = start_i, j = read_length, prev_i = 0, prev_j = 0;
     int32_t tile_top = -1, tile_col = 0; // matrix row in tile row 0 and the column the windows are anchored on
     uint32_t* stage  = reinterpret_cast<uint32_t*>(tile + kTileRows * kTileStride);
-    // profiling (GWHIP_DEBUG bits 22-24, outside the table-lookup loop): 2 cycles in load_codes, 3 its calls,
-    // 4 cycles in recomputed steps (incl. their tile loads), 5 their number, 6 cycles of the post-pass, 7 code tiles taken from the look-ahead
-    // (counts are scaled by 1000 to stand out of the "other" accumulator they arrive in)
+    // profiling (GWHIP_DEBUG bits 22-24): 4 cycles in the steps (incl. their tile loads), 5 their number (x 1000), 6 cycles of
+    // the post-pass; arrives in the "other" accumulator
     const int32_t psel = prof_acc ? (dbg >> 22) & 7 : 0;
     uint64_t pacc      = 0;
 
@@ -837,107 +687,15 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
         }
     };
 
-    // ---- trace-code fast path: where the forward pass left a move code the step is a table lookup ----
-    // matrix row in code-tile row 0 (far below any row while no tile is loaded, so that the range test of the walk
-    // fails without a separate flag) and the column its windows are anchored on
-    int32_t ctop = -(1 << 20), ccol = 0, ccol_lead = 0;
-    auto lo_of   = [&](int32_t col, int32_t t) -> int32_t { return ((col - kLead - t) & ~3) + 1; };
-    auto code_lo = [&](int32_t t) -> int32_t { return lo_of(ccol, t); };
-    // Loader: 4 lanes per tile row (16 bytes each), 16 rows per pass; band starts come from the LDS row table. Bytes
-    // that are not cells of the band (window reaching past a band edge, rows < 1) become code 0.
-    // A tile load is one cold HBM round trip (~5 000 cycles with 1024 windows in flight) and the walk needs one every
-    // ~40 steps, so the NEXT tile is requested as soon as the current one is in place -- 56 rows further up, at the
-    // column the band's slope predicts -- and waits in registers; when the walk leaves the current tile inside the
-    // predicted one, that one is committed to LDS without a wait. A wrong prediction costs an ordinary load.
-    struct __attribute__((packed, aligned(4))) CodeSeg { uint32_t d[4]; };
-    constexpr int kPasses = kCodeRows / 16, kAhead = 56;
-    const int seg = lane & 3;
-    auto issue_codes = [&](int32_t top, int32_t col, CodeSeg (&v)[kPasses]) {
-#pragma unroll
-        for (int pass = 0; pass < kPasses; pass++)
-        {
-            const int32_t t    = pass * 16 + (lane >> 2);
-            const int32_t rowc = max(top - t, 1);
-            const int32_t e0   = lo_of(col, t) - rowinfo[rowc].bs() + kRelShift; // byte index in the code row, multiple of 4
-            v[pass] = *reinterpret_cast<const CodeSeg*>(codes + (int64_t)rowc * b.stride + e0 + seg * 16);
-        }
-    };
-    auto commit_codes = [&](int32_t top, int32_t col, CodeSeg (&v)[kPasses]) {
-        wave_sync();
-        ctop = top;
-        ccol = col;
-        ccol_lead = col - kLead;
-#pragma unroll
-        for (int pass = 0; pass < kPasses; pass++)
-        {
-            const int32_t t    = pass * 16 + (lane >> 2);
-            const int32_t row  = top - t;
-            const int32_t e0   = lo_of(col, t) - rowinfo[max(row, 1)].bs() + kRelShift;
-            const int32_t klo  = row >= 1 ? (1 + kRelShift) - e0 : 1; // window bytes that are cells of the band
-            const int32_t khi  = row >= 1 ? (b.band_width + kRelShift) - e0 : 0;
-            if (__ballot(!(klo <= 0 && khi >= kCodeCols - 1)) != 0)
-            {
-#pragma unroll
-                for (int d = 0; d < 4; d++)
-                {
-                    const int32_t k0 = seg * 16 + d * 4;
-                    const int32_t lo = min(max(klo - k0, 0), 4), hi = min(max(khi - k0 + 1, 0), 4);
-                    const uint32_t mhi = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
-                    const uint32_t mlo = lo >= 4 ? 0xffffffffu : ((1u << (8 * lo)) - 1u);
-                    v[pass].d[d] &= hi > lo ? (mhi & ~mlo) : 0u;
-                }
-            }
-            *reinterpret_cast<uint4*>(ctile + t * kCodeCols + seg * 16) = make_uint4(v[pass].d[0], v[pass].d[1], v[pass].d[2], v[pass].d[3]);
-        }
-        wave_sync();
-    };
-    CodeSeg ahead[kPasses] = {};
-    int32_t atop = -1, acol = 0; // anchor of the tile in `ahead` (atop < 0: none)
-    // columns the path moves per row, and where inside a 64-column window it should enter so that the drift between
-    // the window's slope (1 column per row) and the path's stays inside the window
-    const int32_t ahead_bias = min(max((int32_t)((1.0f - b.gradient) * 32.0f), -12), 12);
-    // columns per row in 1/256: the band's slope. (The walk's own slope between two tile changes predicts better --
-    // 94 % instead of 72 % of the tiles are taken without a wait -- but its integer division per tile costs more than
-    // the extra hits save: 17.21 M vs 17.11 M cycles per window, measured on one box.)
-    const int32_t slope_q8 = (int32_t)(b.gradient * 256.0f);
-    auto load_codes = [&](int32_t top, int32_t col) {
-        const uint64_t t_lc = psel == 2 ? clock64() : 0;
-        if (psel == 3) pacc += 1000;
-        bool hit = false;
-        if (atop >= 0)
-        {
-            const int32_t t   = atop - top;
-            const int32_t off = col - lo_of(acol, t);
-            hit = ((uint32_t)t < (uint32_t)kCodeReanchor) & ((uint32_t)(off - 2) < (uint32_t)(kCodeCols - 2));
-        }
-        if (hit)
-        {
-            if (psel == 7) pacc += 1000;
-            commit_codes(atop, acol, ahead);
-        }
-        else
-        {
-            CodeSeg now[kPasses];
-            issue_codes(top, col, now);
-            commit_codes(top, col, now);
-        }
-        atop = ctop - kAhead;
-        acol = col - ((slope_q8 * (top - atop)) >> 8) + ahead_bias; // where the walk should be when it reaches row atop
-        if (atop >= 1) issue_codes(atop, acol, ahead);
-        else atop = -1;
-        if (psel == 2) pacc += clock64() - t_lc;
-    };
-
     // lane roles (VGPR constants)
     const int kind        = lane < kHalf ? 0 : (lane < 2 * kHalf ? 1 : (lane == 2 * kHalf ? 2 : 3));
     const int p           = kind == 0 ? lane : lane - kHalf;
     const int psh         = 24 + 12 * min(p, 2);
     const bool is_diag    = kind == 0, is_vert = kind == 1, is_horiz = kind == 2, is_self = kind == 3;
     const int32_t col_dec = (is_vert | is_self) ? 0 : 1; // candidate column = j - col_dec
-    // With trace codes the recomputed steps are isolated (about 2 % of the steps, scattered along the path): a
-    // 60-row score tile per such step cost ~8 700 cycles. They read their few operands straight from the HBM matrix
-    // instead, all in one round trip: the candidates and, on lane 63, H(i, j) itself.
-    const bool use_tile = codes == nullptr;
+    // (the 256-column band of int16 scores has its own walk over move bytes, poa_traceback_moves.h; this one serves the
+    // other band widths of graphs that fit the LDS tables)
+    constexpr bool use_tile = true;
     // Wave-uniform walk state, kept in SGPRs (every update goes through readfirstlane / readlane so that the
     // loop control stays scalar): position, H(i, j), the row-table word of row i and the read character j - 1.
     int32_t scores_ij = 0;
@@ -946,49 +704,6 @@ __device__ __forceinline__ int32_t traceback_banded_lanes(const BandedCtx<ScoreT
     // (every step appends one entry, so the reference's loop counter is aligned_nodes)
     while (!(i == 0 && j == 0) && aligned_nodes < bound)
     {
-        if (codes != nullptr)
-        {
-            // tight loop over consecutive steps whose move code is known
-            bool stop = false;
-            // shift of the predecessor slot a code names inside the row-table word (codes 2..4 diagonal, 5..7 vertical)
-            constexpr uint64_t kShiftLut = 0x3024183024181818ull;
-            while (i > 0 && aligned_nodes < bound)
-            {
-                const int32_t t  = ctop - i;
-                const int32_t lo = (ccol_lead - t) & ~3; // code_lo(t) - 1
-                if (((uint32_t)t >= (uint32_t)kCodeReanchor) | ((uint32_t)(j - lo - 3) >= (uint32_t)(kCodeCols - 2)))
-                {
-                    load_codes(i, j);
-                    continue;
-                }
-                const uint32_t code = (uint32_t)wave_first((int32_t)ctile[t * kCodeCols + (j - lo - 1)]);
-                const uint64_t riw  = wave_first64(rowinfo[i].w);
-                if (code == 0) break; // undecided cell: recompute this step below
-                if (ADAPTIVE)
-                {
-                    if (j != 0 && rerun == 0 && b.band_width < kMaxAdaptiveBand)
-                    {
-                        int32_t threshold = max(1, b.max_column / 1024);
-                        if (j > threshold && j < b.max_column - threshold)
-                        {
-                            int32_t bs = band_start_for_row(i, b.gradient, b.band_width, b.band_shift, b.max_column);
-                            if (j <= bs + threshold) { aligned_nodes = kShiftLeft; stop = true; break; }
-                            if (j >= (bs + b.band_width - threshold)) { aligned_nodes = kShiftRight; stop = true; break; }
-                        }
-                    }
-                }
-                lane0_store_u32(stage + (aligned_nodes & (kStage - 1)), (uint32_t)i | ((uint32_t)j << 16));
-                aligned_nodes++;
-                const uint32_t sh = (uint32_t)(kShiftLut >> (code * 8)) & 0xffu;
-                const int32_t pr  = (int32_t)((riw >> sh) & 0xfff);
-                i                 = code == 1 ? i : pr;
-                j                 = code >= 5 ? j : j - 1;
-                if ((aligned_nodes & (kStage - 1)) == 0) flush_stage(aligned_nodes - kStage, kStage);
-                have = false;
-            }
-            if (stop) break;
-            if ((i == 0 && j == 0) || aligned_nodes >= bound) continue; // the outer condition ends the walk
-        }
         const uint64_t t_rc = psel == 4 ? clock64() : 0;
         if (psel == 5) pacc += 1000;
         // keep the current cell and its near predecessors inside the tile
@@ -1238,7 +953,7 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
                                                      int32_t graph_count, const uint8_t* lds_read, ScoreT* scores,
                                                      ScoreT* ring, int32_t ring_rows, int32_t band_width,
                                                      int32_t max_column, int32_t gap_score, int32_t mismatch_score,
-                                                     int32_t match_score, int32_t dbg, uint64_t* general_row_acc)
+                                                     int32_t match_score, int32_t dbg, uint64_t* general_row_acc, bool& wrapped)
 {
     const int lane          = threadIdx.x & (kWave - 1);
     const int32_t min_score = Limits<ScoreT>::min / 2;
@@ -1272,7 +987,8 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
         ring_slot = (ring_slot + 1 == ring_rows) ? 0 : ring_slot + 1;
         ring_out  = (ring_slot == 0) ? ring : ring_out + stride;
         Quad<ScoreT> out;
-        out.v[0] = (ScoreT)P0; out.v[1] = (ScoreT)P1; out.v[2] = (ScoreT)P2; out.v[3] = (ScoreT)P3;
+        out.v[0] = (ScoreT)narrow_chk<ScoreT>(P0, wrapped); out.v[1] = (ScoreT)narrow_chk<ScoreT>(P1, wrapped);
+        out.v[2] = (ScoreT)narrow_chk<ScoreT>(P2, wrapped); out.v[3] = (ScoreT)narrow_chk<ScoreT>(P3, wrapped);
         if (full_wave)
         {
             if (!(dbg & 1)) *reinterpret_cast<Quad<ScoreT>*>(row_out + lane4 + 1 + kRelShift) = out;
@@ -2478,31 +2194,26 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
 
     constexpr bool kFastOk = std::is_same<RowT, RowInfo<true>>::value && LDS_READ;
     bool fast_done = false, codes_valid = false, moves_valid = false;
+    bool wrapped = false; // a score did not fit the matrix type (narrow_chk)
     if constexpr (kFastOk && std::is_same<ScoreT, int16_t>::value)
     {
         // packed 16-bit pass for the 256-column band (preconditions: poa_forward_packed.h)
         const bool packed_ok = band_width == 256 && max_column >= band_width && ring_bytes >= kPkSlots * kPkSlotBytes &&
                                abs(gap_score) <= 30 && abs(match_score) <= 100 && abs(mismatch_score) <= 100 &&
-                               codes != nullptr && !(dbg & 256) && ring_bytes >= kMtBytes;
-        if (packed_ok && !(dbg & (1 << 25)))
+                               codes != nullptr && !(dbg & 256) && ring_bytes >= kMtBytes &&
+                               // no packed operation can leave int16: the largest score (all matches) plus the u-space offset of
+                               // the last band cell, and the smallest (every step at the worst penalty; min_score-derived cells)
+                               max(match_score, 0) * min(read_length, graph_count) + 256 * abs(gap_score) + abs(match_score) <= 32767 &&
+                               (graph_count + read_length) * min(min(gap_score, mismatch_score), 0) >= -32768 + 256 &&
+                               min_score + 4 * min(min(gap_score, mismatch_score), 0) - 256 * abs(gap_score) >= -32768;
+        if (packed_ok)
         {
-            // round 3: move bytes, row kinds, descriptors in registers (poa_forward_moves.h); GWHIP_DEBUG bit 25 selects the
-            // round-2 pass with its code-table traceback instead (A/B)
+            // move bytes, row kinds, descriptors in registers (poa_forward_moves.h)
             banded_forward_moves<IdT>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
                                       reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score, dbg,
                                       pc.acc ? &pc.acc[kPhOther] : nullptr);
             fast_done   = true;
             moves_valid = true;
-        }
-        else if (packed_ok)
-        {
-            classify_rows(rowinfo, graph_count, lane, reinterpret_cast<const uint64_t*>(code_tile), dbg, pc.acc ? &pc.acc[kPhOther] : nullptr);
-            wave_sync();
-            banded_forward_packed<IdT>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
-                                       reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score, dbg,
-                                       pc.acc ? &pc.acc[kPhOther] : nullptr);
-            fast_done   = true;
-            codes_valid = true;
         }
     }
     if constexpr (kFastOk)
@@ -2511,7 +2222,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
         {
             banded_forward_1pass<ScoreT, IdT>(g, rowinfo, graph_count, lds_read, scores, b.ring, b.ring_rows, band_width,
                                               max_column, gap_score, mismatch_score, match_score, dbg,
-                                              pc.acc ? &pc.acc[kPhOther] : nullptr);
+                                              pc.acc ? &pc.acc[kPhOther] : nullptr, wrapped);
             fast_done = true;
         }
     }
@@ -2678,10 +2389,10 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                 int32_t t0, t1, t2, t3;
                 if (valid)
                 {
-                    t0 = (ScoreT)max(S0 + cp0, S1 + gap_score);
-                    t1 = (ScoreT)max(S1 + cp1, S2 + gap_score);
-                    t2 = (ScoreT)max(S2 + cp2, S3 + gap_score);
-                    t3 = (ScoreT)max(S3 + cp3, S4 + gap_score);
+                    t0 = narrow_chk<ScoreT>(max(S0 + cp0, S1 + gap_score), wrapped);
+                    t1 = narrow_chk<ScoreT>(max(S1 + cp1, S2 + gap_score), wrapped);
+                    t2 = narrow_chk<ScoreT>(max(S2 + cp2, S3 + gap_score), wrapped);
+                    t3 = narrow_chk<ScoreT>(max(S3 + cp3, S4 + gap_score), wrapped);
                 }
                 else { t0 = t1 = t2 = t3 = min_score; }
                 if (p == 0) { s0 = t0; s1 = t1; s2 = t2; s3 = t3; }
@@ -2699,10 +2410,10 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             const int32_t incl  = wave_inclusive_max(m3);
             const int32_t cu    = carry + gap_score; // carry as element t = -1: carry - (-1)*gap
             const int32_t excl  = max(wave_shr1(incl, INT32_MIN), cu);
-            N0 = (ScoreT)(max(m0, excl) + (tb + 0) * gap_score);
-            N1 = (ScoreT)(max(m1, excl) + (tb + 1) * gap_score);
-            N2 = (ScoreT)(max(m2, excl) + (tb + 2) * gap_score);
-            N3 = (ScoreT)(max(m3, excl) + (tb + 3) * gap_score);
+            N0 = narrow_chk<ScoreT>(max(m0, excl) + (tb + 0) * gap_score, wrapped);
+            N1 = narrow_chk<ScoreT>(max(m1, excl) + (tb + 1) * gap_score, wrapped);
+            N2 = narrow_chk<ScoreT>(max(m2, excl) + (tb + 2) * gap_score, wrapped);
+            N3 = narrow_chk<ScoreT>(max(m3, excl) + (tb + 3) * gap_score, wrapped);
             // carry into the next pass = last cell of the last lane
             carry = wave_bcast(N3, kWave - 1);
             if (active)
@@ -2753,6 +2464,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     }
     wave_sync(); // score matrix complete and visible to lane 0's traceback
     pc.tick(kPhForward);
+    if (__ballot(wrapped) != 0) return kNwScoreWrapped; // enforced precondition, see narrow_chk
 
     // ---- sink selection (:410-426): first row with the strictly greatest H(row, L) among sink rows ----
     const uint64_t t_sink = (pc.acc && ((dbg >> 22) & 7) == 1) ? clock64() : 0;
@@ -2816,8 +2528,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
         {
             aligned_nodes = traceback_banded_lanes<ScoreT, IdT, ADAPTIVE>(b, g, rowinfo, graph_count, lds_read, read_length,
                                                                           wave_first(best_i), alignment_graph, alignment_read, gap_score,
-                                                                          mismatch_score, match_score, rerun, ring_base,
-                                                                          (codes_valid && code_tile && !(dbg & 64)) ? codes : nullptr, code_tile, dbg,
+                                                                          mismatch_score, match_score, rerun, ring_base, dbg,
                                                                           pc.acc ? &pc.acc[kPhOther] : nullptr);
             tb_done = true;
         }
@@ -2845,16 +2556,6 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                                                                                   wave_first(best_i), alignment_graph, alignment_read,
                                                                                   gap_score, mismatch_score, match_score, rerun,
                                                                                   reinterpret_cast<uint8_t*>(ring_base));
-    }
-    else if (LDS_READ && tile_fits && !(dbg & 128))
-    {
-        // the LDS ring is dead after the forward pass: reuse it as the traceback tile
-        ScoreT* tile       = ring_base;
-        int32_t* tile_meta = reinterpret_cast<int32_t*>(ring_base + 64 * 64);
-        aligned_nodes = traceback_banded_tiled<ScoreT, IdT, RowT, ADAPTIVE>(b, g, rowinfo, graph_count, LDS_READ ? lds_read : read,
-                                                                           read_length, best_i, alignment_graph,
-                                                                           alignment_read, gap_score, mismatch_score,
-                                                                           match_score, rerun, tile, tile_meta);
     }
     else if (lane == 0)
         aligned_nodes = traceback_banded<ScoreT, IdT, RowT, ADAPTIVE>(b, g, rowinfo, graph_count, read, read_length, best_i,

@@ -57,7 +57,7 @@ __device__ __forceinline__ void gstore_u16_lane0_below(const void* vptr, uint32_
 // Row kinds, all lanes in parallel. Needs the band starts in the table already. Returns the first row whose band
 // starts past column 0 (graph_count + 1 if there is none); band starts never decrease from row to row.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int32_t classify_kinds(RowInfo<true>* rowinfo, int32_t graph_count, int lane, const uint64_t* xpred)
+__device__ __forceinline__ int32_t classify_kinds(RowInfo<true>* rowinfo, int32_t graph_count, int lane, const uint64_t* xpred, int32_t dbg = 0)
 {
     int32_t first_moved = graph_count + 1;
     for (int32_t r = 1 + lane; r <= graph_count; r += kWave)
@@ -67,7 +67,7 @@ __device__ __forceinline__ int32_t classify_kinds(RowInfo<true>* rowinfo, int32_
         uint64_t kind     = 4;
         // 4..6 predecessors: rows 3..5 from the side table build_rowinfo left (a row that lost its slot stays kind 4)
         const uint64_t xe  = (cnt > 3 && cnt <= 6 && xpred != nullptr) ? xpred[r & 255] : 0ull;
-        const bool many_ok = cnt > 3 && cnt <= 6 && xpred_hit(xe, r, cnt);
+        const bool many_ok = cnt > 3 && cnt <= 6 && xpred_hit(xe, r, cnt) && !(dbg & (1 << 30));
         if (cnt >= 1 && (cnt <= 3 || many_ok))
         {
             bool ok    = true;
@@ -82,6 +82,13 @@ __device__ __forceinline__ int32_t classify_kinds(RowInfo<true>* rowinfo, int32_
             }
             if (ok) kind = cnt > 1 ? 3 : ((d0 == 1 && pbs0 == bs) ? 0 : ((d0 == 1 && bs - pbs0 == kCellsPerLane) ? 1 : 2));
         }
+        // A/B selectors (GWHIP_DEBUG, debug instantiation): demote kinds so that the routines can be checked against each
+        // other -- bit 10: registers -> ring (kinds 0, 1 -> 2), bit 15: kind 1 -> 2, bit 9: ring -> general (2, 3 -> 4),
+        // bit 11: registers -> general (0, 1 -> 4), bit 30 (above): rows with 4..6 predecessors -> general
+        if ((dbg & 1024) && kind <= 1) kind = 2;
+        if ((dbg & 32768) && kind == 1) kind = 2;
+        if ((dbg & 512) && (kind == 2 || kind == 3)) kind = 4;
+        if ((dbg & 2048) && kind <= 1) kind = 4;
         ri.w       = (ri.w & ~(7ull << kKindShift)) | (kind << kKindShift);
         rowinfo[r] = ri;
         if (bs > 0) first_moved = min(first_moved, r);
@@ -120,7 +127,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
     const int32_t lane4 = lane * 4, lane8 = lane * 8;
     const int32_t min_score = Limits<int16_t>::min / 2;
 
-    const int32_t first_moved = classify_kinds(rowinfo, graph_count, lane, xpred);
+    const int32_t first_moved = classify_kinds(rowinfo, graph_count, lane, xpred, dbg);
     wave_sync();
 
     const uint32_t MIN2   = pin_vgpr(pk_dup(min_score));

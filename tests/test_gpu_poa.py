@@ -280,10 +280,12 @@ def test_group_with_every_read_rejected_keeps_its_output_slot():
 
 
 def test_kernel_shortcuts_equal_the_plain_schedule(monkeypatch):
-    """A/B inside the kernel: the incremental Kahn order (default) vs the full re-sort after every read
-    (GWHIP_DEBUG bit 21, the reference's schedule), and rows with 4..6 predecessors in the LDS-ring class (default) vs
-    the general routine (bit 30), must give identical consensus, coverage, status and cell counts on the config-3
-    windows and on windows of varied shape."""
+    """A/B inside the kernel (GWHIP_DEBUG selectors of the debug instantiation; the production instantiation is the first
+    arm): the incremental Kahn order vs the full re-sort after every read (bit 21, the reference's schedule); rows with
+    4..6 predecessors in the LDS-ring kind vs the general routine (bit 30); the row kinds of the forward pass demoted into
+    each other -- register rows through the ring (bit 10), moved-band rows through the ring (bit 15), ring rows through the
+    general routine (bit 9), register rows through the general routine (bit 11) -- must give identical consensus, coverage,
+    status and cell counts on config-3 windows and on windows of varied shape."""
     import random
     from genomeworks_amd import synthetic
     rng = random.Random(5)
@@ -297,8 +299,11 @@ def test_kernel_shortcuts_equal_the_plain_schedule(monkeypatch):
             w = [("GATTACA"[: rng.randrange(8)] + r)[rng.randrange(5):] for r in w]
         windows.append([r for r in w if 0 < len(r) < 1024])
     out = {}
-    for name, flag in (("incremental", None), ("full", str(1 << 21)), ("general_rows", str(1 << 30)),
-                       ("plain", str((1 << 21) | (1 << 30)))):
+    arms = (("production", None), ("full_resort", str(1 << 21)), ("many_predecessors_general", str(1 << 30)),
+            ("plain", str((1 << 21) | (1 << 30))), ("registers_through_ring", str(1 << 10)), ("moved_band_through_ring", str(1 << 15)),
+            ("ring_through_general", str(1 << 9)), ("registers_through_general", str(1 << 11)),
+            ("everything_general", str((1 << 9) | (1 << 11) | (1 << 30))))
+    for name, flag in arms:
         if flag is None:
             monkeypatch.delenv("GWHIP_DEBUG", raising=False)
         else:
@@ -307,8 +312,8 @@ def test_kernel_shortcuts_equal_the_plain_schedule(monkeypatch):
             b = run_gpu(windows, mode)
             out[name, mode] = (b.get_consensus(), b.total_cells())
     for mode in ("static_band", "adaptive_band"):
-        for name in ("full", "general_rows", "plain"):
-            assert out["incremental", mode] == out[name, mode], (name, mode)
+        for name, _ in arms[1:]:
+            assert out["production", mode] == out[name, mode], (name, mode)
 
 
 def test_consensus_kernel_with_small_lds_tables_and_oversized_graphs():

@@ -191,3 +191,21 @@ def test_consensus_known_answers(idx):
     c = cons.cpu().numpy()
     n = int(np.argmax(c == 0))
     assert bytes(c[:n]).decode() == case["answer"]
+
+
+def test_scores_that_leave_int16_end_as_an_error_not_as_a_result():
+    """The kernels equal the reference only while no int16 store wraps (with a wrap the reference's result depends on its
+    relaxation order). The precondition is enforced: the 493-node case through the static band with a match score that drives
+    the scores past 32767 returns the kernel's "score wrapped" code (StatusType::generic_error at the batch level), while the
+    same call with the default scores still gives the known answer."""
+    nb = V["nw_banded"]
+    nodes, read = nb["nodes"], nb["read"]
+    outgoing = [[i + 1] for i in range(len(nodes) - 1)] + [[]]
+    cb = O.make_cfg(1024, 2, 128, 1)
+    g = O.graph_buffers(nodes, outgoing, cb.max_nodes_per_graph, list(range(len(nodes))))
+    n_ok, _, _ = run_nw_gpu(cb, g, read)
+    assert n_ok == 550
+    hot = O.make_cfg(1024, 2, 128, 1, match=120)  # ~490 matches x 120 > 32767; the hook keeps the int16 instantiation
+    hot.score32 = 0
+    n_bad, _, _ = run_nw_gpu(hot, g, read)
+    assert n_bad == -5  # kNwScoreWrapped (poa_layout.h)
