@@ -734,30 +734,6 @@ template <int G> struct GroupCtx
     int32_t lo;
 };
 
-// target character of column t (1-based): refilled by the group's lanes together, 64 characters at a time
-template <int G> __device__ __forceinline__ char group_target_char(GroupCtx<G>& c, int32_t idx)
-{
-    if (idx < c.lo || idx >= c.lo + 64)
-    {
-        c.lo = idx;
-        for (int k = c.gl; k < 16; k += G)
-        {
-            uint32_t w = 0;
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
-            {
-                const int32_t q  = idx + 4 * k + bb;
-                const uint32_t ch = q < c.target_size ? (uint32_t)(unsigned char)c.target[q] : 0u;
-                w |= ch << (8 * bb);
-            }
-            c.tbuf[k] = w;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    }
-    const uint32_t w = c.tbuf[(idx - c.lo) >> 2];
-    return (char)((w >> (8 * ((idx - c.lo) & 3))) & 0xffu);
-}
-
 // one column of the band for the whole group: lane k holds word k (pv, mv as they enter the column: for the sliding band
 // already shifted down by one row). Returns ph / mh (before the shift) for the deltas.
 template <int G>
@@ -789,6 +765,64 @@ __device__ __forceinline__ void group_advance(const GroupCtx<G>& c, uint32_t eq,
     mh_out = mh;
 }
 
+// The pattern words of a band word, cached in registers (round 3). Band word k of a stripe looks at the query through a
+// window that starts `begin` bits into the pattern table; its 32 bits for base ci are the funnel shift of table words
+// k + begin / 32 and k + begin / 32 + 1 by begin % 32 (get_pattern above). A lane keeps those two words for all four bases
+// (eight registers), so a column costs no LDS round trip: the horizontal stripes (fixed window) shift them once, the sliding
+// stripe shifts them by one more bit per column and reloads a word every 32 columns.
+struct PatternWindow
+{
+    uint32_t lo[4], hi[4];
+    int32_t word; // table word in lo
+    __device__ __forceinline__ void load(const PairTable& patterns, int32_t n_words, int32_t w)
+    {
+        word = w;
+#pragma unroll
+        for (int ci = 0; ci < 4; ci++)
+        {
+            lo[ci] = (w >= 0 && w < n_words) ? patterns[w * 4 + ci] : 0u;
+            hi[ci] = (w + 1 >= 0 && w + 1 < n_words) ? patterns[(w + 1) * 4 + ci] : 0u;
+        }
+    }
+};
+__device__ __forceinline__ uint32_t select4(uint32_t ci, uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3)
+{
+    const uint32_t a = (ci & 1u) ? e1 : e0, b = (ci & 1u) ? e3 : e2;
+    return (ci & 2u) ? b : a;
+}
+// target characters four at a time: word (idx >> 2) of the group's 64-character buffer, refilled by the group together
+template <int G> struct TargetWords
+{
+    uint32_t w;
+    int32_t q; // idx >> 2 of the cached word
+};
+template <int G> __device__ __forceinline__ uint32_t group_target_code(GroupCtx<G>& c, TargetWords<G>& tw, int32_t idx)
+{
+    if ((idx >> 2) != tw.q)
+    {
+        if (idx < c.lo || idx >= c.lo + 64)
+        {
+            c.lo = idx & ~3;
+            for (int k = c.gl; k < 16; k += G)
+            {
+                uint32_t w = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb)
+                {
+                    const int32_t q   = c.lo + 4 * k + bb;
+                    const uint32_t ch = (q >= 0 && q < c.target_size) ? (uint32_t)(unsigned char)c.target[q] : 0u;
+                    w |= ch << (8 * bb);
+                }
+                c.tbuf[k] = w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+        tw.q = idx >> 2;
+        tw.w = c.tbuf[(idx - c.lo) >> 2];
+    }
+    return (tw.w >> (8 * (idx & 3) + 1)) & 3u; // (character >> 1) & 3: A, C, T, G
+}
+
 template <int G>
 __device__ __forceinline__ void group_horizontal_band(Band& b, GroupCtx<G>& c, const PairTable& patterns, int32_t n_words_query, int32_t t_begin,
                                                       int32_t t_end, int32_t width, int32_t n_words, int32_t pattern_offset, uint32_t& pv,
@@ -796,18 +830,27 @@ __device__ __forceinline__ void group_horizontal_band(Band& b, GroupCtx<G>& c, c
 {
     const int32_t k     = c.gl;
     const uint32_t hbit = 1u << (k == n_words - 1 ? width - (n_words - 1) * kWord - 1 : kWord - 1);
-    for (int32_t t = t_begin; t < t_end; ++t)
+    // the window does not move in this stripe: one funnel shift per base
+    PatternWindow pw;
+    pw.load(patterns, n_words_query, k + pattern_offset / kWord);
+    const uint32_t sh = (uint32_t)(pattern_offset % kWord);
+    const uint32_t e0 = __builtin_amdgcn_alignbit(pw.hi[0], pw.lo[0], sh), e1 = __builtin_amdgcn_alignbit(pw.hi[1], pw.lo[1], sh),
+                   e2 = __builtin_amdgcn_alignbit(pw.hi[2], pw.lo[2], sh), e3 = __builtin_amdgcn_alignbit(pw.hi[3], pw.lo[3], sh);
+    TargetWords<G> tw{0u, INT32_MIN};
+    size_t at = b.at(k, t_begin);
+    const size_t step = (size_t)b.n_rows * 64;
+    for (int32_t t = t_begin; t < t_end; ++t, at += step)
     {
-        const char tc     = group_target_char<G>(c, t - 1);
-        const uint32_t eq = get_pattern(patterns, n_words_query, k, pattern_offset, tc);
+        const uint32_t ci = group_target_code<G>(c, tw, t - 1);
+        const uint32_t eq = select4(ci, e0, e1, e2, e3);
         uint32_t ph, mh;
         group_advance<G>(c, eq, pv, mv, ph, mh);
         sc += ((ph & hbit) ? 1 : 0) - ((mh & hbit) ? 1 : 0);
         if (k < n_words)
         {
-            b.score[b.at(k, t)] = sc;
-            b.pv[b.at(k, t)]    = pv;
-            b.mv[b.at(k, t)]    = mv;
+            b.score[at] = sc;
+            b.pv[at]    = pv;
+            b.mv[at]    = mv;
         }
     }
 }
@@ -820,9 +863,16 @@ __device__ __forceinline__ void group_diagonal_band(Band& b, GroupCtx<G>& c, con
     const int32_t k    = c.gl;
     const uint32_t drb = 1u << (k == n_words - 1 ? band_width - (n_words - 1) * kWord - 2 : kWord - 2);
     const uint32_t ddb = drb << 1;
-    for (int32_t t = t_begin; t < t_end; ++t)
+    // the window slides one bit per column: begin = pattern_offset + (t - t_begin) + 1
+    int32_t begin = pattern_offset + 1;
+    PatternWindow pw;
+    pw.load(patterns, n_words_query, k + begin / kWord);
+    TargetWords<G> tw{0u, INT32_MIN};
+    size_t at = b.at(k, t_begin);
+    const size_t step = (size_t)b.n_rows * 64;
+    for (int32_t t = t_begin; t < t_end; ++t, ++begin, at += step)
     {
-        const char tc = group_target_char<G>(c, t - 1);
+        const uint32_t ci = group_target_code<G>(c, tw, t - 1);
         // the band slides one row down: word k takes the low bit of word k + 1 as its top bit
         const uint32_t pv_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)pv, 0x101, 0xf, 0xf, false); // row_shl:1
         const uint32_t mv_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)mv, 0x101, 0xf, 0xf, false);
@@ -838,7 +888,10 @@ __device__ __forceinline__ void group_diagonal_band(Band& b, GroupCtx<G>& c, con
             pv |= ddb; // bottom bit has no left neighbour: assume the worst case (+1)
             mv &= ~ddb;
         }
-        const uint32_t eq = get_pattern(patterns, n_words_query, k, pattern_offset + t - t_begin + 1, tc);
+        if (k + begin / kWord != pw.word) pw.load(patterns, n_words_query, k + begin / kWord); // every 32 columns
+        const uint32_t sh = (uint32_t)(begin % kWord);
+        const uint32_t eq = __builtin_amdgcn_alignbit(select4(ci, pw.hi[0], pw.hi[1], pw.hi[2], pw.hi[3]),
+                                                      select4(ci, pw.lo[0], pw.lo[1], pw.lo[2], pw.lo[3]), sh);
         uint32_t ph, mh;
         group_advance<G>(c, eq, pv, mv, ph, mh);
         const int32_t hx   = ((ph & drb) ? 1 : 0) - ((mh & drb) ? 1 : 0);
@@ -846,9 +899,9 @@ __device__ __forceinline__ void group_diagonal_band(Band& b, GroupCtx<G>& c, con
         sc += hx + down;
         if (k < n_words)
         {
-            b.score[b.at(k, t)] = sc;
-            b.pv[b.at(k, t)]    = pv;
-            b.mv[b.at(k, t)]    = mv;
+            b.score[at] = sc;
+            b.pv[at]    = pv;
+            b.mv[at]    = mv;
         }
     }
 }
@@ -1809,11 +1862,15 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
             ka.lds_band_words    = 224; // words of the backtrace's column window per pair
         }
     }
+    // (four lanes per pair -- half the wavefronts for 10 000 pairs, one per SIMD instead of two on a fifth of them -- was
+    // measured and is no faster: 1.71 vs 1.68 ms on configs[1], profiles/r03_h_aligner_group_lanes.txt; a wavefront lasts as
+    // long as its unluckiest pair's band attempts, and sixteen pairs per wavefront make an unlucky one near certain)
     if (use_group)
+    {
+        const size_t lds = (size_t)(32 * (ka.lds_pattern_words + 1) + 32 * 17 + 64 * ka.lds_band_words) * sizeof(uint32_t);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&myers_banded_group_kernel<8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (use_group)
-        hipLaunchKernelGGL((myers_banded_group_kernel<8, 32>), dim3((n + 31) / 32), dim3(32 * 8),
-                           (size_t)(32 * (ka.lds_pattern_words + 1) + 32 * 17 + 64 * ka.lds_band_words) * sizeof(uint32_t), stream, ka);
+        hipLaunchKernelGGL((myers_banded_group_kernel<8, 32>), dim3((n + 31) / 32), dim3(32 * 8), lds, stream, ka);
+    }
     else if (use_lds)
         hipLaunchKernelGGL(myers_banded_kernel<true>, dim3((n + 63) / 64), dim3(64),
                            (size_t)(ka.lds_pattern_words + 3 * ka.lds_band_words + 16) * 64 * sizeof(uint32_t), stream, ka);
