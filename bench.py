@@ -137,13 +137,15 @@ def reduce_scalars(dist, torch, values, op):
     return [float(x) for x in t.tolist()]
 
 
-def bench_aligner(name, cfg, rank, world, local_rank, sync, dist, torch, reps, cpu_budget_s):
+def bench_aligner(name, cfg, rank, world, local_rank, sync, dist, torch, reps, cpu_budget_s, cpu_all_cores=None):
     """One aligner config, index-split over the ranks. Timed regions: align_all() + sync_alignments() (the reference
     benchmark's, cudaaligner/benchmarks/main.cpp:96-143), align_all() + stream sync with the results left on the
     device (get_alignments_device), and the kernels alone (HIP events, inputs resident)."""
     from genomeworks_amd import cudaaligner, multi_gpu, synthetic
     pairs = synthetic.generate_pairs(cfg["seed"], cfg["pairs"], cfg["length"], cfg["mut"], cfg["ins"], cfg["dele"])
-    cpu = cpu_baseline_pairs(pairs, cfg["max_bandwidth"], cpu_budget_s) if (rank == 0 and cpu_budget_s > 0) else None
+    # the all-core baseline was taken before the process's first device call (its workers are forked); else one core, in process
+    cpu = cpu_all_cores if cpu_all_cores is not None else (
+        cpu_baseline_pairs(pairs, cfg["max_bandwidth"], cpu_budget_s) if (rank == 0 and cpu_budget_s > 0) else None)
     lo, hi = multi_gpu.shard_range(len(pairs), rank, world)
     mine = pairs[lo:hi]
     al = cudaaligner.CudaAlignerBatch(max_bandwidth=cfg["max_bandwidth"], max_device_memory_allocator_caching_size=32 << 30,
@@ -284,6 +286,94 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_
     return rec
 
 
+def cpu_baseline_pairs_all_cores(pairs, max_bandwidth, seconds):
+    """The aligner CPU baseline on ALL host cores: one forked process per core, each running the reference's own
+    needleman_wunsch_cpu (oracle/_ref, kind "reference"; the C port of the banded kernel if that library is absent) over
+    its share of the pairs for `seconds`. Runs before the process's first device call."""
+    import multiprocessing as mp
+    cores = max(1, os.cpu_count() or 1)
+    _CPU_SHARED.update(pairs=pairs, cores=cores, seconds=seconds, max_bandwidth=max_bandwidth)
+    try:
+        with mp.get_context("fork").Pool(cores) as pool:
+            res = pool.map(_cpu_pairs_worker, range(cores), chunksize=1)
+    except Exception as e:
+        print("bench.py: all-core aligner CPU baseline unavailable (%s)" % e, file=sys.stderr)
+        return None
+    kind = res[0][3]
+    return {"value": round(sum(n / dt for n, _, dt, _ in res), 1), "unit": "pairs/s", "cores": cores, "kind": kind,
+            "gcups": round(sum(c / dt for _, c, dt, _ in res) / 1e9, 3),
+            "sample": "%d pairs over %d processes, %.1f s each, %s" % (
+                sum(n for n, _, _, _ in res), cores, seconds,
+                "needleman_wunsch_cpu of the reference (full |q| x |t| matrix + backtrace)" if kind == "reference"
+                else "C port of the banded Myers kernel (band cells)")}
+
+
+def _cpu_pairs_worker(k):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_aligner as A
+    pairs, cores, seconds, max_bandwidth = (_CPU_SHARED[x] for x in ("pairs", "cores", "seconds", "max_bandwidth"))
+    share = pairs[k::cores] or pairs[:1]
+    R = A.ref()
+    out = np.zeros(2 * max(len(q) + len(t) for q, t in share[:64]) + 4096, np.int8)
+    n = cells = 0
+    t0 = time.perf_counter()
+    while True:
+        for q, t in share:
+            if R is not None and 2 * (len(q) + len(t)) + 64 <= len(out):
+                R.ref_needleman_wunsch_cpu(t, len(t), q, len(q), out.ctypes.data, len(out))
+                cells += len(q) * len(t)
+            else:
+                cells += A.align(q, t, max_bandwidth)["cells"]
+            n += 1
+            if time.perf_counter() - t0 > seconds:
+                return n, cells, time.perf_counter() - t0, "reference" if R is not None else "port"
+
+
+def bench_default_aligner(local_rank, sync, cpu_all_cores=None):
+    """The default aligner -- create_aligner(max_query, max_target, n): Hirschberg + Myers, the one the Python bindings reach
+    -- on the reference's benchmark shapes (cudaaligner/benchmarks/main.cpp:39-67 BM_SingleAlignment: one pair of 100 ..
+    100 000 bases; :69-143 BM_SingleBatchAlignment: 1024 pairs x 2048 bases) and on 2 000 pairs x 1 kbp. Timed region as
+    there: align_all() + sync_alignments() with the pairs queued. Rank 0 only."""
+    from genomeworks_amd import cudaaligner, synthetic
+    shapes = [(1, 100), (1, 1000), (1, 10000), (1, 100000), (1024, 2048), (2000, 1000)]
+    rows = []
+    cpu = cpu_all_cores
+    for n, size in shapes:
+        pairs = synthetic.generate_pairs(1, n, size, size // 30, size // 30, size // 30)
+        pairs = [(q, t[:size]) for q, t in pairs]
+        al = cudaaligner.CudaAlignerBatch(size, size, n, max_device_memory_allocator_caching_size=32 << 30, device_id=local_rank)
+        best = None
+        for _ in range(3):
+            for q, t in pairs:
+                assert al.add_alignment(q, t) == 0
+            sync()
+            t0 = time.perf_counter()
+            al.align_all()
+            assert al.sync() == n
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            al.reset()
+        del al
+        cells = sum(len(q) * len(t) for q, t in pairs)
+        rows.append({"pairs": n, "length": size, "ms": round(best * 1e3, 3), "pairs_per_s": round(n / best, 1),
+                     "full_matrix_gcups": round(cells / best / 1e9, 2)})
+    head = rows[-1]
+    achieved = 2000 * 1000 * 1000 * BYTES_PER_MYERS_CELL / (head["ms"] * 1e-3) / 1e9
+    out = {"workload": "default aligner (Hirschberg + Myers bit vectors, one wavefront per pair): reference benchmark shapes",
+           "metric": "pairs/s, align_all() + sync_alignments(), 2 000 pairs x 1 kbp (about 10 % divergence)",
+           "value": head["pairs_per_s"], "unit": "pairs/s", "ms": head["ms"], "shapes": rows,
+           "roofline": {"bound": "hbm", "kernel": "hirschberg_wave_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_cell": BYTES_PER_MYERS_CELL,
+                        "note": "|q| x |t| cells of the full matrix at the bit-vector cost of 12 B per 32-cell word column; the divide "
+                                "and conquer computes every cell about twice and keeps its state in registers and LDS, so HBM "
+                                "carries little: the kernel is bound by the dependent column steps of a wavefront",
+                        "kernel_ms": head["ms"]}}
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    return out
+
+
 def bench_reference_shapes(windows, local_rank, sync, steps):
     """The reference's own cudapoa benchmark shapes on the config-3 inputs (no published numbers exist for them):
     BM_SingleBatchTest -- one batch, BatchConfig(1024, 200) = full band, generate_poa() + get_consensus()
@@ -334,9 +424,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--windows", type=int, default=WINDOWS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sub-configs", default="aligner,long_reads,reference_shapes",
-                    help="comma list of the sub-records to measure next to the metric config: aligner, long_reads, "
-                         "reference_shapes, none")
+    ap.add_argument("--sub-configs", default="aligner,default_aligner,long_reads,reference_shapes",
+                    help="comma list of the sub-records to measure next to the metric config: aligner, default_aligner, "
+                         "long_reads, reference_shapes, none")
     ap.add_argument("--long-read-windows", type=int, default=598)
     args = ap.parse_args()
     subs = set(x for x in args.sub_configs.split(",") if x and x != "none")
@@ -356,6 +446,18 @@ def main():
     # the CPU baseline forks one worker per core: before this process makes its first device call
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     cpu = cpu_baseline(windows) if want_cpu else None
+    cpu_pairs = {}
+    if want_cpu:  # the aligner baselines on all host cores too (reference needleman_wunsch_cpu from oracle/_ref when it travelled)
+        if "aligner" in subs:
+            cpu_pairs["configs[1]"] = cpu_baseline_pairs_all_cores(
+                synthetic.generate_pairs(CONFIG2["seed"], CONFIG2["pairs"], CONFIG2["length"], CONFIG2["mut"], CONFIG2["ins"], CONFIG2["dele"]),
+                CONFIG2["max_bandwidth"], 3.0)
+            cpu_pairs["configs[4]"] = cpu_baseline_pairs_all_cores(
+                synthetic.generate_pairs(CONFIG5["seed"], 65536, CONFIG5["length"], CONFIG5["mut"], CONFIG5["ins"], CONFIG5["dele"]),
+                CONFIG5["max_bandwidth"], 3.0)
+        if "default_aligner" in subs:
+            p1k = synthetic.generate_pairs(1, 2000, 1000, 33, 33, 33)
+            cpu_pairs["default_aligner"] = cpu_baseline_pairs_all_cores([(q, t[:1000]) for q, t in p1k], 1024, 3.0)
 
     import torch
     if not torch.cuda.is_available():
@@ -490,10 +592,14 @@ def main():
     cpu_s = 0 if args.no_cpu_baseline else 1
     if "aligner" in subs:
         sub["configs[1]"] = bench_aligner("BASELINE configs[1]: cudaaligner banded Myers, 10 000 pairs x 1 kbp, <=33 sub/ins/del, "
-                                          "max_bandwidth 1024", CONFIG2, rank, world, local_rank, sync, dist, torch, 3, 3.0 * cpu_s)
+                                          "max_bandwidth 1024", CONFIG2, rank, world, local_rank, sync, dist, torch, 3, 3.0 * cpu_s,
+                                          cpu_pairs.get("configs[1]"))
         sub["configs[4]"] = bench_aligner("BASELINE configs[4]: cudaaligner 1 000 000 pairs x 150 bp, <=2 sub, <=1 ins, <=1 del, "
                                           "max_bandwidth 150, index split over the ranks", CONFIG5, rank, world, local_rank, sync, dist, torch, 2,
-                                          3.0 * cpu_s)
+                                          3.0 * cpu_s, cpu_pairs.get("configs[4]"))
+    if "default_aligner" in subs and rank == 0:
+        sub["default_aligner"] = bench_default_aligner(local_rank, sync if world == 1 else (lambda: torch.cuda.synchronize()),
+                                                       cpu_pairs.get("default_aligner"))
     if "reference_shapes" in subs and world == 1:
         sub["reference_benchmark_shapes"] = bench_reference_shapes(windows, local_rank, sync, 2)
     if "long_reads" in subs:

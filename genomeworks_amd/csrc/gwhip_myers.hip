@@ -41,8 +41,11 @@ struct Band
     uint32_t* mv;
     int32_t* score;
     int32_t n_rows; // words in the band
-    // workspace arrays are interleaved across the 64 lanes of a wave: element k of a lane at word k * 64 (+ lane)
-    __device__ __forceinline__ size_t at(int32_t w, int32_t t) const { return ((size_t)t * n_rows + w) * 64; }
+    // one-lane kernels: the arrays are interleaved across the 64 lanes of a wave, element k of a lane at word k * 64 (+ lane).
+    // Group kernel: a pair's elements are contiguous records {pv, mv, score} (stride 3, mv = pv + 1, score = pv + 2), so
+    // the eight lanes of a group store one 96-byte run per column instead of 24 words scattered over 24 cache lines.
+    int32_t stride = 64;
+    __device__ __forceinline__ size_t at(int32_t w, int32_t t) const { return ((size_t)t * n_rows + w) * stride; }
 };
 
 // Per-lane arrays in LDS, element e of lane l at word e * 64 + l (conflict-free across the lanes of a wave).
@@ -354,7 +357,7 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
 #pragma unroll
             for (int u = 0; u < kU; ++u)
             {
-                const size_t at = src + (size_t)min(e0 + u, n - 1) * 64;
+                const size_t at = src + (size_t)min(e0 + u, n - 1) * b.stride;
                 p[u]  = b.pv[at];
                 m[u]  = b.mv[at];
                 sc[u] = (uint32_t)b.score[at];
@@ -408,9 +411,10 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
         const bool cached = tile_cols >= 2 && min(jj0, min(jj1, jj2)) >= tile_lo && max(jj0, max(jj1, jj2)) <= tile_hi;
         if (cached)
         {
-            // element of (word w, column j) in the tile: ((j - tile_lo) * n_rows + w) * 3; x / 64 is (j * n_rows + w)
+            // element of (word w, column j) in the tile: ((j - tile_lo) * n_rows + w) * 3; x / stride is (j * n_rows + w)
             const int32_t base = tile_lo * b.n_rows;
-            const int32_t e0 = ((int32_t)(x0 / 64) - base) * 3, e1 = ((int32_t)(x1 / 64) - base) * 3, e2 = ((int32_t)(x2 / 64) - base) * 3;
+            const int32_t st   = b.stride;
+            const int32_t e0 = ((int32_t)(x0 / st) - base) * 3, e1 = ((int32_t)(x1 / st) - base) * 3, e2 = ((int32_t)(x2 / st) - base) * 3;
             p0 = tile[e0]; n0 = tile[e0 + 1]; c0 = (int32_t)tile[e0 + 2];
             p1 = tile[e1]; n1 = tile[e1 + 1]; c1 = (int32_t)tile[e1 + 2];
             p2 = tile[e2]; n2 = tile[e2 + 1]; c2 = (int32_t)tile[e2 + 2];
@@ -838,7 +842,7 @@ __device__ __forceinline__ void group_horizontal_band(Band& b, GroupCtx<G>& c, c
                    e2 = __builtin_amdgcn_alignbit(pw.hi[2], pw.lo[2], sh), e3 = __builtin_amdgcn_alignbit(pw.hi[3], pw.lo[3], sh);
     TargetWords<G> tw{0u, INT32_MIN};
     size_t at = b.at(k, t_begin);
-    const size_t step = (size_t)b.n_rows * 64;
+    const size_t step = (size_t)b.n_rows * b.stride;
     for (int32_t t = t_begin; t < t_end; ++t, at += step)
     {
         const uint32_t ci = group_target_code<G>(c, tw, t - 1);
@@ -848,9 +852,9 @@ __device__ __forceinline__ void group_horizontal_band(Band& b, GroupCtx<G>& c, c
         sc += ((ph & hbit) ? 1 : 0) - ((mh & hbit) ? 1 : 0);
         if (k < n_words)
         {
-            b.score[at] = sc;
-            b.pv[at]    = pv;
+            b.pv[at]    = pv; // one record: a 12-byte store per lane
             b.mv[at]    = mv;
+            b.score[at] = sc;
         }
     }
 }
@@ -869,7 +873,7 @@ __device__ __forceinline__ void group_diagonal_band(Band& b, GroupCtx<G>& c, con
     pw.load(patterns, n_words_query, k + begin / kWord);
     TargetWords<G> tw{0u, INT32_MIN};
     size_t at = b.at(k, t_begin);
-    const size_t step = (size_t)b.n_rows * 64;
+    const size_t step = (size_t)b.n_rows * b.stride;
     for (int32_t t = t_begin; t < t_end; ++t, ++begin, at += step)
     {
         const uint32_t ci = group_target_code<G>(c, tw, t - 1);
@@ -899,9 +903,9 @@ __device__ __forceinline__ void group_diagonal_band(Band& b, GroupCtx<G>& c, con
         sc += hx + down;
         if (k < n_words)
         {
-            b.score[at] = sc;
-            b.pv[at]    = pv;
+            b.pv[at]    = pv; // one record: a 12-byte store per lane
             b.mv[at]    = mv;
+            b.score[at] = sc;
         }
     }
 }
@@ -991,11 +995,13 @@ __global__ __launch_bounds__(PAIRS * G) void myers_banded_group_kernel(KernelArg
         }
         return;
     }
-    uint32_t* base = a.ws + region + s;
+    // slot s owns words [3 me_max s, 3 me_max (s + 1)) of its region: records {pv, mv, score}, element (column, word) after element
+    uint32_t* base = a.ws + region + (size_t)s * 3 * (size_t)me_max;
     Band b;
     b.pv     = base;
-    b.mv     = base + 64 * me_max;
-    b.score  = reinterpret_cast<int32_t*>(base + 128 * me_max);
+    b.mv     = base + 1;
+    b.score  = reinterpret_cast<int32_t*>(base + 2);
+    b.stride = 3;
     b.n_rows = 0;
     // LDS: per pair the pattern table (odd stride: the lanes of a group read neighbouring words), 17 words of target
     // characters, and the backtrace's column window (interleaved over the 64 pairs like the workspace)
@@ -1649,6 +1655,369 @@ __global__ __launch_bounds__(64) void hirschberg_myers_kernel(HirschbergArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// The default aligner with ONE WAVEFRONT PER PAIR (round 3). The one-lane kernel above walks a query part's words one
+// after the other for every target character -- 32 dependent word steps per column at 1 kbp, 64 pairs per wavefront,
+// so 2 000 pairs are 32 wavefronts on 1 024 SIMDs. Here a pair owns a wavefront (the reference gives it a warp): lane l
+// holds band word l of the running column in registers, the multi-word addition of the column step is a carry lookahead
+// over the lanes (two ballots, one 64-bit scalar add: the scheme of the group kernel with a group of 64), the bits that
+// cross a word boundary move with one DPP shift, the last word's horizontal delta comes back through v_readlane. Query
+// parts of more than 64 words (2 048 bases) run in chunks of 64 words with the three boundary bits (addition carry,
+// +1 / -1 delta) handed from chunk to chunk as scalars and their column state and pattern words in LDS. Everything that
+// decides the output is the one-lane kernel's (and the reference's): range stack, leaves, query midpoint, the 32-lane
+// argmin of the target midpoint (now on 32 real lanes), so the two kernels give identical paths
+// (test_default_aligner_kernels_agree, and the oracle tests run on this kernel).
+// Workspace: the region of 64 pairs is that of the one-lane kernel (same sizing), a pair's arrays are contiguous in it.
+// ------------------------------------------------------------------------------------------------
+struct PlainWords
+{
+    const uint32_t* p;
+    __device__ __forceinline__ uint32_t operator[](int32_t e) const { return p[e]; }
+};
+
+constexpr int32_t kHwLeafElems = 320; // (word, column) elements of a leaf whose matrices stay in LDS (three arrays of that size)
+
+__global__ __launch_bounds__(64) void hirschberg_wave_kernel(HirschbergArgs a)
+{
+    extern __shared__ uint32_t hw_lds[];
+    const int32_t lane = threadIdx.x & 63;
+    const int32_t idx  = blockIdx.x;
+    if (idx >= a.n) return;
+    const int32_t region_index = idx >> 6, s = idx & 63;
+    const int64_t max_elems = (int64_t)ceil_div(max(a.max_query_length, 1), kWord) * (kHbSwitchToMyers + 1);
+    // geometry of the 64-pair region (sized by its longest query / target)
+    int32_t qw_max = 0, t_max = 0;
+    {
+        const int32_t sj = region_index * 64 + lane;
+        if (sj < a.n)
+        {
+            qw_max = ceil_div((int32_t)(a.starts[2 * sj + 1] - a.starts[2 * sj]), kWord);
+            t_max  = (int32_t)(a.starts[2 * sj + 2] - a.starts[2 * sj + 1]);
+        }
+        for (int off = 32; off > 0; off >>= 1)
+        {
+            qw_max = max(qw_max, __shfl_xor(qw_max, off));
+            t_max  = max(t_max, __shfl_xor(t_max, off));
+        }
+    }
+    const char* query         = a.sequences + a.starts[2 * idx];
+    const char* target        = a.sequences + a.starts[2 * idx + 1];
+    const int32_t query_size  = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
+    const int32_t target_size = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
+    int8_t* path              = a.results + a.starts[2 * idx];
+    const int64_t region      = a.wave_offsets[region_index];
+    const int64_t per_pair    = hb_lane_words(qw_max, t_max, max_elems);
+    if (region + 64 * per_pair > a.ws_capacity_words)
+    {
+        if (lane == 0) a.result_lengths[idx] = 0;
+        return;
+    }
+    uint32_t* base  = a.ws + region + (size_t)s * (size_t)per_pair;
+    uint32_t* fwd   = base + 4 * kHbStackEntries;
+    uint32_t* rev   = fwd + ((size_t)t_max + 1);
+    uint32_t* pat_f = rev + ((size_t)t_max + 1);
+    uint32_t* pat_r = pat_f + (size_t)4 * qw_max;
+    const int64_t leaf_words = hb_leaf_words(t_max, max_elems);
+    Band leaf; // full Myers matrices of a leaf (column-major), lane 0 only
+    leaf.pv     = pat_r + (size_t)4 * qw_max + (size_t)2 * qw_max;
+    leaf.mv     = leaf.pv + (size_t)leaf_words;
+    leaf.score  = reinterpret_cast<int32_t*>(leaf.mv + (size_t)leaf_words);
+    leaf.n_rows = 0;
+    leaf.stride = 1;
+    // LDS: range stack | chunked column state (pv, mv) | chunked pattern words of the current part (4 per word)
+    uint32_t* stack = hw_lds;
+    uint32_t* st_pv = hw_lds + 4 * kHbStackEntries;
+    uint32_t* st_mv = st_pv + (size_t)a.lds_state_words * 64; // lds_state_words = chunks of the longest part
+    uint32_t* st_pt = st_mv + (size_t)a.lds_state_words * 64;
+    uint32_t* leaf_lds = st_pt + (size_t)a.lds_state_words * 256; // kHwLeafLdsWords: the matrices of a leaf that fits
+
+    // pattern tables of the whole query, forward and back to front, one word per lane at a time
+    const int32_t n_words_query = ceil_div(query_size, kWord);
+    for (int32_t w = lane; w < n_words_query; w += 64)
+    {
+        uint32_t f[4], r[4];
+        pattern_words(query, query_size, w, f, r);
+#pragma unroll
+        for (int ci = 0; ci < 4; ci++)
+        {
+            pat_f[w * 4 + ci] = f[ci];
+            pat_r[w * 4 + ci] = r[ci];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const PlainWords tab_f{pat_f}, tab_r{pat_r};
+
+    // last row of the edit-distance matrix of query[qb, qe) against target[tb, te): out[t], t = 0 .. te - tb
+    auto last_row_impl = [&](auto single_tag, int32_t qb, int32_t qe, int32_t tb, int32_t te, bool reverse, uint32_t* out) {
+        constexpr bool SINGLE = decltype(single_tag)::value; // the part fits one chunk of 64 words: state and patterns in registers
+        const int32_t qn = qe - qb, tn = te - tb;
+        const int32_t nw = ceil_div(qn, kWord), nch = SINGLE ? 1 : ceil_div(nw, 64);
+        const int32_t pattern_offset = reverse ? query_size - qe : qb;
+        const char acgt[4] = {'A', 'C', 'T', 'G'};
+        uint32_t e[4] = {0u, 0u, 0u, 0u}; // single chunk: the lane's pattern word for each base
+        uint32_t pv = ~0u, mv = 0u;       // single chunk: the lane's column state
+        for (int32_t c = 0; c < nch; ++c)
+        {
+            const int32_t w = c * 64 + lane;
+            uint32_t ew[4];
+#pragma unroll
+            for (int ci = 0; ci < 4; ci++)
+                ew[ci] = w < nw ? (reverse ? get_pattern(tab_r, n_words_query, w, pattern_offset, acgt[ci])
+                                           : get_pattern(tab_f, n_words_query, w, pattern_offset, acgt[ci]))
+                                : 0u;
+            if constexpr (SINGLE)
+            {
+#pragma unroll
+                for (int ci = 0; ci < 4; ci++) e[ci] = ew[ci];
+                if (w >= nw) pv = 0u; // lanes past the part: no carry generated or propagated
+            }
+            else
+            {
+#pragma unroll
+                for (int ci = 0; ci < 4; ci++) st_pt[(c * 4 + ci) * 64 + lane] = ew[ci];
+                st_pv[c * 64 + lane] = w < nw ? ~0u : 0u;
+                st_mv[c * 64 + lane] = 0u;
+            }
+        }
+        if constexpr (!SINGLE) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int32_t last_lane  = (nw - 1) & 63;
+        const uint32_t last_hbit = 1u << (qn - (nw - 1) * kWord - 1);
+        int32_t sc  = qn;
+        uint32_t acc = (uint32_t)sc; // out[t] for t == lane (mod 64), flushed 64 columns at a time
+        uint32_t tcv = 0;            // target characters of 64 columns, one per lane
+        for (int32_t t = 1; t <= tn; ++t)
+        {
+            if (((t - 1) & 63) == 0)
+            {
+                const int32_t tt = t + lane; // column of this lane's character
+                tcv = tt <= tn ? (uint32_t)(unsigned char)(reverse ? target[te - tt] : target[tb + tt - 1]) : 0u;
+            }
+            const uint32_t tc = (uint32_t)__builtin_amdgcn_readlane((int32_t)tcv, (t - 1) & 63);
+            const uint32_t ci = (tc >> 1) & 3u;
+            uint32_t carry = 0u, hin_p = 1u, hin_m = 0u; // the implicit first row is 0, 1, 2, ...
+            int32_t h = 0;
+            for (int32_t c = 0; c < nch; ++c)
+            {
+                uint32_t eq;
+                if constexpr (SINGLE)
+                {
+                    // branch-free select on the wave-uniform base index: two scalar masks, three bit-field inserts
+                    const uint32_t m1 = 0u - (ci & 1u), m2 = 0u - (ci >> 1);
+                    const uint32_t lo = (e[1] & m1) | (e[0] & ~m1), hi = (e[3] & m1) | (e[2] & ~m1);
+                    eq = (hi & m2) | (lo & ~m2);
+                }
+                else
+                {
+                    pv = st_pv[c * 64 + lane];
+                    mv = st_mv[c * 64 + lane];
+                    eq = st_pt[(c * 4 + (int32_t)ci) * 64 + lane];
+                }
+                const uint32_t xv  = eq | mv;
+                const uint32_t an  = eq & pv;
+                const uint32_t s0  = an + pv;
+                const uint64_t gen = __ballot(s0 < an), prp = __ballot(s0 == 0xffffffffu);
+                const uint64_t top = 1ull << 63;
+                const uint64_t cin = (((gen | prp) & ~top) + (gen & ~top) + carry) ^ (prp & ~top);
+                carry              = (uint32_t)(((gen >> 63) | ((prp >> 63) & (cin >> 63))) & 1ull);
+                const uint32_t sum = s0 + (uint32_t)((cin >> lane) & 1ull);
+                const uint32_t xh  = (sum ^ pv) | eq;
+                const uint32_t ph  = mv | ~(xh | pv);
+                const uint32_t mh  = pv & xh;
+                uint32_t ph_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(ph >> 31), 0x138, 0xf, 0xf, false); // wave_shr:1
+                uint32_t mh_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(mh >> 31), 0x138, 0xf, 0xf, false);
+                if (lane == 0)
+                {
+                    ph_lo = hin_p;
+                    mh_lo = hin_m;
+                }
+                hin_p = (uint32_t)__builtin_amdgcn_readlane((int32_t)(ph >> 31), 63);
+                hin_m = (uint32_t)__builtin_amdgcn_readlane((int32_t)(mh >> 31), 63);
+                if (c == nch - 1)
+                {
+                    const uint32_t php = (uint32_t)__builtin_amdgcn_readlane((int32_t)ph, last_lane);
+                    const uint32_t mhp = (uint32_t)__builtin_amdgcn_readlane((int32_t)mh, last_lane);
+                    h = ((php & last_hbit) ? 1 : 0) - ((mhp & last_hbit) ? 1 : 0);
+                }
+                const uint32_t phs = (ph << 1) | ph_lo, mhs = (mh << 1) | mh_lo;
+                pv = mhs | ~(xv | phs);
+                mv = phs & xv;
+                if constexpr (!SINGLE)
+                {
+                    st_pv[c * 64 + lane] = pv;
+                    st_mv[c * 64 + lane] = mv;
+                }
+            }
+            sc += h;
+            if ((t & 63) == 0) // columns t - 64 .. t - 1 are complete in `acc`
+            {
+                out[t - 64 + lane] = acc;
+            }
+            if (lane == (t & 63)) acc = (uint32_t)sc;
+        }
+        // the remaining columns: t in [tn & ~63, tn]
+        if (lane <= (tn & 63)) out[(tn & ~63) + lane] = acc;
+    };
+    auto last_row = [&](int32_t qb, int32_t qe, int32_t tb, int32_t te, bool reverse, uint32_t* out) {
+        if (qe - qb <= 64 * kWord) last_row_impl(std::true_type{}, qb, qe, tb, te, reverse, out);
+        else last_row_impl(std::false_type{}, qb, qe, tb, te, reverse, out);
+    };
+
+    int32_t sp = 0;
+    auto push = [&](int32_t qb, int32_t qe, int32_t tb, int32_t te) -> bool {
+        if (sp >= kHbStackEntries) return false;
+        if (lane == 0)
+        {
+            stack[4 * sp + 0] = (uint32_t)qb; stack[4 * sp + 1] = (uint32_t)qe; stack[4 * sp + 2] = (uint32_t)tb; stack[4 * sp + 3] = (uint32_t)te;
+        }
+        ++sp;
+        return true;
+    };
+    push(0, query_size, 0, target_size);
+    bool ok     = true;
+    int32_t len = 0;
+    while (ok && sp > 0)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        --sp;
+        const int32_t qb = __builtin_amdgcn_readfirstlane((int32_t)stack[4 * sp + 0]), qe = __builtin_amdgcn_readfirstlane((int32_t)stack[4 * sp + 1]);
+        const int32_t tb = __builtin_amdgcn_readfirstlane((int32_t)stack[4 * sp + 2]), te = __builtin_amdgcn_readfirstlane((int32_t)stack[4 * sp + 3]);
+        const int32_t qn = qe - qb, tn = te - tb;
+        const int32_t nw = ceil_div(max(qn, 1), kWord);
+        const bool is_leaf = qn >= 2 && tn > 0 && qn < kHbSwitchToMyers && (int64_t)(tn + 1) * nw <= max_elems;
+        if (tn == 0 || qn == 0)
+        {
+            // one side empty: a run of deletions / insertions, written by all lanes
+            const int32_t count = tn == 0 ? qn : tn;
+            const int8_t state  = tn == 0 ? kDeletion : kInsertion;
+            for (int32_t k = lane; k < count; k += 64) path[len + k] = state;
+            len += count;
+        }
+        else if (is_leaf && qn != 1)
+        {
+            // leaf: full Myers matrix (hirschberg_myers_compute_path, :383-410) + append_myers_backtrace (:124-181). The
+            // matrices (at most two words per column) live in LDS when they fit, the forward pass runs on lane 0 (a chain of
+            // word steps), the walk evaluates its three neighbour cells on three lanes at once.
+            Band lf     = leaf;
+            lf.n_rows   = nw;
+            const bool in_lds = (int64_t)(tn + 1) * nw <= kHwLeafElems;
+            if (in_lds)
+            {
+                lf.pv    = leaf_lds;
+                lf.mv    = leaf_lds + kHwLeafElems;
+                lf.score = reinterpret_cast<int32_t*>(leaf_lds + 2 * kHwLeafElems);
+            }
+            if (lane == 0)
+            {
+                for (int32_t w = 0; w < nw; ++w)
+                {
+                    lf.pv[lf.at(w, 0)]    = ~0u;
+                    lf.mv[lf.at(w, 0)]    = 0u;
+                    lf.score[lf.at(w, 0)] = min((w + 1) * kWord, qn);
+                }
+                const uint32_t last_hbit = 1u << (qn - (nw - 1) * kWord - 1);
+                // the leaf's pattern words (query part qb .. qe) for the four bases
+                uint32_t lp[2][4];
+                const char acgt[4] = {'A', 'C', 'T', 'G'};
+                for (int32_t w = 0; w < 2; ++w)
+                    for (int ci = 0; ci < 4; ci++) lp[w][ci] = w < nw ? get_pattern(tab_f, n_words_query, w, qb, acgt[ci]) : 0u;
+                uint32_t pv0 = ~0u, mv0 = 0u, pv1 = ~0u, mv1 = 0u;
+                int32_t s0 = min(kWord, qn), s1 = qn;
+                for (int32_t t = 1; t <= tn; ++t)
+                {
+                    const int32_t ci = (((unsigned char)target[tb + t - 1]) >> 1) & 3;
+                    int32_t h = advance_word(nw == 1 ? last_hbit : (1u << (kWord - 1)), lp[0][ci], pv0, mv0, 1, nullptr);
+                    s0 += h;
+                    lf.score[lf.at(0, t)] = s0;
+                    lf.pv[lf.at(0, t)]    = pv0;
+                    lf.mv[lf.at(0, t)]    = mv0;
+                    if (nw == 2)
+                    {
+                        h = advance_word(last_hbit, lp[1][ci], pv1, mv1, h, nullptr);
+                        s1 += h;
+                        lf.score[lf.at(1, t)] = s1;
+                        lf.pv[lf.at(1, t)]    = pv1;
+                        lf.mv[lf.at(1, t)]    = mv1;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (!in_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t last_mask = qn % kWord != 0 ? ((1u << (qn % kWord)) - 1) : ~0u;
+            int32_t i = qn, j = tn, l = len;
+            int32_t myscore = __builtin_amdgcn_readfirstlane(lf.score[lf.at((i - 1) / kWord, j)]);
+            while (i > 0 && j > 0)
+            {
+                // lane 0: above (i - 1, j), lane 1: diagonal (i - 1, j - 1), lane 2: left (i, j - 1)
+                const int32_t ci_ = lane == 2 ? i : i - 1, cj_ = lane == 0 ? j : j - 1;
+                int32_t v = 0;
+                if (lane < 3) v = ci_ == 0 ? cj_ : cell_score(lf, max(ci_, 1), cj_, last_mask); // row 0 of the matrix is 0, 1, 2, ...
+                const int32_t above = __builtin_amdgcn_readlane(v, 0), diag = __builtin_amdgcn_readlane(v, 1), left = __builtin_amdgcn_readlane(v, 2);
+                int8_t r;
+                if (left + 1 == myscore) { r = kInsertion; myscore = left; --j; }
+                else if (above + 1 == myscore) { r = kDeletion; myscore = above; --i; }
+                else { r = diag == myscore ? kMatch : kMismatch; myscore = diag; --i; --j; }
+                if (lane == 0) path[l] = r;
+                l++;
+            }
+            for (int32_t k = lane; k < i; k += 64) path[l + k] = kDeletion;
+            l += i;
+            for (int32_t k = lane; k < j; k += 64) path[l + k] = kInsertion;
+            l += j;
+            len = l;
+        }
+        else if (qn == 1)
+        {
+            int32_t new_len = len;
+            if (lane == 0)
+            {
+                {
+                    // hirschberg_myers_single_char_warp (:483-515): right-to-left scan for the first equal character
+                    const char qc = query[qb];
+                    int32_t p     = len;
+                    int32_t t     = te - 1;
+                    while (t >= tb)
+                    {
+                        if (target[t] == qc) { path[p++] = kMatch; --t; break; }
+                        path[p++] = kInsertion;
+                        --t;
+                    }
+                    if (path[p - 1] != kMatch) path[p - 1] = kMismatch;
+                    while (t >= tb) { path[p++] = kInsertion; --t; }
+                    new_len = len + tn;
+                }
+            }
+            len = __builtin_amdgcn_readfirstlane(new_len);
+        }
+        else
+        {
+            const int32_t qmid = qb + qn / 2;
+            last_row(qb, qmid, tb, te, false, fwd);
+            last_row(qmid, qe, tb, te, true, rev);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // hirschberg_myers_compute_target_mid_warp (:461-481) on 32 real lanes: lane L sees t = L, L + 32, ...; the
+            // shuffle-down tree keeps the lower lane on equal sums
+            int32_t cm = INT32_MAX, mp = 0;
+            if (lane < 32)
+                for (int32_t t = lane; t <= tn; t += 32)
+                {
+                    const int32_t sum = (int32_t)fwd[t] + (int32_t)rev[tn - t];
+                    if (sum < cm) { cm = sum; mp = t; }
+                }
+            for (int32_t step = 16; step > 0; step >>= 1)
+            {
+                const int32_t om = __shfl_down(cm, step, 32), ot = __shfl_down(mp, step, 32);
+                if ((lane & 31) + step < 32 && om < cm) { cm = om; mp = ot; }
+            }
+            const int32_t tmid = tb + __builtin_amdgcn_readfirstlane(mp);
+            ok = ok && push(qb, qmid, tb, tmid);
+            ok = ok && push(qmid, qe, tmid, te);
+        }
+    }
+    if (lane == 0) a.result_lengths[idx] = ok ? len : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Unit hooks (the reference's test kernels: Test_HirschbergMyers.cu:37-53, Test_MyersAlgorithm.cu:42-97): they run the
 // production device functions above on one pair with one active lane.
 // ------------------------------------------------------------------------------------------------
@@ -1982,7 +2351,25 @@ int gwhip_hirschberg_myers(const gwhip_hirschberg_args* args, gwhip_stream_t str
     hipLaunchKernelGGL(hb_offsets_kernel, dim3(1), dim3(1024), 0, stream, args->sequence_starts,
                        const_cast<int64_t*>(ka.wave_offsets), n, max_elems);
     const int32_t qwords = (std::max(args->max_query_length, 1) + kWord - 1) / kWord;
-    if ((size_t)qwords * 6 * 64 * sizeof(uint32_t) <= 60 * 1024)
+    // One wavefront per pair unless the batch alone fills the device with one lane per pair many times over
+    // (GWHIP_HIRSCHBERG_WAVE = 0 / 1 forces the choice). Its LDS: range stack + (pv, mv, 4 pattern words) per word of the
+    // longest query part (half the longest query), in chunks of 64 words.
+    const int32_t part_chunks = std::max(1, ((qwords + 1) / 2 + 1 + 63) / 64);
+    const size_t wave_lds     = (size_t)(4 * kHbStackEntries + 6 * 64 * part_chunks + 3 * kHwLeafElems) * sizeof(uint32_t);
+    bool use_wave             = n <= 262144 && wave_lds <= 150 * 1024;
+    {
+        const char* hw = std::getenv("GWHIP_HIRSCHBERG_WAVE");
+        if (hw && hw[0] == '0') use_wave = false;
+        if (hw && hw[0] == '1') use_wave = wave_lds <= 150 * 1024;
+    }
+    if (use_wave)
+    {
+        ka.lds_state_words = part_chunks;
+        if (wave_lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hirschberg_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave_lds);
+        hipLaunchKernelGGL(hirschberg_wave_kernel, dim3(n), dim3(64), wave_lds, stream, ka);
+    }
+    else if ((size_t)qwords * 6 * 64 * sizeof(uint32_t) <= 60 * 1024)
     {
         ka.lds_state_words = qwords;
         hipLaunchKernelGGL(hirschberg_myers_kernel<true>, dim3(n_waves), dim3(64), (size_t)qwords * 6 * 64 * sizeof(uint32_t), stream, ka);

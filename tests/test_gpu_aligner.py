@@ -157,6 +157,51 @@ def test_default_aligner_bit_exact_vs_hirschberg_oracle(max_len):
         assert r.cigar == ref["cigar"]
 
 
+def test_default_aligner_kernels_agree(monkeypatch):
+    """The default aligner's two kernels -- one wavefront per pair (default: the words of a query part across the lanes,
+    carry lookahead over the lanes, parts beyond 64 words in chunks) and one lane per pair (GWHIP_HIRSCHBERG_WAVE=0) -- must
+    give identical alignments, also for queries of several thousand bases (two and more chunks per part, carries and
+    deltas handed from chunk to chunk) and for very unequal lengths; short ones are checked against the oracle as well."""
+    import random
+    from genomeworks_amd import cudaaligner
+    rng = random.Random(4242)
+    pairs = []
+    for k in range(48):
+        n = rng.choice([70, 500, 1000, 2040, 2049, 2500, 4100, 4500, 6000])
+        q = "".join(rng.choice("ACGT") for _ in range(n))
+        t = list(q)
+        for _ in range(max(1, n // rng.choice([8, 15, 40]))):
+            op, p = rng.random(), rng.randrange(max(1, len(t)))
+            if op < 0.4 and t:
+                t[p] = rng.choice("ACGT")
+            elif op < 0.7:
+                t.insert(p, rng.choice("ACGT"))
+            elif t:
+                del t[p]
+        if k % 7 == 0:
+            t = t[: len(t) // 3]                      # target much shorter than the query
+        if k % 11 == 0:
+            q = q[: max(2, len(q) // 4)]              # query much shorter than the target
+        pairs.append((q, "".join(t)))
+    max_len = 8192
+    out = {}
+    for name, flag in (("wave", None), ("lane", "0")):
+        if flag is None:
+            monkeypatch.delenv("GWHIP_HIRSCHBERG_WAVE", raising=False)
+        else:
+            monkeypatch.setenv("GWHIP_HIRSCHBERG_WAVE", flag)
+        al = cudaaligner.CudaAlignerBatch(max_len, max_len, len(pairs), max_device_memory_allocator_caching_size=8 << 30)
+        for q, t in pairs:
+            assert al.add_alignment(q, t) == 0
+        al.align_all()
+        out[name] = [(r.status, list(r.alignment)) for r in al.get_alignments()]
+    assert out["wave"] == out["lane"]
+    for (st, states), (q, t) in zip(out["wave"], pairs):
+        assert st == 0
+        if len(q) <= 1000:
+            assert states == A.hirschberg(q, t, max_len)["states"]
+
+
 # ---- the non-default classes: AlignerGlobalUkkonen / AlignerGlobalMyers (SURVEY 8(f) rank 3) ----
 def _run_algorithm(algorithm, pairs, max_len):
     from genomeworks_amd import cudaaligner

@@ -6,7 +6,8 @@ OUT=${1:-gpurun_out/pmc}
 REPO=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --sub-configs none"
+# SUBS: the sub-records whose kernels should run under the counters as well (aligner, default_aligner, long_reads)
+CMD="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --sub-configs ${SUBS:-none}"
 PASSES=${PASSES:-all}
 pass() { name=$1; shift; case " $PASSES " in *" all "*|*" $name "*) ;; *) return;; esac; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$REPO/$OUT/$name" -o $name -- $CMD > "$REPO/$OUT/$name.log" 2>&1; echo "$name rc=$?"; }
 pass insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES

@@ -10,7 +10,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if not any(t in k for t in ("poa_", "myers", "ukkonen", "cal_")):
+        if not any(t in k for t in ("poa_", "myers", "hirschberg", "ukkonen", "cal_")):
             continue
         acc[k.split("(")[0][:70]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 print("kernel,counter,mean_per_dispatch,dispatches")
