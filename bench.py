@@ -128,6 +128,15 @@ def consensus_digest(consensus_strings):
     return hashlib.sha256("\n".join(consensus_strings).encode()).hexdigest()
 
 
+def sub_traffic(key):
+    """HBM bytes of a sub-record's kernels from the committed PMC passes (tools/pmc_passes.sh with SUBS=..., calibrated like the
+    headline's: profiles/r03_pmc_traffic_sub.json); None if that file has no entry."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_sub.json")))[key]["hbm_bytes"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def reduce_scalars(dist, torch, values, op):
     if dist is None:
         return list(values)
@@ -200,26 +209,83 @@ def bench_aligner(name, cfg, rank, world, local_rank, sync, dist, torch, reps, c
            "kernel_only": {"pairs_per_s": round(len(pairs) / (k_max * 1e-3), 1), "ms": round(k_max, 3),
                            "band_gcups": round(cells_all / (k_max * 1e-3) / 1e9, 2)},
            "sync_over_kernel": round((full * 1e3 - k_max) / k_max, 2),
-           "roofline": {"bound": "hbm", "kernel": "myers_banded_kernel (+ scan, compaction)", "achieved": round(achieved, 2),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+           "roofline": {"bound": "hbm", "kernel": "myers_banded_group_kernel<8,32> (+ scan, compaction)" if cfg is CONFIG2 else "myers_banded_kernel (+ scan, compaction)",
+                        "achieved": round(achieved, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                        "traffic": sub_traffic("configs[1]" if cfg is CONFIG2 else "configs[4]"),
                         "algorithmic_bytes_per_cell": BYTES_PER_MYERS_CELL, "kernel_ms": round(k_ms, 3)}}
     if cpu is not None:
         out["cpu_baseline"] = cpu
     return out
 
 
-def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_windows, ranks_per_device=1):
+def _load_long_read_plan():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_long_read_goldens", os.path.join(ROOT, "tests", "golden", "make_long_read_goldens.py"))
+    lr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lr)
+    return lr
+
+
+def _cpu_long_worker(k):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_poa as O
+    lr, windows, cfg_of, sample, cores, seconds = (_CPU_SHARED[x] for x in ("lr", "lr_windows", "lr_cfg_of", "lr_sample", "cores", "seconds"))
+    cells = n = 0
+    t0 = time.perf_counter()
+    for w in sample[k::cores]:
+        c = cfg_of[w]
+        with O.Workspace(lr.oracle_cfg(c)) as ws:
+            cells += ws.process(windows[w][:c["max_sequences_per_poa"]])["cells"]
+        n += 1
+        if time.perf_counter() - t0 > seconds:
+            break
+    return cells, n, time.perf_counter() - t0
+
+
+def cpu_baseline_long_reads(n_windows, seconds=25.0):
+    """CPU oracle on ALL host cores over a cost-stratified sample of the long-read set: the windows sorted by estimated
+    cells, every m-th taken (so cheap, middling and heavy windows appear in the set's own proportions), dealt round-robin
+    to one forked process per core; a process stops after the window during which its `seconds` ran out. `value` = sum of
+    the per-process rates. Runs before the process's first device call."""
+    import multiprocessing as mp
+    from genomeworks_amd import multi_gpu
+    lr = _load_long_read_plan()
+    windows, cfgs, groups = lr.plan(max(n_windows, lr.CONFIG4["windows"]))
+    cfg_of = {w: c for c, members in zip(cfgs, groups) for w in members}
+    cost = [multi_gpu.poa_window_cost(w, 256) for w in windows[:n_windows]]
+    order = sorted(range(n_windows), key=lambda w: cost[w])
+    cores = max(1, os.cpu_count() or 1)
+    # about 0.25 GCUPS per core and estimated cells 6 x too low for wide adaptive bands: aim at ~seconds of work per core
+    budget_cells = cores * seconds * 0.25e9 / 6.0
+    total = float(sum(cost))
+    step = max(1, int(round(total / max(budget_cells, 1.0))))
+    sample = order[step // 2::step] or order[:1]
+    _CPU_SHARED.update(lr=lr, lr_windows=windows, lr_cfg_of=cfg_of, lr_sample=sample, cores=min(cores, len(sample)), seconds=seconds)
+    used = min(cores, len(sample))
+    try:
+        with mp.get_context("fork").Pool(used) as pool:
+            res = pool.map(_cpu_long_worker, range(used), chunksize=1)
+    except Exception as e:
+        print("bench.py: long-read CPU baseline unavailable (%s)" % e, file=sys.stderr)
+        return None
+    res = [r for r in res if r[1] > 0]
+    return {"value": round(sum(c / dt for c, _, dt in res) / 1e9, 4), "unit": "GCUPS", "cores": used, "kind": "port",
+            "windows_per_s": round(sum(n / dt for _, n, dt in res), 3),
+            "sample": "%d windows (every %d-th of the %d by estimated cost) over %d processes, %.0f-%.0f s each (gcc -O2 scalar oracle, "
+                      "the window's own BatchConfig)" % (sum(n for _, n, _ in res), step, n_windows, used,
+                                                          min(dt for _, _, dt in res), max(dt for _, _, dt in res))}
+
+
+def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu, ranks_per_device=1):
     """BASELINE configs[3]: the long-read MSA set, windows dealt to the ranks by estimated cost (no collective). The set is
     planned into size classes (cudapoa::plan_size_classes: geometric in the longest read, one BatchConfig per class) and
     all classes run at once, one host thread + stream + Batch each (process_windows_size_classes) -- the multi-batch
     pattern of the reference (cudapoa/benchmarks/multi_batch.hpp) with its size binning (cudapoa/src/utils.cu:66-146).
     Timed region: from the moment every class has filled its batch (add_poa_group excluded, as in the reference
     benchmarks) to the last class's end of generate_poa() + get_msa()."""
-    import importlib.util
     from genomeworks_amd import cudapoa, multi_gpu
-    spec = importlib.util.spec_from_file_location("make_long_read_goldens", os.path.join(ROOT, "tests", "golden", "make_long_read_goldens.py"))
-    lr = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(lr)
+    lr = _load_long_read_plan()
     # the plan (and with it every window's BatchConfig) is that of the whole 598-window set, also when only the first
     # n_windows are run or when the windows are dealt to several ranks: the goldens are keyed to it
     windows, cfgs, groups = lr.plan(max(n_windows, lr.CONFIG4["windows"]))
@@ -234,21 +300,6 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_
             golden = {d["w"]: d for d in json.load(f)["windows_detail"]}
     except (OSError, ValueError):
         pass
-    cpu = None
-    if rank == 0 and cpu_windows > 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_poa as O
-        cfg_of = {w: c for c, members in zip(cfgs, groups) for w in members}
-        order = sorted(range(n_windows), key=lambda w: cost[w])[:cpu_windows]
-        t0, c_cells = time.perf_counter(), 0
-        for w in order:
-            c = cfg_of[w]
-            with O.Workspace(lr.oracle_cfg(c)) as ws:
-                c_cells += ws.process(windows[w][:c["max_sequences_per_poa"]])["cells"]
-        dt = time.perf_counter() - t0
-        cpu = {"value": round(c_cells / dt / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": "port",
-               "windows_per_s": round(len(order) / dt, 3),
-               "sample": "the %d cheapest windows of the set, %.1f s (gcc -O2 scalar oracle, 32-bit scores)" % (len(order), dt)}
     sync()
     out = cudapoa.process_windows_size_classes(windows, plan, device=local_rank,
                                                memory_budget=lr.CONFIG4["memory_budget_bytes"] // ranks_per_device,
@@ -259,7 +310,7 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_
     checked = sum(1 for w in mine if w in golden and out["status"][w] == golden[w]["status"] and
                   (out["status"][w] != 0 or out["msa"][w] == golden[w]["msa_sha"]))
     mismatched = sum(1 for w in mine if w in golden) - checked
-    seconds, total_s = reduce_scalars(dist, torch, [out["compute_seconds"], out["seconds"]], "MAX")
+    seconds, total_s, fill_s = reduce_scalars(dist, torch, [out["compute_seconds"], out["seconds"], out["seconds_after_creation"]], "MAX")
     cells, n_done, n_ok, checked, mismatched = reduce_scalars(
         dist, torch, [float(my_cells), float(len(mine)), float(n_ok), float(checked), float(mismatched)], "SUM")
     if rank != 0:
@@ -270,13 +321,18 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu_
                        "running at once (%.0f GB of slabs on rank 0)" % (n_windows, len(cfgs), plan.total_bytes / 1e9),
            "metric": "GCUPS, generate_poa() + get_msa() of all size classes (concurrent batches)", "value": round(cells / seconds / 1e9, 3),
            "unit": "GCUPS", "windows": int(n_done), "windows_ok": int(n_ok), "windows_per_s": round(n_done / seconds, 2),
-           "ms": round(seconds * 1e3, 1), "ms_with_batch_creation_and_filling": round(total_s * 1e3, 1), "cells": int(cells),
+           "ms": round(seconds * 1e3, 1),
+           # the reference's multi-batch benchmark (cudapoa/benchmarks/multi_batch.hpp:72-177) times filling + generate_poa() +
+           # get_msa() of batches that exist already: that clock, next to the kernels-and-results clock of `value`
+           "fill_inclusive": {"ms": round(fill_s * 1e3, 1), "gcups": round(cells / max(fill_s, 1e-9) / 1e9, 3),
+                              "what": "add_poa_group() of every window + generate_poa() + get_msa(), batches created before the clock starts"},
+           "ms_with_batch_creation_and_filling": round(total_s * 1e3, 1), "cells": int(cells),
            "launches_rank0": out["launches"], "dtype": "int32",
            "windows_equal_to_oracle_golden": int(checked), "windows_differing_from_golden": int(mismatched),
            "size_classes": [{"max_sequence_size": c["max_sequence_size"], "windows": len(g)} for c, g in zip(cfgs, plan.groups)],
            "roofline": {"bound": "hbm", "kernel": "poa_window_kernel<int32,int32,adaptive_band,HBM tables, 8 waves per window> (4 launches, admitted by residency)",
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": sub_traffic("configs[3]"),
                         "algorithmic_bytes_per_cell": BYTES_PER_CELL_LONG,
                         "kernel_ms": round(out["compute_seconds"] * 1e3, 1),
                         "note": "the launches of the classes overlap: the duration is the concurrent region's (host clock), "
@@ -364,7 +420,7 @@ def bench_default_aligner(local_rank, sync, cpu_all_cores=None):
            "metric": "pairs/s, align_all() + sync_alignments(), 2 000 pairs x 1 kbp (about 10 % divergence)",
            "value": head["pairs_per_s"], "unit": "pairs/s", "ms": head["ms"], "shapes": rows,
            "roofline": {"bound": "hbm", "kernel": "hirschberg_wave_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_cell": BYTES_PER_MYERS_CELL,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": sub_traffic("default_aligner"), "algorithmic_bytes_per_cell": BYTES_PER_MYERS_CELL,
                         "note": "|q| x |t| cells of the full matrix at the bit-vector cost of 12 B per 32-cell word column; the divide "
                                 "and conquer computes every cell about twice and keeps its state in registers and LDS, so HBM "
                                 "carries little: the kernel is bound by the dependent column steps of a wavefront",
@@ -447,6 +503,7 @@ def main():
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     cpu = cpu_baseline(windows) if want_cpu else None
     cpu_pairs = {}
+    cpu_long = None
     if want_cpu:  # the aligner baselines on all host cores too (reference needleman_wunsch_cpu from oracle/_ref when it travelled)
         if "aligner" in subs:
             cpu_pairs["configs[1]"] = cpu_baseline_pairs_all_cores(
@@ -455,6 +512,8 @@ def main():
             cpu_pairs["configs[4]"] = cpu_baseline_pairs_all_cores(
                 synthetic.generate_pairs(CONFIG5["seed"], 65536, CONFIG5["length"], CONFIG5["mut"], CONFIG5["ins"], CONFIG5["dele"]),
                 CONFIG5["max_bandwidth"], 3.0)
+        if "long_reads" in subs:
+            cpu_long = cpu_baseline_long_reads(args.long_read_windows, 25.0)
         if "default_aligner" in subs:
             p1k = synthetic.generate_pairs(1, 2000, 1000, 33, 33, 33)
             cpu_pairs["default_aligner"] = cpu_baseline_pairs_all_cores([(q, t[:1000]) for q, t in p1k], 1024, 3.0)
@@ -603,7 +662,7 @@ def main():
     if "reference_shapes" in subs and world == 1:
         sub["reference_benchmark_shapes"] = bench_reference_shapes(windows, local_rank, sync, 2)
     if "long_reads" in subs:
-        sub["configs[3]"] = bench_long_reads(args.long_read_windows, rank, world, local_rank, sync, dist, torch, 3 * cpu_s,
+        sub["configs[3]"] = bench_long_reads(args.long_read_windows, rank, world, local_rank, sync, dist, torch, cpu_long,
                                              ranks_per_device)
 
     if rank == 0:

@@ -437,6 +437,12 @@ class SizeClassPlan:
             pass
 
 
+def _multi_seconds_after_creation(L, h):
+    L.gw_poa_multi_seconds_after_creation.argtypes = [C.c_void_p]
+    L.gw_poa_multi_seconds_after_creation.restype = C.c_double
+    return L.gw_poa_multi_seconds_after_creation(h)
+
+
 def process_windows_size_classes(windows, plan, device=0, memory_budget=-1, output_type="msa", gap_score=-8, mismatch_score=-6,
                                  match_score=8, collect=True, digest=None):
     """cudapoa::process_windows_size_classes: every class of `plan` (SizeClassPlan) in its own batch on its own host
@@ -476,7 +482,8 @@ def process_windows_size_classes(windows, plan, device=0, memory_budget=-1, outp
         raise RuntimeError(L.gw_last_error().decode())
     try:
         out = dict(status=[L.gw_poa_multi_status(h, w) for w in range(n)], worker=[L.gw_poa_multi_worker(h, w) for w in range(n)],
-                   launches=L.gw_poa_multi_launches(h), seconds=L.gw_poa_multi_seconds(h), compute_seconds=compute.value)
+                   launches=L.gw_poa_multi_launches(h), seconds=L.gw_poa_multi_seconds(h), compute_seconds=compute.value,
+                   seconds_after_creation=_multi_seconds_after_creation(L, h))
         ln = i32(0)
         if collect and mask == 1:
             out["consensus"], out["coverage"] = [], []

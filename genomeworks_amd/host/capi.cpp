@@ -555,6 +555,7 @@ gw_poa_multi* gw_poa_multi_device_run(int32_t n_windows, const int32_t* reads_pe
 void gw_poa_multi_destroy(gw_poa_multi* h) { delete h; }
 int32_t gw_poa_multi_launches(gw_poa_multi* h) { return h->out.launches; }
 double gw_poa_multi_seconds(gw_poa_multi* h) { return h->out.seconds; }
+double gw_poa_multi_seconds_after_creation(gw_poa_multi* h) { return h->out.seconds_after_creation; }
 // Accessors by window index: an index out of range, or asking for an output the run did not produce (consensus of an
 // MSA-only run and vice versa), is an error return with gw_last_error() set -- never an exception across the C ABI.
 int32_t gw_poa_multi_status(gw_poa_multi* h, int32_t w)

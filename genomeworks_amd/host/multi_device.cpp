@@ -393,7 +393,8 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
             // numerically lower = more urgent; the range is narrow (three levels on this hardware), later classes share the last
             stream_of[k] = class_streams.create(device, true, std::min(priority_least, priority_greatest + launch_rank[k]));
     std::mutex start_mutex;
-    std::chrono::steady_clock::time_point compute_begin{};
+    std::chrono::steady_clock::time_point compute_begin{}, fill_begin{};
+    std::atomic<int32_t> created{0};
     std::vector<std::exception_ptr> errors(classes);
     std::vector<std::thread> threads;
     JoinAll join_on_exit{threads};
@@ -421,6 +422,12 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                     DefaultDeviceAllocator allocator(static_cast<size_t>(share[k]), stream);
                     std::unique_ptr<Batch> batch = create_batch(device, stream, allocator, share[k], output_mask, plan.configs[k], gap_score,
                                                                 mismatch_score, match_score);
+                    // every class's Batch exists: the fill-inclusive clock (the reference's multi-batch region) starts
+                    if (created.fetch_add(1) + 1 == static_cast<int32_t>(active_classes))
+                    {
+                        std::lock_guard<std::mutex> g(start_mutex);
+                        fill_begin = std::chrono::steady_clock::now();
+                    }
                     // heaviest windows first: blocks are dispatched in window order, and a class that does not fit the free CUs
                     // at once should not keep its long chains for the end
                     std::vector<int32_t> mine = plan.groups[k];
@@ -550,6 +557,8 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                                                           : std::chrono::duration<double>(t_end - compute_begin).count();
     }
     out.launches = launches.load();
+    if (created.load() == static_cast<int32_t>(active_classes) && results_done_ns.load() > 0)
+        out.seconds_after_creation = std::chrono::duration<double>(t_begin + std::chrono::nanoseconds(results_done_ns.load()) - fill_begin).count();
     for (const std::exception_ptr& e : errors)
         if (e) std::rethrow_exception(e);
 }

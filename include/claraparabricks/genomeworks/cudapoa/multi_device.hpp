@@ -46,6 +46,9 @@ struct MultiDeviceOutput
     int32_t launches = 0;                           ///< generate_poa() calls over all workers
     double seconds   = 0;                           ///< wall time from the first worker's start to the last worker's end
                                                     ///< (batch creation, filling, kernels, result unpacking)
+    double seconds_after_creation = 0;              ///< process_windows_size_classes: from the moment every class's Batch exists to the
+                                                    ///< last results -- filling + generate_poa() + get_*(), the region the reference's
+                                                    ///< multi-batch benchmark times (cudapoa/benchmarks/multi_batch.hpp:72-177)
 };
 
 /// Windows binned by size so that every bin's batch is resident at the same time (MI355X addition). get_multi_batch_sizes

@@ -130,6 +130,7 @@ gw_poa_multi* gw_poa_multi_device_run(int32_t n_windows, const int32_t* reads_pe
 void gw_poa_multi_destroy(gw_poa_multi* h);
 int32_t gw_poa_multi_launches(gw_poa_multi* h);
 double gw_poa_multi_seconds(gw_poa_multi* h); /* workers' wall time: batch creation, filling, kernels, result unpacking */
+double gw_poa_multi_seconds_after_creation(gw_poa_multi* h); /* size-class runs: filling + generate_poa() + get_*() (multi_batch.hpp:72-177) */
 int32_t gw_poa_multi_status(gw_poa_multi* h, int32_t window);
 int32_t gw_poa_multi_worker(gw_poa_multi* h, int32_t window);
 const char* gw_poa_multi_consensus(gw_poa_multi* h, int32_t window, int32_t* length);
