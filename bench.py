@@ -433,6 +433,43 @@ def bench_default_aligner(local_rank, sync, cpu_all_cores=None):
     return out
 
 
+def bench_band_modes(windows, local_rank, sync):
+    """Every banded mode x band width of the reference's parameter space (multiples of 128, cudapoa/src/batch.cu:41; the
+    traceback-buffer modes of cudapoa_nw_tb_banded.cuh:264-643) on the 1024 config-3 windows: generate_poa() +
+    get_consensus(), steady state, plus the graph-build kernel's own duration. Only static / adaptive band 256 with int16
+    scores has the packed forward pass and the move-byte traceback (poa_forward_moves.h); the other cells of the table run
+    the general 32-bit-register passes -- this table is what they cost."""
+    from genomeworks_amd import cudapoa
+    rows = []
+    for mode, widths in (("static_band", (128, 256, 384, 512)), ("adaptive_band", (128, 256, 512)),
+                         ("static_band_traceback", (128, 256, 512)), ("adaptive_band_traceback", (128, 256, 512))):
+        for bw in widths:
+            b = cudapoa.CudaPoaBatch(32, 1024, 24 << 30, output_type="consensus", band_mode=mode, alignment_band_width=bw,
+                                     max_nodes_per_graph=3072, device_id=local_rank)
+            for w in windows:
+                st, _ = b.add_poa_group(w)
+                assert st == 0, st
+            b.generate_poa()
+            n_ok = b.get_consensus_native()
+            cells = b.total_cells()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                b.generate_poa()
+                b.get_consensus_native()
+            sync()
+            dt = (time.perf_counter() - t0) / 2
+            k_ms, _o = b.relaunch_timed()
+            _c, _v, status = b.get_consensus()
+            del b
+            rows.append({"band_mode": mode, "band_width": bw, "ms": round(dt * 1e3, 2), "kernel_ms": round(k_ms, 2),
+                         "gcups": round(cells / dt / 1e9, 1), "cells": cells, "windows_ok": sum(1 for x in status if int(x) == 0)})
+    ref = next(r for r in rows if r["band_mode"] == "static_band" and r["band_width"] == 256)
+    for r in rows:
+        r["gcups_vs_static_256"] = round(r["gcups"] / ref["gcups"], 3)
+    return {"workload": "the 1024 config-3 windows through every banded mode and band width", "rows": rows}
+
+
 def bench_reference_shapes(windows, local_rank, sync, steps):
     """The reference's own cudapoa benchmark shapes on the config-3 inputs (no published numbers exist for them):
     BM_SingleBatchTest -- one batch, BatchConfig(1024, 200) = full band, generate_poa() + get_consensus()
@@ -483,9 +520,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--windows", type=int, default=WINDOWS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sub-configs", default="aligner,default_aligner,long_reads,reference_shapes",
+    ap.add_argument("--sub-configs", default="aligner,default_aligner,long_reads,reference_shapes,band_modes",
                     help="comma list of the sub-records to measure next to the metric config: aligner, default_aligner, "
-                         "long_reads, reference_shapes, none")
+                         "long_reads, reference_shapes, band_modes, none")
     ap.add_argument("--long-read-windows", type=int, default=598)
     args = ap.parse_args()
     subs = set(x for x in args.sub_configs.split(",") if x and x != "none")
@@ -662,6 +699,8 @@ def main():
     if "default_aligner" in subs and rank == 0:
         sub["default_aligner"] = bench_default_aligner(local_rank, sync if world == 1 else (lambda: torch.cuda.synchronize()),
                                                        cpu_pairs.get("default_aligner"))
+    if "band_modes" in subs and world == 1:
+        sub["band_modes"] = bench_band_modes(windows, local_rank, sync)
     if "reference_shapes" in subs and world == 1:
         sub["reference_benchmark_shapes"] = bench_reference_shapes(windows, local_rank, sync, 2)
     if "long_reads" in subs:

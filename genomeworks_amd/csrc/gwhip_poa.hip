@@ -108,9 +108,14 @@ __device__ GraphView<IdT> carve_graph(uint8_t* slab, const PoaLayout& L)
 // phase is wave 0's, the helper wavefronts wait at a barrier in between.
 // DBG: the instantiation that honours GWHIP_DEBUG selectors and the per-phase cycle accounting. Production launches
 // (no selector, no phase buffer) run DBG = false, in which every selector test and profiling hook folds away.
-template <typename ScoreT, typename IdT, typename TraceT, int BM, bool MSA, bool LDS_TABLES, int NW, bool DBG>
+// VARIANT: 0 = production, alignment_band_width != 128; 1 = debug (below); 2 = production for alignment_band_width 128 (the
+// packed pass with the band in lanes 0..31 next to the 256-column one an adaptive band may widen to: a separate instantiation,
+// so that the metric configuration's kernel carries none of its code -- with both in one kernel the headline lost 1 %).
+template <typename ScoreT, typename IdT, typename TraceT, int BM, bool MSA, bool LDS_TABLES, int NW, int VARIANT>
 __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
 {
+    constexpr bool DBG  = VARIANT == 1;
+    constexpr bool B128 = VARIANT != 0;
     const int32_t debug_flags = DBG ? a.debug_flags : 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane       = threadIdx.x & (kWave - 1);
@@ -277,12 +282,12 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
         }
         else if (BM == GWHIP_ADAPTIVE_BAND && c.alignment_band_width < kMaxAdaptiveBand)
         {
-            alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
+            alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ, B128>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                 banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring,
                                                 mw_args, mw_shared);
             if (alen == kShiftLeft || alen == kShiftRight)
-                alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
+                alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ, B128>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                     banded_buffer_size, alignment_graph, alignment_read,
                                                     c.alignment_band_width, c.gap_score, c.mismatch_score, c.match_score,
                                                     alen, cells, pc, debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring,
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
         }
         else if (BM == GWHIP_STATIC_BAND || BM == GWHIP_ADAPTIVE_BAND)
         {
-            alen = nw_banded<ScoreT, IdT, RowT, false, LDS_READ>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
+            alen = nw_banded<ScoreT, IdT, RowT, false, LDS_READ, B128>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                  banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
                                                  c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring);
         }
@@ -605,15 +610,19 @@ static hipError_t launch_window_kernel(const KernelArgs& ka_in, hipStream_t stre
         {                                                                                                          \
             lds_req            = kReservedCuLds;                                                                   \
             ka.wide_ring_bytes = (int32_t)(kReservedCuLds - wide_rest);                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, false>), \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, 0>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReservedCuLds);             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, true>), \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, 1>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReservedCuLds);             \
         }                                                                                                          \
+        constexpr bool kHas128 = LDS_TABLES && std::is_same<ScoreT, int16_t>::value &&                             \
+                                 (BM == GWHIP_STATIC_BAND || BM == GWHIP_ADAPTIVE_BAND);                           \
         if (ka.debug_flags != 0 || ka.phase_cycles != nullptr)                                                     \
-            hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, true>), grid, dim3(kWave * NW), lds_req, stream, ka); \
+            hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, 1>), grid, dim3(kWave * NW), lds_req, stream, ka); \
+        else if (kHas128 && ka.cfg.alignment_band_width == 128)                                                    \
+            hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, kHas128 ? 2 : 0>), grid, dim3(kWave * NW), lds_req, stream, ka); \
         else                                                                                                       \
-            hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, false>), grid, dim3(kWave * NW), lds_req, stream, ka); \
+            hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, 0>), grid, dim3(kWave * NW), lds_req, stream, ka); \
     }                                                                                                              \
     break;
     switch (ka.cfg.band_mode)

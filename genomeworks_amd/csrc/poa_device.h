@@ -2084,7 +2084,7 @@ __device__ __forceinline__ int32_t traceback_codes_staged(const BandedCtx<ScoreT
 // Banded NW (score-matrix modes): forward pass wave-wide, then sink selection (wave reduction with the
 // reference's first-maximum tie rule) and the lane-0 traceback.
 // ------------------------------------------------------------------------------------------------
-template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE, bool LDS_READ>
+template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE, bool LDS_READ, bool B128 = false>
 __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowinfo, int32_t graph_count, const uint8_t* read,
                              const uint8_t* lds_read, int32_t read_length, ScoreT* scores, ScoreT* ring_base, int32_t ring_bytes,
                              float max_buffer_size, int32_t* alignment_graph, int32_t* alignment_read,
@@ -2198,7 +2198,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     if constexpr (kFastOk && std::is_same<ScoreT, int16_t>::value)
     {
         // packed 16-bit pass for the 256-column band (preconditions: poa_forward_packed.h)
-        const bool packed_ok = band_width == 256 && max_column >= band_width && ring_bytes >= kPkSlots * kPkSlotBytes &&
+        const bool packed_ok = (band_width == 256 || (B128 && band_width == 128)) && max_column >= band_width && ring_bytes >= kPkSlots * kPkSlotBytes &&
                                abs(gap_score) <= 30 && abs(match_score) <= 100 && abs(mismatch_score) <= 100 &&
                                codes != nullptr && !(dbg & 256) && ring_bytes >= kMtBytes &&
                                // no packed operation can leave int16: the largest score (all matches) plus the u-space offset of
@@ -2209,9 +2209,14 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
         if (packed_ok)
         {
             // move bytes, row kinds, descriptors in registers (poa_forward_moves.h)
-            banded_forward_moves<IdT>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
-                                      reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score, dbg,
-                                      pc.acc ? &pc.acc[kPhOther] : nullptr);
+            if (band_width == 256)
+                banded_forward_moves<IdT, 256>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
+                                               reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score,
+                                               dbg, pc.acc ? &pc.acc[kPhOther] : nullptr);
+            else if constexpr (B128)
+                banded_forward_moves<IdT, 128>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
+                                               reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score,
+                                               dbg, pc.acc ? &pc.acc[kPhOther] : nullptr);
             fast_done   = true;
             moves_valid = true;
         }

@@ -102,7 +102,11 @@ __device__ __forceinline__ int32_t classify_kinds(RowInfo<true>* rowinfo, int32_
 // first); `scores` the HBM score matrix and `moves` the HBM move-byte matrix (row stride 264 elements / bytes);
 // lds_read the LDS copy of the read.
 // ------------------------------------------------------------------------------------------------
-template <typename IdT>
+// BW = 256: every lane owns four band cells. BW = 128: the same instruction stream with the band in lanes 0..31 -- lanes
+// 32..63 compute cells right of the band that nobody reads (a prefix scan runs left to right, so they cannot reach into the
+// band) and their stores are masked; a row then costs what a 256-column row costs, which is still 2-3 x less than the
+// general pass.
+template <typename IdT, int BW>
 __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, RowInfo<true>* rowinfo, int32_t graph_count,
                                                      const uint8_t* lds_read, int16_t* scores, uint8_t* moves, uint8_t* ring,
                                                      const uint64_t* xpred, int32_t max_column, int32_t gap_score,
@@ -121,9 +125,12 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
     const int32_t ksel = prof_acc ? ((dbg >> 28) & 7) - 1 : -1;
     const bool kcount  = (dbg & (1 << 12)) != 0;
     uint64_t kacc      = 0;
-    constexpr int32_t band_width = 256;
+    static_assert(BW == 128 || BW == 256, "band widths of the packed pass");
+    constexpr int32_t band_width = BW;
     constexpr int32_t stride     = band_width + kRightPad;
+    constexpr int kBandLanes     = BW / kCellsPerLane; // lanes that own band cells
     const int lane               = threadIdx.x & (kWave - 1);
+    const bool band_lane         = lane < kBandLanes;
     const int32_t lane4 = lane * 4, lane8 = lane * 8;
     const int32_t min_score = Limits<int16_t>::min / 2;
 
@@ -145,9 +152,9 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
     const uint32_t read_base = lds_addr(lds_read);
     // guard store: lanes 0..15 write sentinel cells for columns band_end + 1 .. + 64, lane 16 the quad that ends in
     // the left-boundary slot (column band_start); byte offsets relative to the lane's own cell offset
-    const uint32_t guard_off  = lane < 16 ? 512u : (uint32_t)-136;
+    const uint32_t guard_off  = lane < 16 ? (uint32_t)(2 * BW) : (uint32_t)-136;
     const bool is_lane16      = lane == 16;
-    const bool is_lane63      = lane == kWave - 1;
+    const bool is_lane63      = lane == kBandLanes - 1; // the band's last lane
     const uint32_t move_keep  = lane == 0 ? 0xffffff00u : 0xffffffffu; // the band's first cell stays undecided
     // the guard quad's second dword in rows whose left boundary is min_score by construction
     const uint32_t GUARD_HI_MIN = pin_vgpr(is_lane16 ? (((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)min_score << 16)) : pk_dup(kPkSentinel));
@@ -168,7 +175,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
     uint8_t* move_ptr  = moves + lane4 + (1 + kRelShift);
 
     // row 0 into ring slot 0
-    lds_store_u64(ring_base + a1, P01, P23);
+    if (BW == 256 || band_lane) lds_store_u64(ring_base + a1, P01, P23);
     lds_store_u64_lanes17(ring_base + ga, SENT2, is_lane16 ? (((uint32_t)kPkSentinel & 0xffffu) | (0u << 16)) : SENT2);
 
     // horizontal max-plus scan of the row's candidates; cu = carry-in as element t = -1 of u; leaves the row in P01/P23
@@ -209,8 +216,8 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
         score_ptr += stride * 2;
         move_ptr += stride;
         const uint32_t sbase = ring_base + (((uint32_t)r & (kPkSlots - 1)) * kPkSlotBytes);
-        if (st_scores) *reinterpret_cast<uint2*>(score_ptr) = make_uint2(P01, P23);
-        if (ab_ring) lds_store_u64(sbase + a1, P01, P23);
+        if (st_scores && (BW == 256 || band_lane)) *reinterpret_cast<uint2*>(score_ptr) = make_uint2(P01, P23);
+        if (ab_ring && (BW == 256 || band_lane)) lds_store_u64(sbase + a1, P01, P23);
         if constexpr (BS0)
         {
             const uint32_t rel0pk = ((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)rel0_val << 16);
@@ -220,7 +227,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
         }
         else if (ab_guard)
             lds_store_u64_lanes17(sbase + ga, SENT2, GUARD_HI_MIN);
-        if (st_moves) *reinterpret_cast<uint32_t*>(move_ptr) = mv4;
+        if (st_moves && (BW == 256 || band_lane)) *reinterpret_cast<uint32_t*>(move_ptr) = mv4;
     };
     // four move bytes from two registers of 16-bit moves
     auto pack_moves = [&](uint32_t m01, uint32_t m23) -> uint32_t {
@@ -323,11 +330,14 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
         move_ptr += stride;
         const uint32_t sbase  = ring_base + (((uint32_t)r & (kPkSlots - 1)) * kPkSlotBytes);
         const uint32_t rel0pk = ((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)rel0_val << 16);
-        *reinterpret_cast<uint2*>(score_ptr) = make_uint2(P01, P23);
-        lds_store_u64(sbase + a1, P01, P23);
+        if (BW == 256 || band_lane)
+        {
+            *reinterpret_cast<uint2*>(score_ptr) = make_uint2(P01, P23);
+            lds_store_u64(sbase + a1, P01, P23);
+        }
         lds_store_u64_lanes17(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
         if (bs == 0) gstore_u16_lane0_below(score_ptr, (uint32_t)rel0_val);
-        *reinterpret_cast<uint32_t*>(move_ptr) = 0u;
+        if (BW == 256 || band_lane) *reinterpret_cast<uint32_t*>(move_ptr) = 0u;
         prev_rel0_io = rel0_val;
     };
 

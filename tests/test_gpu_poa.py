@@ -279,6 +279,36 @@ def test_group_with_every_read_rejected_keeps_its_output_slot():
             assert list(cov[slot]) == list(ref["coverage"])
 
 
+@pytest.mark.parametrize("band_mode", ["static_band", "adaptive_band"])
+def test_band_128_through_the_packed_pass_bit_exact_vs_oracle(band_mode):
+    """alignment_band_width 128 (the reference's minimum, cudapoa/src/batch.cu:41) takes the packed forward pass and the
+    move-byte traceback with the band in lanes 0..31: consensus, coverage, status and cell counts equal the oracle's on
+    config-3 windows and on windows with heavy indels (paths near the band edges, adaptive widening to 256)."""
+    import random
+    from genomeworks_amd import synthetic
+    rng = random.Random(128)
+    windows = config3(24)
+    for k in range(24):
+        blen = rng.choice([200, 500, 900, 1000])
+        mut, ins, dele = rng.choice([(5, 2, 2), (40, 20, 20), (90, 40, 40), (10, 60, 5), (10, 5, 60)])
+        w = [r.decode() for r in synthetic.generate_window(8800 + k, blen, rng.choice([5, 16, 32]), mut, ins, dele)]
+        windows.append([r for r in w if 130 < len(r) < 1024])
+    windows = [w for w in windows if len(w) >= 2]
+    b = run_gpu(windows, band_mode, band_width=128)
+    cons, cov, status = b.get_consensus()
+    cells_ref = 0
+    with O.Workspace(oracle_cfg(band_mode, band_width=128)) as ws:
+        for i, w in enumerate(windows):
+            ref = ws.process(w)
+            cells_ref += ref["cells"]
+            assert status[i] == ref["status"], (i, status[i], ref["status"])
+            if ref["status"] == 0:
+                assert cons[i] == ref["consensus"], "window %d consensus differs" % i
+                assert cov[i] == list(ref["coverage"]), "window %d coverage differs" % i
+        assert ws.overflow_events() == 0
+    assert b.total_cells() == cells_ref
+
+
 def test_kernel_shortcuts_equal_the_plain_schedule(monkeypatch):
     """A/B inside the kernel (GWHIP_DEBUG selectors of the debug instantiation; the production instantiation is the first
     arm): the incremental Kahn order vs the full re-sort after every read (bit 21, the reference's schedule); rows with

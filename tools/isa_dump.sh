@@ -2,7 +2,7 @@
 # Dump the gfx950 ISA of one poa_window_kernel instantiation (default: the config-3 kernel) to $OUT (default /tmp/isa/k.s).
 # usage: tools/isa_dump.sh ["int16_t,int16_t,int8_t,1,false,true,1"]
 set -e
-INST=${1:-"int16_t,int16_t,int8_t,1,false,true,1,false"}
+INST=${1:-"int16_t,int16_t,int8_t,1,false,true,1,0"}
 OUT=${OUT:-/tmp/isa/k.s}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$(dirname "$OUT")"

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kWave) void rows_kernel(MbArgs a)
     const unsigned long long t0 = clock64();
     for (int32_t rep = 0; rep < a.reps; rep++)
     {
-        banded_forward_moves<int16_t>(g, rowinfo, a.graph_count, lds_read, scores, moves, ring, xpred, max_column, -8, -6, 8, a.dbg, nullptr);
+        banded_forward_moves<int16_t, 256>(g, rowinfo, a.graph_count, lds_read, scores, moves, ring, xpred, max_column, -8, -6, 8, a.dbg, nullptr);
         wave_sync();
     }
     const unsigned long long t1 = clock64();
