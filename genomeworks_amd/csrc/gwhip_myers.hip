@@ -2365,9 +2365,10 @@ int gwhip_hirschberg_myers(const gwhip_hirschberg_args* args, gwhip_stream_t str
     if (use_wave)
     {
         ka.lds_state_words = part_chunks;
-        if (wave_lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hirschberg_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave_lds);
-        hipLaunchKernelGGL(hirschberg_wave_kernel, dim3(n), dim3(64), wave_lds, stream, ka);
+        const size_t lds_request = wave_lds;
+        if (lds_request > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hirschberg_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_request);
+        hipLaunchKernelGGL(hirschberg_wave_kernel, dim3(n), dim3(64), lds_request, stream, ka);
     }
     else if ((size_t)qwords * 6 * 64 * sizeof(uint32_t) <= 60 * 1024)
     {

@@ -401,7 +401,12 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
             if (status_and_count >= 0 && !c.spoa_accurate && !(debug_flags & (1 << 21)) && incr_ok)
             {
                 wave_sync();
-                topsort_kahn_incr_hbm<IdT>(g, node_count, status_and_count, reinterpret_cast<int32_t*>(scores), lane);
+                // hot state in LDS (the idle score ring) when the graph's counters fit beside the window of the previous
+                // order; GWHIP_DEBUG bit 16: the HBM routine only (A/B)
+                bool done = false;
+                if (!(debug_flags & (1 << 16)) && topsort_incr_cnt8_lds_bytes(status_and_count) <= ring_bytes)
+                    done = topsort_kahn_incr_cnt8<IdT>(g, node_count, status_and_count, smem, reinterpret_cast<int32_t*>(scores), lane);
+                if (!done) topsort_kahn_incr_hbm<IdT>(g, node_count, status_and_count, reinterpret_cast<int32_t*>(scores), lane);
                 sorted_here = true;
             }
             else if (status_and_count >= 0 && !c.spoa_accurate && !(debug_flags & (1 << 21)) &&

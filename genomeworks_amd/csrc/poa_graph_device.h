@@ -1168,6 +1168,201 @@ __device__ __forceinline__ void topsort_kahn_incr_hbm(const GraphView<IdT>& g, i
     wave_sync();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The incremental Kahn order for long-read graphs with its hot state in LDS (round 3). topsort_kahn_incr_hbm pays half a
+// dozen dependent L2 / HBM round trips per replayed block and three or four per ordinary step: its node words (in-edge
+// counters, change flags, previous position) and the previous order live in HBM. A multi-wave block owns its CU's LDS and
+// the score ring is idle during the sort, so here
+//   cnt8[n]   one byte per node: unvisited in-edges [0:6) | new in-edge or new node [6] | new out-edge or new node [7];
+//             decremented with ds_sub_rtn_u32 on the dword around the byte (a counter is only decremented while >= 1, so
+//             no borrow crosses into the neighbour bytes)
+//   win[]     a sliding window over 1024 positions of the PREVIOUS order, slot = position & 1023: {out-edges 0..2,
+//             node [0:20) | min(out-degree, 4) [20:23) | previous queue length [28:32)}, refilled 256 positions at a time by
+//             all lanes (four 64-position chunks per round trip) while the sort is still more than 512 positions behind
+//             its end -- positions only move forward (p = old nodes output so far)
+//   qring[]   the live part of the queue (1024 entries; a longer queue gives up: the caller re-runs the HBM routine,
+//             nothing has been published yet)
+// "In sync at p" needs no previous position of the head node: the old nodes output so far are sigma[0..p) iff their count
+// is p and the highest position output is p - 1, and the head is then compared with sigma[p] from the window like the rest
+// of the queue. A replayed block and an ordinary step on the expected node (most of them: an old node popped where the
+// previous run popped it, but with a changed neighbourhood) touch LDS only; HBM round trips remain for new nodes, old nodes
+// popped out of turn, nodes with more than three out-edges (lane e fetches edge e: one trip) and the window refills.
+// The popped entries go to the HBM queue (node | queue length << 28) as before and phase 3 publishes from there; the record
+// carried from read to read (GraphView::local_cnt) is the same, so a window may switch between this routine and
+// topsort_kahn_incr_hbm from read to read.
+// ------------------------------------------------------------------------------------------------
+constexpr int32_t kTwWin   = 1024;
+constexpr int32_t kTwRing  = 1024;
+constexpr int32_t kTwFixed = kTwWin * 16 + kTwRing * 4;
+__device__ __forceinline__ int32_t topsort_incr_cnt8_lds_bytes(int32_t node_count) { return kTwFixed + ((node_count + 3) & ~3) + 64; }
+
+template <typename IdT>
+__device__ __forceinline__ bool topsort_kahn_incr_cnt8(const GraphView<IdT>& g, int32_t n_old, int32_t node_count, uint8_t* lds,
+                                                       int32_t* queue, int lane)
+{
+    constexpr int32_t kQClip = 15;
+    constexpr uint32_t kId   = 0xfffffu;
+    uint4* win      = reinterpret_cast<uint4*>(lds);
+    uint32_t* qring = reinterpret_cast<uint32_t*>(lds + kTwWin * 16);
+    uint8_t* cnt8   = lds + kTwFixed;
+    uint32_t* cntw  = reinterpret_cast<uint32_t*>(cnt8);
+    const unsigned long long lanes_below = (1ull << lane) - 1;
+    auto dec8 = [&](int32_t n) -> uint32_t { // old value of node n's byte
+        const uint32_t sh  = ((uint32_t)n & 3u) * 8u;
+        const uint32_t old = __hip_atomic_fetch_sub(cntw + (n >> 2), 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (old >> sh) & 0xffu;
+    };
+    // phase 1 (all lanes, four chunks per round trip): counters and change flags, sources in ascending node id
+    int32_t tail = 0;
+    for (int32_t base = 0; base < node_count; base += 4 * kWave)
+    {
+        uint32_t ic[4], oc[4], m[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int32_t nc = min(base + q * kWave + lane, node_count - 1);
+            ic[q]            = g.incoming_edge_count[nc];
+            oc[q]            = g.outgoing_edge_count[nc];
+            m[q]             = g.local_cnt[nc >= n_old ? 0 : nc];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int32_t n     = base + q * kWave + lane;
+            const bool in       = n < node_count;
+            const bool is_new   = n >= n_old;
+            const uint32_t din  = (is_new || ((m[q] >> 10) & 63u) != ic[q]) ? 1u : 0u;
+            const uint32_t dout = (is_new || ((m[q] >> 4) & 63u) != oc[q]) ? 1u : 0u;
+            if (in) cnt8[n] = (uint8_t)((ic[q] & 0x3fu) | (din << 6) | (dout << 7));
+            const bool is_src           = in && ic[q] == 0;
+            const unsigned long long ms = __ballot(is_src);
+            const int32_t slot          = tail + __popcll(ms & lanes_below);
+            if (is_src && slot < kTwRing) qring[slot] = (uint32_t)n;
+            tail += __popcll(ms);
+        }
+    }
+    if (tail > kTwRing) return false;
+    auto fill = [&](int32_t pos0) { // window slots of positions [pos0, pos0 + 256)
+        int32_t node[4];
+        uint32_t oc[4], e0[4], e1[4], e2[4], m[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) node[q] = (int32_t)g.sorted_poa[min(pos0 + q * kWave + lane, n_old - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            oc[q] = g.outgoing_edge_count[node[q]];
+            e0[q] = (uint32_t)(int32_t)g.outgoing_edges[(int64_t)node[q] * kEdges];
+            e1[q] = (uint32_t)(int32_t)g.outgoing_edges[(int64_t)node[q] * kEdges + 1];
+            e2[q] = (uint32_t)(int32_t)g.outgoing_edges[(int64_t)node[q] * kEdges + 2];
+            m[q]  = g.local_cnt[node[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int32_t pos = pos0 + q * kWave + lane;
+            if (pos < n_old)
+                win[pos & (kTwWin - 1)] = make_uint4(e0[q], e1[q], e2[q], (uint32_t)node[q] | (min(oc[q], 4u) << 20) | ((m[q] & 15u) << 28));
+        }
+    };
+    for (int32_t pos0 = 0; pos0 < min(n_old, kTwWin); pos0 += 4 * kWave) fill(pos0);
+    wave_sync();
+    // phase 2: wave-uniform control; k = new nodes output so far, M = highest previous position output so far
+    int32_t head = 0, k = 0, M = -1, wbase = 0;
+    while (head < tail)
+    {
+        const int32_t p = head - k; // old nodes output so far = the previous position the state could be in sync with
+        while (p >= wbase + kTwWin / 2 && wbase + kTwWin < n_old)
+        {
+            fill(wbase + kTwWin);
+            wbase += 4 * kWave;
+        }
+        const int32_t len = tail - head;
+        // lane l looks at queue entry head + l and at position p + l of the previous order
+        const uint32_t ql  = qring[(head + lane) & (kTwRing - 1)];
+        const int32_t posl = p + lane;
+        const bool valid   = posl < n_old;
+        const uint4 e      = win[posl & (kTwWin - 1)];
+        const int32_t node = valid ? (int32_t)(e.w & kId) : 0;
+        const int32_t noc  = valid ? (int32_t)((e.w >> 20) & 7u) : 0;
+        const int32_t ch0  = noc > 0 ? (int32_t)e.x : node;
+        const int32_t ch1  = noc > 1 ? (int32_t)e.y : node;
+        const int32_t ch2  = noc > 2 ? (int32_t)e.z : node;
+        const uint32_t fn = cnt8[node], f0 = cnt8[ch0], f1 = cnt8[ch1], f2 = cnt8[ch2];
+        const int32_t u   = wave_first((int32_t)ql);
+        const bool is_new = u >= n_old;
+        // a position cannot be replayed when its node has a new out-edge or more than three children, or a child has a new
+        // in-edge; behind the head also when the node itself has a new in-edge (the head has really been pushed)
+        const bool bad = !valid | ((fn & 0x80u) != 0) | (noc > 3) | ((lane > 0) & ((fn & 0x40u) != 0)) | ((noc > 0) & ((f0 & 0x40u) != 0)) |
+                         ((noc > 1) & ((f1 & 0x40u) != 0)) | ((noc > 2) & ((f2 & 0x40u) != 0));
+        const unsigned long long mb = __ballot(bad);
+        const bool q_differs        = lane < len && !(valid && (int32_t)ql == node);
+        const uint32_t w0           = (uint32_t)wave_first((int32_t)e.w);
+        const bool expected         = !is_new && p < n_old && (int32_t)(w0 & kId) == u; // u is sigma[p]
+        const int32_t qo            = (int32_t)(w0 >> 28);
+        const bool block            = expected && !(mb & 1ull) && M == p - 1 && len == qo && qo < kQClip && __ballot(q_differs) == 0;
+        if (block)
+        {
+            // lane l replays the pop of position p + l; all decrements in flight together; a child whose counter reaches 0 was
+            // pushed here by the previous run, and the pushed entries continue the previous order
+            const int32_t b = mb ? __ffsll((unsigned long long)mb) - 1 : kWave;
+            const bool do0 = lane < b && noc > 0, do1 = lane < b && noc > 1, do2 = lane < b && noc > 2;
+            uint32_t r0 = 0, r1 = 0, r2 = 0;
+            if (do0) r0 = dec8(ch0);
+            if (do1) r1 = dec8(ch1);
+            if (do2) r2 = dec8(ch2);
+            const int32_t npush = __popcll(__ballot(do0 && (r0 & 0x3fu) == 1u)) + __popcll(__ballot(do1 && (r1 & 0x3fu) == 1u)) +
+                                  __popcll(__ballot(do2 && (r2 & 0x3fu) == 1u));
+            for (int32_t j = lane; j < npush; j += kWave) qring[(tail + j) & (kTwRing - 1)] = win[(p + len + j) & (kTwWin - 1)].w & kId;
+            if (lane < b) queue[head + lane] = (int32_t)(e.w & (kId | 0xf0000000u));
+            head += b;
+            tail += npush;
+            M = p + b - 1;
+            if (tail - head > kTwRing) return false;
+            continue;
+        }
+        // ordinary Kahn step: lane e owns out-edge e
+        int32_t oc, child, pos = p;
+        if (expected && ((w0 >> 20) & 7u) <= 3u)
+        {
+            oc               = (int32_t)((w0 >> 20) & 7u);
+            const int32_t c0 = wave_first((int32_t)e.x), c1 = wave_first((int32_t)e.y), c2 = wave_first((int32_t)e.z);
+            child            = lane == 0 ? c0 : (lane == 1 ? c1 : c2);
+        }
+        else
+        {
+            const int32_t pu = (int32_t)g.node_id_to_pos[is_new ? 0 : u];
+            child            = (int32_t)g.outgoing_edges[(int64_t)u * kEdges + min(lane, kEdges - 1)];
+            oc               = wave_first((int32_t)g.outgoing_edge_count[u]);
+            if (!expected) pos = wave_first(pu);
+        }
+        const bool act     = lane < oc;
+        uint32_t old       = 0;
+        if (act) old = dec8(child);
+        const bool hit              = act && (old & 0x3fu) == 1u;
+        const unsigned long long mh = __ballot(hit);
+        if (hit) qring[(tail + __popcll(mh & lanes_below)) & (kTwRing - 1)] = (uint32_t)child;
+        if (lane == 0) queue[head] = (int32_t)((uint32_t)u | ((uint32_t)min(len, kQClip) << 28));
+        head++;
+        tail += __popcll(mh);
+        k += is_new ? 1 : 0;
+        M = is_new ? M : max(M, pos);
+        if (tail - head > kTwRing) return false;
+    }
+    wave_sync();
+    // phase 3 (all lanes): publish order, inverse map and the per-node record for the next read
+    for (int32_t i = lane; i < node_count; i += kWave)
+    {
+        const uint32_t e   = (uint32_t)queue[i];
+        const int32_t node = (int32_t)(e & kId);
+        const uint32_t oc = g.outgoing_edge_count[node], ic = g.incoming_edge_count[node];
+        g.sorted_poa[i]        = (IdT)node;
+        g.node_id_to_pos[node] = (IdT)i;
+        g.local_cnt[node]      = (uint16_t)((e >> 28) | (oc << 4) | (ic << 10));
+    }
+    wave_sync();
+    return true;
+}
+
 // racon/spoa DFS order (aligned nodes adjacent)
 template <typename IdT>
 __device__ void topsort_racon(const GraphView<IdT>& g, int32_t node_count, int32_t max_nodes_per_graph)

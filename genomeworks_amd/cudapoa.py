@@ -74,6 +74,8 @@ def _bind(L):
     L.gw_poa_total_cells.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.gw_poa_relaunch_timed.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.gw_poa_profile_phases.argtypes = [vp, C.POINTER(C.c_double)]
+    L.gw_poa_profile_phases_per_window.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32]
+    L.gw_poa_profile_phases_per_window.restype = C.c_int32
     L._gw_poa_bound = True
     return L
 
@@ -193,6 +195,16 @@ class CudaPoaBatch:
             raise RuntimeError(self._L.gw_last_error().decode())
         names = ("row_table", "nw_forward", "sink_traceback", "graph_merge", "topsort", "other")
         return dict(zip(names, [float(x) for x in out]))
+
+    def profile_phases_per_window(self):
+        """Profiling aid: the six phase counters of every window of the batch (one extra launch), a list of dicts."""
+        n = self.total_poas
+        out = (C.c_uint64 * (6 * max(n, 1)))()
+        got = self._L.gw_poa_profile_phases_per_window(self._h, out, n)
+        if got < 0:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        names = ("row_table", "nw_forward", "sink_traceback", "graph_merge", "topsort", "other")
+        return [dict(zip(names, [int(out[6 * w + k]) for k in range(6)])) for w in range(got)]
 
     def get_consensus_native(self):
         """D2H + host unpack inside the library, without marshalling the strings to Python. Returns window count."""

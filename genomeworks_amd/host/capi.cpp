@@ -275,6 +275,18 @@ int gw_poa_profile_phases(gw_poa_batch* b, double* out6)
     GW_CATCH(-1)
 }
 
+int gw_poa_profile_phases_per_window(gw_poa_batch* b, uint64_t* out, int32_t capacity_windows)
+{
+    GW_TRY
+    if (!b->impl) return -1;
+    std::vector<uint64_t> ticks;
+    b->impl->profile_phases_per_window(ticks);
+    const int32_t n = std::min<int32_t>(static_cast<int32_t>(ticks.size() / 6), capacity_windows);
+    std::copy(ticks.begin(), ticks.begin() + static_cast<size_t>(n) * 6, out);
+    return n;
+    GW_CATCH(-1)
+}
+
 // ---- cudaaligner --------------------------------------------------------------------------------------
 gw_aligner* gw_aligner_create_banded(int32_t max_bandwidth, void* stream, int32_t device_id, int64_t max_device_memory)
 {

@@ -507,20 +507,27 @@ void PoaBatch::relaunch_resident_timed(float* graph_build_ms, float* output_ms)
 
 void PoaBatch::profile_phases(double out[6])
 {
-    scoped_device_switch dev(device_id_);
     for (int k = 0; k < 6; k++) out[k] = 0;
     if (poa_count_ == 0) return;
+    std::vector<uint64_t> h;
+    profile_phases_per_window(h);
+    for (size_t i = 0; i < h.size(); i++) out[i % 6] += static_cast<double>(h[i]);
+    for (int k = 0; k < 6; k++) out[k] /= poa_count_;
+}
+
+void PoaBatch::profile_phases_per_window(std::vector<uint64_t>& ticks)
+{
+    scoped_device_switch dev(device_id_);
     const size_t n = static_cast<size_t>(poa_count_) * 6;
-    uint64_t* d    = nullptr;
+    ticks.assign(n, 0);
+    if (n == 0) return;
+    uint64_t* d = nullptr;
     GW_CU_CHECK_ERR(hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(uint64_t)));
     GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq_lens_, h_seq_lens_, static_cast<size_t>(global_sequence_idx_) * sizeof(int32_t), hipMemcpyHostToDevice, stream_));
     launch(nullptr, d);
-    std::vector<uint64_t> h(n);
-    GW_CU_CHECK_ERR(hipMemcpyAsync(h.data(), d, n * sizeof(uint64_t), hipMemcpyDeviceToHost, stream_));
+    GW_CU_CHECK_ERR(hipMemcpyAsync(ticks.data(), d, n * sizeof(uint64_t), hipMemcpyDeviceToHost, stream_));
     GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
     GW_CU_CHECK_ERR(hipFree(d));
-    for (size_t i = 0; i < n; i++) out[i % 6] += static_cast<double>(h[i]);
-    for (int k = 0; k < 6; k++) out[k] /= poa_count_;
 }
 
 void PoaBatch::log_kernel_error(StatusType error_type, std::vector<StatusType>& output_status)

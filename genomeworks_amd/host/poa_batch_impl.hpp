@@ -45,6 +45,7 @@ public:
     /// Profiling aid: relaunch with per-phase cycle accounting; out[6] = mean ticks per window of
     /// {row table, NW forward, sink+traceback, graph merge, topsort, other}.
     void profile_phases(double out[6]);
+    void profile_phases_per_window(std::vector<uint64_t>& ticks); // six phase counters per window, in window order
     const gwhip_poa_config& device_config() const { return cfg_; }
     cudaStream_t stream() const { return stream_; }
 

@@ -116,6 +116,8 @@ int gw_poa_relaunch(gw_poa_batch* b);
 int gw_poa_relaunch_timed(gw_poa_batch* b, float* graph_build_ms, float* output_ms);
 /* profiling aid: mean s_memtime ticks per window of {row table, NW forward, sink+traceback, graph merge, topsort, other} */
 int gw_poa_profile_phases(gw_poa_batch* b, double* out6);
+/* the same six counters for every window of the batch (window-major); returns the number of windows written, <0 on error */
+int gw_poa_profile_phases_per_window(gw_poa_batch* b, uint64_t* out, int32_t capacity_windows);
 
 /* ---- cudapoa/multi_device.hpp: windows over several devices / several batches per device (one host thread, stream
    and Batch per worker; windows pulled from a shared cursor; results by global window index; no collective) ---- */

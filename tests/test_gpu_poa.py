@@ -223,7 +223,8 @@ def test_long_read_forward_and_traceback_variants_agree(monkeypatch):
     """A/B inside the long-read kernel (graphs beyond the LDS tables, adaptive band): the pipelined multi-wave forward
     pass with trace codes and the table-lookup traceback (default) against the table-lookup traceback switched off
     (GWHIP_DEBUG bit 6: recomputation from the score matrix), against the single-wave forward pass (bit 18) and against the
-    full topological re-sorts (bit 17: cached Kahn order, bit 21: serial; default: incremental order with block replay), on
+    full topological re-sorts (bit 17: cached Kahn order, bit 21: serial; default: incremental order with block replay and
+    its hot state in LDS; bit 16: the same with its state in HBM), on
     divergent long reads whose bands widen to 512 .. 1536 columns: identical MSA, status and cell counts, and equal to
     the oracle."""
     from genomeworks_amd import synthetic
@@ -232,7 +233,8 @@ def test_long_read_forward_and_traceback_variants_agree(monkeypatch):
     windows.append([r.decode() for r in synthetic.generate_window(9201, 3000, 5, 20, 900, 20)])    # reads much longer than the backbone
     out = {}
     for name, flag in (("default", None), ("recomputed_traceback", str(1 << 6)), ("single_wave", str(1 << 18)),
-                       ("cached_full_resort", str(1 << 17)), ("serial_full_resort", str(1 << 21))):
+                       ("cached_full_resort", str(1 << 17)), ("serial_full_resort", str(1 << 21)),
+                       ("incremental_in_hbm", str(1 << 16))):
         if flag is None:
             monkeypatch.delenv("GWHIP_DEBUG", raising=False)
         else:
@@ -241,7 +243,8 @@ def test_long_read_forward_and_traceback_variants_agree(monkeypatch):
         out[name] = (b.get_msa(), b.total_cells())
     assert out["default"] == out["recomputed_traceback"]
     assert out["default"] == out["single_wave"]
-    assert out["default"] == out["cached_full_resort"]   # incremental Kahn order in HBM (default) vs the cached full re-sort
+    assert out["default"] == out["cached_full_resort"]   # incremental Kahn order (default) vs the cached full re-sort
+    assert out["default"] == out["incremental_in_hbm"]   # ... LDS counters and window vs node words in HBM
     assert out["default"] == out["serial_full_resort"]   # ... vs the reference's schedule on one lane
     (msa, status), _ = out["default"]
     cfg = oracle_cfg("adaptive_band", 8192, 12, output_mask=2, nodes=4 * 8192)
