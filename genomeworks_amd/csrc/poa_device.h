@@ -1231,11 +1231,11 @@ namespace gwhip
 //   * The row table is read 64 rows at a time into registers (lane l holds row base + l, a row's record is six
 //     v_readlane), prefetched one batch ahead, so the row loop issues no load that would wait for the score stores.
 //
-// The pass also writes the trace codes of poa_forward_packed.h (one byte per cell: the move the reference's traceback
-// takes from that cell, 0 = undecided), which turn the traceback of wide bands into table lookups
-// (traceback_codes_staged). A code is written only where the forward pass saw exactly the operands the traceback's
-// get_score() would see: not in chunks outside some predecessor's band, not in the band's first cell (its horizontal
-// operand is the carry-in), not where only predecessor slot 3 or later attains the maximum.
+// The pass also writes the move bytes of poa_traceback_moves.h (one byte per cell: the move the reference's traceback
+// takes from that cell -- rows up << 1 | columns left -- 0 = undecided), which turn the traceback of wide bands into a
+// walk over a sheared LDS tile with run skipping. A move is written only where the forward pass saw exactly the operands
+// the traceback's get_score() would see: not in chunks outside some predecessor's band, not in the band's first cell
+// (its horizontal operand is the carry-in), not where the predecessor that attains the maximum is more than 63 rows up.
 //
 // All waves of the block call generic_forward_skew with the same arguments (wave 0 hands them over through MwArgs in
 // LDS). Wave 0 alone runs every other phase.
@@ -1545,6 +1545,7 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                     return ring_lds + (uint32_t)o + (uint32_t)(kRelShift + e) * esz;
                 };
                 const int32_t d0 = (int32_t)((m0 >> 16) & 0xff), e0 = (int32_t)((m1 >> 8) & 0xff) << 2;
+                const int32_t d1 = (int32_t)(m0 >> 24), d2 = (int32_t)(m1 & 0xff); // rows up to predecessors 1 and 2
                 const int32_t tg4 = tg * (int32_t)esz;
                 // predecessor k: cells of columns c .. c+4 sit at ring element (c - pbs) + kRelShift of its row; a read outside
                 // the LDS allocation (chunks that lie outside that row's band) returns zero and is masked below
@@ -1557,7 +1558,7 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                 bool vb = true, vc = true;
                 if constexpr (NP > 1)
                 {
-                    const int32_t d1 = (int32_t)(m0 >> 24), e1 = (int32_t)((m1 >> 16) & 0xff) << 2;
+                    const int32_t e1 = (int32_t)((m1 >> 16) & 0xff) << 2;
                     const uint32_t a1 = pred_base(d1, e1) + (uint32_t)tg4;
                     Sb = lds_ld_at<ScoreT>(a1);
                     qb = lds_ld_qv<ScoreT>(a1 + esz);
@@ -1565,7 +1566,7 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                 }
                 if constexpr (NP > 2)
                 {
-                    const int32_t d2 = (int32_t)(m1 & 0xff), e2 = (int32_t)(m1 >> 24) << 2;
+                    const int32_t e2 = (int32_t)(m1 >> 24) << 2;
                     const uint32_t a2 = pred_base(d2, e2) + (uint32_t)tg4;
                     Sc = lds_ld_at<ScoreT>(a2);
                     qc = lds_ld_qv<ScoreT>(a2 + esz);
@@ -1588,7 +1589,9 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                 V[0] = (int32_t)qa.x + gap_score; V[1] = (int32_t)qa.y + gap_score; V[2] = (int32_t)qa.z + gap_score; V[3] = (int32_t)qa.w + gap_score;
 #pragma unroll
                 for (int k = 0; k < 4; k++) s[k] = va ? (int32_t)(ScoreT)max(D[k], V[k]) : min_score;
-                uint32_t kD[4] = {0, 0, 0, 0}, kV[4] = {0, 0, 0, 0};
+                // the move a cell's maximum stands for (poa_traceback_moves.h): rows up << 1 | columns left
+                const uint32_t mvV0 = (uint32_t)d0 << 1, mvD0 = mvV0 | 1u;
+                uint32_t kD[4] = {mvD0, mvD0, mvD0, mvD0}, kV[4] = {mvV0, mvV0, mvV0, mvV0};
                 bool undecided = !va;
                 if constexpr (NP > 1)
                 {
@@ -1596,12 +1599,13 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                     Db[0] = Sb + cp0; Db[1] = (int32_t)qb.x + cp1; Db[2] = (int32_t)qb.y + cp2; Db[3] = (int32_t)qb.z + cp3;
                     Vb[0] = (int32_t)qb.x + gap_score; Vb[1] = (int32_t)qb.y + gap_score; Vb[2] = (int32_t)qb.z + gap_score; Vb[3] = (int32_t)qb.w + gap_score;
                     undecided = undecided || !vb;
+                    const uint32_t mvV1 = (uint32_t)d1 << 1, mvD1 = mvV1 | 1u;
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                     {
                         s[k]  = max(s[k], vb ? (int32_t)(ScoreT)max(Db[k], Vb[k]) : min_score);
-                        kD[k] = Db[k] > D[k] ? 1u : 0u; D[k] = max(D[k], Db[k]);
-                        kV[k] = Vb[k] > V[k] ? 1u : 0u; V[k] = max(V[k], Vb[k]);
+                        kD[k] = Db[k] > D[k] ? mvD1 : kD[k]; D[k] = max(D[k], Db[k]);
+                        kV[k] = Vb[k] > V[k] ? mvV1 : kV[k]; V[k] = max(V[k], Vb[k]);
                     }
                 }
                 if constexpr (NP > 2)
@@ -1610,12 +1614,13 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                     Dc[0] = Sc + cp0; Dc[1] = (int32_t)qc.x + cp1; Dc[2] = (int32_t)qc.y + cp2; Dc[3] = (int32_t)qc.z + cp3;
                     Vc[0] = (int32_t)qc.x + gap_score; Vc[1] = (int32_t)qc.y + gap_score; Vc[2] = (int32_t)qc.z + gap_score; Vc[3] = (int32_t)qc.w + gap_score;
                     undecided = undecided || !vc;
+                    const uint32_t mvV2 = (uint32_t)d2 << 1, mvD2 = mvV2 | 1u;
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                     {
                         s[k]  = max(s[k], vc ? (int32_t)(ScoreT)max(Dc[k], Vc[k]) : min_score);
-                        kD[k] = Dc[k] > D[k] ? 2u : kD[k]; D[k] = max(D[k], Dc[k]);
-                        kV[k] = Vc[k] > V[k] ? 2u : kV[k]; V[k] = max(V[k], Vc[k]);
+                        kD[k] = Dc[k] > D[k] ? mvD2 : kD[k]; D[k] = max(D[k], Dc[k]);
+                        kV[k] = Vc[k] > V[k] ? mvV2 : kV[k]; V[k] = max(V[k], Vc[k]);
                     }
                 }
                 // prefix maximum in u space (u = v - (c + k) * gap: an offset common to the whole row, so a carry is converted
@@ -1673,12 +1678,12 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                 const int32_t excl = max(wave_shr1(incl, INT32_MIN), carry_u);
                 const int32_t Hk[4] = {(int32_t)(ScoreT)(max(m0_, excl) + cg0), (int32_t)(ScoreT)(max(m1_, excl) + cg1),
                                        (int32_t)(ScoreT)(max(m2_, excl) + cg2), (int32_t)(ScoreT)(max(m3_, excl) + cg3)};
-                // move codes: diagonal through the first slot attaining H, else vertical, else horizontal
+                // move bytes: diagonal through the first slot attaining H, else vertical, else horizontal (0 rows up, 1 left)
                 uint32_t code4 = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                 {
-                    const uint32_t ck = Hk[k] == D[k] ? (uint32_t)kCodeDiag + kD[k] : (Hk[k] == V[k] ? (uint32_t)kCodeVert + kV[k] : (uint32_t)kCodeHoriz);
+                    const uint32_t ck = Hk[k] == D[k] ? kD[k] : (Hk[k] == V[k] ? kV[k] : 1u);
                     code4 |= ck << (8 * k);
                 }
                 if constexpr (FIRST) code4 = tg == 0 ? (code4 & 0xffffff00u) : code4; // the band's first cell
@@ -1776,22 +1781,24 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                     D0 = D1 = D2 = D3 = V0 = V1 = V2 = V3 = t0 = t1 = t2 = t3 = min_score;
                     undecided = true;
                 }
+                const int32_t up = r - prow <= MtGeometry<true>::kMaxUp ? r - prow : 0; // rows up, 0 = too far for a move byte
                 if (p == 0)
                 {
                     s0 = t0; s1 = t1; s2 = t2; s3 = t3;
                     bD0 = D0; bD1 = D1; bD2 = D2; bD3 = D3; bV0 = V0; bV1 = V1; bV2 = V2; bV3 = V3;
+                    kD0 = kD1 = kD2 = kD3 = kV0 = kV1 = kV2 = kV3 = up;
                 }
                 else
                 {
                     s0 = max(s0, t0); s1 = max(s1, t1); s2 = max(s2, t2); s3 = max(s3, t3);
-                    if (D0 > bD0) { bD0 = D0; kD0 = p; }
-                    if (D1 > bD1) { bD1 = D1; kD1 = p; }
-                    if (D2 > bD2) { bD2 = D2; kD2 = p; }
-                    if (D3 > bD3) { bD3 = D3; kD3 = p; }
-                    if (V0 > bV0) { bV0 = V0; kV0 = p; }
-                    if (V1 > bV1) { bV1 = V1; kV1 = p; }
-                    if (V2 > bV2) { bV2 = V2; kV2 = p; }
-                    if (V3 > bV3) { bV3 = V3; kV3 = p; }
+                    if (D0 > bD0) { bD0 = D0; kD0 = up; }
+                    if (D1 > bD1) { bD1 = D1; kD1 = up; }
+                    if (D2 > bD2) { bD2 = D2; kD2 = up; }
+                    if (D3 > bD3) { bD3 = D3; kD3 = up; }
+                    if (V0 > bV0) { bV0 = V0; kV0 = up; }
+                    if (V1 > bV1) { bV1 = V1; kV1 = up; }
+                    if (V2 > bV2) { bV2 = V2; kV2 = up; }
+                    if (V3 > bV3) { bV3 = V3; kV3 = up; }
                 }
             }
             int32_t fe = 0;
@@ -1824,9 +1831,9 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
             __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
             finish_row(s0, s1, s2, s3, fe);
             auto code_of = [&](int32_t H, int32_t bD, int32_t kD, int32_t bV, int32_t kV) -> uint32_t {
-                const uint32_t cd = kD < 3 ? (uint32_t)(kCodeDiag + kD) : 0u;
-                const uint32_t cv = kV < 3 ? (uint32_t)(kCodeVert + kV) : 0u;
-                return H == bD ? cd : (H == bV ? cv : (uint32_t)kCodeHoriz);
+                const uint32_t cd = kD != 0 ? ((uint32_t)kD << 1) | 1u : 0u; // (kD, kV: rows up to the slot that attains the maximum)
+                const uint32_t cv = kV != 0 ? (uint32_t)kV << 1 : 0u;
+                return H == bD ? cd : (H == bV ? cv : 1u);
             };
             code4 = code_of(H0, bD0, kD0, bV0, kV0) | (code_of(H1, bD1, kD1, bV1, kV1) << 8) |
                     (code_of(H2, bD2, kD2, bV2, kV2) << 16) | (code_of(H3, bD3, kD3, bV3, kV3) << 24);
@@ -1858,226 +1865,6 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
     if (gave_up && lane == 0) shared->fail = 1;
     block_barrier(); // the score and code matrices are complete in HBM (wave 0's traceback reads them)
     if (sksel && prof_out && lane == 0) *prof_out += shared->prof;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Traceback by table lookup for graphs whose row table lives in HBM (long reads), on the trace codes the pipelined
-// forward pass (generic_forward_skew) left in HBM. Same decision sequence as traceback_banded (cudapoa_nw_banded.cuh:
-// 428-549): a code names the move the reference's search order (diagonal through predecessor 0..n-1, vertical through
-// predecessor 0..n-1, horizontal; first equality wins) takes from that cell. The walk is wave-uniform; all lanes stage
-// 64 rows x 64 columns of codes around the path together with the row-table records of those rows (one HBM round
-// trip), so a step is two LDS reads. Undecided cells (code 0: band edges, predecessor slots beyond 2) and row 0 are
-// stepped by recomputation from the HBM score matrix, exactly as traceback_banded does. The walk's output is staged in
-// LDS and flushed 64 steps at a time; graph positions are translated to node ids by all lanes after the walk.
-// LDS (the forward pass's ring, dead by now): codes[64][64] | rows[64] | stage[64].
-// ------------------------------------------------------------------------------------------------
-template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE>
-__device__ __forceinline__ int32_t traceback_codes_staged(const BandedCtx<ScoreT>& b, const GraphView<IdT>& g, const RowT* rowinfo,
-                                                          int32_t graph_count, const uint8_t* read, int32_t read_length,
-                                                          int32_t start_i, int32_t* alignment_graph, int32_t* alignment_read,
-                                                          int32_t gap_score, int32_t mismatch_score, int32_t match_score,
-                                                          int32_t rerun, uint8_t* lds, const uint8_t* codes, int32_t dbg = 0,
-                                                          uint64_t* prof_acc = nullptr)
-{
-    constexpr int kRows = 64, kCols = 64, kReanchor = 60, kLead = 40, kStage = 64;
-    // LDS: codes[64][64] | per tile row: predecessor rows of slots 0..2 and the band start (4 x 64 words) | stage[64]
-    typedef __attribute__((address_space(3))) uint8_t LByte;
-    typedef __attribute__((address_space(3))) int32_t LWord;
-    LByte* ctile  = (LByte*)lds;
-    LWord* rowmeta = (LWord*)(lds + kRows * kCols); // [k * 64 + t]: k = 0..2 predecessor row of slot k, k = 3 band start
-    const uint32_t stage_lds = lds_addr(lds + kRows * kCols + 4 * kRows * 4);
-    __attribute__((address_space(3))) const unsigned long long* stage = (__attribute__((address_space(3))) const unsigned long long*)(lds + kRows * kCols + 4 * kRows * 4);
-    const int lane      = threadIdx.x & (kWave - 1);
-    const int32_t bound = read_length + graph_count + 2;
-    int32_t aligned_nodes = 0;
-    int32_t i = start_i, j = read_length, prev_i = 0, prev_j = 0;
-    int32_t ctop = -(1 << 20), ccol = 0;
-
-    auto lo_of = [&](int32_t col, int32_t t) -> int32_t { return ((col - kLead - t) & ~3) + 1; };
-    struct __attribute__((packed, aligned(4))) CodeSeg { uint32_t d[4]; };
-    // 4 lanes per tile row (16 bytes each), 16 rows per pass; bytes that are not cells of the band become code 0
-    auto load_codes = [&](int32_t top, int32_t col) {
-        wave_sync();
-        ctop = top;
-        ccol = col;
-        const int seg = lane & 3;
-        CodeSeg v[4];
-        int32_t e0s[4];
-#pragma unroll
-        for (int pass = 0; pass < 4; pass++)
-        {
-            const int32_t t    = pass * 16 + (lane >> 2);
-            const int32_t rowc = max(top - t, 1);
-            const int32_t bs   = band_start_for_row(rowc, b.gradient, b.band_width, b.band_shift, b.max_column);
-            const int32_t e0   = lo_of(col, t) - bs + kRelShift; // byte index in the code row, multiple of 4
-            e0s[pass]          = e0;
-            const int32_t ec   = min(max(e0 + seg * 16, 0), b.stride - 16); // keep the load inside the row
-            v[pass] = *reinterpret_cast<const CodeSeg*>(codes + (int64_t)rowc * b.stride + ec);
-        }
-        {
-            const int32_t rrow = max(top - lane, 1);
-            const RowT ri      = rowinfo[rrow];
-            const bool none    = ri.cnt() == 0 || top - lane < 1;
-            rowmeta[0 * kRows + lane] = none ? 0 : ri.pred(0);
-            rowmeta[1 * kRows + lane] = ri.pred(1);
-            rowmeta[2 * kRows + lane] = ri.pred(2);
-            rowmeta[3 * kRows + lane] = band_start_for_row(rrow, b.gradient, b.band_width, b.band_shift, b.max_column);
-        }
-#pragma unroll
-        for (int pass = 0; pass < 4; pass++)
-        {
-            const int32_t t   = pass * 16 + (lane >> 2);
-            const int32_t row = top - t;
-            const int32_t e0  = e0s[pass];
-            const int32_t ec  = min(max(e0 + seg * 16, 0), b.stride - 16);
-            const int32_t klo = row >= 1 ? (1 + kRelShift) - e0 : 1; // window bytes that are cells of the band
-            const int32_t khi = row >= 1 ? (b.band_width + kRelShift) - e0 : 0;
-#pragma unroll
-            for (int d = 0; d < 4; d++)
-            {
-                const int32_t k0 = seg * 16 + d * 4;
-                const int32_t lo = min(max(klo - k0, 0), 4), hi = min(max(khi - k0 + 1, 0), 4);
-                const uint32_t mhi = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
-                const uint32_t mlo = lo >= 4 ? 0xffffffffu : ((1u << (8 * lo)) - 1u);
-                // a clamped load (window reaching past the row's storage) holds other bytes: those are outside the band too
-                v[pass].d[d] = (ec == e0 + seg * 16 && hi > lo) ? (v[pass].d[d] & mhi & ~mlo) : 0u;
-            }
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            u32x4 w = {v[pass].d[0], v[pass].d[1], v[pass].d[2], v[pass].d[3]};
-            *(__attribute__((address_space(3))) u32x4*)(ctile + t * kCols + seg * 16) = w;
-        }
-        wave_sync();
-    };
-    // stage[k] = the cell step k left; the reference's entry for a step follows from two consecutive cells
-    auto flush_stage = [&](int32_t first, int32_t count) {
-        if (lane < count)
-        {
-            const uint64_t cur = stage[lane];
-            const uint64_t nxt = lane + 1 < count ? (uint64_t)stage[lane + 1] : ((uint64_t)(uint32_t)i | ((uint64_t)(uint32_t)j << 32));
-            const int32_t ci = (int32_t)(uint32_t)cur, cj = (int32_t)(cur >> 32);
-            const int32_t ni = (int32_t)(uint32_t)nxt, nj = (int32_t)(nxt >> 32);
-            alignment_graph[first + lane] = ci == ni ? -1 : ci - 1; // sorted position; node ids are filled in below
-            alignment_read[first + lane]  = cj == nj ? -1 : cj - 1;
-        }
-    };
-    auto stage_cell = [&](int32_t slot, int32_t ci, int32_t cj) { // lane-0 LDS store without a branch
-        const uint64_t v  = (uint64_t)(uint32_t)ci | ((uint64_t)(uint32_t)cj << 32);
-        const uint32_t ad = stage_lds + 8u * (uint32_t)slot;
-        asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(ad), "v"(v) : "memory");
-    };
-    const bool shift_check = ADAPTIVE && rerun == 0 && b.band_width < kMaxAdaptiveBand;
-    const int32_t threshold = max(1, b.max_column / 1024);
-
-    // profiling (GWHIP_DEBUG bits 22-24): 6 steps, 2 cycles in tile loads, 3 tile loads x 1000, 4 cycles in recomputed
-    // steps, 5 recomputed steps x 1000
-    const int32_t psel = prof_acc ? (dbg >> 22) & 7 : 0;
-    uint64_t pacc      = 0;
-    bool rerun_break = false;
-    while (!(i == 0 && j == 0) && aligned_nodes < bound) // every step appends one entry: the reference's loop counter
-    {
-        uint32_t code = 0;
-        int32_t pr0 = 0, pr1 = 0, pr2 = 0, bs_i = 0;
-        if (i > 0)
-        {
-            const int32_t t   = ctop - i;
-            const int32_t off = j - lo_of(ccol, t);
-            if (((uint32_t)t >= (uint32_t)kReanchor) | ((uint32_t)(off - 2) >= (uint32_t)(kCols - 2)))
-            {
-                const uint64_t t_l = psel == 2 ? clock64() : 0;
-                load_codes(i, j);
-                if (psel == 2) pacc += clock64() - t_l;
-                if (psel == 3) pacc += 1000;
-                continue;
-            }
-            // one LDS round trip: the cell's code, the row's predecessor rows and its band start
-            const uint32_t cv = ctile[t * kCols + off];
-            const int32_t a0 = rowmeta[t], a1 = rowmeta[kRows + t], a2 = rowmeta[2 * kRows + t], a3 = rowmeta[3 * kRows + t];
-            code = (uint32_t)wave_first((int32_t)cv);
-            pr0 = wave_first(a0); pr1 = wave_first(a1); pr2 = wave_first(a2); bs_i = wave_first(a3);
-        }
-        if (shift_check && i != 0 && j != 0 && j > threshold && j < b.max_column - threshold)
-        {
-            if (j <= bs_i + threshold) { aligned_nodes = kShiftLeft; rerun_break = true; }
-            else if (j >= (bs_i + b.band_width - threshold)) { aligned_nodes = kShiftRight; rerun_break = true; }
-        }
-        if (rerun_break) break;
-        if (code != 0)
-        {
-            const int32_t k  = code >= (uint32_t)kCodeVert ? (int32_t)code - kCodeVert : (int32_t)code - kCodeDiag;
-            const int32_t pr = k == 0 ? pr0 : (k == 1 ? pr1 : pr2);
-            prev_i = code == (uint32_t)kCodeHoriz ? i : pr;
-            prev_j = code >= (uint32_t)kCodeVert ? j : j - 1;
-        }
-        else
-        {
-            // one step of traceback_banded, from the HBM matrix and the HBM row table
-            const uint64_t t_rc = psel == 4 ? clock64() : 0;
-            if (psel == 5) pacc += 1000;
-            const int32_t scores_ij = wave_first(get_score(b, i, j));
-            bool pred_found         = false;
-            RowT ri{};
-            int32_t pred_count = 0, node_id = 0;
-            if (i != 0)
-            {
-                ri         = uniform_row(rowinfo[i]);
-                pred_count = ri.cnt();
-            }
-            auto pred_row = [&](int32_t p) -> int32_t {
-                if (pred_count == 0) return 0;
-                if (p < 3) return ri.pred(p);
-                return wave_first((int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + p]] + 1);
-            };
-            if (i != 0 && pred_count > 3) node_id = wave_first((int32_t)g.sorted_poa[i - 1]);
-            const int32_t np = max(pred_count, 1);
-            if (i != 0 && j != 0)
-            {
-                const int32_t match_cost = ((uint32_t)ri.base() == (uint32_t)wave_first((int32_t)read[j - 1]) ? match_score : mismatch_score);
-                for (int32_t p = 0; p < np && !pred_found; p++)
-                {
-                    const int32_t pi = pred_row(p);
-                    if (scores_ij == wave_first(get_score(b, pi, j - 1)) + match_cost) { prev_i = pi; prev_j = j - 1; pred_found = true; }
-                }
-            }
-            if (!pred_found && i != 0)
-                for (int32_t p = 0; p < np && !pred_found; p++)
-                {
-                    const int32_t pi = pred_row(p);
-                    if (scores_ij == wave_first(get_score(b, pi, j)) + gap_score) { prev_i = pi; prev_j = j; pred_found = true; }
-                }
-            if (!pred_found && scores_ij == wave_first(get_score(b, i, j - 1)) + gap_score) { prev_i = i; prev_j = j - 1; pred_found = true; }
-            if (psel == 4) pacc += clock64() - t_rc;
-        }
-        stage_cell(aligned_nodes & (kStage - 1), i, j);
-        aligned_nodes++;
-        i = prev_i;
-        j = prev_j;
-        if ((aligned_nodes & (kStage - 1)) == 0)
-        {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the staged cells (this wave's own LDS stores)
-            flush_stage(aligned_nodes - kStage, kStage);
-        }
-    }
-    if (psel == 6) pacc += (uint64_t)max(aligned_nodes, 0);
-    if (psel && lane == 0) *prof_acc += pacc;
-    if (rerun_break) return aligned_nodes;
-    wave_sync();
-    if (aligned_nodes > 0 && (aligned_nodes & (kStage - 1)) != 0)
-        flush_stage(aligned_nodes & ~(kStage - 1), aligned_nodes & (kStage - 1));
-    if (aligned_nodes >= bound) aligned_nodes = kNwLoopFailed;
-    wave_sync();
-    for (int32_t k0 = lane; k0 < aligned_nodes; k0 += 4 * kWave) // positions -> node ids, four load chains per lane
-    {
-        int32_t pos[4], node[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) pos[u] = (k0 + u * kWave < aligned_nodes) ? alignment_graph[k0 + u * kWave] : -1;
-#pragma unroll
-        for (int u = 0; u < 4; u++) node[u] = (int32_t)g.sorted_poa[max(pos[u], 0)];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (pos[u] >= 0) alignment_graph[k0 + u * kWave] = node[u];
-    }
-    wave_sync();
-    return aligned_nodes;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2521,7 +2308,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     {
         if (moves_valid)
         {
-            aligned_nodes = traceback_moves<IdT, ADAPTIVE>(b, g, rowinfo, graph_count, lds_read, read_length, wave_first(best_i),
+            aligned_nodes = traceback_moves<int16_t, IdT, RowInfo<true>, ADAPTIVE>(b, g, rowinfo, graph_count, lds_read, read_length, wave_first(best_i),
                                                            alignment_graph, alignment_read, gap_score, mismatch_score, match_score,
                                                            rerun, reinterpret_cast<uint8_t*>(ring_base), codes);
             tb_done = true;
@@ -2542,14 +2329,12 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     const bool staged_fits   = (int32_t)(64 * 64 * sizeof(ScoreT) + 64 * 4 + 64 * sizeof(RowT) + 256 + 64 * 8) <= ring_bytes;
     if constexpr (kStagedOk)
     {
-        if (codes_valid && codes != nullptr && staged_fits && b.stride >= 80 && !(dbg & 64))
+        if (codes_valid && codes != nullptr && ring_bytes >= kMtBytesWide && b.stride >= 80 && !(dbg & 64))
         {
-            // wide bands, graphs beyond the LDS tables: the pipelined forward pass left trace codes
-            aligned_nodes = traceback_codes_staged<ScoreT, IdT, RowT, ADAPTIVE>(b, g, rowinfo, graph_count, read, read_length,
-                                                                               wave_first(best_i), alignment_graph, alignment_read,
-                                                                               gap_score, mismatch_score, match_score, rerun,
-                                                                               reinterpret_cast<uint8_t*>(ring_base), codes, dbg,
-                                                                               pc.acc ? &pc.acc[kPhOther] : nullptr);
+            // wide bands, graphs beyond the LDS tables: the pipelined forward pass left move bytes
+            aligned_nodes = traceback_moves<ScoreT, IdT, RowT, ADAPTIVE>(b, g, rowinfo, graph_count, read, read_length, wave_first(best_i),
+                                                                         alignment_graph, alignment_read, gap_score, mismatch_score,
+                                                                         match_score, rerun, reinterpret_cast<uint8_t*>(ring_base), codes);
             tb_done = true;
         }
     }

@@ -80,19 +80,6 @@ __device__ __forceinline__ bool xpred_hit(uint64_t e, int32_t row, int32_t cnt)
 }
 __device__ __forceinline__ int32_t xpred_row(uint64_t e, int32_t k) { return (int32_t)((e >> (20 + 12 * (k - 3))) & 0xfffu); } // k = 3..5
 
-// ------------------------------------------------------------------------------------------------
-// Trace codes. Besides the score row, classes 0, 1 and 2 store one byte per cell that names the move the reference's
-// traceback (cudapoa_nw_banded.cuh:428-549: diagonal through predecessor 0..n-1, then vertical through
-// predecessor 0..n-1, then horizontal, first equality wins) takes from that cell:
-//   0 undecided here -> the traceback recomputes the step from the score matrix
-//   1 horizontal     2 + k diagonal through predecessor slot k     5 + k vertical through predecessor slot k
-// A code is only written where the forward pass saw exactly the operands the traceback's get_score() would see:
-// the first cell of the band (its horizontal operand is the carry-in, not a stored cell), chunks that lie outside
-// some predecessor's band, cells whose maximum is only attained by predecessor slot 3 or later (a code names slots
-// 0..2) and all class 3 rows stay 0. Equality of H with a candidate is tested on the stored 16-bit values, which is
-// the comparison the traceback makes.
-// ------------------------------------------------------------------------------------------------
-constexpr int kCodeHoriz = 1, kCodeDiag = 2, kCodeVert = 5;
 
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
 {

@@ -22,13 +22,27 @@
 //     one is in place and waits in registers.
 // In the adaptive band mode the cells inside the band-edge margins of cudapoa_nw_banded.cuh:442-465 are committed
 // to the tile as 0, so the shift-left / shift-right tests run in the slow path only.
+//
+// Two geometries. Row table in LDS (RowInfo<true>: the 256 / 128-column int16 pass): a predecessor is at most 7 rows up, so
+// 8 pad bytes per tile row and 8 zero rows catch every move that leaves the window. Row table in HBM (RowInfo<false>: long
+// reads, generic_forward_skew, 16- or 32-bit scores, bands up to 1 536 columns): moves go up to 63 rows up, so a tile row is
+// 64 columns + 72 zero bytes (136: still an even number of dwords that is not a multiple of 4, i.e. a two-way bank conflict
+// at worst for the 64 lanes of a run probe) above 64 zero rows; band starts come from the band formula instead of the table.
 #pragma once
 
 namespace gwhip
 {
 
-constexpr int kMtRows = 96, kMtZeroRows = 8, kMtCols = 64, kMtStride = 72, kMtFront = 8, kMtPasses = kMtRows / 16;
-constexpr int kMtBytes = kMtFront + (kMtRows + kMtZeroRows) * kMtStride;
+constexpr int kMtRows = 96, kMtCols = 64, kMtFront = 8, kMtPasses = kMtRows / 16;
+template <bool WIDE> struct MtGeometry
+{
+    static constexpr int kStride   = WIDE ? 136 : 72; // bytes between tile rows: 64 columns + zero bytes
+    static constexpr int kZeroRows = WIDE ? 64 : 8;   // zero rows below the tile
+    static constexpr int kMaxUp    = WIDE ? 63 : 7;   // rows a move may go up
+    static constexpr int kBytes    = kMtFront + (kMtRows + kZeroRows) * kStride;
+};
+constexpr int kMtBytes     = MtGeometry<false>::kBytes;
+constexpr int kMtBytesWide = MtGeometry<true>::kBytes;
 
 __device__ __forceinline__ uint32_t lds_load_u8(uint32_t addr)
 {
@@ -41,13 +55,15 @@ __device__ __forceinline__ void lds_store_zero_u64(uint32_t addr)
     *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(addr) = v;
 }
 
-template <typename IdT, bool ADAPTIVE>
-__device__ __forceinline__ int32_t traceback_moves(const BandedCtx<int16_t>& b, const GraphView<IdT>& g, const RowInfo<true>* rowinfo,
+template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE>
+__device__ __forceinline__ int32_t traceback_moves(const BandedCtx<ScoreT>& b, const GraphView<IdT>& g, const RowT* rowinfo,
                                                    int32_t graph_count, const uint8_t* read, int32_t read_length, int32_t start_i,
                                                    int32_t* alignment_graph, int32_t* alignment_read, int32_t gap_score,
                                                    int32_t mismatch_score, int32_t match_score, int32_t rerun, uint8_t* tile_region,
                                                    const uint8_t* moves)
 {
+    constexpr bool kWide    = !std::is_same<RowT, RowInfo<true>>::value;
+    constexpr int kMtStride = MtGeometry<kWide>::kStride, kMtZeroRows = MtGeometry<kWide>::kZeroRows;
     constexpr int kHalf = 31;
     const int lane      = threadIdx.x & (kWave - 1);
     const int32_t bound = read_length + graph_count + 2;
@@ -57,7 +73,8 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<int16_t>& b, 
 
     // zero bytes the loader never touches: the front pad, the 8 pad bytes of every row, the rows below the tile
     wave_sync();
-    for (int32_t t = lane; t < kMtRows; t += kWave) lds_store_zero_u64(T0 + (uint32_t)t * kMtStride + kMtCols);
+    for (int32_t q = lane; q < kMtRows * ((kMtStride - kMtCols) / 8); q += kWave)
+        lds_store_zero_u64(T0 + (uint32_t)(q / ((kMtStride - kMtCols) / 8)) * kMtStride + kMtCols + (uint32_t)(q % ((kMtStride - kMtCols) / 8)) * 8);
     for (int32_t q = lane; q < kMtZeroRows * kMtStride / 8; q += kWave) lds_store_zero_u64(T0 + kMtRows * kMtStride + (uint32_t)q * 8);
     if (lane == 0) lds_store_zero_u64(T0 - kMtFront);
 
@@ -76,13 +93,19 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<int16_t>& b, 
             hi_rel = b.band_width - threshold - 1;
         }
     }
+    auto band_start_of = [&](int32_t row) -> int32_t { // row >= 1
+        if constexpr (kWide)
+            return band_start_for_row(row, b.gradient, b.band_width, b.band_shift, b.max_column);
+        else
+            return rowinfo[row].bs();
+    };
     auto issue_tile = [&](int32_t top, int32_t L, Seg (&v)[kMtPasses]) {
 #pragma unroll
         for (int pass = 0; pass < kMtPasses; pass++)
         {
             const int32_t t    = pass * 16 + (lane >> 2);
             const int32_t rowc = max(top - t, 1);
-            const int32_t e0   = (L - t) + 16 * seg - rowinfo[rowc].bs() + kRelShift;
+            const int32_t e0   = (L - t) + 16 * seg - band_start_of(rowc) + kRelShift;
             const uint32_t* p  = reinterpret_cast<const uint32_t*>(moves + (int64_t)rowc * b.stride + (e0 & ~3));
 #pragma unroll
             for (int k = 0; k < 5; k++) v[pass].d[k] = p[k];
@@ -97,7 +120,7 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<int16_t>& b, 
         {
             const int32_t t   = pass * 16 + (lane >> 2);
             const int32_t row = top - t;
-            const int32_t bsr = rowinfo[max(row, 1)].bs();
+            const int32_t bsr = band_start_of(max(row, 1));
             const int32_t e0  = (L - t) + 16 * seg - bsr + kRelShift;
             uint32_t w[4];
 #pragma unroll
@@ -208,11 +231,25 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<int16_t>& b, 
             if ((i == 0 && j == 0) || n >= bound) continue; // the outer condition ends the walk
         }
         // ---------------- one step by recomputation (exact restatement of :428-549), one candidate per lane ----------------
-        const uint64_t riw = i != 0 ? wave_first64(rowinfo[i].w) : 0;
-        const uint32_t ri_lo = (uint32_t)riw;
-        const uint32_t rch   = j > 0 ? (uint32_t)wave_first((int32_t)read[j - 1]) : 0u;
-        const int32_t pred_count = (int32_t)((ri_lo >> 8) & 0x3f);
-        const int32_t np         = max(pred_count, 1);
+        // the row's record, wave-uniform: base, predecessor count, the rows of predecessor slots 0..2
+        uint64_t riw = 0;
+        int32_t pred_count = 0, pr0 = 0, pr1 = 0, pr2 = 0;
+        uint32_t row_base = 0;
+        if constexpr (!kWide)
+        {
+            riw        = i != 0 ? wave_first64(rowinfo[i].w) : 0;
+            row_base   = (uint32_t)riw & 0xffu;
+            pred_count = (int32_t)(((uint32_t)riw >> 8) & 0x3f);
+        }
+        else if (i != 0)
+        {
+            const RowT ri = uniform_row(rowinfo[i]);
+            row_base      = (uint32_t)ri.base();
+            pred_count    = ri.cnt();
+            pr0 = ri.pred(0); pr1 = ri.pred(1); pr2 = ri.pred(2);
+        }
+        const uint32_t rch = j > 0 ? (uint32_t)wave_first((int32_t)read[j - 1]) : 0u;
+        const int32_t np   = max(pred_count, 1);
         if (ADAPTIVE)
         {
             if (i != 0 && j != 0 && rerun == 0 && b.band_width < kMaxAdaptiveBand)
@@ -226,7 +263,7 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<int16_t>& b, 
                 }
             }
         }
-        const int32_t match_cost = ((ri_lo & 0xff) == rch ? match_score : mismatch_score);
+        const int32_t match_cost = (row_base == rch ? match_score : mismatch_score);
         // the reference keeps the previous step's target when no candidate matches: that is the current cell (or (0, 0)
         // on the first step)
         int32_t next_i = n > 0 ? i : 0, next_j = n > 0 ? j : 0;
@@ -234,7 +271,11 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<int16_t>& b, 
         if (np <= kHalf)
         {
             const bool en = (is_diag & (i != 0) & (j != 0) & (p < np)) | (is_vert & (i != 0) & (p < np)) | is_horiz;
-            int32_t crow  = pred_count != 0 ? (int32_t)((riw >> psh) & 0xfff) : 0;
+            int32_t crow;
+            if constexpr (!kWide)
+                crow = pred_count != 0 ? (int32_t)((riw >> psh) & 0xfff) : 0;
+            else
+                crow = pred_count != 0 ? (p == 0 ? pr0 : (p == 1 ? pr1 : pr2)) : 0;
             crow          = (is_horiz | is_self) ? i : crow;
             if (pred_count > 3) // predecessor slots beyond the three packed ones live in the HBM edge list
             {
@@ -262,10 +303,15 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<int16_t>& b, 
         {
             scores_ij             = wave_first(get_score(b, i, j));
             const int32_t node_id = g.sorted_poa[i - 1];
-            RowInfo<true> ri;
-            ri.w = riw;
             auto pred_row = [&](int32_t q) -> int32_t {
-                if (q < 3) return ri.pred(q);
+                if constexpr (!kWide)
+                {
+                    RowInfo<true> ri;
+                    ri.w = riw;
+                    if (q < 3) return ri.pred(q);
+                }
+                else if (q < 3)
+                    return q == 0 ? pr0 : (q == 1 ? pr1 : pr2);
                 return wave_first((int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + q]] + 1);
             };
             bool f = false;
