@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
                 block_barrier();
                 const MwArgs<ScoreT> A = *mw_args;
                 if (A.op != 1) return;
-                generic_forward_skew<ScoreT, IdT, RowT>(A, g, rowinfo, ring, mw_shared, wave, lane);
+                generic_forward_skew<ScoreT, IdT, RowT, DBG>(A, g, rowinfo, ring, mw_shared, wave, lane);
             }
         }
     }

@@ -1269,7 +1269,7 @@ __device__ __forceinline__ int32_t lds_poll(const int32_t* p)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <typename ScoreT, typename IdT, typename RowT>
+template <typename ScoreT, typename IdT, typename RowT, bool PROF = true>
 __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, const GraphView<IdT>& g, const RowT* rowinfo, ScoreT* ring,
                                                      MwShared* shared, int wave, int lane, uint64_t* prof_out = nullptr)
 {
@@ -1278,7 +1278,9 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
     // for ring space, 7 rows on the general path, 8 cycles in the row bodies (waits included), 9 polls, 10 cycles waiting
     // for the left neighbour at the start of a row, 11 cycles in the bodies of first-block rows, 12 their number, 13 cycles
     // in the row-table batches
-    const int32_t sksel = (A.dbg >> 12) & 15;
+    // (PROF = false: the helper wavefronts of a production kernel, whose copy of the arguments comes out of LDS and could
+    // not be folded: no counter code in their row loop. Wave 0 passes a compile-time 0 in production kernels.)
+    const int32_t sksel = PROF ? (A.dbg >> 12) & 15 : 0;
     uint64_t skacc      = 0;
     const uint64_t t_pass = sksel == 4 ? clock64() : 0;
     static_assert(sizeof(RowT) == 24, "the register copy of the row table holds six dwords per row");
