@@ -1375,6 +1375,7 @@ struct HirschbergArgs
     const int64_t* wave_offsets; // [n_waves + 1] words
     int64_t ws_capacity_words;
     int32_t lds_state_words;     // LDS_STATE kernels: words per lane of one column-state array
+    int32_t levels_first;        // hirschberg_levels_kernel has run: the depth-first wave kernel only takes what it left
 };
 
 __host__ __device__ inline int64_t hb_leaf_words(int32_t t, int64_t max_elems)
@@ -1674,6 +1675,44 @@ struct PlainWords
     __device__ __forceinline__ uint32_t operator[](int32_t e) const { return p[e]; }
 };
 
+// limits, LDS layout and eligibility test of hirschberg_levels_kernel (below, after the depth-first wave kernel)
+constexpr int32_t kLvMaxQuery = 2048;
+constexpr int32_t kLvMaxParts = 64;
+constexpr int32_t kLvMaxTerm  = 256;
+constexpr int32_t kLvFlagRedo = -2;
+struct LvPart { int32_t qb, qe, tb, te; };
+struct LvLayout
+{
+    int32_t pat_f, pat_r, tgt, rows_f, rows_r, parts, term, keys, order, segtab, total; // byte offsets
+    int32_t row_entries, leaf_elems;
+};
+__host__ __device__ inline int32_t lv_target_cap(int32_t max_query) { return (max_query + max_query / 8 + 64 + 3) & ~3; }
+__host__ __device__ inline LvLayout lv_layout(int32_t max_query)
+{
+    LvLayout L{};
+    const int32_t qw = (max_query + kWord - 1) / kWord, tcap = lv_target_cap(max_query);
+    int32_t off = 0;
+    auto take   = [&](int32_t bytes) { const int32_t o = off; off = (off + bytes + 15) & ~15; return o; };
+    L.pat_f       = take(qw * 16);
+    L.pat_r       = take(qw * 16);
+    L.tgt         = take(tcap + 4);
+    L.row_entries = tcap + kLvMaxParts + 8;
+    L.rows_f      = take(L.row_entries * 2);
+    L.rows_r      = take(L.row_entries * 2);
+    L.parts       = take(2 * kLvMaxParts * 16);
+    L.leaf_elems  = (off - L.rows_f) / 12; // the leaves' matrices reuse the rows and the part lists (dead by then)
+    L.term        = take(kLvMaxTerm * 16);
+    L.keys        = take(kLvMaxTerm * 4);
+    L.order       = take(kLvMaxTerm * 2);
+    L.segtab      = take(64 * 4);
+    L.total       = off;
+    return L;
+}
+__host__ __device__ inline bool lv_eligible(int32_t query_size, int32_t target_size, int32_t max_query)
+{
+    return max_query <= kLvMaxQuery && query_size <= max_query && target_size <= lv_target_cap(max_query) - 4;
+}
+
 constexpr int32_t kHwLeafElems = 320; // (word, column) elements of a leaf whose matrices stay in LDS (three arrays of that size)
 
 __global__ __launch_bounds__(64) void hirschberg_wave_kernel(HirschbergArgs a)
@@ -1704,6 +1743,8 @@ __global__ __launch_bounds__(64) void hirschberg_wave_kernel(HirschbergArgs a)
     const int32_t query_size  = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
     const int32_t target_size = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
     int8_t* path              = a.results + a.starts[2 * idx];
+    // pairs the level-by-level kernel has already aligned (it ran first on this stream) are not touched again
+    if (a.levels_first && lv_eligible(query_size, target_size, a.max_query_length) && a.result_lengths[idx] != kLvFlagRedo) return;
     const int64_t region      = a.wave_offsets[region_index];
     const int64_t per_pair    = hb_lane_words(qw_max, t_max, max_elems);
     if (region + 64 * per_pair > a.ws_capacity_words)
@@ -2015,6 +2056,397 @@ __global__ __launch_bounds__(64) void hirschberg_wave_kernel(HirschbergArgs a)
         }
     }
     if (lane == 0) a.result_lengths[idx] = ok ? len : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Default aligner, one wavefront per pair, LEVEL BY LEVEL (round 3). The depth-first kernel above spends a 1 kbp pair on
+// 4 levels x 2 x 1 000 dependent column steps with at most 16 of its 64 lanes at work (a part of 500 bases is 16 words),
+// because it handles one (part, direction) at a time. The split of a part depends on nothing but the part, so the tree can
+// just as well be grown a whole level at a time: here every lane owns one word of one SEGMENT -- the forward half or the
+// reversed second half of one part of the current level -- all segments of a level stand side by side in the wavefront
+// (about query words + parts lanes; greedy batches of parts when they exceed 64) and advance one target column per step.
+// The multi-word addition is the carry-lookahead of the other kernels with the chain cut at every segment's last lane
+// (generate and propagate cleared there); a segment's first lane takes the +1 of the implicit first row instead of its
+// neighbour's bit; each lane reads ITS segment's target character (forward or back to front) from an LDS copy of the
+// target; each segment's last lane tracks the score of its last row and writes it (uint16) to the part's row in LDS.
+// Level k then costs about T / 2^k column steps instead of T -- 2 T for the whole tree instead of 2 T per level.
+// What decides the output is unchanged: query midpoint len / 2, the target midpoint as the reference's 32 lanes pick it
+// among equal sums (hirschberg_myers_compute_target_mid_warp, :461-481), the terminal cases (empty side, single query
+// character, full Myers matrix + backtrace below 63 query characters when the matrix fits). The reference emits the path
+// back to front by popping the right child first; here the terminals of all levels are ordered by (query begin, target
+// begin) descending and appended in that order by the same three handlers as above.
+// Eligible pairs: query <= 2 048 (<= 64 words per level-0 segment pair), target <= the LDS row capacity chosen from
+// max_query_length; every other pair, and a pair whose lists overflow (flag -2 in result_lengths), is left to
+// hirschberg_wave_kernel, launched right behind on the same stream.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void hirschberg_levels_kernel(HirschbergArgs a)
+{
+    extern __shared__ uint32_t lv_lds[];
+    const int32_t lane = threadIdx.x & 63;
+    const int32_t idx  = blockIdx.x;
+    if (idx >= a.n) return;
+    const int32_t query_size  = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
+    const int32_t target_size = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
+    if (!lv_eligible(query_size, target_size, a.max_query_length)) return;
+    const int32_t region_index = idx >> 6, s = idx & 63;
+    const int64_t max_elems = (int64_t)ceil_div(max(a.max_query_length, 1), kWord) * (kHbSwitchToMyers + 1);
+    // the pair's HBM workspace (geometry of the depth-first kernel): only a leaf too large for LDS uses it
+    int32_t qw_max = 0, t_max = 0;
+    {
+        const int32_t sj = region_index * 64 + lane;
+        if (sj < a.n)
+        {
+            qw_max = ceil_div((int32_t)(a.starts[2 * sj + 1] - a.starts[2 * sj]), kWord);
+            t_max  = (int32_t)(a.starts[2 * sj + 2] - a.starts[2 * sj + 1]);
+        }
+        for (int off = 32; off > 0; off >>= 1)
+        {
+            qw_max = max(qw_max, __shfl_xor(qw_max, off));
+            t_max  = max(t_max, __shfl_xor(t_max, off));
+        }
+    }
+    const char* query  = a.sequences + a.starts[2 * idx];
+    const char* target = a.sequences + a.starts[2 * idx + 1];
+    int8_t* path       = a.results + a.starts[2 * idx];
+    const int64_t region   = a.wave_offsets[region_index];
+    const int64_t per_pair = hb_lane_words(qw_max, t_max, max_elems);
+    if (region + 64 * per_pair > a.ws_capacity_words)
+    {
+        if (lane == 0) a.result_lengths[idx] = 0;
+        return;
+    }
+    uint32_t* ws_base = a.ws + region + (size_t)s * (size_t)per_pair;
+    const int64_t leaf_words_hbm = hb_leaf_words(t_max, max_elems);
+    uint32_t* leaf_hbm = ws_base + 4 * kHbStackEntries + 2 * ((size_t)t_max + 1) + (size_t)10 * qw_max;
+
+    const LvLayout L = lv_layout(a.max_query_length);
+    uint8_t* lds8    = reinterpret_cast<uint8_t*>(lv_lds);
+    uint32_t* pat_f  = reinterpret_cast<uint32_t*>(lds8 + L.pat_f);
+    uint32_t* pat_r  = reinterpret_cast<uint32_t*>(lds8 + L.pat_r);
+    uint8_t* tgt     = lds8 + L.tgt;
+    uint16_t* rows_f = reinterpret_cast<uint16_t*>(lds8 + L.rows_f);
+    uint16_t* rows_r = reinterpret_cast<uint16_t*>(lds8 + L.rows_r);
+    LvPart* parts    = reinterpret_cast<LvPart*>(lds8 + L.parts);
+    LvPart* term     = reinterpret_cast<LvPart*>(lds8 + L.term);
+    uint32_t* keys   = reinterpret_cast<uint32_t*>(lds8 + L.keys);
+    uint16_t* order  = reinterpret_cast<uint16_t*>(lds8 + L.order);
+    uint32_t* segtab = reinterpret_cast<uint32_t*>(lds8 + L.segtab);
+    uint32_t* leaf_lds = reinterpret_cast<uint32_t*>(lds8 + L.rows_f);
+
+    // pattern tables of the whole query (forward and back to front) and the target, into LDS
+    const int32_t n_words_query = ceil_div(query_size, kWord);
+    for (int32_t w = lane; w < n_words_query; w += 64)
+    {
+        uint32_t f[4], r[4];
+        pattern_words(query, query_size, w, f, r);
+#pragma unroll
+        for (int ci = 0; ci < 4; ci++)
+        {
+            pat_f[w * 4 + ci] = f[ci];
+            pat_r[w * 4 + ci] = r[ci];
+        }
+    }
+    for (int32_t i = lane; i < target_size; i += 64) tgt[i] = (uint8_t)target[i];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const PlainWords tab_f{pat_f}, tab_r{pat_r};
+
+    // what becomes of a part (same case order as the depth-first kernels): 0 split, 1 run of deletions / insertions,
+    // 2 full Myers matrix + backtrace, 3 single query character
+    auto kind_of = [&](int32_t qn, int32_t tn) -> int32_t {
+        if (tn == 0 || qn == 0) return 1;
+        const int32_t nw = ceil_div(qn, kWord);
+        if (qn >= 2 && qn < kHbSwitchToMyers && (int64_t)(tn + 1) * nw <= max_elems) return 2;
+        if (qn == 1) return 3;
+        return 0;
+    };
+    int32_t n_cur = 0, n_next = 0, n_term = 0, cur = 0; // wave-uniform; parts[cur * kLvMaxParts + k] is the current level
+    bool redo = false;
+    auto add_part = [&](int32_t qb, int32_t qe, int32_t tb, int32_t te, bool to_current) {
+        const int32_t qn = qe - qb, tn = te - tb;
+        if (qn == 0 && tn == 0) return;
+        const LvPart pp{qb, qe, tb, te};
+        if (kind_of(qn, tn) == 0)
+        {
+            int32_t& cnt = to_current ? n_cur : n_next;
+            if (cnt >= kLvMaxParts) { redo = true; return; }
+            if (lane == 0) parts[(to_current ? cur : (cur ^ 1)) * kLvMaxParts + cnt] = pp;
+            ++cnt;
+        }
+        else
+        {
+            if (n_term >= kLvMaxTerm) { redo = true; return; }
+            if (lane == 0) term[n_term] = pp;
+            ++n_term;
+        }
+    };
+    add_part(0, query_size, 0, target_size, true);
+
+    const char acgt[4] = {'A', 'C', 'T', 'G'};
+    while (n_cur > 0 && !redo)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // lane p looks at part p of the level: words of its forward and of its reversed segment
+        int32_t wf = 0, wr = 0;
+        if (lane < n_cur)
+        {
+            const LvPart pp  = parts[cur * kLvMaxParts + lane];
+            const int32_t qn = pp.qe - pp.qb, qh = qn / 2;
+            wf = ceil_div(qh, kWord);
+            wr = ceil_div(qn - qh, kWord);
+        }
+        const int32_t wsum = wf + wr;
+        int32_t first = 0;
+        while (first < n_cur)
+        {
+            // lanes of the parts from `first` on: exclusive prefix sum of their words; the batch is what fits 64 lanes
+            int32_t incl = lane >= first ? wsum : 0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1)
+            {
+                const int32_t o = __shfl_up(incl, off);
+                if (lane >= off) incl += o;
+            }
+            const int32_t excl = incl - (lane >= first ? wsum : 0);
+            const bool in_b    = lane >= first && lane < n_cur && incl <= 64;
+            const int32_t nb   = __popcll(__ballot(in_b));
+            segtab[lane] = 0xffffffffu;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (in_b)
+                for (int32_t i = 0; i < wsum; ++i)
+                    segtab[excl + i] = (uint32_t)lane | (i >= wf ? 0x100u : 0u) | ((uint32_t)(i >= wf ? i - wf : i) << 16);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            // ---- this lane's word ----
+            const uint32_t ent = segtab[lane];
+            const bool idle    = ent == 0xffffffffu;
+            const int32_t p    = idle ? first : (int32_t)(ent & 0xffu);
+            const bool rev     = !idle && (ent & 0x100u) != 0;
+            const int32_t w    = idle ? 0 : (int32_t)(ent >> 16);
+            const LvPart pp    = parts[cur * kLvMaxParts + p];
+            const int32_t qmid = pp.qb + (pp.qe - pp.qb) / 2;
+            const int32_t slen = rev ? pp.qe - qmid : qmid - pp.qb;
+            const int32_t nws  = ceil_div(slen, kWord);
+            const int32_t poff = rev ? query_size - pp.qe : pp.qb;
+            uint32_t e[4];
+#pragma unroll
+            for (int ci = 0; ci < 4; ci++)
+                e[ci] = idle ? 0u : (rev ? get_pattern(tab_r, n_words_query, w, poff, acgt[ci]) : get_pattern(tab_f, n_words_query, w, poff, acgt[ci]));
+            const bool is_first = idle || w == 0;
+            const bool is_last  = !idle && w == nws - 1;
+            const uint32_t hbit = 1u << ((slen - (nws - 1) * kWord - 1) & 31);
+            const int32_t tn    = idle ? 0 : pp.te - pp.tb;
+            const int32_t tstep = rev ? -1 : 1;
+            const int32_t taddr = idle ? 0 : (rev ? pp.te : pp.tb - 1); // column t reads tgt[taddr + tstep * t]
+            uint16_t* row       = (rev ? rows_r : rows_f) + pp.tb + p;
+            const uint64_t cutmask = __ballot(idle || is_last);
+            int32_t tmax = tn;
+            for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
+            tmax = __builtin_amdgcn_readfirstlane(tmax);
+            uint32_t pv = idle ? 0u : ~0u, mv = 0u;
+            int32_t sc  = slen;
+            if (is_last) row[0] = (uint16_t)sc;
+            for (int32_t t = 1; t <= tmax; ++t)
+            {
+                const int32_t tt  = min(t, tn);
+                const uint32_t tc = tgt[taddr + tstep * tt];
+                const uint32_t ci = (tc >> 1) & 3u;
+                const uint32_t lo = (ci & 1u) ? e[1] : e[0], hi = (ci & 1u) ? e[3] : e[2];
+                const uint32_t eq = (ci & 2u) ? hi : lo;
+                const uint32_t xv = eq | mv;
+                const uint32_t an = eq & pv;
+                const uint32_t s0 = an + pv;
+                const uint64_t gen = __ballot(s0 < an) & ~cutmask, prp = __ballot(s0 == 0xffffffffu) & ~cutmask;
+                const uint64_t cin = ((gen | prp) + gen) ^ prp;
+                const uint32_t sum = s0 + (uint32_t)((cin >> lane) & 1ull);
+                const uint32_t xh  = (sum ^ pv) | eq;
+                const uint32_t ph  = mv | ~(xh | pv);
+                const uint32_t mh  = pv & xh;
+                uint32_t ph_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(ph >> 31), 0x138, 0xf, 0xf, false); // wave_shr:1
+                uint32_t mh_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(mh >> 31), 0x138, 0xf, 0xf, false);
+                if (is_first) // the implicit first row is 0, 1, 2, ...
+                {
+                    ph_lo = 1u;
+                    mh_lo = 0u;
+                }
+                if (is_last)
+                {
+                    sc += ((ph & hbit) ? 1 : 0) - ((mh & hbit) ? 1 : 0);
+                    if (t <= tn) row[t] = (uint16_t)sc;
+                }
+                const uint32_t phs = (ph << 1) | ph_lo, mhs = (mh << 1) | mh_lo;
+                pv = mhs | ~(xv | phs);
+                mv = phs & xv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            // ---- target midpoints of the batch's parts and their children ----
+            for (int32_t k = first; k < first + nb; ++k)
+            {
+                const LvPart q     = parts[cur * kLvMaxParts + k];
+                const int32_t qb = __builtin_amdgcn_readfirstlane(q.qb), qe = __builtin_amdgcn_readfirstlane(q.qe);
+                const int32_t tb = __builtin_amdgcn_readfirstlane(q.tb), te = __builtin_amdgcn_readfirstlane(q.te);
+                const int32_t tnk = te - tb;
+                const uint16_t* rf = rows_f + tb + k;
+                const uint16_t* rr = rows_r + tb + k;
+                // hirschberg_myers_compute_target_mid_warp (:461-481) on 32 real lanes: lane L sees t = L, L + 32, ...; the
+                // shuffle-down tree keeps the lower lane on equal sums
+                int32_t cm = INT32_MAX, mp = 0;
+                if (lane < 32)
+                    for (int32_t t = lane; t <= tnk; t += 32)
+                    {
+                        const int32_t sum = (int32_t)rf[t] + (int32_t)rr[tnk - t];
+                        if (sum < cm) { cm = sum; mp = t; }
+                    }
+                for (int32_t step = 16; step > 0; step >>= 1)
+                {
+                    const int32_t om = __shfl_down(cm, step, 32), ot = __shfl_down(mp, step, 32);
+                    if ((lane & 31) + step < 32 && om < cm) { cm = om; mp = ot; }
+                }
+                const int32_t tmid = tb + __builtin_amdgcn_readfirstlane(mp);
+                const int32_t qm   = qb + (qe - qb) / 2;
+                add_part(qb, qm, tb, tmid, false);
+                add_part(qm, qe, tmid, te, false);
+            }
+            first += nb;
+        }
+        cur ^= 1;
+        n_cur  = n_next;
+        n_next = 0;
+    }
+    if (redo)
+    {
+        if (lane == 0) a.result_lengths[idx] = kLvFlagRedo;
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // ---- order of the terminals: the reference pops the right child first, i.e. descending (query begin, target begin) ----
+    for (int32_t k = lane; k < n_term; k += 64) keys[k] = ((uint32_t)term[k].qb << 16) | (uint32_t)term[k].tb;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    for (int32_t k = lane; k < n_term; k += 64)
+    {
+        const uint32_t mine = keys[k];
+        int32_t rank        = 0;
+        for (int32_t j = 0; j < n_term; ++j) rank += keys[j] > mine ? 1 : 0;
+        order[rank] = (uint16_t)k;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+
+    Band leaf; // matrices of a leaf that does not fit LDS (column-major), lane 0 only
+    leaf.pv     = leaf_hbm;
+    leaf.mv     = leaf.pv + (size_t)leaf_words_hbm;
+    leaf.score  = reinterpret_cast<int32_t*>(leaf.mv + (size_t)leaf_words_hbm);
+    leaf.n_rows = 0;
+    leaf.stride = 1;
+    int32_t len = 0;
+    for (int32_t r = 0; r < n_term; ++r)
+    {
+        const int32_t k  = __builtin_amdgcn_readfirstlane((int32_t)order[r]);
+        const LvPart q   = term[k];
+        const int32_t qb = __builtin_amdgcn_readfirstlane(q.qb), qe = __builtin_amdgcn_readfirstlane(q.qe);
+        const int32_t tb = __builtin_amdgcn_readfirstlane(q.tb), te = __builtin_amdgcn_readfirstlane(q.te);
+        const int32_t qn = qe - qb, tn = te - tb;
+        const int32_t nw = ceil_div(max(qn, 1), kWord);
+        const int32_t kind = kind_of(qn, tn);
+        if (kind == 1)
+        {
+            // one side empty: a run of deletions / insertions, written by all lanes
+            const int32_t count = tn == 0 ? qn : tn;
+            const int8_t state  = tn == 0 ? kDeletion : kInsertion;
+            for (int32_t c = lane; c < count; c += 64) path[len + c] = state;
+            len += count;
+        }
+        else if (kind == 2)
+        {
+            // leaf: full Myers matrix (hirschberg_myers_compute_path, :383-410) + append_myers_backtrace (:124-181): the
+            // forward pass runs on lane 0 (a chain of word steps), the walk evaluates its three neighbour cells on three lanes
+            Band lf   = leaf;
+            lf.n_rows = nw;
+            const bool in_lds = (tn + 1) * nw <= L.leaf_elems;
+            if (in_lds)
+            {
+                lf.pv    = leaf_lds;
+                lf.mv    = leaf_lds + L.leaf_elems;
+                lf.score = reinterpret_cast<int32_t*>(leaf_lds + 2 * L.leaf_elems);
+            }
+            if (lane == 0)
+            {
+                for (int32_t w = 0; w < nw; ++w)
+                {
+                    lf.pv[lf.at(w, 0)]    = ~0u;
+                    lf.mv[lf.at(w, 0)]    = 0u;
+                    lf.score[lf.at(w, 0)] = min((w + 1) * kWord, qn);
+                }
+                const uint32_t last_hbit = 1u << (qn - (nw - 1) * kWord - 1);
+                uint32_t lp[2][4];
+                for (int32_t w = 0; w < 2; ++w)
+                    for (int ci = 0; ci < 4; ci++) lp[w][ci] = w < nw ? get_pattern(tab_f, n_words_query, w, qb, acgt[ci]) : 0u;
+                uint32_t pv0 = ~0u, mv0 = 0u, pv1 = ~0u, mv1 = 0u;
+                int32_t s0 = min(kWord, qn), s1 = qn;
+                for (int32_t t = 1; t <= tn; ++t)
+                {
+                    const int32_t ci = (tgt[tb + t - 1] >> 1) & 3;
+                    int32_t h = advance_word(nw == 1 ? last_hbit : (1u << (kWord - 1)), lp[0][ci], pv0, mv0, 1, nullptr);
+                    s0 += h;
+                    lf.score[lf.at(0, t)] = s0;
+                    lf.pv[lf.at(0, t)]    = pv0;
+                    lf.mv[lf.at(0, t)]    = mv0;
+                    if (nw == 2)
+                    {
+                        h = advance_word(last_hbit, lp[1][ci], pv1, mv1, h, nullptr);
+                        s1 += h;
+                        lf.score[lf.at(1, t)] = s1;
+                        lf.pv[lf.at(1, t)]    = pv1;
+                        lf.mv[lf.at(1, t)]    = mv1;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            if (!in_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t last_mask = qn % kWord != 0 ? ((1u << (qn % kWord)) - 1) : ~0u;
+            int32_t i = qn, j = tn, l = len;
+            int32_t myscore = __builtin_amdgcn_readfirstlane(lf.score[lf.at((i - 1) / kWord, j)]);
+            while (i > 0 && j > 0)
+            {
+                // lane 0: above (i - 1, j), lane 1: diagonal (i - 1, j - 1), lane 2: left (i, j - 1)
+                const int32_t ci_ = lane == 2 ? i : i - 1, cj_ = lane == 0 ? j : j - 1;
+                int32_t v = 0;
+                if (lane < 3) v = ci_ == 0 ? cj_ : cell_score(lf, max(ci_, 1), cj_, last_mask); // row 0 of the matrix is 0, 1, 2, ...
+                const int32_t above = __builtin_amdgcn_readlane(v, 0), diag = __builtin_amdgcn_readlane(v, 1), left = __builtin_amdgcn_readlane(v, 2);
+                int8_t st;
+                if (left + 1 == myscore) { st = kInsertion; myscore = left; --j; }
+                else if (above + 1 == myscore) { st = kDeletion; myscore = above; --i; }
+                else { st = diag == myscore ? kMatch : kMismatch; myscore = diag; --i; --j; }
+                if (lane == 0) path[l] = st;
+                l++;
+            }
+            for (int32_t c = lane; c < i; c += 64) path[l + c] = kDeletion;
+            l += i;
+            for (int32_t c = lane; c < j; c += 64) path[l + c] = kInsertion;
+            l += j;
+            len = l;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // the next leaf reuses the matrices
+        }
+        else
+        {
+            // hirschberg_myers_single_char_warp (:483-515): right-to-left scan for the first equal character
+            int32_t new_len = len;
+            if (lane == 0)
+            {
+                const uint8_t qc = (uint8_t)query[qb];
+                int32_t pz       = len;
+                int32_t t        = te - 1;
+                while (t >= tb)
+                {
+                    if (tgt[t] == qc) { path[pz++] = kMatch; --t; break; }
+                    path[pz++] = kInsertion;
+                    --t;
+                }
+                if (path[pz - 1] != kMatch) path[pz - 1] = kMismatch;
+                while (t >= tb) { path[pz++] = kInsertion; --t; }
+                new_len = len + tn;
+            }
+            len = __builtin_amdgcn_readfirstlane(new_len);
+        }
+    }
+    if (lane == 0) a.result_lengths[idx] = len;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2366,6 +2798,19 @@ int gwhip_hirschberg_myers(const gwhip_hirschberg_args* args, gwhip_stream_t str
     {
         ka.lds_state_words = part_chunks;
         const size_t lds_request = wave_lds;
+        // queries of up to 2 048 bases: the level-by-level kernel first (GWHIP_HIRSCHBERG_LEVELS=0: depth-first only), the
+        // depth-first kernel behind it for what that one leaves (targets beyond its LDS rows, list overflows)
+        {
+            const char* lv = std::getenv("GWHIP_HIRSCHBERG_LEVELS");
+            if (args->max_query_length <= kLvMaxQuery && !(lv && lv[0] == '0'))
+            {
+                const size_t lv_lds = (size_t)lv_layout(std::max(args->max_query_length, 1)).total;
+                if (lv_lds > 48 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hirschberg_levels_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lv_lds);
+                ka.levels_first = 1;
+                hipLaunchKernelGGL(hirschberg_levels_kernel, dim3(n), dim3(64), lv_lds, stream, ka);
+            }
+        }
         if (lds_request > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hirschberg_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_request);
         hipLaunchKernelGGL(hirschberg_wave_kernel, dim3(n), dim3(64), lds_request, stream, ka);

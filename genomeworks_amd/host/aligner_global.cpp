@@ -1,6 +1,7 @@
 // aligner_global.cpp -- host side of the fixed-limit global aligners (see aligner_global.hpp).
 // The sequences are packed back to back (q0 t0 q1 t1 ...) instead of the reference's fixed 2 * max_length stride;
 // limits, statuses and the host-side reversal of the kernels' back-to-front paths follow aligner_global.cpp.
+#include <thread>
 #include "aligner_global.hpp"
 
 #include <claraparabricks/genomeworks/utils/cudautils.hpp>
@@ -32,6 +33,7 @@ AlignerGlobal::AlignerGlobal(int32_t max_query_length, int32_t max_target_length
     , device_id_(device_id)
 {
     if (max_alignments < 1) throw std::runtime_error("Max alignments must be at least 1.");
+    seq_starts_h_.assign(1, 0);
 }
 
 AlignerGlobal::~AlignerGlobal()
@@ -61,6 +63,11 @@ StatusType AlignerGlobal::add_alignment(const char* query, int32_t query_length,
     }
     if (num_alignments() >= max_alignments_) return StatusType::exceeded_max_alignments;
     if (query_length > max_query_length_ || target_length > max_target_length_) return StatusType::exceeded_max_length;
+    if (launched_) // the staging arrays are pinned: a batch still in flight reads them by DMA
+    {
+        scoped_device_switch dev(device_id_);
+        GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+    }
     const int64_t begin = seq_starts_h_.back();
     seq_h_.resize(static_cast<size_t>(begin + query_length + target_length));
     genomeutils::copy_sequence(query, query_length, seq_h_.data() + begin, reverse_complement_query);
@@ -117,25 +124,40 @@ StatusType AlignerGlobal::sync_alignments()
 {
     scoped_device_switch dev(device_id_);
     GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
-    const int32_t n = num_alignments();
-    for (int32_t i = 0; i < n; ++i)
-    {
-        const int32_t qlen = static_cast<int32_t>(seq_starts_h_[2 * i + 1] - seq_starts_h_[2 * i]);
-        const int32_t tlen = static_cast<int32_t>(seq_starts_h_[2 * i + 2] - seq_starts_h_[2 * i + 1]);
-        AlignmentImpl* alignment = dynamic_cast<AlignmentImpl*>(alignments_[static_cast<size_t>(i)].get());
-        if (launched_)
+    const size_t n = static_cast<size_t>(num_alignments());
+    if (!launched_ || n == 0) return StatusType::success;
+    // the device writes every path back to front; one reversed copy per alignment, handed over without a second one.
+    // Big batches are split over a few host threads (the alignments are independent objects).
+    auto fill_range = [&](size_t first, size_t last) {
+        for (size_t i = first; i < last; ++i)
         {
-            const int32_t len     = result_lengths_h_[static_cast<size_t>(i)];
-            const int8_t* r_begin = results_h_.data() + seq_starts_h_[2 * i];
-            std::vector<AlignmentState> states;
-            states.reserve(static_cast<size_t>(std::abs(len)));
-            for (int32_t k = std::abs(len) - 1; k >= 0; --k) states.push_back(static_cast<AlignmentState>(r_begin[k])); // back to front
-            if (!states.empty() || (qlen == 0 && tlen == 0))
+            const int64_t qlen = seq_starts_h_[2 * i + 1] - seq_starts_h_[2 * i];
+            const int64_t tlen = seq_starts_h_[2 * i + 2] - seq_starts_h_[2 * i + 1];
+            AlignmentImpl* alignment = dynamic_cast<AlignmentImpl*>(alignments_[i].get());
+            const int32_t len        = result_lengths_h_[i];
+            const size_t count       = static_cast<size_t>(std::abs(len));
+            const int8_t* r_begin    = results_h_.data() + seq_starts_h_[2 * i];
+            std::vector<AlignmentState> states(count);
+            for (size_t k = 0; k < count; ++k) states[k] = static_cast<AlignmentState>(r_begin[count - 1 - k]);
+            if (count != 0 || (qlen == 0 && tlen == 0))
             {
-                alignment->set_alignment(states, len >= 0);
+                alignment->set_alignment(std::move(states), len >= 0);
                 alignment->set_status(StatusType::success);
             }
         }
+    };
+    const size_t total     = static_cast<size_t>(seq_starts_h_.back());
+    const size_t n_threads = (n >= 256 && total >= (size_t(1) << 20)) ? std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (n_threads <= 1)
+        fill_range(0, n);
+    else
+    {
+        const size_t chunk = (n + n_threads - 1) / n_threads;
+        std::vector<std::thread> workers;
+        for (size_t t = 1; t < n_threads; ++t)
+            workers.emplace_back([&, t] { fill_range(std::min(n, t * chunk), std::min(n, (t + 1) * chunk)); });
+        fill_range(0, std::min(n, chunk));
+        for (std::thread& w : workers) w.join();
     }
     return StatusType::success;
 }

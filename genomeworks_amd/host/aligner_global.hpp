@@ -8,6 +8,7 @@
 //   AlignerGlobalMyers            full bit-vector matrices (aligner_global_myers.cpp): the banded kernel with a band
 //                                 that covers the whole query                          -> gwhip_myers_banded
 #pragma once
+#include "pinned_vector.hpp"
 #include <claraparabricks/genomeworks/cudaaligner/aligner.hpp>
 #include <claraparabricks/genomeworks/cudaaligner/alignment.hpp>
 
@@ -60,11 +61,12 @@ private:
     DefaultDeviceAllocator allocator_;
     cudaStream_t stream_;
     int32_t device_id_;
-    std::vector<char> seq_h_;
-    std::vector<int64_t> seq_starts_h_{0};
+    // staging arrays in pinned memory (process-wide cache of pinned buffers): the copies of align_all() are true async DMA
+    PinnedVector<char> seq_h_;
+    PinnedVector<int64_t> seq_starts_h_;
     std::vector<std::shared_ptr<Alignment>> alignments_;
-    std::vector<int8_t> results_h_;
-    std::vector<int32_t> result_lengths_h_;
+    PinnedVector<int8_t> results_h_;
+    PinnedVector<int32_t> result_lengths_h_;
     char* device_block_        = nullptr;
     size_t device_block_bytes_ = 0;
     int8_t* d_results_         = nullptr;

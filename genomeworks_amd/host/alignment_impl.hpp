@@ -40,6 +40,11 @@ public:
         alignment_  = alignment;
         is_optimal_ = is_optimal;
     }
+    void set_alignment(std::vector<AlignmentState>&& alignment, bool is_optimal)
+    {
+        alignment_  = std::move(alignment);
+        is_optimal_ = is_optimal;
+    }
     /// run-length encoded form
     void set_alignment(std::vector<int8_t>&& action, std::vector<int32_t>&& runlength, bool is_optimal)
     {

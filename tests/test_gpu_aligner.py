@@ -202,6 +202,54 @@ def test_default_aligner_kernels_agree(monkeypatch):
             assert states == A.hirschberg(q, t, max_len)["states"]
 
 
+def test_default_aligner_level_by_level_kernel_agrees(monkeypatch):
+    """Aligners for queries of up to 2 048 bases grow Hirschberg's tree a level at a time (all parts of a level side by side
+    in the wavefront, default) -- the alignments must equal the depth-first kernel's (GWHIP_HIRSCHBERG_LEVELS=0) and the
+    oracle's: lengths around the word and leaf thresholds, single characters, very unequal lengths (targets beyond the
+    kernel's LDS rows stay with the depth-first kernel inside the same batch), identical and unrelated sequences."""
+    import random
+    from genomeworks_amd import cudaaligner
+    rng = random.Random(777)
+    pairs = []
+    for n in [1, 2, 3, 31, 32, 33, 62, 63, 64, 65, 125, 126, 127, 128, 129, 250, 500, 999, 1000, 1023, 1024, 1025, 2000, 2047, 2048]:
+        for div in (3, 10, 40):
+            q = "".join(rng.choice("ACGT") for _ in range(n))
+            t = list(q)
+            for _ in range(max(1, n // div)):
+                op, p = rng.random(), rng.randrange(max(1, len(t)))
+                if op < 0.4 and t:
+                    t[p] = rng.choice("ACGT")
+                elif op < 0.7 and len(t) < 2048:
+                    t.insert(p, rng.choice("ACGT"))
+                elif len(t) > 1:
+                    del t[p]
+            pairs.append((q, "".join(t)[:2048]))
+    for n in (5, 40, 300, 1500):
+        q = "".join(rng.choice("ACGT") for _ in range(n))
+        pairs.append((q, q))                                                      # identical
+        pairs.append((q, "".join(rng.choice("ACGT") for _ in range(n))))          # unrelated
+        pairs.append((q, "".join(rng.choice("ACGT") for _ in range(2048))))       # target much longer than the query
+        pairs.append(("".join(rng.choice("ACGT") for _ in range(2048)), q))       # query much longer than the target
+        pairs.append((q, q[: max(1, n // 20)]))
+    max_len = 2048
+    out = {}
+    for name, flag in (("levels", None), ("depth_first", "0")):
+        if flag is None:
+            monkeypatch.delenv("GWHIP_HIRSCHBERG_LEVELS", raising=False)
+        else:
+            monkeypatch.setenv("GWHIP_HIRSCHBERG_LEVELS", flag)
+        al = cudaaligner.CudaAlignerBatch(max_len, max_len, len(pairs), max_device_memory_allocator_caching_size=8 << 30)
+        for q, t in pairs:
+            assert al.add_alignment(q, t) == 0
+        al.align_all()
+        out[name] = [(r.status, list(r.alignment)) for r in al.get_alignments()]
+    bad = [i for i, (x, y) in enumerate(zip(out["levels"], out["depth_first"])) if x != y]
+    assert not bad, [(i, len(pairs[i][0]), len(pairs[i][1])) for i in bad[:10]]
+    for (st, states), (q, t) in zip(out["levels"], pairs):
+        assert st == 0
+        assert states == A.hirschberg(q, t, max_len)["states"]
+
+
 # ---- the non-default classes: AlignerGlobalUkkonen / AlignerGlobalMyers (SURVEY 8(f) rank 3) ----
 def _run_algorithm(algorithm, pairs, max_len):
     from genomeworks_amd import cudaaligner
