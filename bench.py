@@ -412,22 +412,24 @@ def bench_default_aligner(local_rank, sync, cpu_all_cores=None):
             assert al.sync() == n
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
+            k_ms = min(al.relaunch_timed() for _ in range(3))   # the kernels alone, HIP events on the aligner's stream
             al.reset()
         del al
         cells = sum(len(q) * len(t) for q, t in pairs)
         rows.append({"pairs": n, "length": size, "ms": round(best * 1e3, 3), "pairs_per_s": round(n / best, 1),
-                     "full_matrix_gcups": round(cells / best / 1e9, 2)})
+                     "full_matrix_gcups": round(cells / best / 1e9, 2), "kernel_ms": round(k_ms, 3)})
     head = rows[-1]
-    achieved = 2000 * 1000 * 1000 * BYTES_PER_MYERS_CELL / (head["ms"] * 1e-3) / 1e9
-    out = {"workload": "default aligner (Hirschberg + Myers bit vectors, one wavefront per pair): reference benchmark shapes",
+    achieved = 2000 * 1000 * 1000 * BYTES_PER_MYERS_CELL / (head["kernel_ms"] * 1e-3) / 1e9
+    out = {"workload": "default aligner (Hirschberg + Myers bit vectors, one wavefront per pair, the tree grown level by level for queries of up to 2 048 bases): reference benchmark shapes",
            "metric": "pairs/s, align_all() + sync_alignments(), 2 000 pairs x 1 kbp (about 10 % divergence)",
            "value": head["pairs_per_s"], "unit": "pairs/s", "ms": head["ms"], "shapes": rows,
-           "roofline": {"bound": "hbm", "kernel": "hirschberg_wave_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "kernel_only": {"pairs_per_s": round(2000 / (head["kernel_ms"] * 1e-3), 1), "ms": head["kernel_ms"]},
+           "roofline": {"bound": "hbm", "kernel": "hirschberg_levels_kernel (+ hirschberg_wave_kernel for what it leaves)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": sub_traffic("default_aligner"), "algorithmic_bytes_per_cell": BYTES_PER_MYERS_CELL,
                         "note": "|q| x |t| cells of the full matrix at the bit-vector cost of 12 B per 32-cell word column; the divide "
                                 "and conquer computes every cell about twice and keeps its state in registers and LDS, so HBM "
                                 "carries little: the kernel is bound by the dependent column steps of a wavefront",
-                        "kernel_ms": head["ms"]}}
+                        "kernel_ms": head["kernel_ms"]}}
     if cpu is not None:
         out["cpu_baseline"] = cpu
     return out

@@ -351,7 +351,7 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
         const int32_t n  = (tile_hi - tile_lo + 1) * b.n_rows;
         const size_t src = b.at(0, tile_lo); // columns are contiguous in (column, word) order
         constexpr int kU = 8;                // 24 independent loads in flight per lane, then their LDS stores
-        for (int32_t e0 = G > 1 ? (int32_t)(threadIdx.x & (G - 1)) * kU : 0; e0 < n; e0 += G * kU)
+        for (int32_t e0 = G > 1 ? (int32_t)((threadIdx.x & 63) % G) * kU : 0; e0 < n; e0 += G * kU)
         {
             uint32_t p[kU], m[kU], sc[kU];
 #pragma unroll
@@ -755,8 +755,10 @@ __device__ __forceinline__ void group_advance(const GroupCtx<G>& c, uint32_t eq,
     const uint32_t ph  = mv | ~(xh | pv);
     const uint32_t mh  = pv & xh;
     // bits shifted in from the word below (the band's top border is the worst case: +1)
-    uint32_t ph_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(ph >> 31), 0x111, 0xf, 0xf, false); // row_shr:1
-    uint32_t mh_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(mh >> 31), 0x111, 0xf, 0xf, false);
+    // (G = 8: groups lie inside the 16-lane rows; other widths cross them and take the wave-wide shift)
+    constexpr int kShr = (16 % G == 0) ? 0x111 : 0x138; // row_shr:1 / wave_shr:1
+    uint32_t ph_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(ph >> 31), kShr, 0xf, 0xf, false);
+    uint32_t mh_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(mh >> 31), kShr, 0xf, 0xf, false);
     if (c.gl == 0)
     {
         ph_lo = 1u;
@@ -878,8 +880,9 @@ __device__ __forceinline__ void group_diagonal_band(Band& b, GroupCtx<G>& c, con
     {
         const uint32_t ci = group_target_code<G>(c, tw, t - 1);
         // the band slides one row down: word k takes the low bit of word k + 1 as its top bit
-        const uint32_t pv_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)pv, 0x101, 0xf, 0xf, false); // row_shl:1
-        const uint32_t mv_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)mv, 0x101, 0xf, 0xf, false);
+        constexpr int kShl = (16 % G == 0) ? 0x101 : 0x130; // row_shl:1 / wave_shl:1
+        const uint32_t pv_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)pv, kShl, 0xf, 0xf, false);
+        const uint32_t mv_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)mv, kShl, 0xf, 0xf, false);
         pv >>= 1;
         mv >>= 1;
         if (k + 1 < n_words)
@@ -914,37 +917,53 @@ __device__ __forceinline__ void group_diagonal_band(Band& b, GroupCtx<G>& c, con
 // [PAIRS j, PAIRS j + PAIRS) of region PAIRS j / 64 -- but a block is PAIRS G / 64 wavefronts, so that a small batch spreads
 // over all CUs with one busy wavefront per SIMD (the column step is vector work back to back: two such wavefronts on one
 // SIMD halve each other).
-template <int G, int PAIRS>
-__global__ __launch_bounds__(PAIRS * G) void myers_banded_group_kernel(KernelArgs a)
+// G need not divide 64: six lanes per pair are ten pairs per wavefront (four lanes idle), which puts BASELINE configs[1]'s
+// 10 000 pairs on 1 000 wavefronts -- one per SIMD -- where eight lanes per pair make 1 250 and a fifth of the SIMDs carry two.
+template <int G, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void myers_banded_group_kernel(KernelArgs a)
 {
     extern __shared__ uint32_t myers_lds[];
     constexpr int kPairsPerWave = 64 / G;
-    static_assert(64 % PAIRS == 0 && (PAIRS * G) % 64 == 0, "whole wavefronts, whole regions");
+    constexpr int PAIRS         = WAVES * kPairsPerWave;
     const int lane  = threadIdx.x & 63;
     const int wave  = threadIdx.x >> 6;
-    const int gl    = lane & (G - 1);
-    const int sb    = wave * kPairsPerWave + lane / G;           // pair of the block: 0 .. PAIRS - 1
+    const int gl    = lane % G;
+    const int gbase = lane - gl;                                  // first lane of the group
+    const int sb    = wave * kPairsPerWave + min(lane / G, kPairsPerWave - 1); // pair of the block: 0 .. PAIRS - 1
     const int32_t slot = blockIdx.x * PAIRS + sb;
     const int32_t region_index = slot / 64;
     const int s     = slot - region_index * 64;                   // slot inside its 64-slot workspace region
-    // the region is sized by its largest pair: every wave reduces over all 64 slots of the region
+    // the region is sized by its largest pair: every wave reduces over all 64 slots of the region -- of both regions when
+    // its pairs straddle a boundary (ten pairs per wavefront do; the wavefront's slots are consecutive, so two at most)
     int64_t me_max = 0;
     int32_t pw_max = 0;
     {
-        const int32_t sj = region_index * 64 + lane;
-        if (sj < a.n)
+        const int32_t first_slot = blockIdx.x * PAIRS + wave * kPairsPerWave;
+        const int32_t r0 = first_slot / 64, r1 = (first_slot + kPairsPerWave - 1) / 64;
+        for (int32_t r = r0; r <= r1; ++r) // wave-uniform
         {
-            const int32_t i = a.order[sj];
-            pair_ws_dims((int32_t)(a.starts[2 * i + 1] - a.starts[2 * i]), (int32_t)(a.starts[2 * i + 2] - a.starts[2 * i + 1]),
-                         a.max_bandwidths[i], me_max, pw_max);
-        }
-        for (int off = 32; off > 0; off >>= 1)
-        {
-            me_max = max(me_max, (int64_t)__shfl_xor((long long)me_max, off));
-            pw_max = max(pw_max, __shfl_xor(pw_max, off));
+            int64_t me = 0;
+            int32_t pw = 0;
+            const int32_t sj = r * 64 + lane;
+            if (sj < a.n)
+            {
+                const int32_t i = a.order[sj];
+                pair_ws_dims((int32_t)(a.starts[2 * i + 1] - a.starts[2 * i]), (int32_t)(a.starts[2 * i + 2] - a.starts[2 * i + 1]),
+                             a.max_bandwidths[i], me, pw);
+            }
+            for (int off = 32; off > 0; off >>= 1)
+            {
+                me = max(me, (int64_t)__shfl_xor((long long)me, off));
+                pw = max(pw, __shfl_xor(pw, off));
+            }
+            if (r == region_index)
+            {
+                me_max = me;
+                pw_max = pw;
+            }
         }
     }
-    if (slot >= a.n) return;
+    if (slot >= a.n || lane >= kPairsPerWave * G) return; // (lanes beyond the last whole group are idle)
     const bool leader        = gl == 0;
     const int32_t idx        = a.order[slot];
     const char* query        = a.sequences + a.starts[2 * idx];
@@ -1095,7 +1114,7 @@ __global__ __launch_bounds__(PAIRS * G) void myers_banded_group_kernel(KernelArg
                 }
             }
             // the last word's score in the last column, to every lane of the group
-            dist = __shfl(sc, (lane & ~(G - 1)) + n_words_band - 1);
+            dist = __shfl(sc, gbase + n_words_band - 1);
             if (a.debug_skip & 2) dist = b.score[b.at(n_words_band - 1, target_size)];
         }
         else
@@ -1114,11 +1133,11 @@ __global__ __launch_bounds__(PAIRS * G) void myers_banded_group_kernel(KernelArg
                     banded_stripes<false>(b, none, patterns, n_words, target, query_size, target_size, p, n_words_band, band_width, diagonal_begin,
                                           diagonal_end);
             }
-            diagonal_begin = __shfl(diagonal_begin, lane & ~(G - 1));
-            diagonal_end   = __shfl(diagonal_end, lane & ~(G - 1));
+            diagonal_begin = __shfl(diagonal_begin, gbase);
+            diagonal_end   = __shfl(diagonal_end, gbase);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             dist = leader ? b.score[b.at(n_words_band - 1, target_size)] : 0;
-            dist = __shfl(dist, lane & ~(G - 1));
+            dist = __shfl(dist, gbase);
         }
         if (dist <= estimate || band_width == query_size) break;
         if (band_width == max_bw)
@@ -2653,7 +2672,7 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         const int32_t qwords = args->max_query_length > 0 ? (args->max_query_length + kWord - 1) / kWord : 0;
-        const bool fits      = qwords > 0 && (size_t)(32 * (4 * qwords + 1) + 32 * 17 + 64 * 224) * 4 <= 80 * 1024; // two blocks per CU
+        const bool fits      = qwords > 0 && (size_t)(40 * (4 * qwords + 1) + 40 * 17 + 64 * 224) * 4 <= 80 * 1024; // two blocks per CU
         use_group = fits && (n + 63) / 64 < 4 * cus && args->max_query_length >= 256;
         if (gdbg && gdbg[0] == '0') use_group = false;
         if (gdbg && gdbg[0] == '1') use_group = fits;
@@ -2663,14 +2682,31 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
             ka.lds_band_words    = 224; // words of the backtrace's column window per pair
         }
     }
-    // (four lanes per pair -- half the wavefronts for 10 000 pairs, one per SIMD instead of two on a fifth of them -- was
-    // measured and is no faster: 1.71 vs 1.68 ms on configs[1], profiles/r03_h_aligner_group_lanes.txt; a wavefront lasts as
-    // long as its unluckiest pair's band attempts, and sixteen pairs per wavefront make an unlucky one near certain)
+    // (four lanes per pair with two words per lane -- half the wavefronts for 10 000 pairs -- was measured and is no faster:
+    // 1.71 vs 1.68 ms on configs[1], profiles/r03_h_aligner_group_lanes.txt: twice the vector work per column and wavefront.)
+    // Six lanes per pair (ten pairs per wavefront) when that is what puts the batch on one wavefront per SIMD: a band attempt
+    // of up to six words still runs across the lanes (GWHIP_MYERS_GROUP_LANES = 6 / 8 forces the choice).
     if (use_group)
     {
-        const size_t lds = (size_t)(32 * (ka.lds_pattern_words + 1) + 32 * 17 + 64 * ka.lds_band_words) * sizeof(uint32_t);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&myers_banded_group_kernel<8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        hipLaunchKernelGGL((myers_banded_group_kernel<8, 32>), dim3((n + 31) / 32), dim3(32 * 8), lds, stream, ka);
+        int cus = 0, dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        bool six = n > 8 * 4 * cus && n <= 10 * 4 * cus;
+        const char* gl = std::getenv("GWHIP_MYERS_GROUP_LANES");
+        if (gl && gl[0] == '6') six = true;
+        if (gl && gl[0] == '8') six = false;
+        const int pairs  = six ? 40 : 32;
+        const size_t lds = (size_t)(pairs * (ka.lds_pattern_words + 1) + pairs * 17 + 64 * ka.lds_band_words) * sizeof(uint32_t);
+        if (six)
+        {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&myers_banded_group_kernel<6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            hipLaunchKernelGGL((myers_banded_group_kernel<6, 4>), dim3((n + 39) / 40), dim3(256), lds, stream, ka);
+        }
+        else
+        {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&myers_banded_group_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            hipLaunchKernelGGL((myers_banded_group_kernel<8, 4>), dim3((n + 31) / 32), dim3(256), lds, stream, ka);
+        }
     }
     else if (use_lds)
         hipLaunchKernelGGL(myers_banded_kernel<true>, dim3((n + 63) / 64), dim3(64),

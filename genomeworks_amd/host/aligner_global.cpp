@@ -104,6 +104,10 @@ StatusType AlignerGlobal::align_all()
     d_result_lengths_   = reinterpret_cast<int32_t*>(device_block_ + o_len);
     GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq, seq_h_.data(), static_cast<size_t>(total), hipMemcpyHostToDevice, stream_));
     GW_CU_CHECK_ERR(hipMemcpyAsync(d_starts, seq_starts_h_.data(), seq_starts_h_.size() * 8, hipMemcpyHostToDevice, stream_));
+    d_seq_    = d_seq;
+    d_starts_ = d_starts;
+    d_ws_     = device_block_ + o_ws;
+    ws_bytes_ = ws_bytes;
     const int rc = run_alignment(n, d_seq, d_starts, seq_starts_h_.data(), d_results_, d_result_lengths_, device_block_ + o_ws, ws_bytes);
     if (rc != 0)
     {
@@ -160,6 +164,24 @@ StatusType AlignerGlobal::sync_alignments()
         for (std::thread& w : workers) w.join();
     }
     return StatusType::success;
+}
+
+float AlignerGlobal::relaunch_resident_timed()
+{
+    if (!launched_ || device_block_ == nullptr) return -1.f;
+    scoped_device_switch dev(device_id_);
+    hipEvent_t e0, e1;
+    GW_CU_CHECK_ERR(hipEventCreate(&e0));
+    GW_CU_CHECK_ERR(hipEventCreate(&e1));
+    GW_CU_CHECK_ERR(hipEventRecord(e0, stream_));
+    const int rc = run_alignment(num_alignments(), d_seq_, d_starts_, seq_starts_h_.data(), d_results_, d_result_lengths_, d_ws_, ws_bytes_);
+    GW_CU_CHECK_ERR(hipEventRecord(e1, stream_));
+    GW_CU_CHECK_ERR(hipEventSynchronize(e1));
+    float ms = 0.f;
+    GW_CU_CHECK_ERR(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc == 0 ? ms : -1.f;
 }
 
 DeviceAlignmentsPtrs AlignerGlobal::get_alignments_device() const

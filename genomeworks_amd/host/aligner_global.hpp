@@ -43,6 +43,10 @@ public:
     int32_t get_device() const override { return device_id_; }
     DefaultDeviceAllocator get_device_allocator() const override { return allocator_; }
 
+    /// measurement aid: the kernels of the last align_all() once more on the inputs still resident in HBM, timed with HIP
+    /// events on the aligner's stream; < 0 when nothing is resident
+    float relaunch_resident_timed();
+
     int32_t get_max_query_length() const { return max_query_length_; }
     int32_t get_max_target_length() const { return max_target_length_; }
 
@@ -69,6 +73,10 @@ private:
     PinnedVector<int32_t> result_lengths_h_;
     char* device_block_        = nullptr;
     size_t device_block_bytes_ = 0;
+    char* d_seq_               = nullptr;
+    int64_t* d_starts_         = nullptr;
+    char* d_ws_                = nullptr;
+    size_t ws_bytes_           = 0;
     int8_t* d_results_         = nullptr;
     int32_t* d_result_lengths_ = nullptr;
     bool launched_             = false;

@@ -514,9 +514,13 @@ int gw_aligner_relaunch(gw_aligner* a)
 int gw_aligner_relaunch_timed(gw_aligner* a, float* kernels_ms)
 {
     GW_TRY
-    if (!a->impl) return -1;
-    *kernels_ms = a->impl->relaunch_resident_timed();
-    return 0;
+    if (a->impl)
+        *kernels_ms = a->impl->relaunch_resident_timed();
+    else if (auto* global = dynamic_cast<aln::AlignerGlobal*>(a->aligner.get()))
+        *kernels_ms = global->relaunch_resident_timed();
+    else
+        return -1;
+    return *kernels_ms < 0.f ? -1 : 0;
     GW_CATCH(-1)
 }
 

@@ -98,6 +98,12 @@ def test_group_kernel_equals_one_lane_kernel(monkeypatch):
             got[mode] = [(r.status, r.cigar_extended, r.is_optimal, r.edit_distance) for r in run(pairs, max_bandwidth=max_bw)]
         assert got["0"] == got["1"]
         assert got["0"] == got[None]
+        # six lanes per pair (ten pairs per wavefront; groups cross the 16-lane rows, four lanes of a wavefront idle)
+        monkeypatch.setenv("GWHIP_MYERS_GROUP", "1")
+        monkeypatch.setenv("GWHIP_MYERS_GROUP_LANES", "6")
+        six = [(r.status, r.cigar_extended, r.is_optimal, r.edit_distance) for r in run(pairs, max_bandwidth=max_bw)]
+        monkeypatch.delenv("GWHIP_MYERS_GROUP_LANES", raising=False)
+        assert got["0"] == six
 
 
 def test_config2_sample_and_cell_counts():
