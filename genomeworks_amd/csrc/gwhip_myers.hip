@@ -1699,10 +1699,12 @@ constexpr int32_t kLvMaxQuery = 2048;
 constexpr int32_t kLvMaxParts = 64;
 constexpr int32_t kLvMaxTerm  = 256;
 constexpr int32_t kLvFlagRedo = -2;
+constexpr int32_t kLvStageBytes = 1536; // path pieces of the terminals of one round
+constexpr int32_t kLvRound      = 8;    // terminals worked on side by side, one lane each
 struct LvPart { int32_t qb, qe, tb, te; };
 struct LvLayout
 {
-    int32_t pat_f, pat_r, tgt, rows_f, rows_r, parts, term, keys, order, segtab, total; // byte offsets
+    int32_t pat_f, pat_r, tgt, rows_f, rows_r, parts, term, keys, order, segtab, stage, total; // byte offsets
     int32_t row_entries, leaf_elems;
 };
 __host__ __device__ inline int32_t lv_target_cap(int32_t max_query) { return (max_query + max_query / 8 + 64 + 3) & ~3; }
@@ -1724,6 +1726,7 @@ __host__ __device__ inline LvLayout lv_layout(int32_t max_query)
     L.keys        = take(kLvMaxTerm * 4);
     L.order       = take(kLvMaxTerm * 2);
     L.segtab      = take(64 * 4);
+    L.stage       = take(kLvStageBytes);
     L.total       = off;
     return L;
 }
@@ -2355,8 +2358,139 @@ __global__ __launch_bounds__(64) void hirschberg_levels_kernel(HirschbergArgs a)
     leaf.n_rows = 0;
     leaf.stride = 1;
     int32_t len = 0;
+    int8_t* stage = reinterpret_cast<int8_t*>(lds8 + L.stage);
     for (int32_t r = 0; r < n_term; ++r)
     {
+        // ---- a round of terminals side by side: lane l takes terminal r + l, writes its piece of the path to an LDS stage
+        // (its length is only known afterwards), and the pieces are appended in order. A round takes the leading terminals
+        // (at most kLvRound) whose matrices fit the leaf area together and whose pieces fit the stage; a terminal that fits
+        // neither on its own (a long run, a leaf whose matrix needs the HBM workspace) is handled by the whole wavefront below.
+        {
+            int32_t t_kind = 0, t_qb = 0, t_qe = 0, t_tb = 0, t_te = 0, elems = 0, cap = 0;
+            const bool have = lane < kLvRound && r + lane < n_term;
+            if (have)
+            {
+                const LvPart q = term[order[r + lane]];
+                t_qb = q.qb; t_qe = q.qe; t_tb = q.tb; t_te = q.te;
+                const int32_t qn = t_qe - t_qb, tn = t_te - t_tb;
+                t_kind = kind_of(qn, tn);
+                elems  = t_kind == 2 ? (tn + 1) * ceil_div(qn, kWord) : 0;
+                cap    = qn + tn;
+            }
+            int32_t ie = elems, ic = cap; // inclusive prefix sums over the lanes
+#pragma unroll
+            for (int off = 1; off < kLvRound; off <<= 1)
+            {
+                const int32_t oe = __shfl_up(ie, off), oc = __shfl_up(ic, off);
+                if (lane >= off) { ie += oe; ic += oc; }
+            }
+            const bool fits      = have && ie <= L.leaf_elems && ic <= kLvStageBytes;
+            const uint64_t fm    = __ballot(fits) | (~0ull << kLvRound);
+            const int32_t m      = ~fm == 0 ? kLvRound : (int32_t)__builtin_ctzll(~fm); // leading lanes that fit
+            if (m >= 2)
+            {
+                const bool mine  = lane < m;
+                const int32_t eo = ie - elems, so = ic - cap; // this lane's matrix and stage offsets
+                int32_t plen = 0;
+                if (mine)
+                {
+                    const int32_t qn = t_qe - t_qb, tn = t_te - t_tb;
+                    int8_t* out = stage + so;
+                    if (t_kind == 1)
+                    {
+                        const int32_t count = tn == 0 ? qn : tn;
+                        const int8_t state  = tn == 0 ? kDeletion : kInsertion;
+                        for (int32_t c = 0; c < count; ++c) out[c] = state;
+                        plen = count;
+                    }
+                    else if (t_kind == 3)
+                    {
+                        const uint8_t qc = (uint8_t)query[t_qb];
+                        int32_t pz = 0, t = t_te - 1;
+                        bool matched = false;
+                        while (t >= t_tb)
+                        {
+                            if (tgt[t] == qc) { out[pz++] = kMatch; --t; matched = true; break; }
+                            out[pz++] = kInsertion;
+                            --t;
+                        }
+                        if (!matched) out[pz - 1] = kMismatch;
+                        while (t >= t_tb) { out[pz++] = kInsertion; --t; }
+                        plen = tn;
+                    }
+                    else
+                    {
+                        const int32_t nw = ceil_div(qn, kWord);
+                        Band lf;
+                        lf.pv     = leaf_lds + eo;
+                        lf.mv     = leaf_lds + L.leaf_elems + eo;
+                        lf.score  = reinterpret_cast<int32_t*>(leaf_lds + 2 * L.leaf_elems + eo);
+                        lf.n_rows = nw;
+                        lf.stride = 1;
+                        for (int32_t w = 0; w < nw; ++w)
+                        {
+                            lf.pv[lf.at(w, 0)]    = ~0u;
+                            lf.mv[lf.at(w, 0)]    = 0u;
+                            lf.score[lf.at(w, 0)] = min((w + 1) * kWord, qn);
+                        }
+                        const uint32_t last_hbit = 1u << (qn - (nw - 1) * kWord - 1);
+                        uint32_t lp[2][4];
+                        for (int32_t w = 0; w < 2; ++w)
+                            for (int ci = 0; ci < 4; ci++) lp[w][ci] = w < nw ? get_pattern(tab_f, n_words_query, w, t_qb, acgt[ci]) : 0u;
+                        uint32_t pv0 = ~0u, mv0 = 0u, pv1 = ~0u, mv1 = 0u;
+                        int32_t s0 = min(kWord, qn), s1 = qn;
+                        for (int32_t t = 1; t <= tn; ++t)
+                        {
+                            const uint32_t ci = (tgt[t_tb + t - 1] >> 1) & 3u;
+                            int32_t h = advance_word(nw == 1 ? last_hbit : (1u << (kWord - 1)), select4(ci, lp[0][0], lp[0][1], lp[0][2], lp[0][3]), pv0, mv0, 1, nullptr);
+                            s0 += h;
+                            lf.score[lf.at(0, t)] = s0;
+                            lf.pv[lf.at(0, t)]    = pv0;
+                            lf.mv[lf.at(0, t)]    = mv0;
+                            if (nw == 2)
+                            {
+                                h = advance_word(last_hbit, select4(ci, lp[1][0], lp[1][1], lp[1][2], lp[1][3]), pv1, mv1, h, nullptr);
+                                s1 += h;
+                                lf.score[lf.at(1, t)] = s1;
+                                lf.pv[lf.at(1, t)]    = pv1;
+                                lf.mv[lf.at(1, t)]    = mv1;
+                            }
+                        }
+                        const uint32_t last_mask = qn % kWord != 0 ? ((1u << (qn % kWord)) - 1) : ~0u;
+                        int32_t i = qn, j = tn, l = 0;
+                        int32_t myscore = lf.score[lf.at((i - 1) / kWord, j)];
+                        while (i > 0 && j > 0)
+                        {
+                            // row 0 of the matrix is 0, 1, 2, ...
+                            const int32_t above = i - 1 == 0 ? j : cell_score(lf, i - 1, j, last_mask);
+                            const int32_t diag  = i - 1 == 0 ? j - 1 : cell_score(lf, i - 1, j - 1, last_mask);
+                            const int32_t left  = cell_score(lf, i, j - 1, last_mask);
+                            int8_t st;
+                            if (left + 1 == myscore) { st = kInsertion; myscore = left; --j; }
+                            else if (above + 1 == myscore) { st = kDeletion; myscore = above; --i; }
+                            else { st = diag == myscore ? kMatch : kMismatch; myscore = diag; --i; --j; }
+                            out[l++] = st;
+                        }
+                        for (int32_t c = 0; c < i; ++c) out[l + c] = kDeletion;
+                        l += i;
+                        for (int32_t c = 0; c < j; ++c) out[l + c] = kInsertion;
+                        l += j;
+                        plen = l;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                // append the pieces in order
+                for (int32_t q = 0; q < m; ++q)
+                {
+                    const int32_t pl = __builtin_amdgcn_readlane(plen, q), po = __builtin_amdgcn_readlane(so, q);
+                    for (int32_t c = lane; c < pl; c += 64) path[len + c] = stage[po + c];
+                    len += pl;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // the next round reuses the stage and the leaf area
+                r += m - 1;
+                continue;
+            }
+        }
         const int32_t k  = __builtin_amdgcn_readfirstlane((int32_t)order[r]);
         const LvPart q   = term[k];
         const int32_t qb = __builtin_amdgcn_readfirstlane(q.qb), qe = __builtin_amdgcn_readfirstlane(q.qe);
