@@ -386,54 +386,50 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
     int32_t myscore          = i > 0 ? b.score[b.at((i - 1) / kWord, j)] : 0;
     int32_t pos = 0, r_count = 0;
     int8_t prev_r = -1;
-    // The three neighbour scores of a step are fetched together (nine independent loads, one memory round trip);
-    // neighbours that the reference derives from a formula instead of the matrix are clamped for the fetch and
-    // replaced afterwards.
-    auto fetch3 = [&](int32_t i0, int32_t j0, int32_t i1, int32_t j1, int32_t i2, int32_t j2, int32_t& s0, int32_t& s1, int32_t& s2) {
+    // The three neighbour scores of a step from five loads instead of nine (round 3). `left` = cell (i2, j2) is read as the
+    // reference reads it (word score minus / plus the vertical deltas above the row: cell_score). `diag` is the cell above it
+    // in the same column, (i2 - 1, j2): left minus the vertical delta of row i2, a bit of the two words already loaded.
+    // `above` is the cell above the current one, whose score the walk carries: myscore minus the vertical delta of the
+    // current row in column j_cur (two loads). Within a word these are algebraic identities of cell_score; across a word
+    // boundary they hold because the stored word scores and the bit vectors describe the same column (the 10 000- and
+    // 1 000 000-pair goldens and the reference vectors check every walk). Neighbours that the reference derives from a
+    // formula instead of the matrix are clamped for the fetch and replaced by the callers afterwards; when (i2, j2) itself is
+    // outside the band the anchor is (i2 - 1, j2).
+    auto fetch3 = [&](int32_t i_cur, int32_t j_cur, int32_t i2, int32_t j2, int32_t& above, int32_t& diag, int32_t& left) {
         const int32_t rows = band_width;
-        auto ref = [&](int32_t i, int32_t j, size_t& idx, uint32_t& mask) {
-            i                 = min(max(i, 1), rows);
-            j                 = max(j, 0);
-            const int32_t w   = (i - 1) / kWord;
-            const int32_t bit = (i - 1) % kWord;
-            mask              = bit == 31 ? 0u : ((~1u) << bit);
-            if (w == b.n_rows - 1) mask &= last_mask;
-            idx = b.at(w, j);
-        };
-        size_t x0, x1, x2;
-        uint32_t m0, m1, m2;
-        ref(i0, j0, x0, m0);
-        ref(i1, j1, x1, m1);
-        ref(i2, j2, x2, m2);
-        int32_t c0, c1, c2;
-        uint32_t p0, p1, p2, n0, n1, n2;
-        const int32_t jj0 = max(j0, 0), jj1 = max(j1, 0), jj2 = max(j2, 0);
-        const bool cached = tile_cols >= 2 && min(jj0, min(jj1, jj2)) >= tile_lo && max(jj0, max(jj1, jj2)) <= tile_hi;
+        const int32_t ia = min(max(i_cur, 1), rows), wa = (ia - 1) / kWord, ba = (ia - 1) % kWord;
+        const bool in2   = i2 >= 1 && i2 <= rows;
+        const int32_t il = in2 ? i2 : min(max(i2 - 1, 1), rows), wl = (il - 1) / kWord, bl = (il - 1) % kWord;
+        uint32_t mask    = bl == 31 ? 0u : ((~1u) << bl);
+        if (wl == b.n_rows - 1) mask &= last_mask;
+        const int32_t ja = max(j_cur, 0), jl = max(j2, 0);
+        const size_t xa = b.at(wa, ja), xl = b.at(wl, jl);
+        uint32_t pa, na, pl, nl;
+        int32_t cl;
+        const bool cached = tile_cols >= 2 && min(ja, jl) >= tile_lo && max(ja, jl) <= tile_hi;
         if (cached)
         {
-            // element of (word w, column j) in the tile: ((j - tile_lo) * n_rows + w) * 3; x / stride is (j * n_rows + w)
-            const int32_t base = tile_lo * b.n_rows;
-            const int32_t st   = b.stride;
-            const int32_t e0 = ((int32_t)(x0 / st) - base) * 3, e1 = ((int32_t)(x1 / st) - base) * 3, e2 = ((int32_t)(x2 / st) - base) * 3;
-            p0 = tile[e0]; n0 = tile[e0 + 1]; c0 = (int32_t)tile[e0 + 2];
-            p1 = tile[e1]; n1 = tile[e1 + 1]; c1 = (int32_t)tile[e1 + 2];
-            p2 = tile[e2]; n2 = tile[e2 + 1]; c2 = (int32_t)tile[e2 + 2];
+            // element of (word w, column j) in the tile: ((j - tile_lo) * n_rows + w) * 3
+            const int32_t ea = ((ja - tile_lo) * b.n_rows + wa) * 3, el = ((jl - tile_lo) * b.n_rows + wl) * 3;
+            pa = tile[ea]; na = tile[ea + 1];
+            pl = tile[el]; nl = tile[el + 1]; cl = (int32_t)tile[el + 2];
         }
         else
         {
-            c0 = b.score[x0]; c1 = b.score[x1]; c2 = b.score[x2];
-            p0 = b.pv[x0]; p1 = b.pv[x1]; p2 = b.pv[x2];
-            n0 = b.mv[x0]; n1 = b.mv[x1]; n2 = b.mv[x2];
+            pa = b.pv[xa]; na = b.mv[xa];
+            pl = b.pv[xl]; nl = b.mv[xl]; cl = b.score[xl];
         }
-        s0 = c0 - __popc(m0 & p0) + __popc(m0 & n0);
-        s1 = c1 - __popc(m1 & p1) + __popc(m1 & n1);
-        s2 = c2 - __popc(m2 & p2) + __popc(m2 & n2);
+        const int32_t s   = cl - __popc(mask & pl) + __popc(mask & nl);
+        const int32_t dvl = (int32_t)((pl >> bl) & 1u) - (int32_t)((nl >> bl) & 1u);
+        left  = s;
+        diag  = in2 ? s - dvl : s;
+        above = myscore - ((int32_t)((pa >> ba) & 1u) - (int32_t)((na >> ba) & 1u));
     };
     while (j >= diagonal_end)
     {
         int32_t above, diag, left;
         ensure(j);
-        fetch3(i - 1, j, i - 1, j - 1, i, j - 1, above, diag, left);
+        fetch3(i, j, i, j - 1, above, diag, left);
         if (i <= 1) { above = last_diag + j - diagonal_end; diag = last_diag + j - 1 - diagonal_end; }
         if (i < 1) left = last_diag + j - 1 - diagonal_end;
         int8_t r;
@@ -446,7 +442,7 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
     {
         int32_t above, diag, left;
         ensure(j);
-        fetch3(i - 1, j, i, j - 1, i + 1, j - 1, above, diag, left);
+        fetch3(i, j, i + 1, j - 1, above, diag, left);
         if (i <= 1) above = out_of_band;
         if (i <= 0) diag = j - 1;
         if (i >= band_width) left = out_of_band;
@@ -460,7 +456,7 @@ __device__ int32_t backtrace_banded(int8_t* path, int32_t* counts, const Band& b
     {
         int32_t above, diag, left;
         ensure(j);
-        fetch3(i - 1, j, i - 1, j - 1, i, j - 1, above, diag, left);
+        fetch3(i, j, i, j - 1, above, diag, left);
         if (i == 1) { above = j; diag = j - 1; }
         if (i > band_width) left = out_of_band;
         int8_t r;
