@@ -254,6 +254,30 @@ def test_default_aligner_level_by_level_kernel_agrees(monkeypatch):
     for (st, states), (q, t) in zip(out["levels"], pairs):
         assert st == 0
         assert states == A.hirschberg(q, t, max_len)["states"]
+    # an aligner whose targets may be much longer than its queries: the kernel's LDS rows are sized from max_query_length, so
+    # pairs with longer targets are left to the depth-first kernel launched behind it -- inside the same batch
+    mixed = []
+    for k in range(40):
+        n = rng.choice([20, 100, 300, 500])
+        q = "".join(rng.choice("ACGT") for _ in range(n))
+        tl = rng.choice([n, n + 30, 600, 700, 1500, 4000])
+        t = (q + "".join(rng.choice("ACGT") for _ in range(4000)))[:tl]
+        mixed.append((q, t))
+    got = {}
+    for name, flag in (("levels", None), ("depth_first", "0")):
+        if flag is None:
+            monkeypatch.delenv("GWHIP_HIRSCHBERG_LEVELS", raising=False)
+        else:
+            monkeypatch.setenv("GWHIP_HIRSCHBERG_LEVELS", flag)
+        al = cudaaligner.CudaAlignerBatch(500, 4000, len(mixed), max_device_memory_allocator_caching_size=8 << 30)
+        for q, t in mixed:
+            assert al.add_alignment(q, t) == 0
+        al.align_all()
+        got[name] = [(r.status, list(r.alignment)) for r in al.get_alignments()]
+    assert got["levels"] == got["depth_first"]
+    for (st, states), (q, t) in zip(got["levels"], mixed):
+        assert st == 0
+        assert states == A.hirschberg(q, t, 500)["states"]
 
 
 # ---- the non-default classes: AlignerGlobalUkkonen / AlignerGlobalMyers ----
