@@ -1325,6 +1325,11 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
     // one whose band start is too far left to encode.
     int32_t nxt[6];
     int32_t m0v = 0, m1v = 0, bsv = 0, p0v = 0, p1v = 0, p2v = 0, prev_bsv = 0;
+    //   kb = band start [0:16) | what THIS wave does with the row [16:19) | the wave's block in that row [19:27)
+    //        0..2 straight-line row with 1 / 2 / 3 predecessors, 3..5 the same in the first block of the band, 6 general row,
+    //        7 the band does not reach the wave's block. Band starts only move right, so the wave's block of a row is a
+    //        function of the row alone: the first block b >= band start / 256 with b = wave (mod kSkWaves).
+    int32_t kbv = 0;
     auto load_batch = [&](int32_t base, int32_t (&dst)[6]) {
         const int32_t row = min(base + lane, graph_count);
         const __attribute__((address_space(1))) int32_t* src = (const __attribute__((address_space(1))) int32_t*)(rowinfo + row);
@@ -1357,6 +1362,11 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
         const bool general = cnt > 3 || dmax >= near_rows || dmax > 63 || emax > 1020 || row > graph_count;
         m0v = (w0 & 0x7fff) | (general ? 0x8000 : 0) | ((d0 & 0xff) << 16) | ((d1 & 0xff) << 24);
         m1v = (d2 & 0xff) | (((e0 >> 2) & 0xff) << 8) | (((e1 >> 2) & 0xff) << 16) | (((e2 >> 2) & 0xff) << 24);
+        const int32_t b_lo  = bsv >> 8;
+        const int32_t blk_r = b_lo + ((wave - b_lo) & (kSkWaves - 1));
+        const bool skip     = (blk_r << 8) >= bsv + band_width;
+        const int32_t kind  = skip ? 7 : (general ? 6 : (blk_r == b_lo ? 3 : 0) + min(max(cnt, 1), 3) - 1);
+        kbv = bsv | (kind << 16) | (blk_r << 19);
     };
     load_batch(1, nxt);
     adopt_batch(1);
@@ -1438,7 +1448,9 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
         }
         const uint32_t m0        = (uint32_t)__builtin_amdgcn_readlane(m0v, ridx);
         const uint32_t m1        = (uint32_t)__builtin_amdgcn_readlane(m1v, ridx);
-        const int32_t bs         = __builtin_amdgcn_readlane(bsv, ridx);
+        const uint32_t kb        = (uint32_t)__builtin_amdgcn_readlane(kbv, ridx);
+        const int32_t bs         = (int32_t)(kb & 0xffffu);
+        const int32_t kind       = (int32_t)((kb >> 16) & 7u);
         const uint32_t base      = m0 & 0xffu;
         const int32_t pred_count = (int32_t)((m0 >> 8) & 0x7fu);
         const bool general       = (m0 & 0x8000u) != 0;
@@ -1470,12 +1482,12 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
             if (far && sksel == 3) skacc += 1000;
         }
 
-        while (bs >= 256 * (blk + 1)) // the band has passed this wave's block: on to the next one
+        if ((int32_t)(kb >> 19) != blk) // the band has passed this wave's block: on to the next one
         {
-            blk += kSkWaves;
+            blk = (int32_t)(kb >> 19);
             enter_block(blk);
         }
-        if (256 * blk >= bs + band_width) // the band has not reached this block yet
+        if (kind == 7) // the band has not reached this block yet
         {
             publish(r, 0);
             if (sksel == 2) skacc++;
@@ -1485,7 +1497,7 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
         const int32_t tg       = cvec - bs; // index of the lane's first cell in the band
         // cells of column 256 blk of the predecessor rows are the left neighbour's: it must be past row r - 1
         const uint64_t t_ws = sksel == 10 ? clock64() : 0;
-        wait_left(r - 1);
+        if (left_done < r - 1) wait_left(r - 1);
         if (sksel == 10) skacc += clock64() - t_ws;
         if (sksel == 1) skacc++;
         if (sksel == 12 && first_block) skacc++;
@@ -1715,18 +1727,12 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                 publish(r, __builtin_amdgcn_readlane(Hk[3], kWave - 1));
                 asm volatile("; FASTROW_END %0 %1" ::"n"(NP), "n"((int)FIRST));
             };
-            if (first_block)
-            {
-                if (pred_count <= 1) fast_row(std::integral_constant<int, 1>{}, std::true_type{});
-                else if (pred_count == 2) fast_row(std::integral_constant<int, 2>{}, std::true_type{});
-                else fast_row(std::integral_constant<int, 3>{}, std::true_type{});
-            }
-            else
-            {
-                if (pred_count <= 1) fast_row(std::integral_constant<int, 1>{}, std::false_type{});
-                else if (pred_count == 2) fast_row(std::integral_constant<int, 2>{}, std::false_type{});
-                else fast_row(std::integral_constant<int, 3>{}, std::false_type{});
-            }
+            if (kind == 0) fast_row(std::integral_constant<int, 1>{}, std::false_type{});
+            else if (kind == 1) fast_row(std::integral_constant<int, 2>{}, std::false_type{});
+            else if (kind == 3) fast_row(std::integral_constant<int, 1>{}, std::true_type{});
+            else if (kind == 4) fast_row(std::integral_constant<int, 2>{}, std::true_type{});
+            else if (kind == 2) fast_row(std::integral_constant<int, 3>{}, std::false_type{});
+            else fast_row(std::integral_constant<int, 3>{}, std::true_type{});
             if (sksel == 8 || (sksel == 11 && first_block)) skacc += clock64() - t_rb;
             continue;
         }
