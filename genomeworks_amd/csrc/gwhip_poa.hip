@@ -536,8 +536,12 @@ __global__ __launch_bounds__(kWave) void poa_msa_kernel(KernelArgs a)
     wave_sync();
     if (consensus[0] == kKernelError) return;
     uint8_t* msa = a.msa + (size_t)w * c.max_sequences_per_poa * c.max_consensus_size;
-    for (int32_t s = threadIdx.x; s < (int32_t)wd.num_seqs; s += kWave)
-        generate_msa_row<IdT>(g, (uint16_t)s, msa, msa_length, (uint32_t)c.max_sequences_per_poa, (uint32_t)c.max_consensus_size);
+    if (done) // wave mode: one lane per node scatters into the rows
+        generate_msa_rows_wave<IdT>(g, n, (int32_t)wd.num_seqs, msa, msa_length, (uint32_t)c.max_sequences_per_poa,
+                                    (uint32_t)c.max_consensus_size, lane);
+    else
+        for (int32_t s = threadIdx.x; s < (int32_t)wd.num_seqs; s += kWave)
+            generate_msa_row<IdT>(g, (uint16_t)s, msa, msa_length, (uint32_t)c.max_sequences_per_poa, (uint32_t)c.max_consensus_size);
 }
 
 template <typename IdT>

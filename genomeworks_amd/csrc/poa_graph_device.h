@@ -1861,4 +1861,56 @@ __device__ void generate_msa_row(const GraphView<IdT>& g, uint16_t s, uint8_t* m
     row[msa_length] = '\0';
 }
 
+// ------------------------------------------------------------------------------------------------
+// All MSA rows of a window by the whole wavefront (round 3). generate_msa_row above walks one sequence per lane from its
+// first node along the out-edges whose coverage list names it: a chain of two or three dependent HBM round trips per
+// node, 30 000 nodes long on long reads, on at most 32 lanes. The same rows follow from the edges alone: sequence s
+// visits exactly the end points of the edges whose list contains s (a read leaves every node it visits through one
+// edge, and every such edge lies on its path), plus its first node when it has no edge at all. So: fill the rows with
+// '-', then one lane per NODE scatters the node's base into the rows of the sequences on its out-edges -- and the
+// edge's head into the same rows, which covers each sequence's last node. Loads of different nodes are independent,
+// equal bytes may be written twice. Result identical to the walk (GWHIP_MSA_SERIAL=1 selects the walk: A/B in
+// tests/test_gpu_poa.py).
+// ------------------------------------------------------------------------------------------------
+template <typename IdT>
+__device__ __forceinline__ void generate_msa_rows_wave(const GraphView<IdT>& g, int32_t node_count, int32_t num_seqs, uint8_t* msa,
+                                                       int32_t msa_length, uint32_t max_sequences_per_poa,
+                                                       uint32_t max_limit_consensus_size, int lane)
+{
+    for (int32_t s = 0; s < num_seqs; ++s)
+    {
+        uint8_t* row = msa + (size_t)s * max_limit_consensus_size;
+        for (int32_t i = lane; i < msa_length; i += kWave) row[i] = '-';
+    }
+    wave_sync();
+    for (int32_t n = lane; n < node_count; n += kWave)
+    {
+        const int64_t eb   = (int64_t)n * kEdges;
+        const uint8_t base = g.nodes[n];
+        const int32_t pos  = (int32_t)g.msa_pos[n];
+        const int32_t oc   = g.outgoing_edge_count[n];
+        for (int32_t e = 0; e < oc; ++e)
+        {
+            const int32_t to     = (int32_t)g.outgoing_edges[eb + e];
+            const int32_t cc     = (int32_t)g.out_cov_cnt[eb + e];
+            const uint8_t tbase  = g.nodes[to];
+            const int32_t tpos   = (int32_t)g.msa_pos[to];
+            const uint16_t* list = g.out_cov + (eb + e) * max_sequences_per_poa;
+            for (int32_t m = 0; m < cc; ++m)
+            {
+                uint8_t* row = msa + (size_t)list[m] * max_limit_consensus_size;
+                row[pos]     = base;
+                row[tpos]    = tbase;
+            }
+        }
+    }
+    for (int32_t s = lane; s < num_seqs; s += kWave)
+    {
+        uint8_t* row     = msa + (size_t)s * max_limit_consensus_size;
+        const int32_t n0 = (int32_t)g.seq_begin[s];
+        row[(int32_t)g.msa_pos[n0]] = g.nodes[n0];
+        row[msa_length]             = '\0';
+    }
+}
+
 } // namespace gwhip

@@ -245,6 +245,18 @@ def test_long_read_forward_and_traceback_variants_agree(monkeypatch):
     assert out["default"] == out["single_wave"]
     assert out["default"] == out["cached_full_resort"]   # incremental Kahn order (default) vs the cached full re-sort
     assert out["default"] == out["incremental_in_hbm"]   # ... LDS counters and window vs node words in HBM
+    # MSA rows scattered by one lane per node (default) against one lane per sequence walking its path (and the serial
+    # racon order): GWHIP_MSA_SERIAL=1
+    monkeypatch.delenv("GWHIP_DEBUG", raising=False)
+    monkeypatch.setenv("GWHIP_MSA_SERIAL", "1")
+    b = run_gpu(windows, "adaptive_band", max_seq=8192, max_seqs=12, output_type="msa", nodes=4 * 8192)
+    assert (b.get_msa(), b.total_cells()) == out["default"]
+    short = [[r.decode() for r in synthetic.generate_window(9300 + w, 400, 14, 20, 12, 12)] for w in range(6)]
+    short.append(["ACGTACGTAC"])                              # a window of one read
+    short.append(["ACGTACGTAC", "A", "ACGTACGTACGGGT"])       # a read of one base
+    walked = run_gpu(short, "static_band", max_seq=512, max_seqs=16, output_type="msa").get_msa()
+    monkeypatch.delenv("GWHIP_MSA_SERIAL", raising=False)
+    assert run_gpu(short, "static_band", max_seq=512, max_seqs=16, output_type="msa").get_msa() == walked
     assert out["default"] == out["serial_full_resort"]   # ... vs the reference's schedule on one lane
     (msa, status), _ = out["default"]
     cfg = oracle_cfg("adaptive_band", 8192, 12, output_mask=2, nodes=4 * 8192)
