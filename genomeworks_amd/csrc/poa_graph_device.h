@@ -1349,15 +1349,31 @@ __device__ __forceinline__ bool topsort_kahn_incr_cnt8(const GraphView<IdT>& g, 
         if (tail - head > kTwRing) return false;
     }
     wave_sync();
-    // phase 3 (all lanes): publish order, inverse map and the per-node record for the next read
-    for (int32_t i = lane; i < node_count; i += kWave)
+    // phase 3 (all lanes, four chunks per round trip): publish order, inverse map and the per-node record for the next read
+    for (int32_t base = 0; base < node_count; base += 4 * kWave)
     {
-        const uint32_t e   = (uint32_t)queue[i];
-        const int32_t node = (int32_t)(e & kId);
-        const uint32_t oc = g.outgoing_edge_count[node], ic = g.incoming_edge_count[node];
-        g.sorted_poa[i]        = (IdT)node;
-        g.node_id_to_pos[node] = (IdT)i;
-        g.local_cnt[node]      = (uint16_t)((e >> 28) | (oc << 4) | (ic << 10));
+        uint32_t e[4], oc[4], ic[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) e[q] = (uint32_t)queue[min(base + q * kWave + lane, node_count - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int32_t node = (int32_t)(e[q] & kId);
+            oc[q] = g.outgoing_edge_count[node];
+            ic[q] = g.incoming_edge_count[node];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int32_t i = base + q * kWave + lane;
+            if (i < node_count)
+            {
+                const int32_t node     = (int32_t)(e[q] & kId);
+                g.sorted_poa[i]        = (IdT)node;
+                g.node_id_to_pos[node] = (IdT)i;
+                g.local_cnt[node]      = (uint16_t)((e[q] >> 28) | (oc[q] << 4) | (ic[q] << 10));
+            }
+        }
     }
     wave_sync();
     return true;
