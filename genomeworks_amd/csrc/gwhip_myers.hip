@@ -2457,10 +2457,16 @@ __global__ __launch_bounds__(64) void hirschberg_levels_kernel(HirschbergArgs a)
                         int32_t myscore = lf.score[lf.at((i - 1) / kWord, j)];
                         while (i > 0 && j > 0)
                         {
-                            // row 0 of the matrix is 0, 1, 2, ...
-                            const int32_t above = i - 1 == 0 ? j : cell_score(lf, i - 1, j, last_mask);
-                            const int32_t diag  = i - 1 == 0 ? j - 1 : cell_score(lf, i - 1, j - 1, last_mask);
-                            const int32_t left  = cell_score(lf, i, j - 1, last_mask);
+                            // left as the reference reads it; the cell above it (diag) and the cell above the current one from
+                            // the vertical-delta bits of row i (see backtrace_banded's fetch3); row 0 of the matrix is 0, 1, 2, ...
+                            const int32_t wi = (i - 1) / kWord, bi = (i - 1) % kWord;
+                            const uint32_t pl = lf.pv[lf.at(wi, j - 1)], nl = lf.mv[lf.at(wi, j - 1)];
+                            const uint32_t pa = lf.pv[lf.at(wi, j)], na = lf.mv[lf.at(wi, j)];
+                            uint32_t mask     = bi == 31 ? 0u : ((~1u) << bi);
+                            if (wi == nw - 1) mask &= last_mask;
+                            const int32_t left  = lf.score[lf.at(wi, j - 1)] - __popc(mask & pl) + __popc(mask & nl);
+                            const int32_t diag  = i == 1 ? j - 1 : left - ((int32_t)((pl >> bi) & 1u) - (int32_t)((nl >> bi) & 1u));
+                            const int32_t above = i == 1 ? j : myscore - ((int32_t)((pa >> bi) & 1u) - (int32_t)((na >> bi) & 1u));
                             int8_t st;
                             if (left + 1 == myscore) { st = kInsertion; myscore = left; --j; }
                             else if (above + 1 == myscore) { st = kDeletion; myscore = above; --i; }
