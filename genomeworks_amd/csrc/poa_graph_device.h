@@ -1471,31 +1471,50 @@ __device__ __forceinline__ bool topsort_racon_wave(const GraphView<IdT>& g, int3
         if (lane == 0) stack[0] = (uint32_t)i;
         while (top >= 0)
         {
-            const int32_t node = wave_first((int32_t)stack[top]);
-            const uint32_t st  = (uint32_t)wave_first((int32_t)state[node]);
-            bool valid         = true;
+            // a stack entry: node [0:24) | its alignment count [24:30) | "expanded" [31]: this very entry has pushed its
+            // unfinished predecessors and aligned nodes once -- they sat directly above it and are all finished by the
+            // time it is on top again (LIFO), so the second visit needs no look at its edges (a second entry of the same
+            // node, pushed by somebody else in between, carries no such bit and takes the full look)
+            const uint32_t entry = (uint32_t)wave_first((int32_t)stack[top]);
+            const int32_t node   = (int32_t)(entry & 0xffffffu);
+            const uint32_t st    = (uint32_t)wave_first((int32_t)state[node]);
+            bool valid           = true;
             if ((st & 3) != 2)
             {
-                // one round trip: both counts, every in-edge slot, every alignment slot
-                const int32_t ic  = wave_first((int32_t)g.incoming_edge_count[node]);
-                const int32_t ac  = wave_first((int32_t)g.node_alignment_count[node]);
-                const int32_t ed  = lane < kEdges ? (int32_t)g.incoming_edges[(int64_t)node * kEdges + lane] : 0;
-                const int32_t al  = lane < kAligns ? (int32_t)g.node_alignments[(int64_t)node * kAligns + lane] : 0;
-                const bool check  = (st & 4) != 0;
-                const bool push_e = lane < ic && (state[max(ed, 0)] & 3) != 2;
-                const bool push_a = check && lane < ac && (state[max(al, 0)] & 3) != 2;
-                const unsigned long long me = __ballot(push_e), ma = __ballot(push_a);
-                const int32_t ne = __popcll(me), na = __popcll(ma);
-                if (top + ne + na >= stack_cap) return false;
-                const unsigned long long below = (1ull << lane) - 1;
-                if (push_e) stack[top + 1 + __popcll(me & below)] = (uint32_t)ed;
-                if (push_a)
+                const bool check = (st & 4) != 0;
+                int32_t ac = 0, al = 0;
+                if (entry >> 31)
                 {
-                    stack[top + 1 + ne + __popcll(ma & below)] = (uint32_t)al;
-                    state[al] &= (uint8_t)~4u; // check[aid] = 0 (two slots never name the same node)
+                    ac = (int32_t)((entry >> 24) & 63u);
+                    if (check && ac > 0) al = lane < kAligns ? (int32_t)g.node_alignments[(int64_t)node * kAligns + lane] : 0;
                 }
-                valid = ne + na == 0;
-                top += ne + na;
+                else
+                {
+                    // one round trip: both counts, every in-edge slot, every alignment slot
+                    const int32_t ic  = wave_first((int32_t)g.incoming_edge_count[node]);
+                    ac                = wave_first((int32_t)g.node_alignment_count[node]);
+                    const int32_t ed  = lane < kEdges ? (int32_t)g.incoming_edges[(int64_t)node * kEdges + lane] : 0;
+                    al                = lane < kAligns ? (int32_t)g.node_alignments[(int64_t)node * kAligns + lane] : 0;
+                    const bool push_e = lane < ic && (state[max(ed, 0)] & 3) != 2;
+                    const bool push_a = check && lane < ac && (state[max(al, 0)] & 3) != 2;
+                    const unsigned long long me = __ballot(push_e), ma = __ballot(push_a);
+                    const int32_t ne = __popcll(me), na = __popcll(ma);
+                    if (top + ne + na >= stack_cap) return false;
+                    const unsigned long long below = (1ull << lane) - 1;
+                    if (push_e) stack[top + 1 + __popcll(me & below)] = (uint32_t)ed;
+                    if (push_a)
+                    {
+                        stack[top + 1 + ne + __popcll(ma & below)] = (uint32_t)al;
+                        state[al] &= (uint8_t)~4u; // check[aid] = 0 (two slots never name the same node)
+                    }
+                    valid = ne + na == 0;
+                    if (!valid && lane == 0)
+                    {
+                        stack[top]  = (uint32_t)node | ((uint32_t)min(ac, 63) << 24) | 0x80000000u;
+                        state[node] = (uint8_t)((st & ~3u) | 1u);
+                    }
+                    top += ne + na;
+                }
                 if (valid)
                 {
                     if (lane == 0) state[node] = (uint8_t)((st & ~3u) | 2u);
@@ -1514,8 +1533,6 @@ __device__ __forceinline__ bool topsort_racon_wave(const GraphView<IdT>& g, int3
                         sorted_idx += 1 + ac;
                     }
                 }
-                else if (lane == 0)
-                    state[node] = (uint8_t)((st & ~3u) | 1u);
                 // (LDS only: one wavefront's LDS operations execute in order; the order's global stores are not read before
                 // the end and must not be waited for in every visit)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
