@@ -1,6 +1,7 @@
 // aligner_global.cpp -- host side of the fixed-limit global aligners (see aligner_global.hpp).
 // The sequences are packed back to back (q0 t0 q1 t1 ...) instead of the reference's fixed 2 * max_length stride;
 // limits, statuses and the host-side reversal of the kernels' back-to-front paths follow aligner_global.cpp.
+#include <cstring>
 #include <thread>
 #include "aligner_global.hpp"
 
@@ -142,7 +143,21 @@ StatusType AlignerGlobal::sync_alignments()
             const size_t count       = static_cast<size_t>(std::abs(len));
             const int8_t* r_begin    = results_h_.data() + seq_starts_h_[2 * i];
             std::vector<AlignmentState> states(count);
-            for (size_t k = 0; k < count; ++k) states[k] = static_cast<AlignmentState>(r_begin[count - 1 - k]);
+            static_assert(sizeof(AlignmentState) == 1, "the device writes one byte per state");
+            {
+                // reversed copy, eight states at a time (one byte-swapped 64-bit word), the tail byte by byte
+                uint8_t* dst       = reinterpret_cast<uint8_t*>(states.data());
+                const uint8_t* src = reinterpret_cast<const uint8_t*>(r_begin);
+                size_t k           = 0;
+                for (; k + 8 <= count; k += 8)
+                {
+                    uint64_t v;
+                    std::memcpy(&v, src + count - 8 - k, 8);
+                    v = __builtin_bswap64(v);
+                    std::memcpy(dst + k, &v, 8);
+                }
+                for (; k < count; ++k) dst[k] = src[count - 1 - k];
+            }
             if (count != 0 || (qlen == 0 && tlen == 0))
             {
                 alignment->set_alignment(std::move(states), len >= 0);
