@@ -31,6 +31,8 @@ def lib():
         L.poa_workspace_create.argtypes = [C.POINTER(PoaCfg)]
         L.poa_workspace_destroy.argtypes = [C.c_void_p]
         L.poa_workspace_overflow_events.restype = C.c_int64
+        L.poa_oracle_msa_scatter_mismatches.restype = C.c_int64
+        L.poa_oracle_msa_scatter_mismatches.argtypes = []
         L.poa_workspace_overflow_events.argtypes = [C.c_void_p]
         L.poa_process_window.restype = C.c_int32
         L.poa_process_window.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int32, C.c_size_t] + [C.c_void_p] * 4
@@ -133,6 +135,12 @@ class Workspace:
 
     def __exit__(self, *a):
         self.close()
+
+    @staticmethod
+    def msa_scatter_mismatches():
+        """Windows (process-wide) whose MSA rows by scatter over the nodes -- the kernel's formulation -- differed from the
+        reference's per-sequence walk."""
+        return lib().poa_oracle_msa_scatter_mismatches()
 
     def overflow_events(self):
         return lib().poa_workspace_overflow_events(self.h)

@@ -95,3 +95,5 @@ def test_config4_plan_is_reproducible_and_oracle_sample_matches():
             ref = ws.process(reads[:c["max_sequences_per_poa"]])
         assert ref["status"] == det[w]["status"] and ref["cells"] == det[w]["cells"]
         assert lr.msa_digest(ref["msa"]) == det[w]["msa_sha"]
+    # the scalar model of the kernel's MSA rows (scatter over the nodes) ran next to the reference's walk on these windows too
+    assert O.Workspace.msa_scatter_mismatches() == 0

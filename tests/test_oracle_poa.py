@@ -232,3 +232,26 @@ def test_incremental_topsort_model_equals_kahn(lane_order):
     assert st["reads"] > 500 and st["mismatch"] == 0, st
     assert st["empty_blocks"] == 0                       # a block always replays at least the queue head
     assert st["block_nodes"] > 4 * st["real_steps"], st  # and most pops are replayed, not recomputed
+
+
+def test_msa_rows_by_scatter_over_the_nodes_equal_the_walk():
+    """The MSA kernel does not walk every sequence along the edges whose coverage list names it (the reference's rule,
+    cudapoa_generate_msa.cuh:56-125) but scatters every node's base into the rows of the sequences on its out-edges
+    (generate_msa_rows_wave). The oracle runs a scalar model of that next to the walk on every MSA window; over short and
+    long, similar and divergent, single-read and single-base windows, all band modes, the two must never differ."""
+    from genomeworks_amd import synthetic
+    before = O.Workspace.msa_scatter_mismatches()
+    cases = 0
+    for mode, band in (("full_band", 256), ("static_band", 256), ("adaptive_band", 256), ("static_band_traceback", 256)):
+        cfg = O.make_cfg(512, 16, band, {"full_band": 0, "static_band": 1, "adaptive_band": 2, "static_band_traceback": 3}[mode],
+                         output_mask=2)
+        with O.Workspace(cfg) as ws:
+            for w in range(12):
+                reads = [r.decode() for r in synthetic.generate_window(7000 + w, 60 + 35 * w, 3 + w, 4 + 3 * w, 2 + 2 * w, 2 + 2 * w)]
+                ws.process(reads)
+                cases += 1
+            for reads in (["ACGTACGTAC"], ["ACGTACGTAC", "A", "ACGTACGTACGGGT"], ["AAAA", "CCCC", "GGGG", "TTTT"], ["ACGT" * 30, "ACGT" * 29 + "A"]):
+                ws.process(reads)
+                cases += 1
+    assert cases == 64
+    assert O.Workspace.msa_scatter_mismatches() == before
