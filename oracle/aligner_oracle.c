@@ -267,6 +267,33 @@ static void compute_scores_banded(int32_t* diagonal_begin, int32_t* diagonal_end
         ++r_count;                                                                                                     \
     } while (0)
 
+/* Scalar model of the kernels' backtrace step (gwhip_myers.hip, backtrace_banded::fetch3): not three cell scores as the
+ * reference reads them, but `left` = cell (i2, j2) alone, `diag` = the cell above it = left minus the vertical delta of row
+ * i2 (a bit of pv / mv of the same word), `above` = the walk's own score minus the vertical delta of the current row in the
+ * current column. Evaluated next to the reference's three reads in every step of every backtrace of this oracle, wherever
+ * the kernel uses the value (the reference's formula cases override it elsewhere); a difference counts as a mismatch
+ * (aligner_oracle_delta_identity_mismatches, asserted 0 by the tests). */
+static int64_t g_delta_identity_mismatches = 0;
+int64_t aligner_oracle_delta_identity_mismatches(void) { return g_delta_identity_mismatches; }
+
+static int32_t vertical_delta(const band_t* b, int32_t i, int32_t j)
+{
+    const int32_t w = (i - 1) / WORD_SIZE, bit = (i - 1) % WORD_SIZE;
+    return (int32_t)((PV(b, w, j) >> bit) & 1u) - (int32_t)((MV(b, w, j) >> bit) & 1u);
+}
+static void model_step(const band_t* b, WordType mask, int32_t rows, int32_t i, int32_t j, int32_t i2, int32_t j2, int32_t myscore,
+                       int32_t* above, int32_t* diag)
+{
+    const int32_t ia  = i < 1 ? 1 : (i > rows ? rows : i);
+    const int in2     = i2 >= 1 && i2 <= rows;
+    int32_t il        = in2 ? i2 : i2 - 1;
+    il                = il < 1 ? 1 : (il > rows ? rows : il);
+    const int32_t jl  = j2 < 0 ? 0 : j2, ja = j < 0 ? 0 : j;
+    const int32_t s   = get_myers_score(il, jl, b, mask);
+    *diag             = in2 ? s - vertical_delta(b, il, jl) : s;
+    *above            = myscore - vertical_delta(b, ia, ja);
+}
+
 /* myers_backtrace_banded :444-627 */
 static int32_t backtrace_banded(int8_t* path, int32_t* path_count, const band_t* b, int32_t diagonal_begin, int32_t diagonal_end,
                                 int32_t band_width, int32_t target_size, int32_t query_size)
@@ -284,6 +311,12 @@ static int32_t backtrace_banded(int8_t* path, int32_t* path_count, const band_t*
         const int32_t above = i <= 1 ? (last_diagonal_score + j - diagonal_end) : get_myers_score(i - 1, j, b, last_entry_mask);
         const int32_t diag  = i <= 1 ? (last_diagonal_score + j - 1 - diagonal_end) : get_myers_score(i - 1, j - 1, b, last_entry_mask);
         const int32_t left  = i < 1 ? (last_diagonal_score + j - 1 - diagonal_end) : get_myers_score(i, j - 1, b, last_entry_mask);
+        if (i >= 2)
+        {
+            int32_t ka, kd;
+            model_step(b, last_entry_mask, band_width, i, j, i, j - 1, myscore, &ka, &kd);
+            g_delta_identity_mismatches += (ka != above) + (kd != diag);
+        }
         int8_t r;
         if (left + 1 == myscore) { r = ALN_INSERTION; myscore = left; --j; }
         else if (above + 1 == myscore) { r = ALN_DELETION; myscore = above; --i; }
@@ -295,6 +328,12 @@ static int32_t backtrace_banded(int8_t* path, int32_t* path_count, const band_t*
         const int32_t above = i <= 1 ? out_of_band : get_myers_score(i - 1, j, b, last_entry_mask);
         const int32_t diag  = i <= 0 ? j - 1 : get_myers_score(i, j - 1, b, last_entry_mask);
         const int32_t left  = i >= band_width ? out_of_band : get_myers_score(i + 1, j - 1, b, last_entry_mask);
+        if (i >= 1)
+        {
+            int32_t ka, kd;
+            model_step(b, last_entry_mask, band_width, i, j, i + 1, j - 1, myscore, &ka, &kd);
+            g_delta_identity_mismatches += (i >= 2 && ka != above) + (kd != diag);
+        }
         int8_t r;
         if (left + 1 == myscore) { r = ALN_INSERTION; myscore = left; ++i; --j; }
         else if (above + 1 == myscore) { r = ALN_DELETION; myscore = above; --i; }
@@ -306,6 +345,12 @@ static int32_t backtrace_banded(int8_t* path, int32_t* path_count, const band_t*
         const int32_t above = i == 1 ? j : get_myers_score(i - 1, j, b, last_entry_mask);
         const int32_t diag  = i == 1 ? j - 1 : get_myers_score(i - 1, j - 1, b, last_entry_mask);
         const int32_t left  = i > band_width ? out_of_band : get_myers_score(i, j - 1, b, last_entry_mask);
+        if (i >= 2)
+        {
+            int32_t ka, kd;
+            model_step(b, last_entry_mask, band_width, i, j, i, j - 1, myscore, &ka, &kd);
+            g_delta_identity_mismatches += (ka != above) + (kd != diag);
+        }
         int8_t r;
         if (left + 1 == myscore) { r = ALN_INSERTION; myscore = left; --j; }
         else if (above + 1 == myscore) { r = ALN_DELETION; myscore = above; --i; }

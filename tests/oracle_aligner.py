@@ -25,6 +25,8 @@ def lib():
                                                    C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                                    C.POINTER(C.c_int64)]
         _L.aligner_oracle_host_max_bandwidth.restype = C.c_int32
+        _L.aligner_oracle_delta_identity_mismatches.restype = C.c_int64
+        _L.aligner_oracle_delta_identity_mismatches.argtypes = []
     return _L
 
 
@@ -151,3 +153,9 @@ def ref_ukkonen_cpu(query, target, p):
     out = np.zeros(len(q) + len(t) + 8, np.int8)
     n = R.ref_ukkonen_cpu(t, len(t), q, len(q), p, out.ctypes.data, len(out))
     return [int(x) for x in out[:n]]
+
+
+def delta_identity_mismatches():
+    """Backtrace steps (process-wide) in which the kernels' way of getting the neighbour scores -- `left` read, `diag` and
+    `above` from vertical-delta bits -- differed from the reference's three cell reads (oracle/aligner_oracle.c model_step)."""
+    return lib().aligner_oracle_delta_identity_mismatches()

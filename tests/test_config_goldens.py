@@ -68,6 +68,8 @@ def test_config5_file_matches_summary_and_oracle_sample():
         offs.append(len(ops))
     fp = G.run_fingerprints(offs, np.array(ops, np.int8), np.array(cnt, np.int32))
     assert G.block_digests(fp, s["block"])[0] == str(g["block_sha"][0])
+    # the scalar model of the kernels' backtrace step (delta bits instead of three cell reads) ran next to the reference's reads
+    assert A.delta_identity_mismatches() == 0
 
 
 def test_config4_plan_is_reproducible_and_oracle_sample_matches():

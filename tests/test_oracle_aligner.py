@@ -256,3 +256,32 @@ def test_myers_full_is_optimal_and_equals_wide_banded_myers():
         if A.ref() is not None:
             assert r["edit_distance"] == A.ref().ref_nw_edit_distance(t.encode(), len(t), q.encode(), len(q))
         assert sum(1 for s in r["states"] if s != 2) == len(q) and sum(1 for s in r["states"] if s != 3) == len(t)
+
+
+def test_backtrace_step_from_delta_bits_equals_the_three_cell_reads():
+    """The kernels' backtrace step reads `left` as the reference does and derives `diag` and `above` from vertical-delta
+    bits (gwhip_myers.hip backtrace_banded::fetch3). The oracle evaluates that model next to the reference's three reads in
+    every step of every banded backtrace it runs; over narrow and wide bands (one word .. many words, word boundaries inside
+    the walk), approximate results, and very unequal lengths the two must never differ."""
+    import random
+    rng = random.Random(31)
+    before = A.delta_identity_mismatches()
+    steps = 0
+    for k in range(300):
+        n = rng.choice([1, 31, 32, 33, 64, 65, 150, 400, 1000, 1500])
+        q = "".join(rng.choice("ACGT") for _ in range(n))
+        t = list(q)
+        for _ in range(rng.choice([0, 1, n // 30 + 1, n // 8 + 1, n // 3 + 1])):
+            op, p = rng.random(), rng.randrange(max(1, len(t)))
+            if op < 0.4 and t:
+                t[p] = rng.choice("ACGT")
+            elif op < 0.7:
+                t.insert(p, rng.choice("ACGT"))
+            elif len(t) > 1:
+                del t[p]
+        t = "".join(t) or "A"
+        for max_bw in (7, 63, 200, 1024, 4096):
+            r = A.align(q, t, max_bw)
+            steps += len(r.get("cigar_extended", "")) if r.get("status", 1) == 0 else 0
+    assert steps > 100000
+    assert A.delta_identity_mismatches() == before
