@@ -359,6 +359,7 @@ static void topsort_kahn(int32_t* sorted_poa, int32_t* sorted_poa_node_map, int3
 
 #include <stdio.h>
 #include "topsort_incr_model.inc"
+#include "topsort_incr_cnt8_model.inc"
 static int32_t* tsm_sorted = NULL;
 static int32_t* tsm_map    = NULL;
 static uint16_t* tsm_meta  = NULL;
@@ -380,6 +381,28 @@ static void tsm_begin_window(int32_t max_nodes, int32_t len0)
         tsm_meta[n]   = (uint16_t)(1 | ((n < len0 - 1 ? 1 : 0) << 4) | ((n > 0 ? 1 : 0) << 10));
     }
     tsm_nold = len0;
+}
+static int32_t* tsc_sorted = NULL;
+static int32_t* tsc_map    = NULL;
+static uint16_t* tsc_meta  = NULL;
+static int32_t tsc_cap = 0, tsc_nold = 0;
+static void tsc_begin_window(int32_t max_nodes, int32_t len0)
+{
+    if (max_nodes > tsc_cap)
+    {
+        free(tsc_sorted); free(tsc_map); free(tsc_meta);
+        tsc_sorted = (int32_t*)malloc(sizeof(int32_t) * (size_t)max_nodes);
+        tsc_map    = (int32_t*)malloc(sizeof(int32_t) * (size_t)max_nodes);
+        tsc_meta   = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)max_nodes);
+        tsc_cap    = max_nodes;
+    }
+    for (int32_t n = 0; n < len0; n++) /* backbone chain: queue length 1 everywhere */
+    {
+        tsc_sorted[n] = n;
+        tsc_map[n]    = n;
+        tsc_meta[n]   = (uint16_t)(1 | ((n < len0 - 1 ? 1 : 0) << 4) | ((n > 0 ? 1 : 0) << 10));
+    }
+    tsc_nold = len0;
 }
 
 /* raconTopologicalSortDeviceUtil: cudapoa_topsort.cuh:103-197 */
@@ -654,6 +677,7 @@ int32_t poa_process_window(poa_workspace* ws, const uint8_t* seqs, const int8_t*
     }
     consensus[0] = 0;
     if (tsm_enabled && !c->spoa_accurate && c->max_nodes_per_graph <= 4095) tsm_begin_window(c->max_nodes_per_graph, seq_lens[0]);
+    if (tsc_enabled && !c->spoa_accurate && c->max_nodes_per_graph <= 0xfffff) tsc_begin_window(c->max_nodes_per_graph, seq_lens[0]);
 
     float banded_buffer_size = (float)c->max_nodes_per_graph * (float)c->matrix_sequence_dimension; /* :149-162 */
     int32_t scores_width     = 0; /* full band: window_details.scores_width, cudapoa_batch.cuh:502-507 */
@@ -775,6 +799,23 @@ int32_t poa_process_window(poa_workspace* ws, const uint8_t* seqs, const int8_t*
                 tsm_nold = new_node_count;
                 for (int32_t n = 0; n < new_node_count; n++)
                     if (tsm_sorted[n] != g->sorted_poa[n] || tsm_map[n] != g->node_id_to_pos[n]) { tsm_stats[TSM_MISMATCH]++; break; }
+            }
+            if (tsc_enabled && c->max_nodes_per_graph <= 0xfffff) /* model of the long-read kernel's order with its state in LDS */
+            {
+                if (topsort_incr_cnt8_model(tsc_sorted, tsc_map, tsc_nold, new_node_count, g->incoming_edge_count, g->outgoing_edges,
+                                            g->outgoing_edge_count, tsc_meta))
+                {
+                    for (int32_t n = 0; n < new_node_count; n++)
+                        if (tsc_sorted[n] != g->sorted_poa[n] || tsc_map[n] != g->node_id_to_pos[n]) { tsc_stats[TSC_MISMATCH]++; break; }
+                }
+                else /* gave up (queue ring): the kernel re-runs the HBM routine; the model restarts from the plain order */
+                    for (int32_t n = 0; n < new_node_count; n++)
+                    {
+                        tsc_sorted[n] = g->sorted_poa[n];
+                        tsc_map[n]    = g->node_id_to_pos[n];
+                        tsc_meta[n]   = (uint16_t)(15 | ((uint32_t)g->outgoing_edge_count[n] << 4) | ((uint32_t)g->incoming_edge_count[n] << 10));
+                    }
+                tsc_nold = new_node_count;
             }
         }
     }

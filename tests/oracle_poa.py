@@ -41,6 +41,8 @@ def lib():
         L.poa_cfg_select_types.argtypes = [C.POINTER(PoaCfg)]
         L.poa_topsort_model_enable.argtypes = [C.c_int, C.c_int]
         L.poa_topsort_model_stats.argtypes = [C.c_void_p]
+        L.poa_topsort_cnt8_model_enable.argtypes = [C.c_int, C.c_int]
+        L.poa_topsort_cnt8_model_stats.argtypes = [C.c_void_p]
         L.poa_run_nw_full.restype = C.c_int32
         L.poa_run_nw_banded.restype = C.c_int32
         L.poa_run_add_alignment.restype = C.c_int32
@@ -194,3 +196,28 @@ class topsort_model:
 
     def __exit__(self, *a):
         lib().poa_topsort_model_enable(0, 0)
+
+
+TOPSORT_CNT8_MODEL_STATS = ("reads", "nodes", "real_steps", "blocks", "block_nodes", "mismatch", "gave_up", "coverage", "refills",
+                            "hbm_steps")
+
+
+class topsort_cnt8_model:
+    """Context manager: run the scalar model of the long-read kernel's incremental Kahn order with its state in LDS
+    (oracle/topsort_incr_cnt8_model.inc: byte counters, sliding window over the previous order, queue ring) next to the plain
+    topologicalSortDeviceUtil restatement inside poa_process_window and count disagreements."""
+
+    def __init__(self, lane_order=0):
+        self.lane_order = lane_order
+
+    def __enter__(self):
+        lib().poa_topsort_cnt8_model_enable(1, self.lane_order)
+        return self
+
+    def stats(self):
+        st = (C.c_int64 * len(TOPSORT_CNT8_MODEL_STATS))()
+        lib().poa_topsort_cnt8_model_stats(st)
+        return dict(zip(TOPSORT_CNT8_MODEL_STATS, list(st)))
+
+    def __exit__(self, *a):
+        lib().poa_topsort_cnt8_model_enable(0, 0)

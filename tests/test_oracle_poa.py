@@ -255,3 +255,39 @@ def test_msa_rows_by_scatter_over_the_nodes_equal_the_walk():
                 cases += 1
     assert cases == 64
     assert O.Workspace.msa_scatter_mismatches() == before
+
+
+@pytest.mark.parametrize("lane_order", [0, 1])
+def test_incremental_topsort_with_lds_state_model_equals_kahn(lane_order):
+    """The long-read kernel keeps the incremental order's hot state in LDS (topsort_kahn_incr_cnt8: byte counters, a sliding
+    window over 1024 positions of the previous order refilled 256 at a time, a 1024-entry queue ring, "in sync at p" as "the
+    head is sigma[p]"). Its scalar model must give the order of topologicalSortDeviceUtil after every read -- on short-read
+    windows (graphs of 1 400 .. 2 800 nodes: the window slides), on divergent multi-kbp reads (graphs of many thousand
+    nodes), with new sources and sinks, in both lane orders of a block's decrements -- and never read outside its window."""
+    import random
+    from genomeworks_amd import synthetic
+    rng = random.Random(78)
+    windows = [[r.decode() for r in synthetic.generate_window(1000 + w)] for w in range(4)]
+    for k in range(16):
+        blen = rng.choice([40, 300, 900, 1000])
+        reads = rng.choice([2, 8, 17, 32])
+        mut, ins, dele = rng.choice([(0, 0, 0), (5, 2, 2), (40, 20, 20), (90, 40, 40), (10, 60, 5), (10, 5, 60)])
+        w = [r.decode() for r in synthetic.generate_window(7100 + k, blen, reads, mut, ins, dele)]
+        if k % 4 == 0:  # reads that start / end differently: new source and sink nodes
+            w = [("GATTACA"[: rng.randrange(8)] + r)[rng.randrange(5):] for r in w]
+        windows.append([r for r in w if 0 < len(r) < 1024])
+    long_windows = [[r.decode() for r in synthetic.generate_window(9100 + w, 3000 + 900 * w, 6, 150, 190, 190)] for w in range(2)]
+    with O.topsort_cnt8_model(lane_order) as tm:
+        for mode in (1, 2):
+            with O.Workspace(O.make_cfg(1024, 32, 256, mode)) as ws:
+                for w in windows:
+                    ws.process(w)
+        with O.Workspace(O.make_cfg(8192, 8, 256, 2, storage_factor=4.0, graph_factor=4.0)) as ws:
+            for w in long_windows:
+                ws.process(w)
+        st = tm.stats()
+    assert st["reads"] > 400 and st["mismatch"] == 0, st
+    assert st["coverage"] == 0 and st["gave_up"] == 0, st
+    assert st["refills"] > st["reads"], st                 # the window did slide
+    assert st["block_nodes"] > 3 * st["real_steps"], st    # most pops are replayed, not recomputed
+    assert st["hbm_steps"] * 2 < st["real_steps"], st      # and most ordinary steps need no HBM round trip
