@@ -31,6 +31,9 @@ int32_t poa_band_start_for_row(int32_t row, float gradient, int32_t band_width, 
 /* Optional observer of the banded traceback (one call per step: the cell left and the cell entered). NULL unless an
  * analysis tool installs one; it never changes a result. */
 void (*poa_oracle_step_hook)(int32_t i, int32_t j, int32_t prev_i, int32_t prev_j) = 0;
+/* Optional observer of the banded forward pass (one call per DP row: the row, its predecessor count, the distance in rows to
+ * its farthest predecessor, its band start). NULL unless an analysis tool installs one; it never changes a result. */
+void (*poa_oracle_row_hook)(int32_t row, int32_t pred_count, int32_t max_pred_distance, int32_t band_start) = 0;
 
 #include "poa_nw.inc"
 #include "poa_nw_tb.inc"
