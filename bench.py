@@ -209,7 +209,7 @@ def bench_aligner(name, cfg, rank, world, local_rank, sync, dist, torch, reps, c
            "kernel_only": {"pairs_per_s": round(len(pairs) / (k_max * 1e-3), 1), "ms": round(k_max, 3),
                            "band_gcups": round(cells_all / (k_max * 1e-3) / 1e9, 2)},
            "sync_over_kernel": round((full * 1e3 - k_max) / k_max, 2),
-           "roofline": {"bound": "hbm", "kernel": "myers_banded_group_kernel<8,32> (+ scan, compaction)" if cfg is CONFIG2 else "myers_banded_kernel (+ scan, compaction)",
+           "roofline": {"bound": "hbm", "kernel": "myers_banded_group_kernel<6, 4> (six lanes per pair, four wavefronts per block; + scan, compaction)" if cfg is CONFIG2 else "myers_banded_kernel (+ scan, compaction)",
                         "achieved": round(achieved, 2),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                         "traffic": sub_traffic("configs[1]" if cfg is CONFIG2 else "configs[4]"),
@@ -442,10 +442,13 @@ def bench_band_modes(windows, local_rank, sync):
     scores has the packed forward pass and the move-byte traceback (poa_forward_moves.h); the other cells of the table run
     the general 32-bit-register passes -- this table is what they cost."""
     from genomeworks_amd import cudapoa
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    import golden_io as G  # the checker: committed oracle goldens of every cell (tests/golden/make_band_mode_goldens.py)
+    gsum, gold = G.band_mode_summary(), G.band_mode_goldens()
+    assert gsum["windows"] == len(windows) == 1024 and gsum["first_seed"] == 1000
     rows = []
-    for mode, widths in (("static_band", (128, 256, 384, 512)), ("adaptive_band", (128, 256, 512)),
-                         ("static_band_traceback", (128, 256, 512)), ("adaptive_band_traceback", (128, 256, 512))):
-        for bw in widths:
+    for mode in ("static_band", "adaptive_band", "static_band_traceback", "adaptive_band_traceback"):
+        for bw in (128, 256, 384, 512):
             b = cudapoa.CudaPoaBatch(32, 1024, 24 << 30, output_type="consensus", band_mode=mode, alignment_band_width=bw,
                                      max_nodes_per_graph=3072, device_id=local_rank)
             for w in windows:
@@ -462,14 +465,21 @@ def bench_band_modes(windows, local_rank, sync):
             sync()
             dt = (time.perf_counter() - t0) / 2
             k_ms, _o = b.relaunch_timed()
-            _c, _v, status = b.get_consensus()
+            cons, cov, status = b.get_consensus()  # of the last (timed) launch
             del b
+            cell = gsum["cells"]["%s/%d" % (mode, bw)]
+            fp = G.band_mode_fingerprints(cons, cov, status)
+            mi, wi = gsum["modes"].index(mode), gsum["widths"].index(bw)
             rows.append({"band_mode": mode, "band_width": bw, "ms": round(dt * 1e3, 2), "kernel_ms": round(k_ms, 2),
-                         "gcups": round(cells / dt / 1e9, 1), "cells": cells, "windows_ok": sum(1 for x in status if int(x) == 0)})
+                         "gcups": round(cells / dt / 1e9, 1), "cells": cells, "windows_ok": sum(1 for x in status if int(x) == 0),
+                         "windows_equal_oracle_golden": int((fp == gold["fingerprint"][mi, wi]).sum()),
+                         "equals_oracle_golden": bool(G.band_gen.cell_digest(fp) == cell["fingerprint_sha256"] and cells == cell["cells"])})
     ref = next(r for r in rows if r["band_mode"] == "static_band" and r["band_width"] == 256)
     for r in rows:
         r["gcups_vs_static_256"] = round(r["gcups"] / ref["gcups"], 3)
-    return {"workload": "the 1024 config-3 windows through every banded mode and band width", "rows": rows}
+    return {"workload": "the 1024 config-3 windows through every banded mode and band width; every row's 1024 consensus / "
+                        "coverage / status triples and its cell count are compared with the committed oracle golden of that cell",
+            "all_equal_oracle_golden": all(r["equals_oracle_golden"] for r in rows), "rows": rows}
 
 
 def bench_reference_shapes(windows, local_rank, sync, steps):

@@ -2,6 +2,7 @@
 // The sequences are packed back to back (q0 t0 q1 t1 ...) instead of the reference's fixed 2 * max_length stride;
 // limits, statuses and the host-side reversal of the kernels' back-to-front paths follow aligner_global.cpp.
 #include <cstring>
+#include <exception>
 #include <thread>
 #include "aligner_global.hpp"
 
@@ -173,10 +174,35 @@ StatusType AlignerGlobal::sync_alignments()
     {
         const size_t chunk = (n + n_threads - 1) / n_threads;
         std::vector<std::thread> workers;
-        for (size_t t = 1; t < n_threads; ++t)
-            workers.emplace_back([&, t] { fill_range(std::min(n, t * chunk), std::min(n, (t + 1) * chunk)); });
-        fill_range(0, std::min(n, chunk));
-        for (std::thread& w : workers) w.join();
+        std::vector<std::exception_ptr> errors(n_threads);
+        {
+            // joins whatever was started on every exit path (a throwing emplace_back or the caller's own range included);
+            // a worker's exception is carried back to the caller instead of ending the process
+            struct JoinAll
+            {
+                std::vector<std::thread>& threads;
+                ~JoinAll()
+                {
+                    for (std::thread& t : threads)
+                        if (t.joinable()) t.join();
+                }
+            } join_on_exit{workers};
+            workers.reserve(n_threads);
+            for (size_t t = 1; t < n_threads; ++t)
+                workers.emplace_back([&, t] {
+                    try
+                    {
+                        fill_range(std::min(n, t * chunk), std::min(n, (t + 1) * chunk));
+                    }
+                    catch (...)
+                    {
+                        errors[t] = std::current_exception();
+                    }
+                });
+            fill_range(0, std::min(n, chunk));
+        }
+        for (const std::exception_ptr& e : errors)
+            if (e) std::rethrow_exception(e);
     }
     return StatusType::success;
 }
@@ -185,17 +211,23 @@ float AlignerGlobal::relaunch_resident_timed()
 {
     if (!launched_ || device_block_ == nullptr) return -1.f;
     scoped_device_switch dev(device_id_);
-    hipEvent_t e0, e1;
-    GW_CU_CHECK_ERR(hipEventCreate(&e0));
-    GW_CU_CHECK_ERR(hipEventCreate(&e1));
-    GW_CU_CHECK_ERR(hipEventRecord(e0, stream_));
+    struct EventPair // destroyed on every exit path
+    {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~EventPair()
+        {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } ev;
+    GW_CU_CHECK_ERR(hipEventCreate(&ev.e0));
+    GW_CU_CHECK_ERR(hipEventCreate(&ev.e1));
+    GW_CU_CHECK_ERR(hipEventRecord(ev.e0, stream_));
     const int rc = run_alignment(num_alignments(), d_seq_, d_starts_, seq_starts_h_.data(), d_results_, d_result_lengths_, d_ws_, ws_bytes_);
-    GW_CU_CHECK_ERR(hipEventRecord(e1, stream_));
-    GW_CU_CHECK_ERR(hipEventSynchronize(e1));
+    GW_CU_CHECK_ERR(hipEventRecord(ev.e1, stream_));
+    GW_CU_CHECK_ERR(hipEventSynchronize(ev.e1));
     float ms = 0.f;
-    GW_CU_CHECK_ERR(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    GW_CU_CHECK_ERR(hipEventElapsedTime(&ms, ev.e0, ev.e1));
     return rc == 0 ? ms : -1.f;
 }
 

@@ -163,21 +163,32 @@ int gw_poa_get_consensus(gw_poa_batch* b, int32_t* n_out)
     GW_CATCH(-1)
 }
 
+// Accessors of the last get_*() call: an index outside it sets the error string and returns null / -1 (no exception
+// crosses the C ABI).
 const char* gw_poa_consensus_str(gw_poa_batch* b, int32_t poa_idx, int32_t* length)
 {
+    GW_TRY
     const std::string& s = b->consensus.at(static_cast<size_t>(poa_idx));
     if (length) *length = static_cast<int32_t>(s.size());
     return s.c_str();
+    GW_CATCH(nullptr)
 }
 
 const uint16_t* gw_poa_consensus_coverage(gw_poa_batch* b, int32_t poa_idx, int32_t* length)
 {
+    GW_TRY
     const auto& v = b->coverage.at(static_cast<size_t>(poa_idx));
     if (length) *length = static_cast<int32_t>(v.size());
     return v.data();
+    GW_CATCH(nullptr)
 }
 
-int32_t gw_poa_output_status(gw_poa_batch* b, int32_t poa_idx) { return static_cast<int32_t>(b->status.at(static_cast<size_t>(poa_idx))); }
+int32_t gw_poa_output_status(gw_poa_batch* b, int32_t poa_idx)
+{
+    GW_TRY
+    return static_cast<int32_t>(b->status.at(static_cast<size_t>(poa_idx)));
+    GW_CATCH(-1)
+}
 
 int gw_poa_get_msa(gw_poa_batch* b, int32_t* n_out)
 {
@@ -190,13 +201,20 @@ int gw_poa_get_msa(gw_poa_batch* b, int32_t* n_out)
     GW_CATCH(-1)
 }
 
-int32_t gw_poa_msa_rows(gw_poa_batch* b, int32_t poa_idx) { return static_cast<int32_t>(b->msa.at(static_cast<size_t>(poa_idx)).size()); }
+int32_t gw_poa_msa_rows(gw_poa_batch* b, int32_t poa_idx)
+{
+    GW_TRY
+    return static_cast<int32_t>(b->msa.at(static_cast<size_t>(poa_idx)).size());
+    GW_CATCH(-1)
+}
 
 const char* gw_poa_msa_row(gw_poa_batch* b, int32_t poa_idx, int32_t row, int32_t* length)
 {
+    GW_TRY
     const std::string& s = b->msa.at(static_cast<size_t>(poa_idx)).at(static_cast<size_t>(row));
     if (length) *length = static_cast<int32_t>(s.size());
     return s.c_str();
+    GW_CATCH(nullptr)
 }
 
 int gw_poa_get_graphs(gw_poa_batch* b, int32_t* n_out)
@@ -219,8 +237,18 @@ int gw_poa_get_graphs(gw_poa_batch* b, int32_t* n_out)
     GW_CATCH(-1)
 }
 
-int32_t gw_poa_graph_num_nodes(gw_poa_batch* b, int32_t poa_idx) { return b->graph_nodes.at(static_cast<size_t>(poa_idx)); }
-int32_t gw_poa_graph_num_edges(gw_poa_batch* b, int32_t poa_idx) { return static_cast<int32_t>(b->graph_edges.at(static_cast<size_t>(poa_idx)).size()); }
+int32_t gw_poa_graph_num_nodes(gw_poa_batch* b, int32_t poa_idx)
+{
+    GW_TRY
+    return b->graph_nodes.at(static_cast<size_t>(poa_idx));
+    GW_CATCH(-1)
+}
+int32_t gw_poa_graph_num_edges(gw_poa_batch* b, int32_t poa_idx)
+{
+    GW_TRY
+    return static_cast<int32_t>(b->graph_edges.at(static_cast<size_t>(poa_idx)).size());
+    GW_CATCH(-1)
+}
 
 int gw_poa_graph_copy(gw_poa_batch* b, int32_t poa_idx, char* node_labels, int32_t* edge_src, int32_t* edge_dst, int32_t* edge_weight)
 {
@@ -364,7 +392,12 @@ int gw_aligner_sync_alignments(gw_aligner* a)
     GW_CATCH(-1)
 }
 
-int32_t gw_aligner_num_alignments(gw_aligner* a) { return static_cast<int32_t>(a->aligner->get_alignments().size()); }
+int32_t gw_aligner_num_alignments(gw_aligner* a)
+{
+    GW_TRY
+    return static_cast<int32_t>(a->aligner->get_alignments().size());
+    GW_CATCH(-1)
+}
 
 int gw_aligner_reset(gw_aligner* a)
 {
@@ -374,19 +407,38 @@ int gw_aligner_reset(gw_aligner* a)
     GW_CATCH(-1)
 }
 
-int32_t gw_alignment_status(gw_aligner* a, int32_t i) { return static_cast<int32_t>(a->aligner->get_alignments().at(static_cast<size_t>(i))->get_status()); }
-int32_t gw_alignment_is_optimal(gw_aligner* a, int32_t i) { return a->aligner->get_alignments().at(static_cast<size_t>(i))->is_optimal() ? 1 : 0; }
-int32_t gw_alignment_edit_distance(gw_aligner* a, int32_t i) { return a->aligner->get_alignments().at(static_cast<size_t>(i))->get_edit_distance(); }
+// Per-alignment accessors: an index outside get_alignments() sets the error string and returns -1 / null.
+int32_t gw_alignment_status(gw_aligner* a, int32_t i)
+{
+    GW_TRY
+    return static_cast<int32_t>(a->aligner->get_alignments().at(static_cast<size_t>(i))->get_status());
+    GW_CATCH(-1)
+}
+int32_t gw_alignment_is_optimal(gw_aligner* a, int32_t i)
+{
+    GW_TRY
+    return a->aligner->get_alignments().at(static_cast<size_t>(i))->is_optimal() ? 1 : 0;
+    GW_CATCH(-1)
+}
+int32_t gw_alignment_edit_distance(gw_aligner* a, int32_t i)
+{
+    GW_TRY
+    return a->aligner->get_alignments().at(static_cast<size_t>(i))->get_edit_distance();
+    GW_CATCH(-1)
+}
 
 const char* gw_alignment_cigar(gw_aligner* a, int32_t i, int32_t extended, int32_t* length)
 {
+    GW_TRY
     a->cigar = a->aligner->get_alignments().at(static_cast<size_t>(i))->convert_to_cigar(extended ? aln::CigarFormat::extended : aln::CigarFormat::basic);
     if (length) *length = static_cast<int32_t>(a->cigar.size());
     return a->cigar.c_str();
+    GW_CATCH(nullptr)
 }
 
 int32_t gw_alignment_states(gw_aligner* a, int32_t i, int8_t* out, int32_t cap)
 {
+    GW_TRY
     const auto& al = *a->aligner->get_alignments().at(static_cast<size_t>(i));
     // per-position states from whichever form the aligner filled
     int32_t n = 0;
@@ -403,6 +455,7 @@ int32_t gw_alignment_states(gw_aligner* a, int32_t i, int8_t* out, int32_t cap)
             ++n;
         }
     return n;
+    GW_CATCH(-1)
 }
 
 int64_t gw_aligner_get_runs(gw_aligner* a, int64_t* offsets, int8_t* ops, int32_t* counts, int64_t capacity, int32_t* status,
@@ -519,8 +572,16 @@ int gw_aligner_relaunch_timed(gw_aligner* a, float* kernels_ms)
     else if (auto* global = dynamic_cast<aln::AlignerGlobal*>(a->aligner.get()))
         *kernels_ms = global->relaunch_resident_timed();
     else
+    {
+        gwhost::set_last_error("gw_aligner_relaunch_timed: this aligner class keeps no resident batch");
         return -1;
-    return *kernels_ms < 0.f ? -1 : 0;
+    }
+    if (*kernels_ms < 0.f)
+    {
+        gwhost::set_last_error("gw_aligner_relaunch_timed: no batch resident (call align_all() first)");
+        return -1;
+    }
+    return 0;
     GW_CATCH(-1)
 }
 
@@ -812,12 +873,19 @@ gw_windows* gw_windows_parse(const char* const* paths, int32_t n_paths, int32_t 
 }
 void gw_windows_destroy(gw_windows* w) { delete w; }
 int32_t gw_windows_count(const gw_windows* w) { return static_cast<int32_t>(w->windows.size()); }
-int32_t gw_windows_num_sequences(const gw_windows* w, int32_t window) { return static_cast<int32_t>(w->windows.at(static_cast<size_t>(window)).size()); }
+int32_t gw_windows_num_sequences(const gw_windows* w, int32_t window)
+{
+    GW_TRY
+    return static_cast<int32_t>(w->windows.at(static_cast<size_t>(window)).size());
+    GW_CATCH(-1)
+}
 const char* gw_windows_sequence(const gw_windows* w, int32_t window, int32_t seq, int32_t* length)
 {
+    GW_TRY
     const std::string& s = w->windows.at(static_cast<size_t>(window)).at(static_cast<size_t>(seq));
-    *length              = static_cast<int32_t>(s.size());
+    if (length) *length = static_cast<int32_t>(s.size());
     return s.data();
+    GW_CATCH(nullptr)
 }
 
 } // extern "C"

@@ -394,7 +394,7 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
             stream_of[k] = class_streams.create(device, true, std::min(priority_least, priority_greatest + launch_rank[k]));
     std::mutex start_mutex;
     std::chrono::steady_clock::time_point compute_begin{}, fill_begin{};
-    std::atomic<int32_t> created{0};
+    std::atomic<int32_t> created{0}, create_arrived{0};
     std::vector<std::exception_ptr> errors(classes);
     std::vector<std::thread> threads;
     JoinAll join_on_exit{threads};
@@ -414,6 +414,18 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                 }
                 while (filled.load() < static_cast<int32_t>(active_classes)) std::this_thread::yield();
             };
+            bool counted_created = false;
+            auto arrive_created  = [&](bool ok) { // this worker's Batch exists (or its creation failed): barrier before any filling
+                if (counted_created) return;
+                counted_created = true;
+                if (ok) created.fetch_add(1);
+                if (create_arrived.fetch_add(1) + 1 == static_cast<int32_t>(active_classes))
+                {
+                    std::lock_guard<std::mutex> g(start_mutex);
+                    fill_begin = std::chrono::steady_clock::now();
+                }
+                while (create_arrived.load() < static_cast<int32_t>(active_classes)) std::this_thread::yield();
+            };
             try
             {
                 scoped_device_switch d(device);
@@ -422,12 +434,11 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                     DefaultDeviceAllocator allocator(static_cast<size_t>(share[k]), stream);
                     std::unique_ptr<Batch> batch = create_batch(device, stream, allocator, share[k], output_mask, plan.configs[k], gap_score,
                                                                 mismatch_score, match_score);
-                    // every class's Batch exists: the fill-inclusive clock (the reference's multi-batch region) starts
-                    if (created.fetch_add(1) + 1 == static_cast<int32_t>(active_classes))
-                    {
-                        std::lock_guard<std::mutex> g(start_mutex);
-                        fill_begin = std::chrono::steady_clock::now();
-                    }
+                    // every class's Batch exists: the fill-inclusive clock (the reference's multi-batch region,
+                    // cudapoa/benchmarks/multi_batch.hpp:72-177, creates all batches first and times all of the filling)
+                    // starts, and no class fills before that point -- a class that was created early would otherwise do
+                    // its filling outside the clock
+                    arrive_created(true);
                     // heaviest windows first: blocks are dispatched in window order, and a class that does not fit the free CUs
                     // at once should not keep its long chains for the end
                     std::vector<int32_t> mine = plan.groups[k];
@@ -539,6 +550,7 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
             catch (...)
             {
                 errors[k] = std::current_exception();
+                arrive_created(false); // releases the creation barrier on the error path too
                 arrive();
                 // a class that failed before its first launch still passes the turn on
                 while (launch_turn.load() < launch_rank[k]) std::this_thread::yield();

@@ -52,3 +52,24 @@ def edit_distances(offsets, ops, counts):
     c = np.concatenate([[0], np.cumsum(w)])
     offsets = np.asarray(offsets, np.int64)
     return c[offsets[1:]] - c[offsets[:-1]]
+
+
+# ---- band mode x band width table (tests/golden/make_band_mode_goldens.py) ----
+_bspec = importlib.util.spec_from_file_location("make_band_mode_goldens", os.path.join(GOLDEN, "make_band_mode_goldens.py"))
+band_gen = importlib.util.module_from_spec(_bspec)
+_bspec.loader.exec_module(band_gen)
+
+
+def band_mode_summary():
+    with open(os.path.join(GOLDEN, "band_mode_goldens.json")) as f:
+        return json.load(f)
+
+
+def band_mode_goldens():
+    """-> dict(fingerprint[mode, width, window] uint64, cells[...], status[...]) in the order of summary modes / widths"""
+    return dict(np.load(os.path.join(GOLDEN, "band_mode_goldens.npz")))
+
+
+def band_mode_fingerprints(consensus, coverage, status):
+    """The golden's per-window fingerprint from a batch's get_consensus() output."""
+    return np.array([band_gen.fingerprint(int(status[i]), consensus[i], coverage[i]) for i in range(len(status))], np.uint64)

@@ -99,3 +99,29 @@ def test_config4_plan_is_reproducible_and_oracle_sample_matches():
         assert lr.msa_digest(ref["msa"]) == det[w]["msa_sha"]
     # the scalar model of the kernel's MSA rows (scatter over the nodes) ran next to the reference's walk on these windows too
     assert O.Workspace.msa_scatter_mismatches() == 0
+
+
+def test_band_mode_table_file_matches_summary_and_oracle_sample():
+    """tests/golden/band_mode_goldens.{npz,json}: 4 banded modes x 4 band widths x 1024 windows. The file is what its
+    summary says, the static-band / 256 cell is the config-3 golden, and the oracle still reproduces two windows of
+    every cell."""
+    from genomeworks_amd import synthetic
+    s, g = G.band_mode_summary(), G.band_mode_goldens()
+    assert s["windows"] == 1024 and g["fingerprint"].shape == (len(s["modes"]), len(s["widths"]), 1024)
+    for mi, mode in enumerate(s["modes"]):
+        for wi, width in enumerate(s["widths"]):
+            cell = s["cells"]["%s/%d" % (mode, width)]
+            assert int(g["cells"][mi, wi].sum()) == cell["cells"]
+            assert G.band_gen.cell_digest(g["fingerprint"][mi, wi]) == cell["fingerprint_sha256"]
+            assert cell["oracle_int16_overflow_events"] == 0
+            with O.Workspace(G.band_gen.cell_cfg(mode, width)) as ws:
+                for w in (3, 1000):
+                    ref = ws.process([r.decode() for r in synthetic.generate_window(s["first_seed"] + w)])
+                    assert ref["status"] == int(g["status"][mi, wi, w]) and ref["cells"] == int(g["cells"][mi, wi, w])
+                    assert G.band_gen.fingerprint(ref["status"], ref.get("consensus", ""), ref.get("coverage", [])) == int(g["fingerprint"][mi, wi, w])
+    # the metric cell equals the full-text config-3 golden
+    rows, _ = G.config3_windows()
+    mi, wi = s["modes"].index("static_band"), s["widths"].index(256)
+    assert s["cells"]["static_band/256"]["cells"] == G.summary()["config3"]["cells"]
+    for w in (0, 511, 1023):
+        assert G.band_gen.fingerprint(rows[w]["status"], rows[w]["consensus"], rows[w]["coverage"]) == int(g["fingerprint"][mi, wi, w])

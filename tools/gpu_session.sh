@@ -1,0 +1,71 @@
+#!/bin/bash
+# One parameterised GPU-box session (replaces the per-call tools/r0N_gpu_run_*.sh scripts of rounds 2-3, which are in the
+# git history). Run from the repo root through gpurun:
+#
+#   gpurun --timeout 1500 -- 'STEPS="tests bench stats" bash tools/gpu_session.sh r04a'
+#
+# STEPS (any subset, run in this order):
+#   tests        pytest -m gpu (PYTEST_ARGS narrows it, e.g. PYTEST_ARGS="tests/test_gpu_poa.py -k band_mode")
+#   phases       per-phase cycle breakdown of the metric kernel (tools/profile_phases.py 1024)
+#   bench        the driver's bench line (BENCH_ARGS, default none = the full line with all sub-records)
+#   stats        rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline $STATS_ARGS` -> kernel_stats.csv
+#   pmc          tools/pmc_passes.sh with PASSES (default "insts waits lds fetch write") and SUBS (default none)
+#   traffic      derive pmc_traffic.json (headline) and pmc_traffic_sub.json from the pmc step's summary
+#   extra        run $EXTRA_CMD (one-off measurements)
+# Everything lands in gpurun_out/<tag>/; copy what should be judged into profiles/.
+set -u
+TAG=${1:-session}
+STEPS=${STEPS:-tests bench}
+REPO=$(pwd)
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+has() { case " $STEPS " in *" $1 "*) return 0;; *) return 1;; esac; }
+
+if has tests; then
+    ( timeout ${TESTS_TIMEOUT:-1500} python -m pytest ${PYTEST_ARGS:-tests} -m gpu -q ${PYTEST_FLAGS:-} 2>&1 | tail -${PYTEST_TAIL:-25} ) > $OUT/pytest.log
+    tail -${PYTEST_TAIL:-25} $OUT/pytest.log
+fi
+if has phases; then
+    timeout 300 python tools/profile_phases.py 1024 2>/dev/null | tail -1 > $OUT/phase_breakdown.json
+    cut -c1-900 $OUT/phase_breakdown.json; echo
+fi
+if has bench; then
+    ( timeout ${BENCH_TIMEOUT:-1500} python bench.py ${BENCH_ARGS:-} > $OUT/bench.json 2> $OUT/bench.err ); echo "bench rc=$?"; tail -3 $OUT/bench.err
+    python - $OUT/bench.json <<'PY'
+import json, sys
+lines = [x for x in open(sys.argv[1]) if x.startswith('{')]
+if not lines:
+    sys.exit("no bench line")
+d = json.loads(lines[0])
+print("headline", d['value'], d['unit'], "step ms", d['ms_per_step'], "kernel ms", d['roofline']['kernel_ms'], "frac", d['roofline']['frac'],
+      "golden", d.get('equals_oracle_golden'))
+s = d.get('sub_records', {})
+for k in ('configs[1]', 'configs[4]', 'default_aligner', 'configs[3]'):
+    if k in s:
+        print(k, s[k].get('value'), s[k].get('ms'), s[k].get('kernel_only'), s[k]['roofline'].get('frac'))
+if 'band_modes' in s:
+    for r in s['band_modes']['rows']:
+        print("band", r['band_mode'], r['band_width'], "kernel ms", r['kernel_ms'], "gcups", r['gcups'], "golden", r.get('equals_oracle_golden'))
+PY
+fi
+if has stats; then
+    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $REPO/$OUT/stats -- python $REPO/bench.py --no-cpu-baseline ${STATS_ARGS:-} > $REPO/$OUT/bench_under_rocprof.json 2> $REPO/$OUT/stats.log)
+    DB=$(find $OUT/stats -name "*.db" | head -1)
+    [ -n "$DB" ] && python tools/rocpd_summary.py "$DB" > $OUT/kernel_stats.csv && head -14 $OUT/kernel_stats.csv | cut -c1-160
+    rm -rf $OUT/stats
+fi
+if has pmc; then
+    SUBS=${SUBS:-none} PASSES="${PASSES:-insts waits lds fetch write}" bash tools/pmc_passes.sh $OUT/pmc > $OUT/pmc.log 2>&1
+    python tools/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.csv 2>/dev/null
+    rm -rf $OUT/pmc
+    grep -c . $OUT/pmc_summary.csv
+    grep -E "LDS|WAIT_ANY|WAVE_CYCLES|FETCH|WRITE_SIZE" $OUT/pmc_summary.csv | cut -c1-170 | head -60
+fi
+if has traffic; then
+    python tools/pmc_traffic.py $OUT/pmc_summary.csv "$TAG" $OUT
+fi
+if has extra; then
+    bash -c "${EXTRA_CMD:-true}" > $OUT/extra.log 2>&1; echo "extra rc=$?"; tail -${EXTRA_TAIL:-30} $OUT/extra.log
+fi
+du -sh $OUT
