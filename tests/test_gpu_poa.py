@@ -9,9 +9,9 @@ pytestmark = pytest.mark.gpu
 BAND = {"full_band": 0, "static_band": 1, "adaptive_band": 2, "static_band_traceback": 3, "adaptive_band_traceback": 4}
 
 
-def run_gpu(windows, band_mode, max_seq=1024, max_seqs=32, band_width=256, output_type="consensus", nodes=None, **kw):
+def run_gpu(windows, band_mode, max_seq=1024, max_seqs=32, band_width=256, output_type="consensus", nodes=None, mem=8 << 30, **kw):
     from genomeworks_amd import cudapoa
-    b = cudapoa.CudaPoaBatch(max_seqs, max_seq, 8 << 30, output_type=output_type, band_mode=band_mode,
+    b = cudapoa.CudaPoaBatch(max_seqs, max_seq, mem, output_type=output_type, band_mode=band_mode,
                              alignment_band_width=band_width, max_nodes_per_graph=nodes or 3 * max_seq, **kw)
     for w in windows:
         st, seq_st = b.add_poa_group(w)
@@ -222,7 +222,7 @@ def test_band_mode_table_equals_the_golden(band_mode, band_width):
     mi, wi = s["modes"].index(band_mode), s["widths"].index(band_width)
     n = s["windows"]
     windows = config3(n, first=s["first_seed"])
-    b = run_gpu(windows, band_mode, band_width=band_width)
+    b = run_gpu(windows, band_mode, band_width=band_width, mem=24 << 30)  # adaptive modes: 2 x (band + 8) columns per row
     cons, cov, status = b.get_consensus()
     fp = G.band_mode_fingerprints(cons, cov, status)
     bad = [w for w in range(n) if fp[w] != gold["fingerprint"][mi, wi, w] or int(status[w]) != int(gold["status"][mi, wi, w])]

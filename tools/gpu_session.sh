@@ -5,7 +5,7 @@
 #   gpurun --timeout 1500 -- 'STEPS="tests bench stats" bash tools/gpu_session.sh r04a'
 #
 # STEPS (any subset, run in this order):
-#   tests        pytest -m gpu (PYTEST_ARGS narrows it, e.g. PYTEST_ARGS="tests/test_gpu_poa.py -k band_mode")
+#   tests        pytest -m gpu (PYTEST_ARGS = files, PYTEST_K = a -k expression narrow it)
 #   phases       per-phase cycle breakdown of the metric kernel (tools/profile_phases.py 1024)
 #   bench        the driver's bench line (BENCH_ARGS, default none = the full line with all sub-records)
 #   stats        rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline $STATS_ARGS` -> kernel_stats.csv
@@ -23,7 +23,8 @@ export TMPDIR=/tmp
 has() { case " $STEPS " in *" $1 "*) return 0;; *) return 1;; esac; }
 
 if has tests; then
-    ( timeout ${TESTS_TIMEOUT:-1500} python -m pytest ${PYTEST_ARGS:-tests} -m gpu -q ${PYTEST_FLAGS:-} 2>&1 | tail -${PYTEST_TAIL:-25} ) > $OUT/pytest.log
+    # PYTEST_K: a -k expression (may contain spaces)
+    ( timeout ${TESTS_TIMEOUT:-1500} python -m pytest ${PYTEST_ARGS:-tests} -m gpu -q ${PYTEST_K:+-k "$PYTEST_K"} 2>&1 | tail -${PYTEST_TAIL:-25} ) > $OUT/pytest.log
     tail -${PYTEST_TAIL:-25} $OUT/pytest.log
 fi
 if has phases; then
