@@ -16,9 +16,10 @@
 namespace gwhip
 {
 
-// This file is compiled five times: as it stands (everything but the graph-build kernel's instantiations) and, through
-// gwhip_poa_part{0..3}.hip, once per (score type, id type) pair with GWHIP_POA_PART defined -- those translation units hold
-// nothing but that pair's poa_window_kernel instantiations and their launcher, so the four heavy compilations run in parallel.
+// This file is compiled seven times: as it stands (everything but the graph-build kernel's instantiations) and, through
+// gwhip_poa_part{0..5}.hip, with GWHIP_POA_PART defined -- parts 0..3 once per (score type, id type) pair, parts 4 and 5 for
+// the packed passes of band 128 and of bands 384 / 512 (launch_packed_variant below). Those translation units hold nothing but
+// their poa_window_kernel instantiations and their launcher, so the heavy compilations run in parallel.
 #ifndef GWHIP_POA_PART
 thread_local std::string g_last_error;
 
@@ -108,14 +109,16 @@ __device__ GraphView<IdT> carve_graph(uint8_t* slab, const PoaLayout& L)
 // phase is wave 0's, the helper wavefronts wait at a barrier in between.
 // DBG: the instantiation that honours GWHIP_DEBUG selectors and the per-phase cycle accounting. Production launches
 // (no selector, no phase buffer) run DBG = false, in which every selector test and profiling hook folds away.
-// VARIANT: 0 = production, alignment_band_width != 128; 1 = debug (below); 2 = production for alignment_band_width 128 (the
-// packed pass with the band in lanes 0..31 next to the 256-column one an adaptive band may widen to: a separate instantiation,
-// so that the metric configuration's kernel carries none of its code -- with both in one kernel the headline lost 1 %).
+// VARIANT: 0 = production, alignment_band_width 256 (and every width without a packed pass); 1 = debug (below); 2 = production
+// for alignment_band_width 128 (the packed pass with the band in lanes 0..31 next to the 256-column one an adaptive band may
+// widen to: a separate instantiation, so that the metric configuration's kernel carries none of its code -- with both in one
+// kernel the headline lost 1 %); 3 = production for alignment_band_width 384 / 512 (the two-pass packed pass,
+// poa_forward_moves_wide.h); 4 = debug for those widths.
 template <typename ScoreT, typename IdT, typename TraceT, int BM, bool MSA, bool LDS_TABLES, int NW, int VARIANT>
 __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
 {
-    constexpr bool DBG  = VARIANT == 1;
-    constexpr bool B128 = VARIANT != 0;
+    constexpr bool DBG = VARIANT == 1 || VARIANT == 4;
+    constexpr int PV   = VARIANT == 0 ? 0 : (VARIANT <= 2 ? 1 : 2); // packed passes of nw_banded
     const int32_t debug_flags = DBG ? a.debug_flags : 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane       = threadIdx.x & (kWave - 1);
@@ -282,12 +285,12 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
         }
         else if (BM == GWHIP_ADAPTIVE_BAND && c.alignment_band_width < kMaxAdaptiveBand)
         {
-            alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ, B128>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
+            alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ, PV>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                 banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
                                                 c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring,
                                                 mw_args, mw_shared);
             if (alen == kShiftLeft || alen == kShiftRight)
-                alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ, B128>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
+                alen = nw_banded<ScoreT, IdT, RowT, true, LDS_READ, PV>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                     banded_buffer_size, alignment_graph, alignment_read,
                                                     c.alignment_band_width, c.gap_score, c.mismatch_score, c.match_score,
                                                     alen, cells, pc, debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring,
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
         }
         else if (BM == GWHIP_STATIC_BAND || BM == GWHIP_ADAPTIVE_BAND)
         {
-            alen = nw_banded<ScoreT, IdT, RowT, false, LDS_READ, B128>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
+            alen = nw_banded<ScoreT, IdT, RowT, false, LDS_READ, PV>(g, rowinfo, node_count, sequence, lds_read, seq_len, scores, ring, ring_bytes,
                                                  banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
                                                  c.gap_score, c.mismatch_score, c.match_score, 0, cells, pc, debug_flags, codes, lds_code_tile, lds_read_window, lds_bs_ring);
         }
@@ -601,6 +604,32 @@ static bool validate(const gwhip_poa_args* args)
 }
 #endif // GWHIP_POA_PART
 
+// The kernels of the packed int16 passes other than the metric configuration's -- VARIANT 2 (band 128), 3 and 4 (bands 384 /
+// 512, production and debug) of poa_window_kernel<int16, int16, int8, static / adaptive band, MSA, LDS tables> -- are compiled
+// in translation units of their own (gwhip_poa_part4.hip, gwhip_poa_part5.hip) behind this launcher.
+template <int BM, bool MSA, int VARIANT>
+hipError_t launch_packed_variant(const KernelArgs& ka, dim3 grid, size_t lds, hipStream_t stream);
+#if defined(GWHIP_POA_PART) && GWHIP_POA_PART >= 4
+template <int BM, bool MSA, int VARIANT>
+hipError_t launch_packed_variant(const KernelArgs& ka, dim3 grid, size_t lds, hipStream_t stream)
+{
+    hipLaunchKernelGGL((poa_window_kernel<int16_t, int16_t, int8_t, BM, MSA, true, 1, VARIANT>), grid, dim3(kWave), lds, stream, ka);
+    return hipGetLastError();
+}
+#if GWHIP_POA_PART == 4
+#define GW_PACKED_VARIANTS(BM, MSA) template hipError_t launch_packed_variant<BM, MSA, 2>(const KernelArgs&, dim3, size_t, hipStream_t);
+#else
+#define GW_PACKED_VARIANTS(BM, MSA)                                                                       \
+    template hipError_t launch_packed_variant<BM, MSA, 3>(const KernelArgs&, dim3, size_t, hipStream_t); \
+    template hipError_t launch_packed_variant<BM, MSA, 4>(const KernelArgs&, dim3, size_t, hipStream_t);
+#endif
+GW_PACKED_VARIANTS(GWHIP_STATIC_BAND, false)
+GW_PACKED_VARIANTS(GWHIP_STATIC_BAND, true)
+GW_PACKED_VARIANTS(GWHIP_ADAPTIVE_BAND, false)
+GW_PACKED_VARIANTS(GWHIP_ADAPTIVE_BAND, true)
+#undef GW_PACKED_VARIANTS
+#endif
+
 template <typename ScoreT, typename IdT, typename TraceT, bool MSA, bool LDS_TABLES>
 static hipError_t launch_window_kernel(const KernelArgs& ka_in, hipStream_t stream)
 {
@@ -624,12 +653,31 @@ static hipError_t launch_window_kernel(const KernelArgs& ka_in, hipStream_t stre
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, 1>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReservedCuLds);             \
         }                                                                                                          \
-        constexpr bool kHas128 = LDS_TABLES && std::is_same<ScoreT, int16_t>::value &&                             \
-                                 (BM == GWHIP_STATIC_BAND || BM == GWHIP_ADAPTIVE_BAND);                           \
-        if (ka.debug_flags != 0 || ka.phase_cycles != nullptr)                                                     \
+        constexpr bool kHasPacked = LDS_TABLES && std::is_same<ScoreT, int16_t>::value && std::is_same<TraceT, int8_t>::value && \
+                                    (BM == GWHIP_STATIC_BAND || BM == GWHIP_ADAPTIVE_BAND);                        \
+        const bool debug = ka.debug_flags != 0 || ka.phase_cycles != nullptr;                                      \
+        const int32_t bw = ka.cfg.alignment_band_width;                                                            \
+        bool launched    = false;                                                                                  \
+        if constexpr (kHasPacked)                                                                                  \
+        {                                                                                                          \
+            constexpr int PBM = kHasPacked ? BM : GWHIP_STATIC_BAND;                                               \
+            if (bw == 384 || bw == 512)                                                                            \
+            {                                                                                                      \
+                hipError_t pe = debug ? launch_packed_variant<PBM, MSA, 4>(ka, grid, lds_req, stream)             \
+                                      : launch_packed_variant<PBM, MSA, 3>(ka, grid, lds_req, stream);            \
+                if (pe != hipSuccess) return pe;                                                                   \
+                launched = true;                                                                                   \
+            }                                                                                                      \
+            else if (bw == 128 && !debug)                                                                          \
+            {                                                                                                      \
+                hipError_t pe = launch_packed_variant<PBM, MSA, 2>(ka, grid, lds_req, stream);                     \
+                if (pe != hipSuccess) return pe;                                                                   \
+                launched = true;                                                                                   \
+            }                                                                                                      \
+        }                                                                                                          \
+        if (launched) {}                                                                                           \
+        else if (debug)                                                                                            \
             hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, 1>), grid, dim3(kWave * NW), lds_req, stream, ka); \
-        else if (kHas128 && ka.cfg.alignment_band_width == 128)                                                    \
-            hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, kHas128 ? 2 : 0>), grid, dim3(kWave * NW), lds_req, stream, ka); \
         else                                                                                                       \
             hipLaunchKernelGGL((poa_window_kernel<ScoreT, IdT, TraceT, BM, MSA, LDS_TABLES, NW, 0>), grid, dim3(kWave * NW), lds_req, stream, ka); \
     }                                                                                                              \
@@ -678,7 +726,7 @@ template hipError_t launch_trace_split<int32_t, int32_t>(const KernelArgs&, hipS
 template hipError_t launch_trace_split<int32_t, int16_t>(const KernelArgs&, hipStream_t);
 #elif GWHIP_POA_PART == 2
 template hipError_t launch_trace_split<int16_t, int32_t>(const KernelArgs&, hipStream_t);
-#else
+#elif GWHIP_POA_PART == 3
 template hipError_t launch_trace_split<int16_t, int16_t>(const KernelArgs&, hipStream_t);
 #endif
 #else

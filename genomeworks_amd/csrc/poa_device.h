@@ -1199,6 +1199,7 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
 } // namespace gwhip
 #include "poa_forward_packed.h"
 #include "poa_forward_moves.h"
+#include "poa_forward_moves_wide.h"
 #include "poa_traceback_moves.h"
 namespace gwhip
 {
@@ -1879,7 +1880,9 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
 // Banded NW (score-matrix modes): forward pass wave-wide, then sink selection (wave reduction with the
 // reference's first-maximum tie rule) and the lane-0 traceback.
 // ------------------------------------------------------------------------------------------------
-template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE, bool LDS_READ, bool B128 = false>
+// PV: which packed int16 passes the instantiation carries -- 0: the 256-column band only; 1: + the 128-column band
+// (poa_forward_moves.h, band in lanes 0..31); 2: the two-pass 384- and 512-column bands (poa_forward_moves_wide.h)
+template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE, bool LDS_READ, int PV = 0>
 __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowinfo, int32_t graph_count, const uint8_t* read,
                              const uint8_t* lds_read, int32_t read_length, ScoreT* scores, ScoreT* ring_base, int32_t ring_bytes,
                              float max_buffer_size, int32_t* alignment_graph, int32_t* alignment_read,
@@ -1993,22 +1996,34 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
     if constexpr (kFastOk && std::is_same<ScoreT, int16_t>::value)
     {
         // packed 16-bit pass for the 256-column band (preconditions: poa_forward_packed.h)
-        const bool packed_ok = (band_width == 256 || (B128 && band_width == 128)) && max_column >= band_width && ring_bytes >= kPkSlots * kPkSlotBytes &&
+        const bool width_ok  = PV == 2 ? (band_width == 384 || band_width == 512) : (band_width == 256 || (PV == 1 && band_width == 128));
+        const int32_t u_span = max(band_width, 256) * abs(gap_score); // u-space offset of the last band cell
+        const bool packed_ok = width_ok && max_column >= band_width && ring_bytes >= kPkSlots * kPkSlotBytes &&
                                abs(gap_score) <= 30 && abs(match_score) <= 100 && abs(mismatch_score) <= 100 &&
                                codes != nullptr && !(dbg & 256) && ring_bytes >= kMtBytes &&
                                // no packed operation can leave int16: the largest score (all matches) plus the u-space offset of
                                // the last band cell, and the smallest (every step at the worst penalty; min_score-derived cells)
-                               max(match_score, 0) * min(read_length, graph_count) + 256 * abs(gap_score) + abs(match_score) <= 32767 &&
+                               max(match_score, 0) * min(read_length, graph_count) + u_span + abs(match_score) <= 32767 &&
                                (graph_count + read_length) * min(min(gap_score, mismatch_score), 0) >= -32768 + 256 &&
-                               min_score + 4 * min(min(gap_score, mismatch_score), 0) - 256 * abs(gap_score) >= -32768;
+                               min_score + 4 * min(min(gap_score, mismatch_score), 0) - u_span >= -32768;
+        static_assert(kWdSlots * kWdSlotBytes <= kPkSlots * kPkSlotBytes, "the two-pass ring lives in the 256-column pass's ring region");
         if (packed_ok)
         {
-            // move bytes, row kinds, descriptors in registers (poa_forward_moves.h)
-            if (band_width == 256)
+            // move bytes, row kinds, descriptors in registers (poa_forward_moves.h, poa_forward_moves_wide.h)
+            if constexpr (PV == 2)
+            {
+                if (band_width == 384)
+                    banded_forward_moves_wide<IdT, 384>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
+                                                        reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score, dbg);
+                else
+                    banded_forward_moves_wide<IdT, 512>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
+                                                        reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score, dbg);
+            }
+            else if (band_width == 256)
                 banded_forward_moves<IdT, 256>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
                                                reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score,
                                                dbg, pc.acc ? &pc.acc[kPhOther] : nullptr);
-            else if constexpr (B128)
+            else if constexpr (PV == 1)
                 banded_forward_moves<IdT, 128>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
                                                reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score,
                                                dbg, pc.acc ? &pc.acc[kPhOther] : nullptr);

@@ -433,6 +433,54 @@ def test_kernel_shortcuts_equal_the_plain_schedule(monkeypatch):
             assert out["production", mode] == out[name, mode], (name, mode)
 
 
+@pytest.mark.parametrize("band_width", [384, 512])
+def test_two_pass_kernel_shortcuts_equal_the_plain_schedule(monkeypatch, band_width):
+    """The same A/B for the two-pass packed pass of bands 384 / 512 (poa_forward_moves_wide.h; debug instantiation VARIANT 4):
+    register rows through the 4-row ring (bit 10), moved-band rows through the ring (bit 15), ring rows through the general
+    routine (bit 9), register rows through the general routine (bit 11), rows with 4..6 predecessors through the general
+    routine (bit 30), the packed pass switched off altogether (bit 8: the generic multi-pass loop and its traceback, the
+    path these widths took in round 3) -- identical consensus, coverage, status and cell counts, and equal to the oracle's
+    on the production arm."""
+    import random
+    from genomeworks_amd import synthetic
+    rng = random.Random(band_width)
+    windows = config3(96)
+    for k in range(48):
+        blen = rng.choice([520, 640, 900, 1000])
+        reads = rng.choice([3, 8, 17, 32])
+        mut, ins, dele = rng.choice([(0, 0, 0), (5, 2, 2), (40, 20, 20), (90, 40, 40), (10, 60, 5), (10, 5, 60)])
+        w = [r.decode() for r in synthetic.generate_window(7300 + k, blen, reads, mut, ins, dele)]
+        if k % 4 == 0:
+            w = [("GATTACA"[: rng.randrange(8)] + r)[rng.randrange(5):] for r in w]
+        windows.append([r for r in w if 0 < len(r) < 1024])
+    out = {}
+    arms = (("production", None), ("registers_through_ring", str(1 << 10)), ("moved_band_through_ring", str(1 << 15)),
+            ("ring_through_general", str(1 << 9)), ("registers_through_general", str(1 << 11)),
+            ("many_predecessors_general", str(1 << 30)), ("everything_general", str((1 << 9) | (1 << 11) | (1 << 30))),
+            ("generic_passes", str(1 << 8)))
+    for name, flag in arms:
+        if flag is None:
+            monkeypatch.delenv("GWHIP_DEBUG", raising=False)
+        else:
+            monkeypatch.setenv("GWHIP_DEBUG", flag)
+        for mode in ("static_band", "adaptive_band"):
+            b = run_gpu(windows, mode, band_width=band_width, mem=16 << 30)
+            out[name, mode] = (b.get_consensus(), b.total_cells())
+    for mode in ("static_band", "adaptive_band"):
+        for name, _ in arms[1:]:
+            assert out["production", mode] == out[name, mode], (name, mode)
+        (cons, cov, status), cells = out["production", mode]
+        cells_ref = 0
+        with O.Workspace(oracle_cfg(mode, band_width=band_width)) as ws:
+            for i, w in enumerate(windows):
+                ref = ws.process(w)
+                cells_ref += ref["cells"]
+                assert status[i] == ref["status"], (mode, i)
+                if ref["status"] == 0:
+                    assert cons[i] == ref["consensus"] and cov[i] == list(ref["coverage"]), (mode, i)
+        assert cells == cells_ref
+
+
 def test_consensus_kernel_with_small_lds_tables_and_oversized_graphs():
     """More than 512 windows: the consensus kernel sizes its LDS tables for 2176 nodes (four blocks per CU) and a
     window whose graph is larger takes the HBM routine inside the same launch. Results must equal those of the same
