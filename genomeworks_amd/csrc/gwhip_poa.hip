@@ -16,9 +16,10 @@
 namespace gwhip
 {
 
-// This file is compiled seven times: as it stands (everything but the graph-build kernel's instantiations) and, through
-// gwhip_poa_part{0..5}.hip, with GWHIP_POA_PART defined -- parts 0..3 once per (score type, id type) pair, parts 4 and 5 for
-// the packed passes of band 128 and of bands 384 / 512 (launch_packed_variant below). Those translation units hold nothing but
+// This file is compiled eight times: as it stands (everything but the graph-build kernel's instantiations) and, through
+// gwhip_poa_part{0..6}.hip, with GWHIP_POA_PART defined -- parts 0..3 once per (score type, id type) pair, parts 4 and 5 for
+// the packed passes of band 128 and of bands 384 / 512 (launch_packed_variant below), part 6 for the traceback-buffer kernels
+// with 16-bit scores, ids and traces. Those translation units hold nothing but
 // their poa_window_kernel instantiations and their launcher, so the heavy compilations run in parallel.
 #ifndef GWHIP_POA_PART
 thread_local std::string g_last_error;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
         // until the traceback)
         build_rowinfo<IdT, RowT>(g, node_count, rowinfo, lane, LDS_TABLES ? reinterpret_cast<uint64_t*>(lds_code_tile) : nullptr);
         // stage the read (plus the never-consumed read-ahead) in LDS when it fits
-        constexpr bool LDS_READ = LDS_TABLES && BM != GWHIP_FULL_BAND && !TB;
+        constexpr bool LDS_READ = LDS_TABLES && BM != GWHIP_FULL_BAND; // (the traceback-buffer modes: for their packed pass)
         const uint8_t* lds_read = lds_read_buf;
         if constexpr (LDS_READ)
         {
@@ -263,9 +264,39 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
         wave_sync();
         pc.tick(kPhRowInfo);
 
-        int32_t alen;
-        if (BM == GWHIP_ADAPTIVE_BAND_TRACEBACK && c.alignment_band_width < kMaxAdaptiveBand)
+        int32_t alen = 0;
+        // traceback-buffer modes with int16 scores, an int16 trace region and the tables in LDS: the packed pass first
+        // (poa_forward_moves_tb.h); it declines what it cannot reproduce and the memory-faithful routine takes that read
+        constexpr bool kTbPacked = TB && LDS_TABLES && std::is_same<ScoreT, int16_t>::value && std::is_same<TraceT, int16_t>::value;
+        bool tb_handled = false;
+        if constexpr (kTbPacked)
         {
+            constexpr bool kAd = BM == GWHIP_ADAPTIVE_BAND_TRACEBACK;
+            const bool adaptive_now = kAd && c.alignment_band_width < kMaxAdaptiveBand; // else the static routine, as below
+            auto packed = [&](auto ad_tag, int32_t rerun) -> int32_t {
+                return nw_banded_tb_packed<IdT, decltype(ad_tag)::value>(g, rowinfo, node_count, lds_read, seq_len, reinterpret_cast<int16_t*>(scores),
+                                                                         a.L.scores_elems, reinterpret_cast<int16_t*>(traceback), a.L.trace_elems,
+                                                                         banded_buffer_size, alignment_graph, alignment_read, c.alignment_band_width,
+                                                                         c.max_banded_pred_distance, c.gap_score, c.mismatch_score, c.match_score, rerun,
+                                                                         cells, smem, kRingBytes, reinterpret_cast<const uint64_t*>(lds_code_tile),
+                                                                         debug_flags, tb_handled);
+            };
+            if (adaptive_now)
+                alen = packed(std::integral_constant<bool, kAd>{}, 0);
+            else
+                alen = packed(std::false_type{}, 0);
+            // a band-edge rerun doubles the band beyond the packed widths: the routine below handles it (and nothing else of
+            // this read) -- tb_handled stays true, alen carries the shift
+        }
+        if (tb_handled && !(alen == kShiftLeft || alen == kShiftRight)) {}
+        else if (BM == GWHIP_ADAPTIVE_BAND_TRACEBACK && c.alignment_band_width < kMaxAdaptiveBand)
+        {
+            if (tb_handled)
+                alen = nw_banded_tb<ScoreT, IdT, RowT, TraceT, true>(g, rowinfo, node_count, sequence, seq_len, scores, a.L.scores_elems,
+                                                               traceback, a.L.trace_elems, banded_buffer_size, alignment_graph,
+                                                               alignment_read, c.alignment_band_width, c.max_banded_pred_distance,
+                                                               c.gap_score, c.mismatch_score, c.match_score, alen, cells);
+            else
             alen = nw_banded_tb<ScoreT, IdT, RowT, TraceT, true>(g, rowinfo, node_count, sequence, seq_len, scores, a.L.scores_elems,
                                                            traceback, a.L.trace_elems, banded_buffer_size, alignment_graph,
                                                            alignment_read, c.alignment_band_width, c.max_banded_pred_distance,
@@ -695,7 +726,7 @@ static hipError_t launch_window_kernel(const KernelArgs& ka_in, hipStream_t stre
 }
 
 template <typename ScoreT, typename IdT, typename TraceT>
-static hipError_t launch_msa_split(const KernelArgs& ka, hipStream_t stream)
+hipError_t launch_msa_split(const KernelArgs& ka, hipStream_t stream)
 {
     // LDS tables need 16-bit ids, <= 3072 graph rows and a read (+ read-ahead) that fits the LDS copy
     constexpr bool can_lds = sizeof(IdT) == 2;
@@ -710,6 +741,14 @@ static hipError_t launch_msa_split(const KernelArgs& ka, hipStream_t stream)
         if (lds) return launch_window_kernel<ScoreT, IdT, TraceT, false, true>(ka, stream);
     return launch_window_kernel<ScoreT, IdT, TraceT, false, false>(ka, stream);
 }
+
+// the traceback-buffer kernels with int16 scores, ids and traces (the packed pass of poa_forward_moves_tb.h lives there)
+// are compiled in a translation unit of their own (gwhip_poa_part6.hip)
+#if defined(GWHIP_POA_PART) && GWHIP_POA_PART == 6
+template hipError_t launch_msa_split<int16_t, int16_t, int16_t>(const KernelArgs&, hipStream_t);
+#else
+extern template hipError_t launch_msa_split<int16_t, int16_t, int16_t>(const KernelArgs&, hipStream_t);
+#endif
 
 template <typename ScoreT, typename IdT>
 hipError_t launch_trace_split(const KernelArgs& ka, hipStream_t stream)

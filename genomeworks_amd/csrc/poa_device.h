@@ -1200,6 +1200,7 @@ __device__ __forceinline__ void banded_forward_1pass(const GraphView<IdT>& g, co
 #include "poa_forward_packed.h"
 #include "poa_forward_moves.h"
 #include "poa_forward_moves_wide.h"
+#include "poa_forward_moves_tb.h"
 #include "poa_traceback_moves.h"
 namespace gwhip
 {

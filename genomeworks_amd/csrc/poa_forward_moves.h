@@ -57,7 +57,10 @@ __device__ __forceinline__ void gstore_u16_lane0_below(const void* vptr, uint32_
 // Row kinds, all lanes in parallel. Needs the band starts in the table already. Returns the first row whose band
 // starts past column 0 (graph_count + 1 if there is none); band starts never decrease from row to row.
 // ------------------------------------------------------------------------------------------------
-template <int MAXD = kPkMaxDist> // rows up a ring predecessor may be (ring rows - 1, or ring rows: poa_forward_moves_wide.h)
+// MAXD: rows up a ring predecessor may be (ring rows - 1, or ring rows: poa_forward_moves_wide.h). TBRULES: the
+// traceback-buffer modes (poa_forward_moves_tb.h) keep gap_score in the boundary slot of a row without predecessors whatever
+// its band start, so a row that has such a row (band start past column 0) among its predecessors takes the general routine.
+template <int MAXD = kPkMaxDist, bool TBRULES = false>
 __device__ __forceinline__ int32_t classify_kinds(RowInfo<true>* rowinfo, int32_t graph_count, int lane, const uint64_t* xpred, int32_t dbg = 0)
 {
     int32_t first_moved = graph_count + 1;
@@ -77,8 +80,10 @@ __device__ __forceinline__ int32_t classify_kinds(RowInfo<true>* rowinfo, int32_
             {
                 const int32_t p   = k < 3 ? ri.pred(k) : xpred_row(xe, k);
                 const int32_t d   = r - p;
-                const int32_t pbs = rowinfo[p].bs(); // row 0 holds band start 0
+                const RowInfo<true> pri = rowinfo[p];
+                const int32_t pbs = pri.bs(); // row 0 holds band start 0
                 ok                = ok && d >= 1 && d <= MAXD && (bs - pbs) <= kPkGuardCols && (bs == 0 || pbs > 0);
+                if constexpr (TBRULES) ok = ok && !(pri.cnt() == 0 && pbs > 0);
                 if (k == 0) { d0 = d; pbs0 = pbs; }
             }
             if (ok) kind = cnt > 1 ? 3 : ((d0 == 1 && pbs0 == bs) ? 0 : ((d0 == 1 && bs - pbs0 == kCellsPerLane) ? 1 : 2));

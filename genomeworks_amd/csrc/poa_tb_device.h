@@ -297,4 +297,112 @@ __device__ __forceinline__ int32_t nw_banded_tb(const GraphView<IdT>& g, RowT* r
     return wave_first(aligned_nodes);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The packed flavour (round 4): int16 scores, int16 trace region (two byte planes), row table and read in LDS, band 128 /
+// 256 -- poa_forward_moves_tb.h + the sheared-tile walk of poa_traceback_moves.h (MODE 1). `handled` comes back false when
+// the configuration or this read's graph needs the memory-faithful routine above (nothing observable has been written then:
+// nw_banded_tb initialises everything it reads).
+// ------------------------------------------------------------------------------------------------
+template <typename IdT, bool ADAPTIVE>
+__device__ __forceinline__ int32_t nw_banded_tb_packed(const GraphView<IdT>& g, RowInfo<true>* rowinfo, int32_t graph_count,
+                                                       const uint8_t* lds_read, int32_t read_length, int16_t* scores, size_t scores_elems,
+                                                       int16_t* traceback, size_t trace_elems, float max_buffer_size,
+                                                       int32_t* alignment_graph, int32_t* alignment_read, int32_t band_width, int32_t H,
+                                                       int32_t gap_score, int32_t mismatch_score, int32_t match_score, int32_t rerun,
+                                                       uint64_t& cells, uint8_t* ring_lds, int32_t ring_bytes, const uint64_t* xpred,
+                                                       int32_t dbg, bool& handled)
+{
+    handled                  = false;
+    const int lane           = threadIdx.x & (kWave - 1);
+    const int32_t min_score  = Limits<int16_t>::min / 2;
+    const float gradient     = __fdiv_rn((float)(read_length + 1), (float)(graph_count + 1));
+    const int32_t max_column = read_length + 1;
+    int32_t band_shift       = band_width / 2;
+    if (ADAPTIVE) // :306-332
+    {
+        if (rerun == kShiftLeft && band_width <= kMaxAdaptiveBand / 2)
+        {
+            band_width *= 2;
+            band_shift = (int32_t)((double)band_shift * 2.5);
+        }
+        if (rerun == kShiftRight && band_width <= kMaxAdaptiveBand / 2)
+        {
+            band_width *= 2;
+            band_shift = (int32_t)((double)band_shift * 1.5);
+        }
+    }
+    const int32_t u_span = 256 * abs(gap_score);
+    const bool packed_ok = (band_width == 256 || band_width == 128) && max_column >= band_width && ring_bytes >= kPkSlots * kPkSlotBytes &&
+                           ring_bytes >= kMtBytes && xpred != nullptr && H >= 16 && !(dbg & 256) &&
+                           abs(gap_score) <= 30 && abs(match_score) <= 100 && abs(mismatch_score) <= 100 &&
+                           // no packed operation can leave int16 (the bounds of nw_banded's packed pass)
+                           max(match_score, 0) * min(read_length, graph_count) + u_span + abs(match_score) <= 32767 &&
+                           (graph_count + read_length) * min(min(gap_score, mismatch_score), 0) >= -32768 + 256 &&
+                           min_score + 4 * min(min(gap_score, mismatch_score), 0) - u_span >= -32768 &&
+                           // both byte planes inside the int16 trace region, the ring rows inside the score region
+                           (size_t)(graph_count + 1) * (size_t)(band_width + kRightPad) <= trace_elems &&
+                           (size_t)min(H, graph_count + 1) * (size_t)(band_width + kRightPad) <= scores_elems;
+    if (!packed_ok) return 0;
+    if (ADAPTIVE)
+    {
+        float required = __fmul_rn((float)graph_count, (float)(band_width + kRightPad));
+        if (required > max_buffer_size)
+        {
+            handled = true;
+            return kNwAdaptiveStorageFailed;
+        }
+    }
+    const int32_t stride = band_width + kRightPad;
+    TbCtx<int16_t> t;
+    t.scores = scores; t.scores_elems = scores_elems; t.H = H; t.stride = stride;
+    t.band_width = band_width; t.band_shift = band_shift; t.max_column = max_column; t.min_score = min_score;
+    t.gradient = gradient;
+    // row 0 of the ring (:335-338) and the band start of every row into the row table
+    for (int32_t j = lane; j < stride; j += kWave) tb_set_score(t, 0, j, j * gap_score, 0);
+    for (int32_t r = 1 + lane; r <= graph_count; r += kWave)
+        rowinfo[r].set_bs(band_start_for_row(r, gradient, band_width, band_shift, max_column));
+    wave_sync();
+    TbPlanes planes;
+    planes.ring       = scores;
+    planes.ring_elems = scores_elems;
+    planes.H          = H;
+    planes.plane0     = reinterpret_cast<uint8_t*>(traceback);
+    planes.plane1     = reinterpret_cast<uint8_t*>(traceback) + trace_elems;
+    bool ok;
+    if (band_width == 256)
+        ok = banded_forward_tb<IdT, 256>(g, rowinfo, graph_count, lds_read, ring_lds, xpred, max_column, gap_score, mismatch_score, match_score, planes, dbg);
+    else
+        ok = banded_forward_tb<IdT, 128>(g, rowinfo, graph_count, lds_read, ring_lds, xpred, max_column, gap_score, mismatch_score, match_score, planes, dbg);
+    if (!ok) return 0; // the caller reruns this read with nw_banded_tb
+    handled = true;
+    cells += (uint64_t)graph_count * (uint64_t)band_width;
+    wave_sync(); // ring and planes complete and visible
+
+    // sink selection :535-568 (rows restricted to the last H)
+    int32_t best = min_score, best_i = 0;
+    for (int32_t idx = 1 + lane; idx <= graph_count; idx += kWave)
+    {
+        if (rowinfo[idx].sink() && (graph_count - idx) < H)
+        {
+            int32_t s = tb_get_score(t, idx, read_length);
+            if (best < s) { best = s; best_i = idx; }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        int32_t ob = __shfl_xor(best, off), oi = __shfl_xor(best_i, off);
+        if (ob > best || (ob == best && oi != 0 && (best_i == 0 || oi < best_i))) { best = ob; best_i = oi; }
+    }
+    best_i = wave_first(best_i);
+    if (best_i == 0) return kNwTracebackBufferFailed; // :570
+    BandedCtx<int16_t> b;
+    b.scores = nullptr; b.ring = nullptr; b.ring_rows = 0;
+    b.stride = stride; b.band_width = band_width; b.band_shift = band_shift; b.max_column = max_column;
+    b.gradient = gradient; b.min_score = min_score;
+    const int32_t n = traceback_moves<int16_t, IdT, RowInfo<true>, ADAPTIVE, 1>(b, g, rowinfo, graph_count, lds_read, read_length, best_i, alignment_graph,
+                                                                               alignment_read, gap_score, mismatch_score, match_score, rerun, ring_lds,
+                                                                               planes.plane0, planes.plane1);
+    return wave_first(n);
+}
+
 } // namespace gwhip

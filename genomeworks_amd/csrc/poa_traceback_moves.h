@@ -55,12 +55,17 @@ __device__ __forceinline__ void lds_store_zero_u64(uint32_t addr)
     *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(addr) = v;
 }
 
-template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE>
+// MODE 0: score-matrix modes -- a byte 0 is a cell the forward pass left undecided, stepped by recomputation from the HBM score
+// matrix. MODE 1: traceback-buffer modes (poa_forward_moves_tb.h) -- `moves` is plane 0 and `plane1` the exact int8 traces of
+// the general rows; a byte 0 is a cell of a general row (or of a band-edge margin), stepped from the planes the way the
+// reference walks its trace matrix (cudapoa_nw_tb_banded.cuh:572-636), and the band-edge tests of the adaptive mode run where
+// the reference runs them: after a diagonal move, on the cell it arrives at.
+template <typename ScoreT, typename IdT, typename RowT, bool ADAPTIVE, int MODE = 0>
 __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<ScoreT>& b, const GraphView<IdT>& g, const RowT* rowinfo,
                                                    int32_t graph_count, const uint8_t* read, int32_t read_length, int32_t start_i,
                                                    int32_t* alignment_graph, int32_t* alignment_read, int32_t gap_score,
                                                    int32_t mismatch_score, int32_t match_score, int32_t rerun, uint8_t* tile_region,
-                                                   const uint8_t* moves)
+                                                   const uint8_t* moves, const uint8_t* plane1 = nullptr)
 {
     constexpr bool kWide    = !std::is_same<RowT, RowInfo<true>>::value;
     constexpr int kMtStride = MtGeometry<kWide>::kStride, kMtZeroRows = MtGeometry<kWide>::kZeroRows;
@@ -83,7 +88,10 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<ScoreT>& b, c
     // that row of the HBM matrix: any alignment, so five aligned dwords are loaded and funnel-shifted.
     struct Seg { uint32_t d[5]; };
     const int seg = lane & 3;
-    int32_t lo_rel = 1, hi_rel = b.band_width; // relative columns (column - band start) whose bytes are committed
+    // relative columns (column - band start) whose bytes are committed; the boundary cell (relative column 0) is a cell of the
+    // traceback-buffer modes' trace matrix
+    int32_t lo_rel = MODE == 1 ? 0 : 1, hi_rel = b.band_width;
+    bool last_diag = false; // MODE 1, adaptive: the last step taken by the walk over move bytes was diagonal
     if (ADAPTIVE)
     {
         if (rerun == 0 && b.band_width < kMaxAdaptiveBand)
@@ -222,6 +230,7 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<ScoreT>& b, c
                 i -= nrun + drow;
                 j -= nrun + dcol;
                 sa += (uint32_t)(nrun * kMtStride + drow * (kMtStride + 1) - dcol);
+                if constexpr (MODE == 1 && ADAPTIVE) last_diag = mb != 0u ? (drow != 0 && dcol != 0) : (nrun > 0 ? true : last_diag);
                 if (mb == 0u) break;
             }
             // a byte 0: a cell the forward pass left undecided -- or a cell outside the tile
@@ -229,6 +238,74 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<ScoreT>& b, c
             c = j - cL + t;
             if (!(((uint32_t)t < (uint32_t)kMtRows) & ((uint32_t)c < (uint32_t)kMtCols)) && i > 0) continue;
             if ((i == 0 && j == 0) || n >= bound) continue; // the outer condition ends the walk
+        }
+        if constexpr (MODE == 1)
+        {
+            // ---------------- one step of the reference's walk over its trace matrix (cudapoa_nw_tb_banded.cuh:572-636) ----------------
+            auto edge_test = [&](int32_t ii, int32_t jj) -> int32_t { // :603-626, on the cell a diagonal move arrived at
+                if (rerun == 0 && b.band_width < kMaxAdaptiveBand)
+                {
+                    const int32_t threshold = max(1, b.max_column / 1024);
+                    if (jj > threshold && jj < b.max_column - threshold)
+                    {
+                        const int32_t bs2 = band_start_for_row(ii, b.gradient, b.band_width, b.band_shift, b.max_column);
+                        if (jj <= bs2 + threshold) return kShiftLeft;
+                        if (jj >= (bs2 + b.band_width - threshold)) return kShiftRight;
+                    }
+                }
+                return 0;
+            };
+            if constexpr (ADAPTIVE)
+            {
+                if (last_diag)
+                {
+                    const int32_t e = edge_test(i, j);
+                    if (e != 0) { n = e; break; }
+                }
+                last_diag = false;
+            }
+            int32_t drow = 0, dcol = 1; // horizontal: trace row 0, and (pinned) whatever lies outside the band
+            bool to_row0 = false;
+            if (i > 0)
+            {
+                const int32_t rel = j - band_start_of(i);
+                if (rel >= 0 && rel <= b.band_width)
+                {
+                    const int64_t idx = (int64_t)i * b.stride + rel + kRelShift;
+                    const uint32_t m  = (uint32_t)wave_first((int32_t)moves[idx]);
+                    if (m != 0u)
+                    {
+                        drow = (int32_t)(m >> 1);
+                        dcol = (int32_t)(m & 1u);
+                    }
+                    else
+                    {
+                        const int32_t t = (int32_t)(int8_t)wave_first((int32_t)plane1[idx]);
+                        to_row0         = t == kTbVertToRow0 || t == kTbDiagToRow0;
+                        if (t > 0) { drow = t; dcol = 1; }
+                        else if (t < 0) { drow = -t; dcol = 0; }
+                    }
+                }
+            }
+            if (to_row0) drow = i;
+            if (lane == 0)
+            {
+                alignment_graph[n] = drow != 0 ? i - 1 : -1; // sorted position; node ids are filled in below
+                alignment_read[n]  = dcol != 0 ? j - 1 : -1;
+            }
+            i -= drow;
+            j -= dcol;
+            if constexpr (ADAPTIVE)
+            {
+                if (drow != 0 && dcol != 0)
+                {
+                    const int32_t e = edge_test(i, j);
+                    if (e != 0) { n = e; break; }
+                }
+            }
+            n++;
+            if (i < 0 || j < 0) { n = bound; break; } // walked off the matrix: the reference's loop failure
+            continue;
         }
         // ---------------- one step by recomputation (exact restatement of :428-549), one candidate per lane ----------------
         // the row's record, wave-uniform: base, predecessor count, the rows of predecessor slots 0..2

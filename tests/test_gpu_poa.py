@@ -481,6 +481,79 @@ def test_two_pass_kernel_shortcuts_equal_the_plain_schedule(monkeypatch, band_wi
         assert cells == cells_ref
 
 
+@pytest.mark.parametrize("band_width", [128, 256])
+def test_traceback_buffer_packed_pass_equals_the_memory_faithful_routine(monkeypatch, band_width):
+    """The packed pass of the traceback-buffer modes (poa_forward_moves_tb.h: 16-bit pairs, the trace matrix as two byte
+    planes, sheared-tile walk) against the memory-faithful routine of poa_tb_device.h (GWHIP_DEBUG bit 8) and against its own
+    row kinds demoted into each other (bits 9, 10, 11, 15, 30), on config-3 windows and on windows of varied shape with heavy
+    indels -- identical consensus, coverage, status and cell counts, and equal to the oracle's on the production arm."""
+    import random
+    from genomeworks_amd import synthetic
+    rng = random.Random(1000 + band_width)
+    windows = config3(96)
+    for k in range(56):
+        blen = rng.choice([40, 130, 300, 640, 900, 1000])
+        reads = rng.choice([2, 3, 8, 17, 32])
+        mut, ins, dele = rng.choice([(0, 0, 0), (5, 2, 2), (40, 20, 20), (90, 40, 40), (10, 60, 5), (10, 5, 60)])
+        w = [r.decode() for r in synthetic.generate_window(7600 + k, blen, reads, mut, ins, dele)]
+        if k % 4 == 0:
+            w = [("GATTACA"[: rng.randrange(8)] + r)[rng.randrange(5):] for r in w]
+        windows.append([r for r in w if 0 < len(r) < 1024])
+    out = {}
+    arms = (("production", None), ("memory_faithful_routine", str(1 << 8)), ("registers_through_ring", str(1 << 10)),
+            ("moved_band_through_ring", str(1 << 15)), ("ring_through_general", str(1 << 9)),
+            ("registers_through_general", str(1 << 11)), ("many_predecessors_general", str(1 << 30)),
+            ("everything_general", str((1 << 9) | (1 << 11) | (1 << 30))))
+    modes = ("static_band_traceback", "adaptive_band_traceback")
+    for name, flag in arms:
+        if flag is None:
+            monkeypatch.delenv("GWHIP_DEBUG", raising=False)
+        else:
+            monkeypatch.setenv("GWHIP_DEBUG", flag)
+        for mode in modes:
+            b = run_gpu(windows, mode, band_width=band_width, mem=16 << 30)
+            out[name, mode] = (b.get_consensus(), b.total_cells())
+    for mode in modes:
+        for name, _ in arms[1:]:
+            assert out["production", mode] == out[name, mode], (name, mode)
+        (cons, cov, status), cells = out["production", mode]
+        cells_ref = 0
+        with O.Workspace(oracle_cfg(mode, band_width=band_width)) as ws:
+            for i, w in enumerate(windows):
+                ref = ws.process(w)
+                cells_ref += ref["cells"]
+                assert status[i] == ref["status"], (mode, i)
+                if ref["status"] == 0:
+                    assert cons[i] == ref["consensus"] and cov[i] == list(ref["coverage"]), (mode, i)
+        assert cells == cells_ref
+
+
+def test_traceback_buffer_modes_with_a_short_predecessor_window_vs_oracle():
+    """max_banded_pred_distance below the packed pass's limits (8: the packed pass declines, every read takes the
+    memory-faithful routine, predecessors 8 or more rows up are dropped or end the window with
+    exceeded_maximum_predecessor_distance) and just above them (20: packed, with predecessors beyond the window skipped by
+    the general rows) -- status, consensus and coverage equal the oracle's."""
+    from genomeworks_amd import cudapoa, synthetic
+    windows = config3(12) + [[r.decode() for r in synthetic.generate_window(7900 + k, 700, 12, 40, 30, 30)] for k in range(12)]
+    for mode in ("static_band_traceback", "adaptive_band_traceback"):
+        for H in (8, 20, 130):
+            b = cudapoa.CudaPoaBatch(32, 1024, 8 << 30, output_type="consensus", band_mode=mode, alignment_band_width=256,
+                                     max_nodes_per_graph=3072, max_banded_pred_distance=H)
+            for w in windows:
+                assert b.add_poa_group(w)[0] == 0
+            b.generate_poa()
+            cons, cov, status = b.get_consensus()
+            cfg = oracle_cfg(mode)
+            cfg.max_banded_pred_distance = H
+            O.lib().poa_cfg_select_types(cfg)
+            with O.Workspace(cfg) as ws:
+                for i, w in enumerate(windows):
+                    ref = ws.process(w)
+                    assert status[i] == ref["status"], (mode, H, i, status[i], ref["status"])
+                    if ref["status"] == 0:
+                        assert cons[i] == ref["consensus"] and cov[i] == list(ref["coverage"]), (mode, H, i)
+
+
 def test_consensus_kernel_with_small_lds_tables_and_oversized_graphs():
     """More than 512 windows: the consensus kernel sizes its LDS tables for 2176 nodes (four blocks per CU) and a
     window whose graph is larger takes the HBM routine inside the same launch. Results must equal those of the same
