@@ -298,8 +298,8 @@ __device__ __forceinline__ int32_t nw_banded_tb(const GraphView<IdT>& g, RowT* r
 }
 
 // ------------------------------------------------------------------------------------------------
-// The packed flavour (round 4): int16 scores, int16 trace region (two byte planes), row table and read in LDS, band 128 /
-// 256 -- poa_forward_moves_tb.h + the sheared-tile walk of poa_traceback_moves.h (MODE 1). `handled` comes back false when
+// The packed flavour (round 4): int16 scores, int16 trace region (two byte planes), row table and read in LDS, bands 128 /
+// 256 / 384 / 512 -- poa_forward_moves_tb.h + the sheared-tile walk of poa_traceback_moves.h (MODE 1). `handled` comes back false when
 // the configuration or this read's graph needs the memory-faithful routine above (nothing observable has been written then:
 // nw_banded_tb initialises everything it reads).
 // ------------------------------------------------------------------------------------------------
@@ -331,8 +331,8 @@ __device__ __forceinline__ int32_t nw_banded_tb_packed(const GraphView<IdT>& g, 
             band_shift = (int32_t)((double)band_shift * 1.5);
         }
     }
-    const int32_t u_span = 256 * abs(gap_score);
-    const bool packed_ok = (band_width == 256 || band_width == 128) && max_column >= band_width && ring_bytes >= kPkSlots * kPkSlotBytes &&
+    const int32_t u_span = max(band_width, 256) * abs(gap_score); // u-space offset of the last band cell
+    const bool packed_ok = (band_width == 256 || band_width == 128 || band_width == 384 || band_width == 512) && max_column >= band_width && ring_bytes >= kPkSlots * kPkSlotBytes &&
                            ring_bytes >= kMtBytes && xpred != nullptr && H >= 16 && !(dbg & 256) &&
                            abs(gap_score) <= 30 && abs(match_score) <= 100 && abs(mismatch_score) <= 100 &&
                            // no packed operation can leave int16 (the bounds of nw_banded's packed pass)
@@ -371,8 +371,12 @@ __device__ __forceinline__ int32_t nw_banded_tb_packed(const GraphView<IdT>& g, 
     bool ok;
     if (band_width == 256)
         ok = banded_forward_tb<IdT, 256>(g, rowinfo, graph_count, lds_read, ring_lds, xpred, max_column, gap_score, mismatch_score, match_score, planes, dbg);
-    else
+    else if (band_width == 128)
         ok = banded_forward_tb<IdT, 128>(g, rowinfo, graph_count, lds_read, ring_lds, xpred, max_column, gap_score, mismatch_score, match_score, planes, dbg);
+    else if (band_width == 384)
+        ok = banded_forward_tb<IdT, 384>(g, rowinfo, graph_count, lds_read, ring_lds, xpred, max_column, gap_score, mismatch_score, match_score, planes, dbg);
+    else
+        ok = banded_forward_tb<IdT, 512>(g, rowinfo, graph_count, lds_read, ring_lds, xpred, max_column, gap_score, mismatch_score, match_score, planes, dbg);
     if (!ok) return 0; // the caller reruns this read with nw_banded_tb
     handled = true;
     cells += (uint64_t)graph_count * (uint64_t)band_width;

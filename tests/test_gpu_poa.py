@@ -481,7 +481,7 @@ def test_two_pass_kernel_shortcuts_equal_the_plain_schedule(monkeypatch, band_wi
         assert cells == cells_ref
 
 
-@pytest.mark.parametrize("band_width", [128, 256])
+@pytest.mark.parametrize("band_width", [128, 256, 384, 512])
 def test_traceback_buffer_packed_pass_equals_the_memory_faithful_routine(monkeypatch, band_width):
     """The packed pass of the traceback-buffer modes (poa_forward_moves_tb.h: 16-bit pairs, the trace matrix as two byte
     planes, sheared-tile walk) against the memory-faithful routine of poa_tb_device.h (GWHIP_DEBUG bit 8) and against its own
@@ -492,7 +492,7 @@ def test_traceback_buffer_packed_pass_equals_the_memory_faithful_routine(monkeyp
     rng = random.Random(1000 + band_width)
     windows = config3(96)
     for k in range(56):
-        blen = rng.choice([40, 130, 300, 640, 900, 1000])
+        blen = rng.choice([40, 130, 300, 640, 900, 1000] if band_width <= 256 else [520, 640, 900, 1000])
         reads = rng.choice([2, 3, 8, 17, 32])
         mut, ins, dele = rng.choice([(0, 0, 0), (5, 2, 2), (40, 20, 20), (90, 40, 40), (10, 60, 5), (10, 5, 60)])
         w = [r.decode() for r in synthetic.generate_window(7600 + k, blen, reads, mut, ins, dele)]
@@ -529,10 +529,9 @@ def test_traceback_buffer_packed_pass_equals_the_memory_faithful_routine(monkeyp
 
 
 def test_traceback_buffer_modes_with_a_short_predecessor_window_vs_oracle():
-    """max_banded_pred_distance below the packed pass's limits (8: the packed pass declines, every read takes the
-    memory-faithful routine, predecessors 8 or more rows up are dropped or end the window with
-    exceeded_maximum_predecessor_distance) and just above them (20: packed, with predecessors beyond the window skipped by
-    the general rows) -- status, consensus and coverage equal the oracle's."""
+    """max_banded_pred_distance of 8 and 20 (int8 traces: the memory-faithful routine; predecessors that far up are
+    skipped) and of 130 (int16 trace region: the packed pass with a window shorter than its own 126-row limit) -- status,
+    consensus and coverage equal the oracle's."""
     from genomeworks_amd import cudapoa, synthetic
     windows = config3(12) + [[r.decode() for r in synthetic.generate_window(7900 + k, 700, 12, 40, 30, 30)] for k in range(12)]
     for mode in ("static_band_traceback", "adaptive_band_traceback"):
