@@ -80,8 +80,10 @@ private:
     size_t head_cap_                 = 0;
     int32_t n_head_                  = 0;
 
-    char* device_block_        = nullptr;
+    char* device_block_        = nullptr; ///< inputs and outputs (allocated first: the uploads start before the batch is sorted)
     size_t device_block_bytes_ = 0;
+    char* workspace_block_     = nullptr; ///< the kernels' workspace (sized once the processing order is known)
+    size_t workspace_block_bytes_ = 0;
     char* d_seq_               = nullptr;
     int64_t* d_starts_         = nullptr;
     int32_t* d_bw_             = nullptr;

@@ -133,16 +133,19 @@ PackedAlignmentBlock::~PackedAlignmentBlock()
     if (alignments != nullptr)
     {
         for (size_t i = 0; i < n_alignments; ++i) alignments[i].~PackedAlignment();
-        ::operator delete(static_cast<void*>(alignments));
+        host_release(reinterpret_cast<char*>(alignments), alignments_bytes);
     }
     if (pinned != nullptr) pinned_release(pinned, pinned_bytes);
     if (sequences_buffer != nullptr) pinned_release(sequences_buffer, sequences_bytes);
     if (seq_starts_buffer != nullptr) pinned_release(seq_starts_buffer, seq_starts_bytes);
+    if (head_buffer != nullptr) pinned_release(head_buffer, head_bytes);
 }
 
 void PackedAlignmentBlock::allocate_views(size_t n)
 {
-    alignments   = static_cast<PackedAlignment*>(::operator new(std::max<size_t>(n, 1) * sizeof(PackedAlignment)));
+    // from the process-wide cache of host buffers: recycled storage is already mapped (a fresh 32-MB allocation per sync pays
+    // for its page faults on the binder threads)
+    alignments   = reinterpret_cast<PackedAlignment*>(host_acquire(std::max<size_t>(n, 1) * sizeof(PackedAlignment), &alignments_bytes));
     n_alignments = 0; // raised by the caller once the views are constructed
 }
 

@@ -90,8 +90,18 @@ struct PackedAlignmentBlock
     size_t pinned_bytes   = 0;
     const int8_t* ops     = nullptr;
     const int32_t* counts = nullptr;
+    /// [n + 1] offsets of the alignments' runs in ops / counts and [n] metadata words (bit 31 = optimal), by index of
+    /// add_alignment: what the kernels wrote (DeviceAlignmentsPtrs::cigar_offsets / metadata). A view reads its range from
+    /// these arrays when it is asked, so the views can be laid out while the kernels still run.
+    const int32_t* run_starts = nullptr;
+    const uint32_t* metadata  = nullptr;
+    char* head_buffer         = nullptr;     ///< pinned [run_starts | metadata], handed over by the aligner
+    size_t head_bytes         = 0;
+    std::vector<int32_t> run_starts_owned;   ///< tests / callers without pinned buffers
+    std::vector<uint32_t> metadata_owned;
     PackedAlignment* alignments = nullptr;   ///< [n_alignments] by index of add_alignment (raw storage, see allocate_views)
     size_t n_alignments         = 0;
+    size_t alignments_bytes     = 0;         ///< capacity of the views' storage (from the host-buffer cache)
     bool expand_states          = false;     ///< AlignerGlobalMyers: per-position states instead of run lengths
     void allocate_views(size_t n);           ///< uninitialised storage for n views (constructed by the binder threads)
 };
@@ -99,13 +109,9 @@ struct PackedAlignmentBlock
 class PackedAlignment final : public Alignment
 {
 public:
-    PackedAlignment(const PackedAlignmentBlock* block, int32_t index, int32_t run_begin, int32_t run_end, bool has_result, bool is_optimal)
+    PackedAlignment(const PackedAlignmentBlock* block, int32_t index)
         : block_(block)
         , index_(index)
-        , run_begin_(run_begin)
-        , run_end_(run_end)
-        , has_result_(has_result)
-        , is_optimal_(has_result && is_optimal)
     {
     }
     ~PackedAlignment() override;
@@ -114,23 +120,31 @@ public:
     const std::string& get_target_sequence() const override;
     std::string convert_to_cigar(CigarFormat format = CigarFormat::basic) const override;
     AlignmentType get_alignment_type() const override { return AlignmentType::global_alignment; }
-    bool is_optimal() const override { return is_optimal_; }
-    StatusType get_status() const override { return has_result_ ? StatusType::success : StatusType::uninitialized; }
+    bool is_optimal() const override { return has_result() && (block_->metadata[index_] >> 31) != 0; }
+    StatusType get_status() const override { return has_result() ? StatusType::success : StatusType::uninitialized; }
     const std::vector<AlignmentState>& get_alignment() const override;
     const std::vector<int8_t>& get_actions() const override;
     const std::vector<int32_t>& get_runlengths() const override;
     int32_t get_edit_distance() const override;
     FormattedAlignment format_alignment(int32_t maximal_line_length = 80) const override;
 
-    int32_t num_runs() const { return run_end_ - run_begin_; }
+    int32_t run_begin() const { return block_->run_starts[index_]; }
+    int32_t run_end() const { return block_->run_starts[index_ + 1]; }
+    int32_t num_runs() const { return run_end() - run_begin(); }
+    /// a pair the kernels reported nothing for has no runs -- unless both sequences are empty (an empty alignment is a result)
+    bool has_result() const
+    {
+        const int64_t* st = block_->seq_starts + 2 * static_cast<size_t>(index_);
+        return run_begin() != run_end() || (st[0] == st[1] && st[1] == st[2]);
+    }
     /// run k in forward order (the device stores an alignment back to front)
-    int8_t op(int32_t k) const { return block_->ops[run_end_ - 1 - k]; }
-    int32_t count(int32_t k) const { return block_->counts[run_end_ - 1 - k]; }
+    int8_t op(int32_t k) const { return block_->ops[run_end() - 1 - k]; }
+    int32_t count(int32_t k) const { return block_->counts[run_end() - 1 - k]; }
     bool materialised() const { return lazy_.load(std::memory_order_acquire) != nullptr; }
 
 private:
     /// what the accessors that return references need to own; built on first use, one allocation per alignment that is
-    /// actually inspected (a view itself is 40 bytes: a million-pair batch costs 40 MB, not a million string pairs)
+    /// actually inspected (a view itself is 32 bytes: a million-pair batch costs 32 MB, not a million string pairs)
     struct Lazy
     {
         std::once_flag seq_once, runs_once;
@@ -144,8 +158,7 @@ private:
     void materialise_runs() const;
 
     const PackedAlignmentBlock* block_;
-    int32_t index_, run_begin_, run_end_;
-    bool has_result_, is_optimal_;
+    int32_t index_;
     mutable std::atomic<Lazy*> lazy_{nullptr};
 };
 
@@ -153,6 +166,9 @@ private:
 /// they serve); thread-safe
 char* pinned_acquire(size_t bytes, size_t* capacity);
 void pinned_release(char* p, size_t capacity);
+/// pageable host buffers of a megabyte and more, recycled process-wide (a recycled buffer is already mapped); thread-safe
+char* host_acquire(size_t bytes, size_t* capacity);
+void host_release(char* p, size_t capacity);
 
 } // namespace cudaaligner
 } // namespace genomeworks

@@ -14,10 +14,13 @@
 #include <claraparabricks/genomeworks/utils/signed_integer_utils.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
+#include <cstdio>
 #include <new>
 #include <numeric>
 #include <cstdlib>
+#include <exception>
 #include <stdexcept>
 #include <thread>
 
@@ -43,6 +46,19 @@ namespace
 {
 constexpr int32_t kWordSize = 32;
 size_t up256(size_t v) { return (v + 255) & ~size_t(255); }
+// GW_ALIGNER_TRACE=1: host-side timeline of align_all() / sync_alignments() on stderr (debugging aid)
+struct Tracer
+{
+    bool on = std::getenv("GW_ALIGNER_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char* what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[aligner] %-44s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 } // namespace
 
 BandedAligner::BandedAligner(int64_t max_device_memory, int32_t max_bandwidth, DefaultDeviceAllocator allocator,
@@ -86,6 +102,12 @@ void BandedAligner::free_device()
         allocator_.deallocate(device_block_, device_block_bytes_);
         device_block_       = nullptr;
         device_block_bytes_ = 0;
+    }
+    if (workspace_block_ != nullptr)
+    {
+        allocator_.deallocate(workspace_block_, workspace_block_bytes_);
+        workspace_block_       = nullptr;
+        workspace_block_bytes_ = 0;
     }
 }
 
@@ -198,6 +220,36 @@ StatusType BandedAligner::align_all()
     if (n == 0) return StatusType::success;
     scoped_device_switch dev(device_id_);
     const int64_t total_len = seq_starts_h_.back();
+    Tracer trace;
+    // Inputs and outputs first: the sequences (the bulk of the upload: 300 MB for a million 150-bp pairs), their offsets and the
+    // band widths do not depend on the processing order, so their copies are under way while the host sorts the batch and
+    // sizes the workspace below (aligner_global_myers_banded.cpp:364-371 uploads after sorting; the result is the same).
+    size_t off       = 0;
+    auto take        = [&](size_t b) { size_t o = off; off += up256(b); return o; };
+    const size_t o_seq = take(static_cast<size_t>(total_len) + 16), o_starts = take((2 * static_cast<size_t>(n) + 1) * 8);
+    const size_t o_bw = take(static_cast<size_t>(n) * 4), o_order = take(static_cast<size_t>(n) * 4);
+    const size_t o_res = take(static_cast<size_t>(total_len) + 16), o_cnt = take((static_cast<size_t>(total_len) + 16) * 4);
+    const size_t o_rs = take((static_cast<size_t>(n) + 1) * 4), o_meta = take(static_cast<size_t>(n) * 4);
+    const size_t o_cells = take(static_cast<size_t>(n) * 8);
+    // a previous align_all() without a sync in between may still be uploading from / computing on what this replaces
+    if (uploads_in_flight_) GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+    free_device();
+    device_block_bytes_ = off;
+    device_block_       = allocator_.allocate(device_block_bytes_, {stream_});
+    d_seq_              = device_block_ + o_seq;
+    d_starts_           = reinterpret_cast<int64_t*>(device_block_ + o_starts);
+    d_bw_               = reinterpret_cast<int32_t*>(device_block_ + o_bw);
+    d_order_            = reinterpret_cast<int32_t*>(device_block_ + o_order);
+    d_results_          = reinterpret_cast<int8_t*>(device_block_ + o_res);
+    d_result_counts_    = reinterpret_cast<int32_t*>(device_block_ + o_cnt);
+    d_result_starts_    = reinterpret_cast<int32_t*>(device_block_ + o_rs);
+    d_metadata_         = reinterpret_cast<uint32_t*>(device_block_ + o_meta);
+    d_cells_            = reinterpret_cast<uint64_t*>(device_block_ + o_cells);
+    GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq_, seq_h_.data(), static_cast<size_t>(total_len), hipMemcpyHostToDevice, stream_));
+    GW_CU_CHECK_ERR(hipMemcpyAsync(d_starts_, seq_starts_h_.data(), seq_starts_h_.size() * 8, hipMemcpyHostToDevice, stream_));
+    GW_CU_CHECK_ERR(hipMemcpyAsync(d_bw_, max_bandwidths_h_.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, stream_));
+    uploads_in_flight_ = true;
+    trace.mark("align_all: device block, uploads enqueued");
     // longest pairs first (aligner_global_myers_banded.cpp:306-309): lanes of one wave get similar work
     PinnedVector<int32_t> order;
     order.resize(static_cast<size_t>(n));
@@ -220,40 +272,17 @@ StatusType BandedAligner::align_all()
             });
         }
     }
-
+    trace.mark("align_all: length sort");
     workspace_bytes_ = gwhip_myers_banded_workspace_bytes_ordered(n, seq_starts_h_.data(), max_bandwidths_h_.data(), order.data());
-    size_t off       = 0;
-    auto take        = [&](size_t b) { size_t o = off; off += up256(b); return o; };
-    const size_t o_seq = take(static_cast<size_t>(total_len) + 16), o_starts = take((2 * static_cast<size_t>(n) + 1) * 8);
-    const size_t o_bw = take(static_cast<size_t>(n) * 4), o_order = take(static_cast<size_t>(n) * 4);
-    const size_t o_res = take(static_cast<size_t>(total_len) + 16), o_cnt = take((static_cast<size_t>(total_len) + 16) * 4);
-    const size_t o_rs = take((static_cast<size_t>(n) + 1) * 4), o_meta = take(static_cast<size_t>(n) * 4);
-    const size_t o_cells = take(static_cast<size_t>(n) * 8);
-    const size_t o_ws = take(workspace_bytes_);
-    free_device();
-    device_block_bytes_ = off;
-    device_block_       = allocator_.allocate(device_block_bytes_, {stream_});
-    d_seq_              = device_block_ + o_seq;
-    d_starts_           = reinterpret_cast<int64_t*>(device_block_ + o_starts);
-    d_bw_               = reinterpret_cast<int32_t*>(device_block_ + o_bw);
-    d_order_            = reinterpret_cast<int32_t*>(device_block_ + o_order);
-    d_results_          = reinterpret_cast<int8_t*>(device_block_ + o_res);
-    d_result_counts_    = reinterpret_cast<int32_t*>(device_block_ + o_cnt);
-    d_result_starts_    = reinterpret_cast<int32_t*>(device_block_ + o_rs);
-    d_metadata_         = reinterpret_cast<uint32_t*>(device_block_ + o_meta);
-    d_cells_            = reinterpret_cast<uint64_t*>(device_block_ + o_cells);
-    d_workspace_        = device_block_ + o_ws;
-    // a previous align_all() without a sync in between may still be uploading from the buffer this replaces
-    if (uploads_in_flight_) GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
-    order_h_            = std::move(order);
-
-    GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq_, seq_h_.data(), static_cast<size_t>(total_len), hipMemcpyHostToDevice, stream_));
-    GW_CU_CHECK_ERR(hipMemcpyAsync(d_starts_, seq_starts_h_.data(), seq_starts_h_.size() * 8, hipMemcpyHostToDevice, stream_));
-    GW_CU_CHECK_ERR(hipMemcpyAsync(d_bw_, max_bandwidths_h_.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, stream_));
+    trace.mark("align_all: workspace sizing");
+    workspace_block_bytes_ = up256(workspace_bytes_);
+    workspace_block_       = allocator_.allocate(workspace_block_bytes_, {stream_});
+    d_workspace_           = workspace_block_;
+    order_h_               = std::move(order);
     GW_CU_CHECK_ERR(hipMemcpyAsync(d_order_, order_h_.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, stream_));
     launch();
+    trace.mark("align_all: order upload and kernels enqueued");
     launched_          = true;
-    uploads_in_flight_ = true;
     return StatusType::success;
 }
 
@@ -291,7 +320,7 @@ void BandedAligner::launch(void* event_before, void* event_after)
     // result_starts (aligner_global_myers_banded.cpp:372-374): sync_alignments() and get_alignments_device() read
     // them after the stream has drained
     const size_t un = static_cast<size_t>(a.n_alignments);
-    if (head_ == nullptr || head_cap_ < (2 * un + 1) * 4)
+    if (head_ == nullptr || head_cap_ < (2 * un + 1) * 4) // (sync_alignments() hands the buffer to the views' block)
     {
         if (head_ != nullptr) pinned_release(head_, head_cap_);
         head_ = pinned_acquire((2 * un + 1) * 4, &head_cap_);
@@ -344,84 +373,108 @@ StatusType BandedAligner::sync_alignments()
     alignments_.clear();
     if (n == 0) return StatusType::success;
     scoped_device_switch dev(device_id_);
-    // One block per sync: [result_starts | metadata] first (they say how many runs follow), then the packed runs into
-    // pinned memory that the block keeps; the Alignment objects are views into it (alignment_impl.hpp).
+    // One block per sync: the packed runs arrive in pinned memory that the block keeps; the Alignment objects are views into it
+    // (alignment_impl.hpp). A view holds nothing but its index: it reads its run range and flags from the block's copy of
+    // [result_starts | metadata] when asked -- so the million views of a short-read batch are laid out and published on host
+    // threads WHILE the uploads and kernels of align_all() still run, and only the runs themselves wait for the device.
     auto block            = std::make_shared<PackedAlignmentBlock>();
     block->expand_states  = expand_results_;
     const size_t un       = static_cast<size_t>(n);
-    if (!launched_ || n_head_ != n) throw std::runtime_error("sync_alignments() called before align_all()");
-    GW_CU_CHECK_ERR(hipStreamSynchronize(stream_)); // kernels + the offsets / metadata copy queued by align_all()
-    uploads_in_flight_ = false;
-    const int32_t* starts = reinterpret_cast<const int32_t*>(head_);
-    const uint32_t* meta  = reinterpret_cast<const uint32_t*>(head_) + un + 1;
-    const size_t total    = static_cast<size_t>(starts[un]);
-    const size_t counts_at = (total + 63) & ~size_t(63);
-    block->pinned         = pinned_acquire(counts_at + total * 4 + 64, &block->pinned_bytes);
-    block->ops            = reinterpret_cast<const int8_t*>(block->pinned);
-    block->counts         = reinterpret_cast<const int32_t*>(block->pinned + counts_at);
-    if (total > 0)
-    {
-        GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned, d_results_, total, hipMemcpyDeviceToHost, stream_));
-        GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned + counts_at, d_result_counts_, total * 4, hipMemcpyDeviceToHost, stream_));
-    }
-    // From here on copies into the block's pinned memory are in flight and the batch's sequence arrays move into the block:
-    // any exception below (bad_alloc, a HIP error) must first drain the stream -- the block's destructor hands the pinned
-    // buffers back to the process-wide cache -- and leave the aligner in its empty, consistent state.
+    if (!launched_ || n_head_ != n || head_ == nullptr) throw std::runtime_error("sync_alignments() called before align_all()");
+    Tracer trace;
+    // From here on the batch's pinned arrays belong to the block while copies from / into them may be in flight: any exception
+    // below (bad_alloc, a HIP error) must first drain the stream -- the block's destructor hands the pinned buffers back to the
+    // process-wide cache -- and leave the aligner in its empty, consistent state.
     try
     {
-    // while the runs are in flight: hand the batch's (pinned) sequence arrays to the block and lay out the views
-    block->sequences_buffer  = seq_h_.detach(&block->sequences_bytes);
-    block->sequences         = block->sequences_buffer;
-    block->seq_starts_buffer = reinterpret_cast<char*>(seq_starts_h_.detach(&block->seq_starts_bytes));
-    block->seq_starts        = reinterpret_cast<const int64_t*>(block->seq_starts_buffer);
-    block->allocate_views(un);
-    alignments_.resize(un);
-    auto bind_range = [&](size_t first, size_t last) {
-        for (size_t i = first; i < last; ++i)
+        block->sequences_buffer  = seq_h_.detach(&block->sequences_bytes);
+        block->sequences         = block->sequences_buffer;
+        block->seq_starts_buffer = reinterpret_cast<char*>(seq_starts_h_.detach(&block->seq_starts_bytes));
+        block->seq_starts        = reinterpret_cast<const int64_t*>(block->seq_starts_buffer);
+        block->head_buffer       = head_;
+        block->head_bytes        = head_cap_;
+        block->run_starts        = reinterpret_cast<const int32_t*>(head_);
+        block->metadata          = reinterpret_cast<const uint32_t*>(head_) + un + 1; // the kernels write metadata[i] = i | flags
+        head_                    = nullptr;
+        head_cap_                = 0;
+        block->allocate_views(un);
+        alignments_.resize(un);
+        trace.mark("sync: view storage");
+        // the shared_ptr of every view aliases the block (no allocation per alignment); big batches are split over host threads,
+        // each with its own copy of the owner so that the reference count is not one contended cache line
+        auto bind_range = [&](size_t first, size_t last) {
+            // a control block of this thread's own that keeps the block alive: every aliasing shared_ptr below bumps ITS
+            // reference count, so the threads do not fight over one cache line (copies of `block` would share one counter:
+            // a million contended atomic increments were 9 of the 10 ms this loop took)
+            const std::shared_ptr<PackedAlignmentBlock> owner(block.get(), [keep = block](PackedAlignmentBlock*) {});
+            for (size_t i = first; i < last; ++i)
+            {
+                new (&block->alignments[i]) PackedAlignment(block.get(), static_cast<int32_t>(i));
+                alignments_[i] = std::shared_ptr<Alignment>(owner, &block->alignments[i]);
+            }
+        };
+        const size_t n_threads = un >= 65536 ? std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        if (n_threads <= 1)
+            bind_range(0, un);
+        else
         {
-            const bool is_optimal = (meta[i] >> 31) != 0;
-            const size_t index    = meta[i] & DeviceAlignmentsPtrs::index_mask; // the kernels write metadata[i] for pair i: a bijection
-            const int64_t* st     = block->seq_starts + 2 * index;
-            const bool has_result = starts[i] != starts[i + 1] || (st[0] == st[1] && st[1] == st[2]);
-            new (&block->alignments[index]) PackedAlignment(block.get(), static_cast<int32_t>(index), starts[i], starts[i + 1], has_result, is_optimal);
+            const size_t chunk = (un + n_threads - 1) / n_threads;
+            std::vector<std::thread> workers;
+            std::vector<std::exception_ptr> errors(n_threads);
+            {
+                struct JoinAll
+                {
+                    std::vector<std::thread>& threads;
+                    ~JoinAll()
+                    {
+                        for (std::thread& t : threads)
+                            if (t.joinable()) t.join();
+                    }
+                } join_on_exit{workers};
+                workers.reserve(n_threads);
+                for (size_t t = 1; t < n_threads; ++t)
+                    workers.emplace_back([&, t] {
+                        try
+                        {
+                            bind_range(std::min(un, t * chunk), std::min(un, (t + 1) * chunk));
+                        }
+                        catch (...)
+                        {
+                            errors[t] = std::current_exception();
+                        }
+                    });
+                bind_range(0, std::min(un, chunk));
+            }
+            for (const std::exception_ptr& e : errors)
+                if (e) std::rethrow_exception(e);
         }
-    };
-    // the shared_ptr of every view aliases the block (no allocation per alignment); big batches are split over a few
-    // host threads, each with its own copy of the owner so that the reference count is not one contended cache line
-    auto publish_range = [&](size_t first, size_t last) {
-        const std::shared_ptr<PackedAlignmentBlock> owner = block;
-        for (size_t i = first; i < last; ++i) alignments_[i] = std::shared_ptr<Alignment>(owner, &block->alignments[i]);
-    };
-    const size_t n_threads = un >= 65536 ? std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
-    if (n_threads <= 1)
-    {
-        bind_range(0, un);
-        publish_range(0, un);
-    }
-    else
-    {
-        const size_t chunk = (un + n_threads - 1) / n_threads;
-        std::vector<std::thread> workers;
-        for (size_t t = 1; t < n_threads; ++t)
-            workers.emplace_back([&, t] {
-                bind_range(std::min(un, t * chunk), std::min(un, (t + 1) * chunk));
-                publish_range(std::min(un, t * chunk), std::min(un, (t + 1) * chunk));
-            });
-        bind_range(0, std::min(un, chunk));
-        publish_range(0, std::min(un, chunk));
-        for (std::thread& w : workers) w.join();
-    }
-    block->n_alignments = un;
-    GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+        block->n_alignments = un;
+        trace.mark("sync: views bound and published");
+        GW_CU_CHECK_ERR(hipStreamSynchronize(stream_)); // uploads, kernels and the offsets / metadata copy queued by align_all()
+        uploads_in_flight_ = false;
+        trace.mark("sync: stream drained (H2D + kernels)");
+        const size_t total     = static_cast<size_t>(block->run_starts[un]);
+        const size_t counts_at = (total + 63) & ~size_t(63);
+        block->pinned          = pinned_acquire(counts_at + total * 4 + 64, &block->pinned_bytes);
+        block->ops             = reinterpret_cast<const int8_t*>(block->pinned);
+        block->counts          = reinterpret_cast<const int32_t*>(block->pinned + counts_at);
+        if (total > 0)
+        {
+            GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned, d_results_, total, hipMemcpyDeviceToHost, stream_));
+            GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned + counts_at, d_result_counts_, total * 4, hipMemcpyDeviceToHost, stream_));
+            GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+        }
+        trace.mark("sync: D2H of the runs done");
+        total_length_h_ = static_cast<int64_t>(total);
     }
     catch (...)
     {
         (void)hipStreamSynchronize(stream_);
+        uploads_in_flight_ = false;
         alignments_.clear();
         reset_data();
         throw;
     }
-    total_length_h_ = static_cast<int64_t>(total);
     // keep the device block (device-resident results stay valid until reset()); host queues are cleared like the reference
     n_last_ = n;
     reset_data();

@@ -1,7 +1,10 @@
 // runtime.cpp -- device/runtime helpers and synthetic input generators behind include/gw_capi.h.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include <random>
 #include <string>
 
@@ -85,6 +88,60 @@ void pinned_release(char* p, size_t capacity)
         }
     }
     if (drop != nullptr) (void)hipHostFree(drop);
+}
+
+// ---- pageable host buffers, recycled the same way (the views of a million-pair batch: a recycled buffer is already mapped) ----
+namespace
+{
+PinnedCache& host_cache()
+{
+    static PinnedCache* c = new PinnedCache;
+    return *c;
+}
+constexpr size_t kHostKeep = 4;
+} // namespace
+
+char* host_acquire(size_t bytes, size_t* capacity)
+{
+    PinnedCache& c = host_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.m);
+        for (size_t i = 0; i < c.free_list.size(); ++i)
+            if (c.free_list[i].second >= bytes && c.free_list[i].second <= 4 * bytes + (1u << 20))
+            {
+                auto hit = c.free_list[i];
+                c.free_list.erase(c.free_list.begin() + static_cast<long>(i));
+                *capacity = hit.second;
+                return hit.first;
+            }
+    }
+    const size_t cap = std::max<size_t>(bytes, 64);
+    void* p          = std::malloc(cap);
+    if (p == nullptr) throw std::bad_alloc();
+    *capacity = cap;
+    return static_cast<char*>(p);
+}
+
+void host_release(char* p, size_t capacity)
+{
+    if (p == nullptr) return;
+    if (capacity < (size_t(1) << 20)) // small buffers are not worth keeping
+    {
+        std::free(p);
+        return;
+    }
+    PinnedCache& c = host_cache();
+    char* drop     = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c.m);
+        c.free_list.emplace_back(p, capacity);
+        if (c.free_list.size() > kHostKeep)
+        {
+            drop = c.free_list.front().first;
+            c.free_list.erase(c.free_list.begin());
+        }
+    }
+    if (drop != nullptr) std::free(drop);
 }
 } // namespace cudaaligner
 } // namespace genomeworks

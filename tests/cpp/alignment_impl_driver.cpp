@@ -77,8 +77,12 @@ int main()
             }
             block->ops        = ops.data();
             block->counts     = counts.data();
+            block->run_starts_owned = {0, static_cast<int32_t>(ops.size())};
+            block->metadata_owned   = {optimal != 0 ? 0x80000000u : 0u};
+            block->run_starts       = block->run_starts_owned.data();
+            block->metadata         = block->metadata_owned.data();
             block->allocate_views(1);
-            new (&block->alignments[0]) PackedAlignment(block.get(), 0, 0, static_cast<int32_t>(ops.size()), true, optimal != 0);
+            new (&block->alignments[0]) PackedAlignment(block.get(), 0);
             block->n_alignments = 1;
             std::shared_ptr<Alignment> view(block, &block->alignments[0]);
             report(expand ? "PackedAlignment(states)" : "PackedAlignment(runs)", *view);
