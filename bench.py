@@ -128,13 +128,54 @@ def consensus_digest(consensus_strings):
     return hashlib.sha256("\n".join(consensus_strings).encode()).hexdigest()
 
 
+_PMC_PROFILE = None
+
+
+def pmc_profile():
+    """The committed PMC session of this round (tools/gpu_session.sh steps pmc + traffic -> tools/pmc_profile.py): HBM traffic,
+    issued instructions, wave cycles, wait share and LDS bank conflicts per launch of every record's kernels, stamped with the
+    commit it was taken at. rocprofv3 cannot run inside the timed region, so these come from their own passes."""
+    global _PMC_PROFILE
+    if _PMC_PROFILE is None:
+        try:
+            _PMC_PROFILE = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_profile.json")))
+        except (OSError, ValueError):
+            _PMC_PROFILE = {}
+    return _PMC_PROFILE
+
+
 def sub_traffic(key):
-    """HBM bytes of a sub-record's kernels from the committed PMC passes (tools/pmc_passes.sh with SUBS=..., calibrated like the
-    headline's: profiles/r03_pmc_traffic_sub.json); None if that file has no entry."""
+    """HBM bytes of a record's kernels from the committed PMC passes (this round's profile, else round 3's files); None if
+    neither has an entry."""
+    e = pmc_profile().get(key)
+    if isinstance(e, dict) and "hbm_bytes" in e:
+        return e["hbm_bytes"]
     try:
         return json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_sub.json")))[key]["hbm_bytes"]
     except (OSError, ValueError, KeyError):
         return None
+
+
+def roofline_issue(key):
+    """The roofline that explains these kernels: a window / pair is a chain of dependent steps on ONE wavefront, and a lone
+    wavefront issues one instruction per ~4.1 cycles (profiles/r03_microbench_instruction_size.json). issued instructions per
+    wavefront x 4.1 cycles is the floor of its run time; `frac` = that floor / the cycles a wavefront was resident, the rest is
+    exposed latency (`wait_share` = SQ_WAIT_ANY / SQ_WAVE_CYCLES). From the committed PMC session (pmc_profile())."""
+    p = pmc_profile()
+    e = p.get(key)
+    if not isinstance(e, dict) or "issue" not in e:
+        return None
+    out = {"bound": "instruction issue of a lone wavefront", "kernel": e["kernel"], "per": e.get("per"),
+           "instructions": e["instructions"], "waves": e.get("waves"),
+           "instructions_per_wave": e["issue"]["instructions_per_wave"], "cycles_per_wave": e["issue"]["cycles_per_wave"],
+           "cycles_per_instruction": e["issue"]["cycles_per_instruction"],
+           "lone_wave_cycles_per_instruction": e["issue"]["lone_wave_cycles_per_instruction"],
+           "frac": e["issue"]["frac_of_lone_wave_issue_bound"], "wait_share": e.get("wait_share"),
+           "source": "profiles/r04_pmc_profile.json (commit %s, tag %s)" % (p.get("commit"), p.get("tag"))}
+    if "lds" in e:
+        out["lds_bank_conflict_share_of_lds_active"] = e["lds"]["bank_conflict_share_of_lds_active"]
+        out["lds_bank_conflict_share_of_wave_cycles"] = e["lds"].get("bank_conflict_share_of_wave_cycles")
+    return out
 
 
 def reduce_scalars(dist, torch, values, op):
@@ -213,7 +254,8 @@ def bench_aligner(name, cfg, rank, world, local_rank, sync, dist, torch, reps, c
                         "achieved": round(achieved, 2),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                         "traffic": sub_traffic("configs[1]" if cfg is CONFIG2 else "configs[4]"),
-                        "algorithmic_bytes_per_cell": BYTES_PER_MYERS_CELL, "kernel_ms": round(k_ms, 3)}}
+                        "algorithmic_bytes_per_cell": BYTES_PER_MYERS_CELL, "kernel_ms": round(k_ms, 3)},
+           "roofline_issue": roofline_issue("configs[1]" if cfg is CONFIG2 else "configs[4]")}
     if cpu is not None:
         out["cpu_baseline"] = cpu
     return out
@@ -309,13 +351,14 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu,
                                                output_type="msa", digest=lr.msa_digest)
     sync()
     my_cells = sum(golden[w]["cells"] for w in mine if w in golden)  # the kernels' counters equal the oracle's (asserted by the GPU tests)
+    failed_cells = sum(golden[w]["cells"] for w in mine if w in golden and out["status"][w] != 0)
     n_ok = sum(1 for w in mine if out["status"][w] == 0)
     checked = sum(1 for w in mine if w in golden and out["status"][w] == golden[w]["status"] and
                   (out["status"][w] != 0 or out["msa"][w] == golden[w]["msa_sha"]))
     mismatched = sum(1 for w in mine if w in golden) - checked
     seconds, total_s, fill_s = reduce_scalars(dist, torch, [out["compute_seconds"], out["seconds"], out["seconds_after_creation"]], "MAX")
-    cells, n_done, n_ok, checked, mismatched = reduce_scalars(
-        dist, torch, [float(my_cells), float(len(mine)), float(n_ok), float(checked), float(mismatched)], "SUM")
+    cells, n_done, n_ok, checked, mismatched, failed_cells = reduce_scalars(
+        dist, torch, [float(my_cells), float(len(mine)), float(n_ok), float(checked), float(mismatched), float(failed_cells)], "SUM")
     if rank != 0:
         return None
     achieved = my_cells * BYTES_PER_CELL_LONG / out["compute_seconds"] / 1e9
@@ -330,6 +373,10 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu,
            "fill_inclusive": {"ms": round(fill_s * 1e3, 1), "gcups": round(cells / max(fill_s, 1e-9) / 1e9, 3),
                               "what": "add_poa_group() of every window + generate_poa() + get_msa(), batches created before the clock starts"},
            "ms_with_batch_creation_and_filling": round(total_s * 1e3, 1), "cells": int(cells),
+           # windows that end with an error status (exceeded_adaptive_banded_matrix_size, in the oracle too) stop at the read that
+           # failed: the cells they computed up to there are in `cells`; this is how many
+           "cells_of_windows_with_error_status": int(failed_cells),
+           "value_without_those_cells": round((cells - failed_cells) / seconds / 1e9, 3),
            "launches_rank0": out["launches"], "dtype": "int32",
            "windows_equal_to_oracle_golden": int(checked), "windows_differing_from_golden": int(mismatched),
            "size_classes": [{"max_sequence_size": c["max_sequence_size"], "windows": len(g)} for c, g in zip(cfgs, plan.groups)],
@@ -339,7 +386,8 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu,
                         "algorithmic_bytes_per_cell": BYTES_PER_CELL_LONG,
                         "kernel_ms": round(out["compute_seconds"] * 1e3, 1),
                         "note": "the launches of the classes overlap: the duration is the concurrent region's (host clock), "
-                                "of which the kernels are all but the D2H and unpacking of the MSA rows"}}
+                                "of which the kernels are all but the D2H and unpacking of the MSA rows"},
+           "roofline_issue": roofline_issue("configs[3]")}
     if cpu is not None:
         rec["cpu_baseline"] = cpu
     return rec
@@ -429,7 +477,8 @@ def bench_default_aligner(local_rank, sync, cpu_all_cores=None):
                         "note": "|q| x |t| cells of the full matrix at the bit-vector cost of 12 B per 32-cell word column; the divide "
                                 "and conquer computes every cell about twice and keeps its state in registers and LDS, so HBM "
                                 "carries little: the kernel is bound by the dependent column steps of a wavefront",
-                        "kernel_ms": head["kernel_ms"]}}
+                        "kernel_ms": head["kernel_ms"]},
+           "roofline_issue": roofline_issue("default_aligner")}
     if cpu is not None:
         out["cpu_baseline"] = cpu
     return out
@@ -438,9 +487,9 @@ def bench_default_aligner(local_rank, sync, cpu_all_cores=None):
 def bench_band_modes(windows, local_rank, sync):
     """Every banded mode x band width of the reference's parameter space (multiples of 128, cudapoa/src/batch.cu:41; the
     traceback-buffer modes of cudapoa_nw_tb_banded.cuh:264-643) on the 1024 config-3 windows: generate_poa() +
-    get_consensus(), steady state, plus the graph-build kernel's own duration. Only static / adaptive band 256 with int16
-    scores has the packed forward pass and the move-byte traceback (poa_forward_moves.h); the other cells of the table run
-    the general 32-bit-register passes -- this table is what they cost."""
+    get_consensus(), steady state, plus the graph-build kernel's own duration. Every cell runs a packed 16-bit forward pass
+    and the sheared-tile walk (round 4: poa_forward_moves.h for bands 128 / 256, poa_forward_moves_wide.h for 384 / 512,
+    poa_forward_moves_tb.h for the traceback-buffer modes) and is compared with its committed oracle golden."""
     from genomeworks_amd import cudapoa
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
     import golden_io as G  # the checker: committed oracle goldens of every cell (tests/golden/make_band_mode_goldens.py)
@@ -725,8 +774,8 @@ def main():
         achieved = cells * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed PMC pass of this same workload (rocprofv3 cannot run inside the
         # timed region; tools/pmc_passes.sh collects FETCH_SIZE / WRITE_SIZE in their own runs)
-        traffic = None
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        traffic = pmc_profile().get("headline", {}).get("hbm_bytes") if args.windows == WINDOWS else None
+        for name in (() if traffic is not None else ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pmc.get("windows") == args.windows:
@@ -753,6 +802,7 @@ def main():
                          "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
                          "kernel_ms": round(k_ms, 3), "output_kernel_ms": round(o_ms, 3),
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL},
+            "roofline_issue": roofline_issue("headline"),
             "kernel_only": {"what": "relaunch on inputs resident in HBM + get_consensus() (no H2D)",
                             "ms_per_step": round(resident / args.steps * 1e3, 3),
                             "gcups": round(total_cells * args.steps / resident / 1e9, 3),

@@ -10,7 +10,8 @@
 #   bench        the driver's bench line (BENCH_ARGS, default none = the full line with all sub-records)
 #   stats        rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline $STATS_ARGS` -> kernel_stats.csv
 #   pmc          tools/pmc_passes.sh with PASSES (default "insts waits lds fetch write") and SUBS (default none)
-#   traffic      derive pmc_traffic.json (headline) and pmc_traffic_sub.json from the pmc step's summary
+#   traffic      derive pmc_profile.json (HBM traffic, issue and LDS counters per record) from the pmc step's summary; pass
+#                GW_COMMIT=$(git rev-parse --short HEAD) from the submitting side (the box has no .git)
 #   extra        run $EXTRA_CMD (one-off measurements)
 # Everything lands in gpurun_out/<tag>/; copy what should be judged into profiles/.
 set -u
@@ -64,7 +65,7 @@ if has pmc; then
     grep -E "LDS|WAIT_ANY|WAVE_CYCLES|FETCH|WRITE_SIZE" $OUT/pmc_summary.csv | cut -c1-170 | head -60
 fi
 if has traffic; then
-    python tools/pmc_traffic.py $OUT/pmc_summary.csv "$TAG" $OUT
+    python tools/pmc_profile.py $OUT/pmc_summary.csv "$TAG" $OUT "${GW_COMMIT:-unknown}"
 fi
 if has extra; then
     bash -c "${EXTRA_CMD:-true}" > $OUT/extra.log 2>&1; echo "extra rc=$?"; tail -${EXTRA_TAIL:-30} $OUT/extra.log

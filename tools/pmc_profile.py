@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""One JSON per measurement session from the summary of the PMC passes (tools/pmc_passes.sh -> tools/pmc_summary.py) over the
+headline kernel and the sub-records' kernels: what bench.py needs next to its live timings and cannot collect inside the timed
+region -- HBM traffic per launch (FETCH_SIZE x 2, WRITE_SIZE x 0.97: the calibration of profiles/r03_pmc_traffic.json), issued
+instructions, wave cycles, wait share and LDS bank-conflict share per launch.
+
+  python tools/pmc_profile.py <pmc_summary.csv> <tag> <out_dir> [<commit>]   ->  <out_dir>/pmc_profile.json
+"""
+import csv
+import json
+import os
+import sys
+
+rows = {}
+for r in csv.DictReader(open(sys.argv[1])):
+    rows.setdefault(r["kernel"], {})[r["counter"]] = (float(r["mean_per_dispatch"]), int(r["dispatches"]))
+tag = sys.argv[2] if len(sys.argv) > 2 else "session"
+out_dir = sys.argv[3] if len(sys.argv) > 3 else "."
+commit = sys.argv[4] if len(sys.argv) > 4 else os.environ.get("GW_COMMIT", "unknown")
+
+LONE_WAVE_CYCLES_PER_INST = 4.1  # profiles/r03_microbench_instruction_size.json
+
+
+def entry(match, what="mean", note=None):
+    ks = sorted(k for k in rows if match(k))
+    if not ks:
+        return None
+
+    def tot(counter):
+        v, seen = 0.0, False
+        for k in ks:
+            if counter in rows[k]:
+                m, n = rows[k][counter]
+                v += m * (n if what == "sum" else 1)
+                seen = True
+        return v if seen else None
+    e = {"kernel": " + ".join(k.replace("void ", "") for k in ks), "per": "sum over the launches of the set" if what == "sum" else "launch (mean)"}
+    f, w = tot("FETCH_SIZE"), tot("WRITE_SIZE")
+    if f is not None and w is not None:
+        e["read_bytes"], e["write_bytes"] = int(f * 1024 * 2), int(w * 1024 * 0.97)
+        e["hbm_bytes"] = e["read_bytes"] + e["write_bytes"]
+    insts = [tot(c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM")]
+    if all(v is not None for v in insts):
+        e["instructions"] = {"valu": int(insts[0]), "salu": int(insts[1]), "lds": int(insts[2]), "vmem_rd": int(insts[3]),
+                             "vmem_wr": int(insts[4]), "smem": int(insts[5]), "total": int(sum(insts))}
+        br = tot("SQ_INSTS_BRANCH")
+        if br is not None:
+            e["instructions"]["branch_of_salu"] = int(br)
+    waves, wc, wa = tot("SQ_WAVES"), tot("SQ_WAVE_CYCLES"), tot("SQ_WAIT_ANY")
+    if waves:
+        e["waves"] = int(waves)
+    if wc:
+        e["wave_cycles"] = int(wc * 4)  # the counter ticks once per 4 cycles of a resident wave
+        if wa is not None:
+            e["wait_share"] = round(wa / wc, 4)
+        if waves and "instructions" in e:
+            per_wave = e["instructions"]["total"] / waves
+            e["issue"] = {"instructions_per_wave": round(per_wave, 1), "cycles_per_wave": round(wc * 4 / waves, 1),
+                          "cycles_per_instruction": round(wc * 4 / waves / per_wave, 2),
+                          "lone_wave_cycles_per_instruction": LONE_WAVE_CYCLES_PER_INST,
+                          "frac_of_lone_wave_issue_bound": round(per_wave * LONE_WAVE_CYCLES_PER_INST / (wc * 4 / waves), 4)}
+    bc, ia = tot("SQ_LDS_BANK_CONFLICT"), tot("SQ_LDS_IDX_ACTIVE")
+    if bc is not None and ia:
+        e["lds"] = {"bank_conflict_cycles": int(bc), "idx_active_cycles": int(ia), "bank_conflict_share_of_lds_active": round(bc / ia, 4)}
+        if wc:
+            e["lds"]["bank_conflict_share_of_wave_cycles"] = round(bc / (wc * 4), 5)
+    if note:
+        e["note"] = note
+    return e
+
+
+out = {"tag": tag, "commit": commit,
+       "source": "rocprofv3 --kernel-trace --pmc, one counter group per pass (tools/pmc_passes.sh: insts, waits, lds, fetch, write) over "
+                 "`bench.py --steps 1 --warmup 0 --no-cpu-baseline --sub-configs aligner,default_aligner,long_reads`; FETCH_SIZE x 2 and "
+                 "WRITE_SIZE x 0.97 as calibrated in profiles/r03_pmc_traffic.json on microkernels of known size"}
+for key, e in (("headline", entry(lambda k: "poa_window_kernel<short, short, signed char, 1, false, tru" in k)),
+               ("configs[1]", entry(lambda k: "myers_banded_group_kernel" in k)),
+               ("configs[4]", entry(lambda k: "myers_banded_kernel<true>" in k)),
+               ("default_aligner", entry(lambda k: "hirschberg_levels_kernel" in k or "hirschberg_wave_kernel" in k or "hirschberg_span" in k, "mean",
+                                         "all Hirschberg kernels of the sub-record's shapes (1 .. 2000 pairs), mean over their launches")),
+               ("configs[3]", entry(lambda k: "poa_window_kernel<" in k and "2, true, false" in k, "sum",
+                                    "sum over the launches of the set's size classes"))):
+    if e:
+        out[key] = e
+os.makedirs(out_dir, exist_ok=True)
+with open(os.path.join(out_dir, "pmc_profile.json"), "w") as f:
+    json.dump(out, f, indent=1)
+    f.write("\n")
+print(json.dumps({k: {kk: v[kk] for kk in ("hbm_bytes", "wait_share") if kk in v} | ({"issue": v["issue"]} if "issue" in v else {})
+                  for k, v in out.items() if isinstance(v, dict)}, indent=1))
