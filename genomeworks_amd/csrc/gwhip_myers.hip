@@ -1391,6 +1391,7 @@ struct HirschbergArgs
     int64_t ws_capacity_words;
     int32_t lds_state_words;     // LDS_STATE kernels: words per lane of one column-state array
     int32_t levels_first;        // hirschberg_levels_kernel has run: the depth-first wave kernel only takes what it left
+    int32_t span_levels;         // > 0: the span path takes the pairs whose query exceeds kSpanPartQuery (the other kernels skip them)
 };
 
 __host__ __device__ inline int64_t hb_leaf_words(int32_t t, int64_t max_elems)
@@ -1691,6 +1692,8 @@ struct PlainWords
 };
 
 // limits, LDS layout and eligibility test of hirschberg_levels_kernel (below, after the depth-first wave kernel)
+constexpr int32_t kSpanPartQuery = 2048; // span path (below): parts are split across blocks until their query piece is at most this long
+constexpr int32_t kSpanMaxPairs  = 64;   // ... for batches of at most this many pairs
 constexpr int32_t kLvMaxQuery = 2048;
 constexpr int32_t kLvMaxParts = 64;
 constexpr int32_t kLvMaxTerm  = 256;
@@ -1733,62 +1736,35 @@ __host__ __device__ inline bool lv_eligible(int32_t query_size, int32_t target_s
 
 constexpr int32_t kHwLeafElems = 320; // (word, column) elements of a leaf whose matrices stay in LDS (three arrays of that size)
 
-__global__ __launch_bounds__(64) void hirschberg_wave_kernel(HirschbergArgs a)
+// What one wavefront needs to align (a part of) one pair depth-first: the pair's sequences, the whole query's pattern tables,
+// rows and leaf matrices in HBM, range stack / chunked column state / leaf matrices in LDS. Shared by the one-wavefront-per-pair
+// kernel (the part is the whole pair) and the kernels of the span path below (the top of a long pair's tree level by level
+// across blocks, then one wavefront per part).
+struct HbWaveIn
 {
-    extern __shared__ uint32_t hw_lds[];
-    const int32_t lane = threadIdx.x & 63;
-    const int32_t idx  = blockIdx.x;
-    if (idx >= a.n) return;
-    const int32_t region_index = idx >> 6, s = idx & 63;
-    const int64_t max_elems = (int64_t)ceil_div(max(a.max_query_length, 1), kWord) * (kHbSwitchToMyers + 1);
-    // geometry of the 64-pair region (sized by its longest query / target)
-    int32_t qw_max = 0, t_max = 0;
-    {
-        const int32_t sj = region_index * 64 + lane;
-        if (sj < a.n)
-        {
-            qw_max = ceil_div((int32_t)(a.starts[2 * sj + 1] - a.starts[2 * sj]), kWord);
-            t_max  = (int32_t)(a.starts[2 * sj + 2] - a.starts[2 * sj + 1]);
-        }
-        for (int off = 32; off > 0; off >>= 1)
-        {
-            qw_max = max(qw_max, __shfl_xor(qw_max, off));
-            t_max  = max(t_max, __shfl_xor(t_max, off));
-        }
-    }
-    const char* query         = a.sequences + a.starts[2 * idx];
-    const char* target        = a.sequences + a.starts[2 * idx + 1];
-    const int32_t query_size  = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
-    const int32_t target_size = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
-    int8_t* path              = a.results + a.starts[2 * idx];
-    // pairs the level-by-level kernel has already aligned (it ran first on this stream) are not touched again
-    if (a.levels_first && lv_eligible(query_size, target_size, a.max_query_length) && a.result_lengths[idx] != kLvFlagRedo) return;
-    const int64_t region      = a.wave_offsets[region_index];
-    const int64_t per_pair    = hb_lane_words(qw_max, t_max, max_elems);
-    if (region + 64 * per_pair > a.ws_capacity_words)
-    {
-        if (lane == 0) a.result_lengths[idx] = 0;
-        return;
-    }
-    uint32_t* base  = a.ws + region + (size_t)s * (size_t)per_pair;
-    uint32_t* fwd   = base + 4 * kHbStackEntries;
-    uint32_t* rev   = fwd + ((size_t)t_max + 1);
-    uint32_t* pat_f = rev + ((size_t)t_max + 1);
-    uint32_t* pat_r = pat_f + (size_t)4 * qw_max;
-    const int64_t leaf_words = hb_leaf_words(t_max, max_elems);
-    Band leaf; // full Myers matrices of a leaf (column-major), lane 0 only
-    leaf.pv     = pat_r + (size_t)4 * qw_max + (size_t)2 * qw_max;
-    leaf.mv     = leaf.pv + (size_t)leaf_words;
-    leaf.score  = reinterpret_cast<int32_t*>(leaf.mv + (size_t)leaf_words);
-    leaf.n_rows = 0;
-    leaf.stride = 1;
-    // LDS: range stack | chunked column state (pv, mv) | chunked pattern words of the current part (4 per word)
-    uint32_t* stack = hw_lds;
-    uint32_t* st_pv = hw_lds + 4 * kHbStackEntries;
-    uint32_t* st_mv = st_pv + (size_t)a.lds_state_words * 64; // lds_state_words = chunks of the longest part
-    uint32_t* st_pt = st_mv + (size_t)a.lds_state_words * 64;
-    uint32_t* leaf_lds = st_pt + (size_t)a.lds_state_words * 256; // kHwLeafLdsWords: the matrices of a leaf that fits
+    const char* query;
+    const char* target;
+    int32_t query_size, target_size;
+    uint32_t* fwd;      // [target part + 1] last-row scores, forward half
+    uint32_t* rev;      // reversed half
+    uint32_t* pat_f;    // [4 x query words] pattern words of the whole query, forward
+    uint32_t* pat_r;    // back to front
+    Band leaf;          // full Myers matrices of a leaf in HBM (column-major)
+    int64_t max_elems;  // (word, column) elements a leaf may have
+    uint32_t* stack;    // LDS: range stack, 4 x kHbStackEntries words
+    uint32_t* st_pv;    // LDS: chunked column state of a part of more than 64 words
+    uint32_t* st_mv;
+    uint32_t* st_pt;    // LDS: its pattern words (4 per word)
+    uint32_t* leaf_lds; // LDS: the matrices of a leaf that fits kHwLeafElems
+    int32_t qb, qe, tb, te; // the part to align
+};
 
+__device__ __forceinline__ void hb_build_patterns(const HbWaveIn& in, int32_t lane)
+{
+    const char* query = in.query;
+    const int32_t query_size = in.query_size;
+    uint32_t* pat_f = in.pat_f;
+    uint32_t* pat_r = in.pat_r;
     // pattern tables of the whole query, forward and back to front, one word per lane at a time
     const int32_t n_words_query = ceil_div(query_size, kWord);
     for (int32_t w = lane; w < n_words_query; w += 64)
@@ -1804,9 +1780,19 @@ __global__ __launch_bounds__(64) void hirschberg_wave_kernel(HirschbergArgs a)
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const PlainWords tab_f{pat_f}, tab_r{pat_r};
 
-    // last row of the edit-distance matrix of query[qb, qe) against target[tb, te): out[t], t = 0 .. te - tb
+}
+
+// last row of the edit-distance matrix of query[qb, qe) against target[tb, te): out[t], t = 0 .. te - tb
+__device__ __forceinline__ void hb_last_row(const HbWaveIn& in, int32_t lane, int32_t qb, int32_t qe, int32_t tb, int32_t te, bool reverse, uint32_t* out)
+{
+    const char* target = in.target;
+    const int32_t query_size = in.query_size;
+    const int32_t n_words_query = ceil_div(query_size, kWord);
+    const PlainWords tab_f{in.pat_f}, tab_r{in.pat_r};
+    uint32_t* st_pv = in.st_pv;
+    uint32_t* st_mv = in.st_mv;
+    uint32_t* st_pt = in.st_pt;
     auto last_row_impl = [&](auto single_tag, int32_t qb, int32_t qe, int32_t tb, int32_t te, bool reverse, uint32_t* out) {
         constexpr bool SINGLE = decltype(single_tag)::value; // the part fits one chunk of 64 words: state and patterns in registers
         const int32_t qn = qe - qb, tn = te - tb;
@@ -1916,11 +1902,46 @@ __global__ __launch_bounds__(64) void hirschberg_wave_kernel(HirschbergArgs a)
         // the remaining columns: t in [tn & ~63, tn]
         if (lane <= (tn & 63)) out[(tn & ~63) + lane] = acc;
     };
-    auto last_row = [&](int32_t qb, int32_t qe, int32_t tb, int32_t te, bool reverse, uint32_t* out) {
-        if (qe - qb <= 64 * kWord) last_row_impl(std::true_type{}, qb, qe, tb, te, reverse, out);
-        else last_row_impl(std::false_type{}, qb, qe, tb, te, reverse, out);
-    };
+    if (qe - qb <= 64 * kWord) last_row_impl(std::true_type{}, qb, qe, tb, te, reverse, out);
+    else last_row_impl(std::false_type{}, qb, qe, tb, te, reverse, out);
 
+}
+
+// hirschberg_myers_compute_target_mid_warp (:461-481) on 32 real lanes: lane L sees t = L, L + 32, ...; the shuffle-down tree
+// keeps the lower lane on equal sums. Returns the split column relative to the part's first target column.
+__device__ __forceinline__ int32_t hb_target_mid(const uint32_t* fwd, const uint32_t* rev, int32_t tn, int32_t lane)
+{
+    int32_t cm = INT32_MAX, mp = 0;
+    if (lane < 32)
+        for (int32_t t = lane; t <= tn; t += 32)
+        {
+            const int32_t sum = (int32_t)fwd[t] + (int32_t)rev[tn - t];
+            if (sum < cm) { cm = sum; mp = t; }
+        }
+    for (int32_t step = 16; step > 0; step >>= 1)
+    {
+        const int32_t om = __shfl_down(cm, step, 32), ot = __shfl_down(mp, step, 32);
+        if ((lane & 31) + step < 32 && om < cm) { cm = om; mp = ot; }
+    }
+    return __builtin_amdgcn_readfirstlane(mp);
+}
+
+// The depth-first walk of the part's tree; the path is appended to `path` back to front. Returns its length, -1 when the range
+// stack overflows.
+__device__ __forceinline__ int32_t hb_wave_run(const HbWaveIn& in, int8_t* path, int32_t lane)
+{
+    const char* query = in.query;
+    const char* target = in.target;
+    const int32_t query_size = in.query_size;
+    const int32_t n_words_query = ceil_div(query_size, kWord);
+    const int64_t max_elems = in.max_elems;
+    const PlainWords tab_f{in.pat_f};
+    uint32_t* stack = in.stack;
+    uint32_t* leaf_lds = in.leaf_lds;
+    uint32_t* fwd = in.fwd;
+    uint32_t* rev = in.rev;
+    const Band leaf = in.leaf;
+    auto last_row = [&](int32_t qb, int32_t qe, int32_t tb, int32_t te, bool reverse, uint32_t* out) { hb_last_row(in, lane, qb, qe, tb, te, reverse, out); };
     int32_t sp = 0;
     auto push = [&](int32_t qb, int32_t qe, int32_t tb, int32_t te) -> bool {
         if (sp >= kHbStackEntries) return false;
@@ -1931,7 +1952,7 @@ __global__ __launch_bounds__(64) void hirschberg_wave_kernel(HirschbergArgs a)
         ++sp;
         return true;
     };
-    push(0, query_size, 0, target_size);
+    push(in.qb, in.qe, in.tb, in.te);
     bool ok     = true;
     int32_t len = 0;
     while (ok && sp > 0)
@@ -2054,26 +2075,481 @@ __global__ __launch_bounds__(64) void hirschberg_wave_kernel(HirschbergArgs a)
             last_row(qmid, qe, tb, te, true, rev);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // hirschberg_myers_compute_target_mid_warp (:461-481) on 32 real lanes: lane L sees t = L, L + 32, ...; the
-            // shuffle-down tree keeps the lower lane on equal sums
-            int32_t cm = INT32_MAX, mp = 0;
-            if (lane < 32)
-                for (int32_t t = lane; t <= tn; t += 32)
-                {
-                    const int32_t sum = (int32_t)fwd[t] + (int32_t)rev[tn - t];
-                    if (sum < cm) { cm = sum; mp = t; }
-                }
-            for (int32_t step = 16; step > 0; step >>= 1)
-            {
-                const int32_t om = __shfl_down(cm, step, 32), ot = __shfl_down(mp, step, 32);
-                if ((lane & 31) + step < 32 && om < cm) { cm = om; mp = ot; }
-            }
-            const int32_t tmid = tb + __builtin_amdgcn_readfirstlane(mp);
+            const int32_t tmid = tb + hb_target_mid(fwd, rev, tn, lane);
             ok = ok && push(qb, qmid, tb, tmid);
             ok = ok && push(qmid, qe, tmid, te);
         }
     }
-    if (lane == 0) a.result_lengths[idx] = ok ? len : 0;
+    return ok ? len : -1;
+}
+
+__global__ __launch_bounds__(64) void hirschberg_wave_kernel(HirschbergArgs a)
+{
+    extern __shared__ uint32_t hw_lds[];
+    const int32_t lane = threadIdx.x & 63;
+    const int32_t idx  = blockIdx.x;
+    if (idx >= a.n) return;
+    const int32_t region_index = idx >> 6, s = idx & 63;
+    const int64_t max_elems = (int64_t)ceil_div(max(a.max_query_length, 1), kWord) * (kHbSwitchToMyers + 1);
+    // geometry of the 64-pair region (sized by its longest query / target)
+    int32_t qw_max = 0, t_max = 0;
+    {
+        const int32_t sj = region_index * 64 + lane;
+        if (sj < a.n)
+        {
+            qw_max = ceil_div((int32_t)(a.starts[2 * sj + 1] - a.starts[2 * sj]), kWord);
+            t_max  = (int32_t)(a.starts[2 * sj + 2] - a.starts[2 * sj + 1]);
+        }
+        for (int off = 32; off > 0; off >>= 1)
+        {
+            qw_max = max(qw_max, __shfl_xor(qw_max, off));
+            t_max  = max(t_max, __shfl_xor(t_max, off));
+        }
+    }
+    const char* query         = a.sequences + a.starts[2 * idx];
+    const char* target        = a.sequences + a.starts[2 * idx + 1];
+    const int32_t query_size  = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
+    const int32_t target_size = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
+    int8_t* path              = a.results + a.starts[2 * idx];
+    // pairs the level-by-level kernel has already aligned (it ran first on this stream) are not touched again
+    if (a.levels_first && lv_eligible(query_size, target_size, a.max_query_length) && a.result_lengths[idx] != kLvFlagRedo) return;
+    if (a.span_levels > 0 && query_size > kSpanPartQuery) return; // the span path (below) aligns this pair
+    const int64_t region      = a.wave_offsets[region_index];
+    const int64_t per_pair    = hb_lane_words(qw_max, t_max, max_elems);
+    if (region + 64 * per_pair > a.ws_capacity_words)
+    {
+        if (lane == 0) a.result_lengths[idx] = 0;
+        return;
+    }
+    uint32_t* base  = a.ws + region + (size_t)s * (size_t)per_pair;
+    uint32_t* fwd   = base + 4 * kHbStackEntries;
+    uint32_t* rev   = fwd + ((size_t)t_max + 1);
+    uint32_t* pat_f = rev + ((size_t)t_max + 1);
+    uint32_t* pat_r = pat_f + (size_t)4 * qw_max;
+    const int64_t leaf_words = hb_leaf_words(t_max, max_elems);
+    Band leaf; // full Myers matrices of a leaf (column-major), lane 0 only
+    leaf.pv     = pat_r + (size_t)4 * qw_max + (size_t)2 * qw_max;
+    leaf.mv     = leaf.pv + (size_t)leaf_words;
+    leaf.score  = reinterpret_cast<int32_t*>(leaf.mv + (size_t)leaf_words);
+    leaf.n_rows = 0;
+    leaf.stride = 1;
+    // LDS: range stack | chunked column state (pv, mv) | chunked pattern words of the current part (4 per word)
+    uint32_t* stack = hw_lds;
+    uint32_t* st_pv = hw_lds + 4 * kHbStackEntries;
+    uint32_t* st_mv = st_pv + (size_t)a.lds_state_words * 64; // lds_state_words = chunks of the longest part
+    uint32_t* st_pt = st_mv + (size_t)a.lds_state_words * 64;
+    uint32_t* leaf_lds = st_pt + (size_t)a.lds_state_words * 256; // kHwLeafLdsWords: the matrices of a leaf that fits
+
+    HbWaveIn in{};
+    in.query = query; in.target = target; in.query_size = query_size; in.target_size = target_size;
+    in.fwd = fwd; in.rev = rev; in.pat_f = pat_f; in.pat_r = pat_r; in.leaf = leaf; in.max_elems = max_elems;
+    in.stack = stack; in.st_pv = st_pv; in.st_mv = st_mv; in.st_pt = st_pt; in.leaf_lds = leaf_lds;
+    in.qb = 0; in.qe = query_size; in.tb = 0; in.te = target_size;
+    hb_build_patterns(in, lane);
+    const int32_t len = hb_wave_run(in, path, lane);
+    if (lane == 0) a.result_lengths[idx] = len > 0 ? len : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The SPAN path (round 4): long single pairs (the reference's BM_SingleAlignment shapes, cudaaligner/benchmarks/main.cpp:39-67:
+// one pair of up to 100 000 bases). One wavefront walking such a pair's tree depth-first computes every last row one after the
+// other -- 2 s for 100 kbp. But the two last rows of a part (forward half, reversed half) are independent, and so are all parts
+// of one level of Hirschberg's tree: the top of the tree is therefore grown LEVEL BY LEVEL ACROSS BLOCKS -- one wavefront per
+// (part, half) computes a last row (hb_span_rows_kernel), one per part picks the target midpoint the way the reference's 32
+// lanes pick it and writes the two children (hb_span_split_kernel) -- until a part's query piece is at most kSpanPartQuery
+// bases; every such part is then aligned depth-first by a wavefront of its own (hb_span_parts_kernel: hb_wave_run from that
+// part) and the pieces are joined back to front (hb_span_join_kernel). What decides the output -- query midpoint len / 2, the
+// 32-lane argmin with its tie rule, the terminal cases and their order along the path -- is the depth-first kernel's; only the
+// order in which independent sub-problems are COMPUTED changes, so the paths are identical
+// (test_default_aligner_span_path_equals_the_depth_first_kernel). Taken for batches of at most kSpanMaxPairs pairs whose
+// max_query_length exceeds kSpanPartQuery, by the pairs whose query does (the others stay with the kernels above).
+// Workspace, per pair, behind the region of the 64-pair wave (hb_span_words): part lists of two consecutive levels, piece
+// lengths, the rows / leaf matrices of all parts side by side (part j of a level owns [tb_j + j, te_j + j]: parts tile the
+// target), and a staging buffer for the pieces (part j owns [qb_j + tb_j, qe_j + te_j)).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline int32_t hb_span_levels(int32_t max_query)
+{
+    int32_t L = 0;
+    while (((int64_t)kSpanPartQuery << L) < (int64_t)max_query) ++L;
+    return L;
+}
+__host__ __device__ inline int64_t hb_span_words(int32_t qw, int32_t t, int32_t max_query)
+{
+    const int32_t L = hb_span_levels(max_query);
+    if (L == 0) return 0;
+    const int64_t P = (int64_t)1 << L, rows = (int64_t)t + P + 1;
+    return 8 * P + P + 2 * rows + 6 * rows + ((int64_t)32 * qw + t + 64 + 3) / 4 + 16;
+}
+struct SpanGeom
+{
+    LvPart* parts[2];
+    int32_t* piece_len;
+    uint32_t* rows_f;
+    uint32_t* rows_r;
+    uint32_t* leaf;   // 6 words per row entry: pv | mv | score of the parts' leaves, 2 columns' worth per target column
+    int8_t* stage;
+    int32_t P, levels;
+    int64_t rows;
+};
+// geometry of the region of the (at most 64) pairs of the batch: longest query in words, longest target -- every block
+// recomputes it (64 loads, one shuffle tree)
+__device__ __forceinline__ void hb_region_geometry(const HirschbergArgs& a, int32_t lane, int32_t& qw_max, int32_t& t_max)
+{
+    qw_max = 0;
+    t_max  = 0;
+    if (lane < a.n)
+    {
+        qw_max = ceil_div((int32_t)(a.starts[2 * lane + 1] - a.starts[2 * lane]), kWord);
+        t_max  = (int32_t)(a.starts[2 * lane + 2] - a.starts[2 * lane + 1]);
+    }
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        qw_max = max(qw_max, __shfl_xor(qw_max, off));
+        t_max  = max(t_max, __shfl_xor(t_max, off));
+    }
+}
+__device__ __forceinline__ SpanGeom hb_span_geom(const HirschbergArgs& a, int32_t idx, int32_t qw_max, int32_t t_max, int64_t max_elems)
+{
+    SpanGeom g;
+    g.levels = hb_span_levels(a.max_query_length);
+    g.P      = 1 << g.levels;
+    g.rows   = (int64_t)t_max + g.P + 1;
+    uint32_t* area = a.ws + a.wave_offsets[0] + 64 * hb_lane_words(qw_max, t_max, max_elems) + (int64_t)idx * hb_span_words(qw_max, t_max, a.max_query_length);
+    g.parts[0]  = reinterpret_cast<LvPart*>(area);
+    g.parts[1]  = reinterpret_cast<LvPart*>(area + 4 * g.P);
+    g.piece_len = reinterpret_cast<int32_t*>(area + 8 * g.P);
+    g.rows_f    = area + 9 * g.P;
+    g.rows_r    = g.rows_f + g.rows;
+    g.leaf      = g.rows_r + g.rows;
+    g.stage     = reinterpret_cast<int8_t*>(g.leaf + 6 * g.rows);
+    return g;
+}
+// the pair's slots in the wave region (as the depth-first kernel carves them): only the pattern tables are used by the span path
+__device__ __forceinline__ void hb_span_pair_tables(const HirschbergArgs& a, int32_t idx, int32_t qw_max, int32_t t_max, int64_t max_elems, uint32_t*& pat_f,
+                                                    uint32_t*& pat_r)
+{
+    uint32_t* base = a.ws + a.wave_offsets[0] + (size_t)idx * (size_t)hb_lane_words(qw_max, t_max, max_elems);
+    pat_f          = base + 4 * kHbStackEntries + 2 * ((size_t)t_max + 1);
+    pat_r          = pat_f + (size_t)4 * qw_max;
+}
+// the pair takes the span path (and its workspace is there: a caller that sized the workspace with
+// gwhip_hirschberg_myers_workspace_bytes always has it; otherwise the pair reports no result, hb_span_join_kernel)
+__device__ __forceinline__ bool hb_span_pair(const HirschbergArgs& a, int32_t idx)
+{
+    return a.span_levels > 0 && (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]) > kSpanPartQuery;
+}
+__device__ __forceinline__ bool hb_span_fits(const HirschbergArgs& a, int32_t qw_max, int32_t t_max, int64_t max_elems)
+{
+    return a.wave_offsets[0] + 64 * hb_lane_words(qw_max, t_max, max_elems) + (int64_t)a.n * hb_span_words(qw_max, t_max, a.max_query_length) <=
+           a.ws_capacity_words;
+}
+// a part that is split at the next level: long enough, and both sides non-empty (an empty side is a terminal: a run of gaps)
+__device__ __forceinline__ bool hb_span_splits(const LvPart& p) { return p.qe - p.qb > kSpanPartQuery && p.te > p.tb; }
+
+// grid (n): pattern tables of the pair, level-0 part list
+__global__ __launch_bounds__(64) void hb_span_init_kernel(HirschbergArgs a)
+{
+    const int32_t lane = threadIdx.x & 63, idx = blockIdx.x;
+    int32_t qw_max, t_max;
+    hb_region_geometry(a, lane, qw_max, t_max);
+    if (!hb_span_pair(a, idx)) return;
+    const int64_t max_elems = (int64_t)ceil_div(max(a.max_query_length, 1), kWord) * (kHbSwitchToMyers + 1);
+    if (!hb_span_fits(a, qw_max, t_max, max_elems)) return;
+    const SpanGeom g        = hb_span_geom(a, idx, qw_max, t_max, max_elems);
+    HbWaveIn in{};
+    in.query      = a.sequences + a.starts[2 * idx];
+    in.query_size = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
+    hb_span_pair_tables(a, idx, qw_max, t_max, max_elems, in.pat_f, in.pat_r);
+    hb_build_patterns(in, lane);
+    if (lane == 0) g.parts[0][0] = LvPart{0, in.query_size, 0, (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1])};
+}
+
+// grid (2 x parts of the level, n): block (2 j + half, pair) computes the last row of one half of part j
+__global__ __launch_bounds__(64) void hb_span_rows_kernel(HirschbergArgs a, int32_t level)
+{
+    extern __shared__ uint32_t hw_lds[];
+    const int32_t lane = threadIdx.x & 63, idx = blockIdx.y, j = blockIdx.x >> 1;
+    const bool reverse = (blockIdx.x & 1) != 0;
+    int32_t qw_max, t_max;
+    hb_region_geometry(a, lane, qw_max, t_max);
+    if (!hb_span_pair(a, idx)) return;
+    const int64_t max_elems = (int64_t)ceil_div(max(a.max_query_length, 1), kWord) * (kHbSwitchToMyers + 1);
+    if (!hb_span_fits(a, qw_max, t_max, max_elems)) return;
+    const SpanGeom g        = hb_span_geom(a, idx, qw_max, t_max, max_elems);
+    const LvPart p          = g.parts[level & 1][j];
+    if (!hb_span_splits(p)) return;
+    HbWaveIn in{};
+    in.query       = a.sequences + a.starts[2 * idx];
+    in.target      = a.sequences + a.starts[2 * idx + 1];
+    in.query_size  = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
+    in.target_size = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
+    hb_span_pair_tables(a, idx, qw_max, t_max, max_elems, in.pat_f, in.pat_r);
+    in.st_pv = hw_lds + 4 * kHbStackEntries;
+    in.st_mv = in.st_pv + (size_t)a.lds_state_words * 64;
+    in.st_pt = in.st_mv + (size_t)a.lds_state_words * 64;
+    const int32_t qmid = p.qb + (p.qe - p.qb) / 2;
+    if (!reverse) hb_last_row(in, lane, p.qb, qmid, p.tb, p.te, false, g.rows_f + p.tb + j);
+    else hb_last_row(in, lane, qmid, p.qe, p.tb, p.te, true, g.rows_r + p.tb + j);
+}
+
+// The same last row by a PIPELINE OF WAVEFRONTS (block = W wavefronts, grid as above): a half of more than 64 words (2 048 bases)
+// is a chain of 64-word chunks per target column -- the addition carry and the +1 / -1 delta at a chunk's top bit feed the next
+// chunk -- that one wavefront walks chunk after chunk with the column state in LDS (hb_last_row: 25 chunk steps per column
+// for a 100 kbp pair). Here chunk c belongs to wavefront c mod W, which keeps the chunk's column state and pattern words in
+// REGISTERS and works on batches of 64 columns: unit (c, k) = chunk c, columns 64 k + 1 .. 64 k + 64, needs (c - 1, k) -- whose
+// three boundary bits per column arrive as three 64-bit words through an LDS ring -- and (c, k - 1), the wavefront's own
+// previous batch. A wavefront runs its units in the order of c + k, so every dependency lies in an earlier stage (no
+// deadlock); done[c] counts the batches chunk c has finished, a producer stays at most kMwRing batches ahead of its consumer.
+// The chain of a column is as long as before, but the chunks of DIFFERENT columns overlap: a column costs about one chunk step
+// (two when a wavefront owns two chunks) instead of one per chunk. Same bits, same scores as hb_last_row.
+constexpr int32_t kMwMaxWaves  = 16;
+constexpr int32_t kMwMaxChunks = 64;  // halves of up to 131 072 bases
+constexpr int32_t kMwSlots     = kMwMaxChunks / kMwMaxWaves;
+constexpr int32_t kMwRing      = 8;
+struct MwRowsSync
+{
+    int32_t done[kMwMaxChunks];
+    uint64_t hand[kMwMaxChunks][kMwRing][3];
+};
+__device__ __forceinline__ int32_t mw_poll(const int32_t* p) { return *reinterpret_cast<const volatile int32_t*>(p); }
+
+__global__ __launch_bounds__(kMwMaxWaves * 64) void hb_span_rows_mw_kernel(HirschbergArgs a, int32_t level)
+{
+    __shared__ MwRowsSync sync;
+    const int32_t lane = threadIdx.x & 63, idx = blockIdx.y, j = blockIdx.x >> 1;
+    const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)threadIdx.x >> 6), W = (int32_t)(blockDim.x >> 6);
+    const bool reverse = (blockIdx.x & 1) != 0;
+    int32_t qw_max, t_max;
+    hb_region_geometry(a, lane, qw_max, t_max);
+    if (!hb_span_pair(a, idx)) return;
+    const int64_t max_elems = (int64_t)ceil_div(max(a.max_query_length, 1), kWord) * (kHbSwitchToMyers + 1);
+    if (!hb_span_fits(a, qw_max, t_max, max_elems)) return;
+    const SpanGeom g = hb_span_geom(a, idx, qw_max, t_max, max_elems);
+    const LvPart p   = g.parts[level & 1][j];
+    if (!hb_span_splits(p)) return;
+    HbWaveIn in{};
+    in.query       = a.sequences + a.starts[2 * idx];
+    in.target      = a.sequences + a.starts[2 * idx + 1];
+    in.query_size  = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
+    in.target_size = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
+    hb_span_pair_tables(a, idx, qw_max, t_max, max_elems, in.pat_f, in.pat_r);
+    const int32_t qmid = p.qb + (p.qe - p.qb) / 2;
+    const int32_t qb = reverse ? qmid : p.qb, qe = reverse ? p.qe : qmid, tb = p.tb, te = p.te;
+    uint32_t* out    = (reverse ? g.rows_r : g.rows_f) + p.tb + j;
+    const int32_t qn = qe - qb, tn = te - tb;
+    const int32_t nw = ceil_div(qn, kWord), nch = ceil_div(nw, 64);
+    if (nch == 1 || nch > kMwMaxChunks)
+    {
+        // one chunk: the single-wavefront routine with everything in registers (more than kMwMaxChunks: its LDS-state flavour
+        // needs the launch's dynamic LDS, which this kernel does not ask for -- such halves are left to hb_span_rows_kernel)
+        if (wave == 0 && nch == 1) hb_last_row(in, lane, qb, qe, tb, te, reverse, out);
+        return;
+    }
+    if (threadIdx.x < kMwMaxChunks) sync.done[threadIdx.x] = 0;
+    __syncthreads();
+    const int32_t n_words_query = ceil_div(in.query_size, kWord);
+    const PlainWords tab_f{in.pat_f}, tab_r{in.pat_r};
+    const int32_t pattern_offset = reverse ? in.query_size - qe : qb;
+    const char acgt[4] = {'A', 'C', 'T', 'G'};
+    // this wavefront's chunks: slot i holds chunk wave + i W
+    uint32_t pv[kMwSlots], mv[kMwSlots], e[kMwSlots][4];
+    int32_t sc = qn; // running score of the last row (the wavefront that owns the last chunk)
+#pragma unroll
+    for (int i = 0; i < kMwSlots; i++)
+    {
+        const int32_t c = wave + i * W, w = c * 64 + lane;
+        pv[i] = (c < nch && w < nw) ? ~0u : 0u; // lanes past the part: no carry generated or propagated
+        mv[i] = 0u;
+#pragma unroll
+        for (int ci = 0; ci < 4; ci++)
+            e[i][ci] = (c < nch && w < nw) ? (reverse ? get_pattern(tab_r, n_words_query, w, pattern_offset, acgt[ci])
+                                                     : get_pattern(tab_f, n_words_query, w, pattern_offset, acgt[ci]))
+                                           : 0u;
+    }
+    const int32_t last_lane  = (nw - 1) & 63;
+    const uint32_t last_hbit = 1u << (qn - (nw - 1) * kWord - 1);
+    const int32_t nb         = ceil_div(tn, 64);
+    if (wave == ((nch - 1) % W) && lane == 0) out[0] = (uint32_t)qn;
+    for (int32_t stage = 0; stage < nb + nch - 1; ++stage)
+    {
+#pragma unroll
+        for (int i = 0; i < kMwSlots; i++)
+        {
+            const int32_t c = wave + i * W, k = stage - c;
+            if (c >= nch || k < 0 || k >= nb) continue; // wave-uniform
+            const int32_t t0 = 64 * k, cols = min(64, tn - t0);
+            uint64_t in_c = 0ull, in_p = ~0ull, in_m = 0ull; // chunk 0: no carry, the implicit first row 0, 1, 2, ... (+1 per column)
+            if (c > 0)
+            {
+                while (mw_poll(&sync.done[c - 1]) <= k) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const volatile uint64_t* h = sync.hand[c - 1][k % kMwRing];
+                in_c = h[0]; in_p = h[1]; in_m = h[2];
+                in_c = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(in_c >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)in_c);
+                in_p = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(in_p >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)in_p);
+                in_m = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(in_m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)in_m);
+            }
+            const bool last_chunk = c == nch - 1;
+            if (!last_chunk) // the slot this batch's boundary bits go to must have been read by the next chunk
+                while (mw_poll(&sync.done[c + 1]) + kMwRing <= k) __builtin_amdgcn_s_sleep(1);
+            const int32_t tt = t0 + 1 + lane; // column of this lane's target character
+            const uint32_t tcv = tt <= tn ? (uint32_t)(unsigned char)(reverse ? in.target[te - tt] : in.target[tb + tt - 1]) : 0u;
+            uint64_t out_c = 0ull, out_p = 0ull, out_m = 0ull;
+            uint32_t acc = 0u; // last chunk: score after column t0 + 1 + lane
+            uint32_t pvi = pv[i], mvi = mv[i];
+            for (int32_t q = 0; q < cols; ++q)
+            {
+                const uint32_t tc = (uint32_t)__builtin_amdgcn_readlane((int32_t)tcv, q);
+                const uint32_t ci = (tc >> 1) & 3u;
+                const uint32_t m1 = 0u - (ci & 1u), m2 = 0u - (ci >> 1);
+                const uint32_t lo = (e[i][1] & m1) | (e[i][0] & ~m1), hi = (e[i][3] & m1) | (e[i][2] & ~m1);
+                const uint32_t eq = (hi & m2) | (lo & ~m2);
+                const uint32_t carry = (uint32_t)((in_c >> q) & 1ull), hin_p = (uint32_t)((in_p >> q) & 1ull), hin_m = (uint32_t)((in_m >> q) & 1ull);
+                const uint32_t xv  = eq | mvi;
+                const uint32_t an  = eq & pvi;
+                const uint32_t s0  = an + pvi;
+                const uint64_t gen = __ballot(s0 < an), prp = __ballot(s0 == 0xffffffffu);
+                const uint64_t top = 1ull << 63;
+                const uint64_t cin = (((gen | prp) & ~top) + (gen & ~top) + carry) ^ (prp & ~top);
+                const uint32_t carry_out = (uint32_t)(((gen >> 63) | ((prp >> 63) & (cin >> 63))) & 1ull);
+                const uint32_t sum = s0 + (uint32_t)((cin >> lane) & 1ull);
+                const uint32_t xh  = (sum ^ pvi) | eq;
+                const uint32_t ph  = mvi | ~(xh | pvi);
+                const uint32_t mh  = pvi & xh;
+                uint32_t ph_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(ph >> 31), 0x138, 0xf, 0xf, false); // wave_shr:1
+                uint32_t mh_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(mh >> 31), 0x138, 0xf, 0xf, false);
+                if (lane == 0)
+                {
+                    ph_lo = hin_p;
+                    mh_lo = hin_m;
+                }
+                const uint32_t hout_p = (uint32_t)__builtin_amdgcn_readlane((int32_t)(ph >> 31), 63);
+                const uint32_t hout_m = (uint32_t)__builtin_amdgcn_readlane((int32_t)(mh >> 31), 63);
+                out_c |= (uint64_t)carry_out << q;
+                out_p |= (uint64_t)hout_p << q;
+                out_m |= (uint64_t)hout_m << q;
+                if (last_chunk)
+                {
+                    const uint32_t php = (uint32_t)__builtin_amdgcn_readlane((int32_t)ph, last_lane);
+                    const uint32_t mhp = (uint32_t)__builtin_amdgcn_readlane((int32_t)mh, last_lane);
+                    sc += ((php & last_hbit) ? 1 : 0) - ((mhp & last_hbit) ? 1 : 0);
+                    if (lane == q) acc = (uint32_t)sc;
+                }
+                const uint32_t phs = (ph << 1) | ph_lo, mhs = (mh << 1) | mh_lo;
+                pvi = mhs | ~(xv | phs);
+                mvi = phs & xv;
+            }
+            pv[i] = pvi;
+            mv[i] = mvi;
+            if (last_chunk)
+            {
+                if (lane < cols) out[t0 + 1 + lane] = acc;
+            }
+            else
+            {
+                if (lane == 0)
+                {
+                    volatile uint64_t* h = sync.hand[c][k % kMwRing];
+                    h[0] = out_c; h[1] = out_p; h[2] = out_m;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            }
+            if (lane == 0) *reinterpret_cast<volatile int32_t*>(&sync.done[c]) = k + 1;
+        }
+    }
+}
+
+// grid (parts of the level, n): the two children of part j (or the part itself and an empty part, if it is not split)
+__global__ __launch_bounds__(64) void hb_span_split_kernel(HirschbergArgs a, int32_t level)
+{
+    const int32_t lane = threadIdx.x & 63, idx = blockIdx.y, j = blockIdx.x;
+    int32_t qw_max, t_max;
+    hb_region_geometry(a, lane, qw_max, t_max);
+    if (!hb_span_pair(a, idx)) return;
+    const int64_t max_elems = (int64_t)ceil_div(max(a.max_query_length, 1), kWord) * (kHbSwitchToMyers + 1);
+    if (!hb_span_fits(a, qw_max, t_max, max_elems)) return;
+    const SpanGeom g        = hb_span_geom(a, idx, qw_max, t_max, max_elems);
+    const LvPart p          = g.parts[level & 1][j];
+    LvPart left = p, right = LvPart{p.qe, p.qe, p.te, p.te};
+    if (hb_span_splits(p))
+    {
+        const int32_t qmid = p.qb + (p.qe - p.qb) / 2;
+        const int32_t tmid = p.tb + hb_target_mid(g.rows_f + p.tb + j, g.rows_r + p.tb + j, p.te - p.tb, lane);
+        left  = LvPart{p.qb, qmid, p.tb, tmid};
+        right = LvPart{qmid, p.qe, tmid, p.te};
+    }
+    if (lane == 0)
+    {
+        g.parts[(level + 1) & 1][2 * j]     = left;
+        g.parts[(level + 1) & 1][2 * j + 1] = right;
+    }
+}
+
+// grid (parts of the last level, n): part j of the pair, depth-first, into its own piece of the staging buffer
+__global__ __launch_bounds__(64) void hb_span_parts_kernel(HirschbergArgs a)
+{
+    extern __shared__ uint32_t hw_lds[];
+    const int32_t lane = threadIdx.x & 63, idx = blockIdx.y, j = blockIdx.x;
+    int32_t qw_max, t_max;
+    hb_region_geometry(a, lane, qw_max, t_max);
+    if (!hb_span_pair(a, idx)) return;
+    const int64_t max_elems = (int64_t)ceil_div(max(a.max_query_length, 1), kWord) * (kHbSwitchToMyers + 1);
+    if (!hb_span_fits(a, qw_max, t_max, max_elems)) return;
+    const SpanGeom g        = hb_span_geom(a, idx, qw_max, t_max, max_elems);
+    const LvPart p          = g.parts[g.levels & 1][j];
+    HbWaveIn in{};
+    in.query       = a.sequences + a.starts[2 * idx];
+    in.target      = a.sequences + a.starts[2 * idx + 1];
+    in.query_size  = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
+    in.target_size = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
+    hb_span_pair_tables(a, idx, qw_max, t_max, max_elems, in.pat_f, in.pat_r);
+    in.fwd = g.rows_f + p.tb + j;
+    in.rev = g.rows_r + p.tb + j;
+    const int64_t leaf_words = hb_leaf_words(p.te - p.tb, max_elems); // <= 2 x (target part + 1)
+    in.leaf.pv     = g.leaf + 6 * ((int64_t)p.tb + j);
+    in.leaf.mv     = in.leaf.pv + leaf_words;
+    in.leaf.score  = reinterpret_cast<int32_t*>(in.leaf.mv + leaf_words);
+    in.leaf.n_rows = 0;
+    in.leaf.stride = 1;
+    in.max_elems   = max_elems;
+    in.stack       = hw_lds;
+    in.st_pv       = hw_lds + 4 * kHbStackEntries;
+    in.st_mv       = in.st_pv + (size_t)a.lds_state_words * 64;
+    in.st_pt       = in.st_mv + (size_t)a.lds_state_words * 64;
+    in.leaf_lds    = in.st_pt + (size_t)a.lds_state_words * 256;
+    in.qb = p.qb; in.qe = p.qe; in.tb = p.tb; in.te = p.te;
+    int32_t len = 0;
+    if (p.qe > p.qb || p.te > p.tb) len = hb_wave_run(in, g.stage + p.qb + p.tb, lane);
+    if (lane == 0) g.piece_len[j] = len;
+}
+
+// grid (n): the pieces of the pair's parts, last part first (the path is stored back to front), into the pair's result slot
+__global__ __launch_bounds__(256) void hb_span_join_kernel(HirschbergArgs a)
+{
+    const int32_t lane = threadIdx.x & 63, idx = blockIdx.x;
+    int32_t qw_max, t_max;
+    hb_region_geometry(a, lane, qw_max, t_max);
+    if (!hb_span_pair(a, idx)) return;
+    const int64_t max_elems = (int64_t)ceil_div(max(a.max_query_length, 1), kWord) * (kHbSwitchToMyers + 1);
+    if (!hb_span_fits(a, qw_max, t_max, max_elems))
+    {
+        if (threadIdx.x == 0) a.result_lengths[idx] = 0;
+        return;
+    }
+    const SpanGeom g        = hb_span_geom(a, idx, qw_max, t_max, max_elems);
+    const LvPart* parts     = g.parts[g.levels & 1];
+    int8_t* path            = a.results + a.starts[2 * idx];
+    int64_t at = 0;
+    bool ok    = true;
+    for (int32_t j = g.P - 1; j >= 0; --j)
+    {
+        const int32_t len = g.piece_len[j];
+        if (len < 0) { ok = false; break; }
+        const int8_t* src = g.stage + parts[j].qb + parts[j].tb;
+        for (int32_t k = threadIdx.x; k < len; k += blockDim.x) path[at + k] = src[k];
+        at += len;
+    }
+    if (threadIdx.x == 0) a.result_lengths[idx] = ok ? (int32_t)at : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2919,6 +3395,8 @@ size_t gwhip_hirschberg_myers_workspace_bytes(int32_t n_alignments, const int64_
             tm = std::max(tm, (int32_t)(sequence_starts_host[2 * i + 2] - sequence_starts_host[2 * i + 1]));
         }
         words += 64 * hb_lane_words(qw, tm, max_elems);
+        // the span path of long single pairs keeps its part lists, rows and pieces behind the (only) wave region
+        if (n_alignments <= kSpanMaxPairs) words += (int64_t)n_alignments * hb_span_words(qw, tm, max_query_length);
     }
     return 256 + ((size_t)n_waves + 1) * 8 + 256 + (size_t)words * 4 + 256;
 }
@@ -2983,9 +3461,38 @@ int gwhip_hirschberg_myers(const gwhip_hirschberg_args* args, gwhip_stream_t str
                 hipLaunchKernelGGL(hirschberg_levels_kernel, dim3(n), dim3(64), lv_lds, stream, ka);
             }
         }
+        // long single pairs (queries beyond kSpanPartQuery in a batch of at most kSpanMaxPairs pairs): the top of the tree level by
+        // level across blocks, then one wavefront per part (GWHIP_HIRSCHBERG_SPAN=0: the depth-first kernel alone)
+        {
+            const char* sp = std::getenv("GWHIP_HIRSCHBERG_SPAN");
+            ka.span_levels = (n <= kSpanMaxPairs && !(sp && sp[0] == '0')) ? hb_span_levels(args->max_query_length) : 0;
+        }
         if (lds_request > 48 * 1024)
+        {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hirschberg_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_request);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hb_span_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_request);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hb_span_parts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_request);
+        }
         hipLaunchKernelGGL(hirschberg_wave_kernel, dim3(n), dim3(64), lds_request, stream, ka);
+        if (ka.span_levels > 0)
+        {
+            hipLaunchKernelGGL(hb_span_init_kernel, dim3(n), dim3(64), 0, stream, ka);
+            for (int32_t level = 0; level < ka.span_levels; ++level)
+            {
+                // the longest half of this level in 64-word chunks: one wavefront per chunk (at most kMwMaxWaves, which then own
+                // several) -- GWHIP_HIRSCHBERG_SPAN=1: one wavefront per half, chunk after chunk (A/B)
+                const int32_t half   = ((args->max_query_length >> level) + 1) / 2 + 1;
+                const int32_t chunks = (((half + kWord - 1) / kWord) + 63) / 64;
+                const char* sp       = std::getenv("GWHIP_HIRSCHBERG_SPAN");
+                if (chunks > kMwMaxChunks || (sp && sp[0] == '1'))
+                    hipLaunchKernelGGL(hb_span_rows_kernel, dim3(2u << level, n), dim3(64), lds_request, stream, ka, level);
+                else
+                    hipLaunchKernelGGL(hb_span_rows_mw_kernel, dim3(2u << level, n), dim3(64 * std::max(1, std::min(chunks, kMwMaxWaves))), 0, stream, ka, level);
+                hipLaunchKernelGGL(hb_span_split_kernel, dim3(1u << level, n), dim3(64), 0, stream, ka, level);
+            }
+            hipLaunchKernelGGL(hb_span_parts_kernel, dim3(1u << ka.span_levels, n), dim3(64), lds_request, stream, ka);
+            hipLaunchKernelGGL(hb_span_join_kernel, dim3(n), dim3(256), 0, stream, ka);
+        }
     }
     else if ((size_t)qwords * 6 * 64 * sizeof(uint32_t) <= 60 * 1024)
     {

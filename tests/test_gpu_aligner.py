@@ -208,6 +208,59 @@ def test_default_aligner_kernels_agree(monkeypatch):
             assert states == A.hirschberg(q, t, max_len)["states"]
 
 
+def test_default_aligner_span_path_equals_the_depth_first_kernel(monkeypatch):
+    """Long single pairs (the reference's BM_SingleAlignment shapes, cudaaligner/benchmarks/main.cpp:39-67): the span path
+    -- the top of Hirschberg's tree grown level by level across blocks, one wavefront per part below -- against the
+    depth-first wavefront kernel alone (GWHIP_HIRSCHBERG_SPAN=0): identical states for pairs of 2.1 k to 60 k bases, balanced
+    and very unbalanced, alone and in small batches next to short pairs; the oracle on the ones it finishes quickly."""
+    import random
+    from genomeworks_amd import cudaaligner
+    rng = random.Random(777)
+
+    def pair(n, div, cut_t=None, cut_q=None):
+        q = "".join(rng.choice("ACGT") for _ in range(n))
+        t = list(q)
+        for _ in range(max(1, n // div)):
+            op, p = rng.random(), rng.randrange(max(1, len(t)))
+            if op < 0.4 and t:
+                t[p] = rng.choice("ACGT")
+            elif op < 0.7:
+                t.insert(p, rng.choice("ACGT"))
+            elif t:
+                del t[p]
+        t = "".join(t)
+        if cut_t:
+            t = t[: len(t) // cut_t]
+        if cut_q:
+            q = q[: max(2, len(q) // cut_q)]
+        return q, t
+
+    batches = [
+        (65536, [pair(60000, 12)]),
+        (32768, [pair(20000, 8), pair(2100, 10), pair(700, 9), pair(20000, 30, cut_t=5)]),
+        (16384, [pair(9000, 10), pair(16000, 15, cut_q=3), pair(4097, 7), pair(10, 3), pair(12000, 20, cut_t=50)]),
+        (6400, [pair(5999, 9), pair(3000, 11), pair(2049, 6)]),
+    ]
+    for max_len, pairs in batches:
+        out = {}
+        for name, flag in (("span", None), ("depth_first", "0")):
+            if flag is None:
+                monkeypatch.delenv("GWHIP_HIRSCHBERG_SPAN", raising=False)
+            else:
+                monkeypatch.setenv("GWHIP_HIRSCHBERG_SPAN", flag)
+            al = cudaaligner.CudaAlignerBatch(max_len, max_len, len(pairs), max_device_memory_allocator_caching_size=16 << 30)
+            for q, t in pairs:
+                assert al.add_alignment(q, t) == 0
+            al.align_all()
+            out[name] = [(r.status, list(r.alignment)) for r in al.get_alignments()]
+        assert [st for st, _ in out["span"]] == [0] * len(pairs)
+        for k, (a, b) in enumerate(zip(out["span"], out["depth_first"])):
+            assert a == b, (max_len, k)
+        for (st, states), (q, t) in zip(out["span"], pairs):
+            if max_len <= 6400:
+                assert states == A.hirschberg(q, t, max_len)["states"]
+
+
 def test_default_aligner_level_by_level_kernel_agrees(monkeypatch):
     """Aligners for queries of up to 2 048 bases grow Hirschberg's tree a level at a time (all parts of a level side by side
     in the wavefront, default) -- the alignments must equal the depth-first kernel's (GWHIP_HIRSCHBERG_LEVELS=0) and the
