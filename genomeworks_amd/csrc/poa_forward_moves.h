@@ -158,7 +158,11 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
     const uint32_t read_base = lds_addr(lds_read);
     // guard store: lanes 0..15 write sentinel cells for columns band_end + 1 .. + 64, lane 16 the quad that ends in
     // the left-boundary slot (column band_start); byte offsets relative to the lane's own cell offset
-    const uint32_t guard_off  = lane < 16 ? (uint32_t)(2 * BW) : (uint32_t)-136;
+    // (lanes 17..63 take part in the same store -- masking them off costs two writes of EXEC per row, ~45 cycles for a lone
+    // wavefront -- and write quads of columns band_start - 7 and below, lane l at byte 2 band_start - 16 - 8 (l - 17): no reader
+    // of this row looks left of column band_start - 3, and the lowest of them, 191 columns down, still lies clear of the
+    // sentinel cells when the slot wraps)
+    const uint32_t guard_off  = lane < 16 ? (uint32_t)(2 * BW) : (lane == 16 ? (uint32_t)-136 : (uint32_t)(120 - 16 * lane));
     const bool is_lane16      = lane == 16;
     const bool is_lane63      = lane == kBandLanes - 1; // the band's last lane
     const uint32_t move_keep  = lane == 0 ? 0xffffff00u : 0xffffffffu; // the band's first cell stays undecided
@@ -182,7 +186,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
 
     // row 0 into ring slot 0
     if (BW == 256 || band_lane) lds_store_u64(ring_base + a1, P01, P23);
-    lds_store_u64_lanes17(ring_base + ga, SENT2, is_lane16 ? (((uint32_t)kPkSentinel & 0xffffu) | (0u << 16)) : SENT2);
+    lds_store_guard(ring_base + ga, SENT2, is_lane16 ? (((uint32_t)kPkSentinel & 0xffffu) | (0u << 16)) : SENT2);
 
     // horizontal max-plus scan of the row's candidates; cu = carry-in as element t = -1 of u; leaves the row in P01/P23
     auto scan_row = [&](uint32_t s01, uint32_t s23, int32_t cu) {
@@ -227,12 +231,12 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
         if constexpr (BS0)
         {
             const uint32_t rel0pk = ((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)rel0_val << 16);
-            if (ab_guard) lds_store_u64_lanes17(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
+            if (ab_guard) lds_store_guard(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
             gstore_u16_lane0_below(score_ptr, (uint32_t)rel0_val); // a real left-boundary value
             prev_rel0 = rel0_val;
         }
         else if (ab_guard)
-            lds_store_u64_lanes17(sbase + ga, SENT2, GUARD_HI_MIN);
+            lds_store_guard(sbase + ga, SENT2, GUARD_HI_MIN);
         if (st_moves && (BW == 256 || band_lane)) *reinterpret_cast<uint32_t*>(move_ptr) = mv4;
     };
     // four move bytes from two registers of 16-bit moves
@@ -341,7 +345,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
             *reinterpret_cast<uint2*>(score_ptr) = make_uint2(P01, P23);
             lds_store_u64(sbase + a1, P01, P23);
         }
-        lds_store_u64_lanes17(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
+        lds_store_guard(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
         if (bs == 0) gstore_u16_lane0_below(score_ptr, (uint32_t)rel0_val);
         if (BW == 256 || band_lane) *reinterpret_cast<uint32_t*>(move_ptr) = 0u;
         prev_rel0_io = rel0_val;

@@ -109,7 +109,11 @@ __device__ __forceinline__ bool banded_forward_tb(const GraphView<IdT>& g, RowIn
     const uint32_t read_base = lds_addr(lds_read);
     // guard store: lanes 0..15 write sentinel cells for columns band_end + 1 .. + 64, lane 16 the quad that ends in the
     // left-boundary slot (column band_start); byte offsets relative to the lane's own pass-0 offset
-    const uint32_t guard_off  = lane < 16 ? (uint32_t)(2 * BW) : (uint32_t)-136;
+    // (lanes 17..63 take part in the same store -- masking them off costs two writes of EXEC per row, ~45 cycles for a lone
+    // wavefront -- and write quads of columns band_start - 7 and below, lane l at byte 2 band_start - 16 - 8 (l - 17): no reader
+    // of this row looks left of column band_start - 3, and the lowest of them, 191 columns down, still lies clear of the
+    // sentinel cells when the slot wraps)
+    const uint32_t guard_off  = lane < 16 ? (uint32_t)(2 * BW) : (lane == 16 ? (uint32_t)-136 : (uint32_t)(120 - 16 * lane));
     const bool is_lane16      = lane == 16;
     const bool is_last        = lane == kLastLanes - 1; // the band's last lane (of the last pass)
     const uint64_t last_mask  = 1ull << (kLastLanes - 1);
@@ -140,7 +144,7 @@ __device__ __forceinline__ bool banded_forward_tb(const GraphView<IdT>& g, RowIn
 #pragma unroll
     for (int p = 0; p < NP; p++)
         if (owns(p)) lds_store_u64(ring_base + a1[p], P01[p], P23[p]);
-    lds_store_u64_lanes17(ring_base + ga, SENT2, is_lane16 ? (((uint32_t)kPkSentinel & 0xffffu) | (0u << 16)) : SENT2);
+    lds_store_guard(ring_base + ga, SENT2, is_lane16 ? (((uint32_t)kPkSentinel & 0xffffu) | (0u << 16)) : SENT2);
 
     // horizontal max-plus scan of the row's candidates, pass after pass; cu = carry-in as element t = -1 of u
     auto scan_row = [&](const uint32_t (&s01)[NP], const uint32_t (&s23)[NP], int32_t cu) {
@@ -208,7 +212,7 @@ __device__ __forceinline__ bool banded_forward_tb(const GraphView<IdT>& g, RowIn
         {
             // the boundary slot's real content behind the guard cells (a row without predecessors keeps gap_score there)
             const uint32_t rel0pk = ((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)rel0_val << 16);
-            lds_store_u64_lanes17(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
+            lds_store_guard(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
         }
         prev_rel0 = rel0_val;
 #pragma unroll

@@ -61,7 +61,11 @@ __device__ __forceinline__ void banded_forward_moves_wide(const GraphView<IdT>& 
     const uint32_t read_base = lds_addr(lds_read);
     // guard store: lanes 0..15 write sentinel cells for columns band_end + 1 .. + 64, lane 16 the quad that ends in the
     // left-boundary slot (column band_start); byte offsets relative to the lane's own pass-A offset
-    const uint32_t guard_off  = lane < 16 ? (uint32_t)(2 * BW) : (uint32_t)-136;
+    // (lanes 17..63 take part in the same store -- masking them off costs two writes of EXEC per row, ~45 cycles for a lone
+    // wavefront -- and write quads of columns band_start - 7 and below, lane l at byte 2 band_start - 16 - 8 (l - 17): no reader
+    // of this row looks left of column band_start - 3, and the lowest of them, 191 columns down, still lies clear of the
+    // sentinel cells when the slot wraps)
+    const uint32_t guard_off  = lane < 16 ? (uint32_t)(2 * BW) : (lane == 16 ? (uint32_t)-136 : (uint32_t)(120 - 16 * lane));
     const bool is_lane16      = lane == 16;
     const bool is_lastB       = lane == kBLanes - 1; // the band's last lane (pass B)
     const uint32_t move_keepA = lane == 0 ? 0xffffff00u : 0xffffffffu; // the band's first cell stays undecided
@@ -88,7 +92,7 @@ __device__ __forceinline__ void banded_forward_moves_wide(const GraphView<IdT>& 
     // row 0 into ring slot 0
     lds_store_u64(ring_base + a1A, PA01, PA23);
     if (BW == 512 || bandB_lane) lds_store_u64(ring_base + a1B, PB01, PB23);
-    lds_store_u64_lanes17(ring_base + ga, SENT2, is_lane16 ? (((uint32_t)kPkSentinel & 0xffffu) | (0u << 16)) : SENT2);
+    lds_store_guard(ring_base + ga, SENT2, is_lane16 ? (((uint32_t)kPkSentinel & 0xffffu) | (0u << 16)) : SENT2);
 
     // horizontal max-plus scan of both passes' candidates; cu = carry-in as element t = -1 of u; leaves the row in P*
     auto scan_row = [&](uint32_t sA01, uint32_t sA23, uint32_t sB01, uint32_t sB23, int32_t cu) {
@@ -145,12 +149,12 @@ __device__ __forceinline__ void banded_forward_moves_wide(const GraphView<IdT>& 
         if constexpr (BS0)
         {
             const uint32_t rel0pk = ((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)rel0_val << 16);
-            lds_store_u64_lanes17(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
+            lds_store_guard(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
             gstore_u16_lane0_below(score_ptr, (uint32_t)rel0_val);
             prev_rel0 = rel0_val;
         }
         else
-            lds_store_u64_lanes17(sbase + ga, SENT2, GUARD_HI_MIN);
+            lds_store_guard(sbase + ga, SENT2, GUARD_HI_MIN);
         *reinterpret_cast<uint32_t*>(move_ptr) = mvA & move_keepA;
         if (BW == 512 || bandB_lane) *reinterpret_cast<uint32_t*>(move_ptr + 256) = mvB;
     };
@@ -270,7 +274,7 @@ __device__ __forceinline__ void banded_forward_moves_wide(const GraphView<IdT>& 
             lds_store_u64(sbase + a1B, PB01, PB23);
             *reinterpret_cast<uint32_t*>(move_ptr + 256) = 0u;
         }
-        lds_store_u64_lanes17(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
+        lds_store_guard(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
         if (bs == 0) gstore_u16_lane0_below(score_ptr, (uint32_t)rel0_val);
         prev_rel0_io = rel0_val;
     };

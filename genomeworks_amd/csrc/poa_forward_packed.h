@@ -64,12 +64,10 @@ __device__ __forceinline__ void lds_store_u64(uint32_t addr, uint32_t lo, uint32
     v.x = lo; v.y = hi;
     *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(addr) = v;
 }
-// 8-byte LDS store by lanes 0..16 only (the guard cells + left-boundary quad of a ring row), no branch
-__device__ __forceinline__ void lds_store_u64_lanes17(uint32_t addr, uint32_t lo, uint32_t hi)
-{
-    const uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
-    asm volatile("s_mov_b64 exec, 0x1ffff\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(v) : "memory");
-}
+// The guard store of a ring row: lanes 0..15 the sentinel cells behind the band end, lane 16 the quad that ends in the
+// left-boundary slot, lanes 17..63 a quad nobody reads (see guard_off in the forward passes): one plain 8-byte LDS store by
+// all lanes. (Rounds 1-3 masked lanes 17..63 off around the store: s_mov_b64 exec twice per row.)
+__device__ __forceinline__ void lds_store_guard(uint32_t addr, uint32_t lo, uint32_t hi) { lds_store_u64(addr, lo, hi); }
 
 // ------------------------------------------------------------------------------------------------
 // Side table of predecessor rows 3..5 (build_rowinfo, poa_device.h): one 64-bit entry per row & 255
