@@ -123,6 +123,27 @@ def test_msa_bit_exact_vs_oracle():
             assert [r.replace("-", "") for r in msa[i]] == w
 
 
+@pytest.mark.parametrize("band_mode,band_width", [(m, w) for m in ("static_band", "adaptive_band", "static_band_traceback", "adaptive_band_traceback")
+                                                  for w in (128, 256, 384, 512)])
+def test_msa_through_every_packed_pass_bit_exact_vs_oracle(band_mode, band_width):
+    """MSA output (the MSA instantiations of the graph-build kernel: sequence-begin and edge-coverage bookkeeping in the merge)
+    through every packed forward pass -- bands 128 / 256, the two-pass bands 384 / 512, the traceback-buffer modes -- on metric
+    windows and on short, deep and divergent ones: every row of every MSA equals the oracle's, and stripping the gaps gives back
+    the reads."""
+    from genomeworks_amd import synthetic
+    windows = config3(6) + [[r.decode() for r in synthetic.generate_window(7100 + w, 700 + 40 * w, 10 + w, 40, 25, 25)] for w in range(6)]
+    windows = [[r for r in w if len(r) < 1024] for w in windows]
+    b = run_gpu(windows, band_mode, band_width=band_width, output_type="msa", mem=16 << 30)
+    msa, status = b.get_msa()
+    with O.Workspace(oracle_cfg(band_mode, band_width=band_width, output_mask=2)) as ws:
+        for i, w in enumerate(windows):
+            ref = ws.process(w)
+            assert status[i] == ref["status"], (i, status[i], ref["status"])
+            if ref["status"] == 0:
+                assert msa[i] == ref["msa"], "window %d" % i
+                assert [r.replace("-", "") for r in msa[i]] == w
+
+
 def test_full_size_batch_properties():
     """1024 windows (BASELINE config 3): size-independent properties + parity on a sample of the same run."""
     windows = config3(1024)
