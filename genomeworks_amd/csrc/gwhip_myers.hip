@@ -3438,11 +3438,29 @@ int gwhip_hirschberg_myers(const gwhip_hirschberg_args* args, gwhip_stream_t str
     // longest query part (half the longest query), in chunks of 64 words.
     const int32_t part_chunks = std::max(1, ((qwords + 1) / 2 + 1 + 63) / 64);
     const size_t wave_lds     = (size_t)(4 * kHbStackEntries + 6 * 64 * part_chunks + 3 * kHwLeafElems) * sizeof(uint32_t);
-    bool use_wave             = n <= 262144 && wave_lds <= 150 * 1024;
+    // LDS a block may ask for on this device (queried once per device: 160 KB on gfx950) minus a margin for the kernels' static
+    // LDS; a launch that would not fit falls through to the kernels below instead of failing
+    static int lds_limit_of_device[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && lds_limit_of_device[dev] == 0)
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 64 * 1024;
+        lds_limit_of_device[dev] = v;
+    }
+    const size_t lds_limit    = (size_t)((dev >= 0 && dev < 64) ? lds_limit_of_device[dev] : 64 * 1024) - 10 * 1024;
+    bool use_wave             = n <= 262144 && wave_lds <= lds_limit;
     {
         const char* hw = std::getenv("GWHIP_HIRSCHBERG_WAVE");
         if (hw && hw[0] == '0') use_wave = false;
-        if (hw && hw[0] == '1') use_wave = wave_lds <= 150 * 1024;
+        if (hw && hw[0] == '1') use_wave = wave_lds <= lds_limit;
+    }
+    if (use_wave && wave_lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&hirschberg_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave_lds) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        use_wave = false; // the one-lane kernels below need no more than 60 KB
     }
     if (use_wave)
     {
@@ -3455,10 +3473,18 @@ int gwhip_hirschberg_myers(const gwhip_hirschberg_args* args, gwhip_stream_t str
             if (args->max_query_length <= kLvMaxQuery && !(lv && lv[0] == '0'))
             {
                 const size_t lv_lds = (size_t)lv_layout(std::max(args->max_query_length, 1)).total;
-                if (lv_lds > 48 * 1024)
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hirschberg_levels_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lv_lds);
-                ka.levels_first = 1;
-                hipLaunchKernelGGL(hirschberg_levels_kernel, dim3(n), dim3(64), lv_lds, stream, ka);
+                bool lv_ok          = lv_lds <= lds_limit;
+                if (lv_ok && lv_lds > 48 * 1024 &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&hirschberg_levels_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lv_lds) != hipSuccess)
+                {
+                    (void)hipGetLastError();
+                    lv_ok = false; // the depth-first kernel behind it takes every pair
+                }
+                if (lv_ok)
+                {
+                    ka.levels_first = 1;
+                    hipLaunchKernelGGL(hirschberg_levels_kernel, dim3(n), dim3(64), lv_lds, stream, ka);
+                }
             }
         }
         // long single pairs (queries beyond kSpanPartQuery in a batch of at most kSpanMaxPairs pairs): the top of the tree level by
