@@ -519,7 +519,8 @@ __global__ __launch_bounds__(kWave) void poa_consensus_lds_kernel(KernelArgs a)
     const int32_t n        = a.sequence_lengths[a.window_details[w].seq_len_buffer_offset];
     if (n <= a.cons_lds_nodes)
         generate_consensus_lds<int16_t>(g, n, cons_smem, a.cons_lds_nodes, consensus, a.coverage + (size_t)w * c.max_consensus_size,
-                                        c.max_consensus_size, threadIdx.x & (kWave - 1));
+                                        c.max_consensus_size, threadIdx.x & (kWave - 1),
+                                        (a.debug_flags & 16) != 0); // GWHIP_DEBUG bit 4: the first bundle pass node by node (A/B)
     else if (threadIdx.x == 0) // a graph beyond the LDS tables of this launch: the serial HBM routine
         generate_consensus<int16_t>(g, n, g.cons_pred, g.cons_scores, consensus, a.coverage + (size_t)w * c.max_consensus_size,
                                     c.max_consensus_size);

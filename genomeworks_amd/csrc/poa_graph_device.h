@@ -1704,30 +1704,74 @@ constexpr int kConsLdsBytes = cons_lds_bytes(kConsLdsNodes);
 template <typename IdT>
 __device__ __forceinline__ void generate_consensus_lds(const GraphView<IdT>& g, int32_t node_count, uint8_t* lds, int32_t cap,
                                                        uint8_t* consensus, uint16_t* coverage,
-                                                       int32_t max_limit_consensus_size, int lane)
+                                                       int32_t max_limit_consensus_size, int lane, bool node_by_node = false)
 {
     uint32_t* rec    = reinterpret_cast<uint32_t*>(lds);
     int32_t* scores  = reinterpret_cast<int32_t*>(lds + cap * 12) + 1; // index -1 is the guard
     int16_t* pred    = reinterpret_cast<int16_t*>(lds + cap * 12 + (cap + 4) * 4);
     uint16_t* path   = reinterpret_cast<uint16_t*>(lds); // aliases rec once the passes are done
 
-    for (int32_t n = lane; n < node_count; n += kWave)
+    // four 64-node chunks share one HBM round trip (seven independent loads per node)
+    constexpr int kU = 4;
+    for (int32_t base = 0; base < node_count; base += kU * kWave)
     {
-        const uint32_t cnt = g.incoming_edge_count[n];
-        const uint32_t e0 = (uint16_t)g.incoming_edges[(int64_t)n * kEdges + 0], e1 = (uint16_t)g.incoming_edges[(int64_t)n * kEdges + 1],
-                       e2 = (uint16_t)g.incoming_edges[(int64_t)n * kEdges + 2];
-        const uint32_t w0 = g.incoming_edge_w[(int64_t)n * kEdges + 0], w1 = g.incoming_edge_w[(int64_t)n * kEdges + 1],
-                       w2 = g.incoming_edge_w[(int64_t)n * kEdges + 2];
-        // slots past the in-degree hold stale values: point them at node 0 so their score reads stay in range
-        rec[3 * n + 0] = (cnt > 0 ? e0 & 0xfff : 0u) | ((cnt > 1 ? e1 & 0xfff : 0u) << 12) | (min(cnt, 255u) << 24);
-        rec[3 * n + 1] = (cnt > 2 ? e2 & 0xfff : 0u) | (w0 << 16);
-        rec[3 * n + 2] = w1 | (w2 << 16);
+        uint32_t cnt[kU], e0[kU], e1[kU], e2[kU], w0[kU], w1[kU], w2[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++)
+        {
+            const int32_t n = min(base + u * kWave + lane, node_count - 1);
+            cnt[u] = g.incoming_edge_count[n];
+            e0[u]  = (uint16_t)g.incoming_edges[(int64_t)n * kEdges + 0];
+            e1[u]  = (uint16_t)g.incoming_edges[(int64_t)n * kEdges + 1];
+            e2[u]  = (uint16_t)g.incoming_edges[(int64_t)n * kEdges + 2];
+            w0[u]  = g.incoming_edge_w[(int64_t)n * kEdges + 0];
+            w1[u]  = g.incoming_edge_w[(int64_t)n * kEdges + 1];
+            w2[u]  = g.incoming_edge_w[(int64_t)n * kEdges + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; u++)
+        {
+            const int32_t n = base + u * kWave + lane;
+            if (n >= node_count) continue;
+            // slots past the in-degree hold stale values: point them at node 0 so their score reads stay in range
+            rec[3 * n + 0] = (cnt[u] > 0 ? e0[u] & 0xfff : 0u) | ((cnt[u] > 1 ? e1[u] & 0xfff : 0u) << 12) | (min(cnt[u], 255u) << 24);
+            rec[3 * n + 1] = (cnt[u] > 2 ? e2[u] & 0xfff : 0u) | (w0[u] << 16);
+            rec[3 * n + 2] = w1[u] | (w2[u] << 16);
+        }
     }
     if (lane == 0) scores[-1] = -1;
     wave_sync();
 
-    // one pass of the heaviest-bundle recurrence over sorted positions [first_pos, node_count);
+    // one node of the heaviest-bundle recurrence, wave-uniform against LDS (cudapoa_generate_consensus.cuh:120-170);
     // skip_cut: edges from nodes whose score was cut to -1 are ignored (branch completion)
+    auto node_step = [&](int32_t node, bool skip_cut, int32_t& best_out, int32_t& score_out) {
+        const uint32_t r0 = (uint32_t)wave_first((int32_t)rec[3 * node + 0]);
+        const uint32_t r1 = (uint32_t)wave_first((int32_t)rec[3 * node + 1]);
+        const uint32_t r2 = (uint32_t)wave_first((int32_t)rec[3 * node + 2]);
+        const int32_t cnt = (int32_t)(r0 >> 24);
+        const int32_t b0 = (int32_t)(r0 & 0xfff), b1 = (int32_t)((r0 >> 12) & 0xfff), b2 = (int32_t)(r1 & 0xfff);
+        const int32_t w0 = (int32_t)(r1 >> 16), w1 = (int32_t)(r2 & 0xffff), w2 = (int32_t)(r2 >> 16);
+        const int32_t s0 = wave_first(scores[b0]), s1 = wave_first(scores[b1]), s2 = wave_first(scores[b2]);
+        int32_t best_w = -1, best = -1, best_score = -1; // scores[-1] == -1
+        auto consider = [&](bool present, int32_t begin, int32_t w, int32_t sc) {
+            const bool take = present && !(skip_cut && sc == -1) && (best_w < w || (best_w == w && best_score <= sc));
+            best_w     = take ? w : best_w;
+            best       = take ? begin : best;
+            best_score = take ? sc : best_score;
+        };
+        consider(cnt > 0, b0, w0, s0);
+        consider(cnt > 1, b1, w1, s1);
+        consider(cnt > 2, b2, w2, s2);
+        for (int32_t e = 3; e < cnt; e++) // rare: more than three in-edges, from the HBM lists
+        {
+            const int32_t begin = wave_first((int32_t)g.incoming_edges[(int64_t)node * kEdges + e]);
+            const int32_t w     = wave_first((int32_t)g.incoming_edge_w[(int64_t)node * kEdges + e]);
+            consider(true, begin, w, wave_first(scores[begin]));
+        }
+        best_out  = best;
+        score_out = best != -1 ? best_w + best_score : best_w;
+    };
+    // one pass over sorted positions [first_pos, node_count), node by node
     auto bundle_pass = [&](int32_t first_pos, bool skip_cut, int32_t max_score) -> int32_t {
         int32_t max_score_id = 0;
         int32_t chunk_base   = first_pos;
@@ -1740,30 +1784,8 @@ __device__ __forceinline__ void generate_consensus_lds(const GraphView<IdT>& g, 
                 chunk      = (chunk_base + lane < node_count) ? (int32_t)g.sorted_poa[chunk_base + lane] : 0;
             }
             const int32_t node = __builtin_amdgcn_readlane(chunk, pos - chunk_base);
-            const uint32_t r0 = (uint32_t)wave_first((int32_t)rec[3 * node + 0]);
-            const uint32_t r1 = (uint32_t)wave_first((int32_t)rec[3 * node + 1]);
-            const uint32_t r2 = (uint32_t)wave_first((int32_t)rec[3 * node + 2]);
-            const int32_t cnt = (int32_t)(r0 >> 24);
-            const int32_t b0 = (int32_t)(r0 & 0xfff), b1 = (int32_t)((r0 >> 12) & 0xfff), b2 = (int32_t)(r1 & 0xfff);
-            const int32_t w0 = (int32_t)(r1 >> 16), w1 = (int32_t)(r2 & 0xffff), w2 = (int32_t)(r2 >> 16);
-            const int32_t s0 = wave_first(scores[b0]), s1 = wave_first(scores[b1]), s2 = wave_first(scores[b2]);
-            int32_t best_w = -1, best = -1, best_score = -1; // scores[-1] == -1
-            auto consider = [&](bool present, int32_t begin, int32_t w, int32_t sc) {
-                const bool take = present && !(skip_cut && sc == -1) && (best_w < w || (best_w == w && best_score <= sc));
-                best_w     = take ? w : best_w;
-                best       = take ? begin : best;
-                best_score = take ? sc : best_score;
-            };
-            consider(cnt > 0, b0, w0, s0);
-            consider(cnt > 1, b1, w1, s1);
-            consider(cnt > 2, b2, w2, s2);
-            for (int32_t e = 3; e < cnt; e++) // rare: more than three in-edges, from the HBM lists
-            {
-                const int32_t begin = wave_first((int32_t)g.incoming_edges[(int64_t)node * kEdges + e]);
-                const int32_t w     = wave_first((int32_t)g.incoming_edge_w[(int64_t)node * kEdges + e]);
-                consider(true, begin, w, wave_first(scores[begin]));
-            }
-            const int32_t score = best != -1 ? best_w + best_score : best_w;
+            int32_t best, score;
+            node_step(node, skip_cut, best, score);
             lane0_store_u16(pred + node, (uint32_t)best);
             lane0_store_u32(scores + node, (uint32_t)score);
             const bool better = max_score <= score;
@@ -1772,8 +1794,87 @@ __device__ __forceinline__ void generate_consensus_lds(const GraphView<IdT>& g, 
         }
         return max_score_id;
     };
+    // The first pass (all positions, nothing cut), 64 positions at a time (round 4). Which in-edge a node takes is decided by the
+    // edge weights; the predecessors' scores only break ties. So every lane decides for its own node, and what is left of the
+    // serial recurrence is score = weight + score of the chosen predecessor for the nodes whose chosen predecessor sits in the
+    // same 64 positions: two v_readlane and a v_writelane each, in position order. A predecessor inside the chunk is recognised
+    // by a marker (-2 - lane) that its lane leaves in the score table before the others look their predecessors up. A node
+    // with a tie that involves such a predecessor, or with more than three in-edges, takes node_step once the scores of the
+    // lanes before it are in LDS. Same decisions, same order of the running maximum (the later position wins a tie).
+    auto bundle_pass_chunked = [&]() -> int32_t {
+        int32_t max_score = -1, max_score_id = 0;
+        int32_t next = lane < node_count ? (int32_t)g.sorted_poa[lane] : 0;
+        for (int32_t base = 0; base < node_count; base += kWave)
+        {
+            const int32_t node = next;
+            const bool valid   = base + lane < node_count;
+            if (base + kWave < node_count) next = (base + kWave + lane < node_count) ? (int32_t)g.sorted_poa[base + kWave + lane] : 0;
+            if (valid) scores[node] = -2 - lane;
+            asm volatile("" ::: "memory"); // one wavefront's LDS operations execute in order
+            const uint32_t r0 = rec[3 * node + 0], r1 = rec[3 * node + 1], r2 = rec[3 * node + 2];
+            const int32_t cnt = (int32_t)(r0 >> 24);
+            const int32_t b0 = (int32_t)(r0 & 0xfff), b1 = (int32_t)((r0 >> 12) & 0xfff), b2 = (int32_t)(r1 & 0xfff);
+            const int32_t w0 = (int32_t)(r1 >> 16), w1 = (int32_t)(r2 & 0xffff), w2 = (int32_t)(r2 >> 16);
+            const int32_t s0 = scores[b0], s1 = scores[b1], s2 = scores[b2];
+            int32_t best_w = -1, best = -1, best_score = -1;
+            bool slow = cnt > 3;
+            auto consider = [&](bool present, int32_t begin, int32_t w, int32_t sc) {
+                slow |= present && best_w == w && (sc <= -2 || best_score <= -2);
+                const bool take = present && (best_w < w || (best_w == w && best_score <= sc));
+                best_w     = take ? w : best_w;
+                best       = take ? begin : best;
+                best_score = take ? sc : best_score;
+            };
+            consider(cnt > 0, b0, w0, s0);
+            consider(cnt > 1, b1, w1, s1);
+            consider(cnt > 2, b2, w2, s2);
+            const bool inside = best_score <= -2; // the chosen predecessor is lane (-2 - best_score) of this chunk
+            int32_t val       = inside ? best_w : (best != -1 ? best_w + best_score : best_w);
+            const int32_t ref = inside ? -2 - best_score : 0;
+            unsigned long long todo = __ballot(valid && (inside || slow));
+            const unsigned long long slow_mask = __ballot(valid && slow);
+            while (todo)
+            {
+                const int32_t j = __ffsll(todo) - 1;
+                todo &= todo - 1;
+                if ((slow_mask >> j) & 1)
+                {
+                    if (valid && lane < j) scores[node] = val; // what the node's in-edges may look up
+                    asm volatile("" ::: "memory");
+                    int32_t bj, sj;
+                    node_step(__builtin_amdgcn_readlane(node, j), false, bj, sj);
+                    val  = lane == j ? sj : val;
+                    best = lane == j ? bj : best;
+                }
+                else
+                {
+                    const int32_t rj = __builtin_amdgcn_readlane(ref, j);
+                    const int32_t v  = __builtin_amdgcn_readlane(val, j) + __builtin_amdgcn_readlane(val, rj);
+                    val              = lane == j ? v : val;
+                }
+            }
+            if (valid)
+            {
+                scores[node] = val;
+                pred[node]   = (int16_t)best;
+            }
+            asm volatile("" ::: "memory");
+            // running maximum: the chunk's largest score replaces an equal one from before; inside the chunk the last wins
+            int32_t m = valid ? val : INT32_MIN;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off, kWave));
+            m = wave_first(m);
+            if (max_score <= m)
+            {
+                const unsigned long long at = __ballot(valid && val == m);
+                max_score                   = m;
+                max_score_id                = __builtin_amdgcn_readlane(node, 63 - __builtin_clzll(at));
+            }
+        }
+        return max_score_id;
+    };
 
-    int32_t max_score_id = bundle_pass(0, false, -1);
+    int32_t max_score_id = node_by_node ? bundle_pass(0, false, -1) : bundle_pass_chunked();
     int32_t loop_count   = 0;
     while (wave_first((int32_t)g.outgoing_edge_count[max_score_id]) != 0 && loop_count < node_count)
     {

@@ -422,7 +422,8 @@ def test_kernel_shortcuts_equal_the_plain_schedule(monkeypatch):
     arm): the incremental Kahn order vs the full re-sort after every read (bit 21, the reference's schedule); rows with
     4..6 predecessors in the LDS-ring kind vs the general routine (bit 30); the row kinds of the forward pass demoted into
     each other -- register rows through the ring (bit 10), moved-band rows through the ring (bit 15), ring rows through the
-    general routine (bit 9), register rows through the general routine (bit 11) -- must give identical consensus, coverage,
+    general routine (bit 9), register rows through the general routine (bit 11) -- and the consensus kernel's first
+    heaviest-bundle pass node by node instead of 64 positions at a time (bit 4) must give identical consensus, coverage,
     status and cell counts on config-3 windows and on windows of varied shape."""
     import random
     from genomeworks_amd import synthetic
@@ -440,7 +441,7 @@ def test_kernel_shortcuts_equal_the_plain_schedule(monkeypatch):
     arms = (("production", None), ("full_resort", str(1 << 21)), ("many_predecessors_general", str(1 << 30)),
             ("plain", str((1 << 21) | (1 << 30))), ("registers_through_ring", str(1 << 10)), ("moved_band_through_ring", str(1 << 15)),
             ("ring_through_general", str(1 << 9)), ("registers_through_general", str(1 << 11)),
-            ("everything_general", str((1 << 9) | (1 << 11) | (1 << 30))))
+            ("everything_general", str((1 << 9) | (1 << 11) | (1 << 30))), ("consensus_node_by_node", str(1 << 4)))
     for name, flag in arms:
         if flag is None:
             monkeypatch.delenv("GWHIP_DEBUG", raising=False)
