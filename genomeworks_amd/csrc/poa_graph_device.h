@@ -1797,12 +1797,13 @@ __device__ __forceinline__ void generate_consensus_lds(const GraphView<IdT>& g, 
     // The first pass (all positions, nothing cut), 64 positions at a time (round 4). Which in-edge a node takes is decided by the
     // edge weights; the predecessors' scores only break ties. So every lane decides for its own node, and what is left of the
     // serial recurrence is score = weight + score of the chosen predecessor for the nodes whose chosen predecessor sits in the
-    // same 64 positions: two v_readlane and a v_writelane each, in position order. A predecessor inside the chunk is recognised
-    // by a marker (-2 - lane) that its lane leaves in the score table before the others look their predecessors up. A node
-    // with a tie that involves such a predecessor, or with more than three in-edges, takes node_step once the scores of the
-    // lanes before it are in LDS. Same decisions, same order of the running maximum (the later position wins a tie).
+    // same 64 positions: sums along chains, taken by pointer jumping (at most six rounds of two ds_bpermute). A predecessor
+    // inside the chunk is recognised by a marker (-2 - lane) that its lane leaves in the score table before the others look
+    // their predecessors up. A node with a tie that involves such a predecessor, or with more than three in-edges, takes
+    // node_step once the scores of the lanes before it are in LDS. Same decisions, same order of the running maximum (the
+    // later position wins a tie).
     auto bundle_pass_chunked = [&]() -> int32_t {
-        int32_t max_score = -1, max_score_id = 0;
+        int32_t lane_max = -2, lane_arg = 0; // every score is >= -1
         int32_t next = lane < node_count ? (int32_t)g.sorted_poa[lane] : 0;
         for (int32_t base = 0; base < node_count; base += kWave)
         {
@@ -1829,28 +1830,47 @@ __device__ __forceinline__ void generate_consensus_lds(const GraphView<IdT>& g, 
             consider(cnt > 1, b1, w1, s1);
             consider(cnt > 2, b2, w2, s2);
             const bool inside = best_score <= -2; // the chosen predecessor is lane (-2 - best_score) of this chunk
-            int32_t val       = inside ? best_w : (best != -1 ? best_w + best_score : best_w);
-            const int32_t ref = inside ? -2 - best_score : 0;
-            unsigned long long todo = __ballot(valid && (inside || slow));
-            const unsigned long long slow_mask = __ballot(valid && slow);
-            while (todo)
+            slow &= valid;
+            // score = weight + score of the chosen predecessor along the chains inside the chunk: pointer jumping. A lane that
+            // waits holds the sum of the weights from its node down to (not including) the node `ref` points at; a lane that
+            // needs node_step stops the chains that run through it (it adds nothing and points at itself) until it is resolved.
+            int32_t val  = slow ? 0 : (inside ? best_w : (best != -1 ? best_w + best_score : best_w));
+            int32_t ref  = (inside && !slow) ? -2 - best_score : lane;
+            bool waiting = valid && (inside || slow);
+            unsigned long long stoppers = __ballot(slow);
+            for (;;)
             {
-                const int32_t j = __ffsll(todo) - 1;
-                todo &= todo - 1;
-                if ((slow_mask >> j) & 1)
+                for (;;)
                 {
-                    if (valid && lane < j) scores[node] = val; // what the node's in-edges may look up
-                    asm volatile("" ::: "memory");
-                    int32_t bj, sj;
-                    node_step(__builtin_amdgcn_readlane(node, j), false, bj, sj);
-                    val  = lane == j ? sj : val;
-                    best = lane == j ? bj : best;
+                    const bool hop = waiting && !((stoppers >> lane) & 1) && !((stoppers >> ref) & 1);
+                    if (__ballot(hop) == 0) break;
+                    const int32_t vr = __shfl(val, ref, kWave);
+                    const int32_t pr = __shfl(ref | (waiting ? 64 : 0), ref, kWave);
+                    if (hop)
+                    {
+                        val += vr;
+                        waiting = (pr & 64) != 0;
+                        ref     = waiting ? (pr & 63) : ref;
+                    }
                 }
-                else
+                if (stoppers == 0) break;
+                // the first node that needs node_step: every lane before it is final
+                const int32_t j = __ffsll(stoppers) - 1;
+                stoppers &= stoppers - 1;
+                if (valid && lane < j) scores[node] = val; // what the node's in-edges may look up
+                asm volatile("" ::: "memory");
+                int32_t bj, sj;
+                node_step(__builtin_amdgcn_readlane(node, j), false, bj, sj);
+                best = lane == j ? bj : best;
+                if (lane == j)
                 {
-                    const int32_t rj = __builtin_amdgcn_readlane(ref, j);
-                    const int32_t v  = __builtin_amdgcn_readlane(val, j) + __builtin_amdgcn_readlane(val, rj);
-                    val              = lane == j ? v : val;
+                    val     = sj;
+                    waiting = false;
+                }
+                else if (waiting && ref == j && !((stoppers >> lane) & 1))
+                {
+                    val += sj;
+                    waiting = false;
                 }
             }
             if (valid)
@@ -1859,18 +1879,21 @@ __device__ __forceinline__ void generate_consensus_lds(const GraphView<IdT>& g, 
                 pred[node]   = (int16_t)best;
             }
             asm volatile("" ::: "memory");
-            // running maximum: the chunk's largest score replaces an equal one from before; inside the chunk the last wins
-            int32_t m = valid ? val : INT32_MIN;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off, kWave));
-            m = wave_first(m);
-            if (max_score <= m)
+            // running maximum per lane (a later position replaces an equal score); reduced over the lanes behind the loop
+            if (valid && lane_max <= val)
             {
-                const unsigned long long at = __ballot(valid && val == m);
-                max_score                   = m;
-                max_score_id                = __builtin_amdgcn_readlane(node, 63 - __builtin_clzll(at));
+                lane_max = val;
+                lane_arg = ((base + lane) << 12) | node;
             }
         }
+        // the largest score; among equal ones the last position (node ids and positions are 12-bit)
+        int32_t m = lane_max;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off, kWave));
+        int32_t arg = lane_max == m ? lane_arg : -1;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) arg = max(arg, __shfl_xor(arg, off, kWave));
+        const int32_t max_score_id = wave_first(arg) & 0xfff;
         return max_score_id;
     };
 
