@@ -154,10 +154,10 @@ int gw_poa_reset(gw_poa_batch* b)
 int gw_poa_get_consensus(gw_poa_batch* b, int32_t* n_out)
 {
     GW_TRY
-    b->consensus.clear();
-    b->coverage.clear();
-    b->status.clear();
-    poa::StatusType r = b->batch->get_consensus(b->consensus, b->coverage, b->status);
+    // the handle owns the results of the last call: their storage is reused (no heap traffic in a steady-state loop)
+    poa::StatusType r = b->impl ? b->impl->get_consensus_in_place(b->consensus, b->coverage, b->status)
+                                : (b->consensus.clear(), b->coverage.clear(), b->status.clear(),
+                                   b->batch->get_consensus(b->consensus, b->coverage, b->status));
     if (n_out) *n_out = static_cast<int32_t>(b->consensus.size());
     return static_cast<int>(r);
     GW_CATCH(-1)

@@ -17,12 +17,14 @@
 #include <atomic>
 #include <climits>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <iomanip>
 #include <stdexcept>
 #include <tuple>
 
 #include "../../include/gwhip.h"
+#include "host_common.hpp"
 #include "poa_batch_impl.hpp"
 
 namespace claraparabricks
@@ -539,59 +541,128 @@ void PoaBatch::log_kernel_error(StatusType error_type, std::vector<StatusType>& 
     output_status.emplace_back(error_type);
 }
 
+namespace
+{
+// dst[0 .. n) = src[n-1 .. 0]: the kernels write consensus and coverage back to front, as the reference's do
+// (cudapoa_generate_consensus.cuh:245-283). Eight bytes / four counters per step through a 64-bit word.
+void reversed_copy_u8(char* dst, const char* src, size_t n)
+{
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8)
+    {
+        uint64_t v;
+        std::memcpy(&v, src + n - i - 8, 8);
+        v = __builtin_bswap64(v);
+        std::memcpy(dst + i, &v, 8);
+    }
+    for (; i < n; i++) dst[i] = src[n - 1 - i];
+}
+void reversed_copy_u16(uint16_t* dst, const uint16_t* src, size_t n)
+{
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4)
+    {
+        uint64_t v;
+        std::memcpy(&v, src + n - i - 4, 8);
+        v = (v >> 48) | ((v >> 16) & 0xffff0000ull) | ((v << 16) & 0xffff00000000ull) | (v << 48);
+        std::memcpy(dst + i, &v, 8);
+    }
+    for (; i < n; i++) dst[i] = src[n - 1 - i];
+}
+} // namespace
+
+// D2H of consensus + coverage, then un-reversal into count = poa_count_ slots (strings / vectors whose storage is reused
+// when they have any); statuses of failed windows are logged in window order.
+void PoaBatch::fetch_consensus(std::string* consensus, std::vector<uint16_t>* coverage, StatusType* output_status)
+{
+    scoped_device_switch dev(device_id_);
+    // D2H of the windows actually in the batch (the reference copies the whole capacity: SURVEY Appendix C.4). The two
+    // arrays are neighbours on both sides with the same spacing: one copy when the unused tail of the first is small.
+    const size_t n        = static_cast<size_t>(poa_count_) * batch_size_.max_consensus_size;
+    const size_t cons_cap = static_cast<size_t>(reinterpret_cast<uint8_t*>(d_coverage_) - d_consensus_);
+    if (n > 0)
+    {
+        if (cons_cap - n <= n / 4 && reinterpret_cast<uint8_t*>(h_coverage_) - h_consensus_ == static_cast<std::ptrdiff_t>(cons_cap))
+            GW_CU_CHECK_ERR(hipMemcpyAsync(h_consensus_, d_consensus_, cons_cap + n * sizeof(uint16_t), hipMemcpyDeviceToHost, stream_));
+        else
+        {
+            GW_CU_CHECK_ERR(hipMemcpyAsync(h_consensus_, d_consensus_, n, hipMemcpyDeviceToHost, stream_));
+            GW_CU_CHECK_ERR(hipMemcpyAsync(h_coverage_, d_coverage_, n * sizeof(uint16_t), hipMemcpyDeviceToHost, stream_));
+        }
+    }
+    GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+    const size_t count = static_cast<size_t>(poa_count_);
+    const size_t row   = static_cast<size_t>(batch_size_.max_consensus_size);
+    // The staging block is pinned memory, which the host reads slowly (measured: 3 GB/s in 8-byte steps from the far end of a
+    // row, 5 GB/s with memcpy): a row goes to a small cached buffer in one forward memcpy and is reversed from there.
+    constexpr size_t kLocalRow = 4096;
+    auto unpack = [&](size_t first, size_t last) {
+        alignas(64) char local_c[kLocalRow];
+        alignas(64) uint16_t local_v[kLocalRow];
+        for (size_t poa = first; poa < last; poa++)
+        {
+            const char* c      = reinterpret_cast<const char*>(&h_consensus_[poa * row]);
+            const uint16_t* cv = &h_coverage_[poa * row];
+            if (static_cast<uint8_t>(c[0]) == kKernelError)
+            {
+                output_status[poa] = static_cast<StatusType>(c[1]); // logged below, in window order
+                consensus[poa].clear();
+                coverage[poa].clear();
+                continue;
+            }
+            output_status[poa] = StatusType::success;
+            size_t len;
+            if (row <= kLocalRow)
+            {
+                std::memcpy(local_c, c, row);
+                len = ::strnlen(local_c, row);
+                std::memcpy(local_v, cv, len * sizeof(uint16_t));
+                c  = local_c;
+                cv = local_v;
+            }
+            else
+                len = ::strnlen(c, row);
+            consensus[poa].resize(len);
+            reversed_copy_u8(&consensus[poa][0], c, len);
+            coverage[poa].resize(len);
+            reversed_copy_u16(coverage[poa].data(), cv, len);
+        }
+    };
+    // the windows are independent: 16 at a time on the library's worker pool
+    constexpr size_t kPerTask = 16;
+    gwhost::parallel_tasks((count + kPerTask - 1) / kPerTask, count >= 256 ? 8 : 1,
+                           [&](size_t t) { unpack(t * kPerTask, std::min(count, (t + 1) * kPerTask)); });
+    for (size_t poa = 0; poa < count; poa++)
+        if (output_status[poa] != StatusType::success)
+        {
+            std::vector<StatusType> sink; // log_kernel_error appends the code; the status slot is already filled
+            log_kernel_error(output_status[poa], sink);
+        }
+}
+
 StatusType PoaBatch::get_consensus(std::vector<std::string>& consensus, std::vector<std::vector<uint16_t>>& coverage,
                                    std::vector<StatusType>& output_status)
 {
     if (!(OutputType::consensus & output_mask_)) return StatusType::output_type_unavailable;
-    scoped_device_switch dev(device_id_);
-    // D2H of the windows actually in the batch (the reference copies the whole capacity: SURVEY Appendix C.4)
-    const size_t n = static_cast<size_t>(poa_count_) * batch_size_.max_consensus_size;
-    if (n > 0)
-    {
-        GW_CU_CHECK_ERR(hipMemcpyAsync(h_consensus_, d_consensus_, n, hipMemcpyDeviceToHost, stream_));
-        GW_CU_CHECK_ERR(hipMemcpyAsync(h_coverage_, d_coverage_, n * sizeof(uint16_t), hipMemcpyDeviceToHost, stream_));
-    }
-    GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
-    // un-reverse into the caller's vectors; the windows are independent, so large batches are split over a few host
-    // threads (the results are appended behind whatever the caller's vectors already hold, as in the reference)
+    // the results are appended behind whatever the caller's vectors already hold, as in the reference (cudapoa_batch.cuh:186-249)
     const size_t base_c = consensus.size(), base_v = coverage.size(), base_s = output_status.size();
     const size_t count  = static_cast<size_t>(poa_count_);
     consensus.resize(base_c + count);
     coverage.resize(base_v + count);
     output_status.resize(base_s + count, StatusType::success);
-    auto unpack = [&](size_t first, size_t last) {
-        for (size_t poa = first; poa < last; poa++)
-        {
-            const char* c = reinterpret_cast<const char*>(&h_consensus_[poa * batch_size_.max_consensus_size]);
-            if (static_cast<uint8_t>(c[0]) == kKernelError)
-            {
-                output_status[base_s + poa] = static_cast<StatusType>(c[1]); // logged below, in window order
-                continue;
-            }
-            std::string& s = consensus[base_c + poa];
-            s.assign(c);
-            std::reverse(s.begin(), s.end());
-            const uint16_t* cv = &h_coverage_[poa * batch_size_.max_consensus_size];
-            coverage[base_v + poa].assign(std::make_reverse_iterator(cv + s.size()), std::make_reverse_iterator(cv));
-        }
-    };
-    const size_t n_threads = count >= 256 ? 4 : 1;
-    if (n_threads == 1)
-        unpack(0, count);
-    else
-    {
-        std::vector<std::thread> workers;
-        const size_t chunk = (count + n_threads - 1) / n_threads;
-        for (size_t t = 1; t < n_threads; t++) workers.emplace_back(unpack, std::min(count, t * chunk), std::min(count, (t + 1) * chunk));
-        unpack(0, std::min(count, chunk));
-        for (std::thread& w : workers) w.join();
-    }
-    for (size_t poa = 0; poa < count; poa++)
-        if (output_status[base_s + poa] != StatusType::success)
-        {
-            std::vector<StatusType> sink; // log_kernel_error appends the code; the status slot is already filled
-            log_kernel_error(output_status[base_s + poa], sink);
-        }
+    fetch_consensus(consensus.data() + base_c, coverage.data() + base_v, output_status.data() + base_s);
+    return StatusType::success;
+}
+
+StatusType PoaBatch::get_consensus_in_place(std::vector<std::string>& consensus, std::vector<std::vector<uint16_t>>& coverage,
+                                            std::vector<StatusType>& output_status)
+{
+    if (!(OutputType::consensus & output_mask_)) return StatusType::output_type_unavailable;
+    const size_t count = static_cast<size_t>(poa_count_);
+    consensus.resize(count); // strings and vectors of an earlier call keep their storage
+    coverage.resize(count);
+    output_status.resize(count);
+    fetch_consensus(consensus.data(), coverage.data(), output_status.data());
     return StatusType::success;
 }
 

@@ -37,6 +37,10 @@ public:
     void reset() override;
 
     // extensions used by the benchmark / tests (not part of the reference interface)
+    /// get_consensus() that overwrites its arguments (resized to the batch's windows) instead of appending to them, so that a
+    /// caller who passes the vectors of its previous call gets the results without a heap allocation per window.
+    StatusType get_consensus_in_place(std::vector<std::string>& consensus, std::vector<std::vector<uint16_t>>& coverage,
+                                      std::vector<StatusType>& output_status);
     int32_t max_poas() const { return max_poas_; }
     uint64_t total_cells();    ///< DP cells computed by the last generate_poa() (device counters)
     void relaunch_resident();  ///< re-run the kernels on the inputs already resident in HBM (no H2D)
@@ -58,6 +62,7 @@ private:
     void launch(void* event_after_graph_build = nullptr, uint64_t* phase_cycles = nullptr);
     gwhip_poa_args kernel_args() const;
     void log_kernel_error(StatusType error_type, std::vector<StatusType>& output_status);
+    void fetch_consensus(std::string* consensus, std::vector<uint16_t>* coverage, StatusType* output_status);
     size_t plan(int32_t n_poas, size_t* offsets) const;
 
     int32_t max_sequences_per_poa_ = 0;

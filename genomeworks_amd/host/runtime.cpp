@@ -13,12 +13,124 @@
 #include "../../include/gw_capi.h"
 #include "host_common.hpp"
 
+#include <atomic>
+#include <condition_variable>
+#include <exception>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "alignment_impl.hpp"
 
 namespace gw = claraparabricks::genomeworks;
+
+// ---- process-wide worker pool (host_common.hpp) --------------------------------------------------------------------
+namespace gwhost
+{
+namespace
+{
+struct WorkerPool
+{
+    std::mutex m;                 // guards the fields below
+    std::condition_variable wake; // workers: a job was posted
+    std::condition_variable idle; // caller: the last worker left the job
+    std::mutex one_caller;        // held for the duration of a job
+    const std::function<void(size_t)>* task = nullptr;
+    size_t n_tasks = 0, wanted = 0, joined = 0, inside = 0;
+    uint64_t job = 0;
+    std::atomic<size_t> next{0};
+    std::exception_ptr error;
+    size_t n_workers = 0;
+
+    void run_tasks(const std::function<void(size_t)>& t, size_t n)
+    {
+        for (;;)
+        {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n) return;
+            try
+            {
+                t(i);
+            }
+            catch (...)
+            {
+                std::lock_guard<std::mutex> lock(m);
+                if (!error) error = std::current_exception();
+            }
+        }
+    }
+    void worker()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lock(m);
+        for (;;)
+        {
+            wake.wait(lock, [&] { return job != seen && joined < wanted; });
+            seen = job;
+            joined++;
+            inside++;
+            const std::function<void(size_t)>* t = task;
+            const size_t n                       = n_tasks;
+            lock.unlock();
+            run_tasks(*t, n);
+            lock.lock();
+            if (--inside == 0) idle.notify_all();
+        }
+    }
+    void ensure_workers(size_t n) // under m
+    {
+        while (n_workers < n)
+        {
+            std::thread([this] { worker(); }).detach(); // parked for the life of the process; never joined (no work at exit)
+            n_workers++;
+        }
+    }
+};
+WorkerPool& pool()
+{
+    static WorkerPool* p = new WorkerPool; // deliberately not destroyed: detached workers may outlive static destructors
+    return *p;
+}
+} // namespace
+
+void parallel_tasks(size_t n_tasks, size_t max_threads, const std::function<void(size_t)>& task)
+{
+    if (n_tasks == 0) return;
+    const size_t hw      = std::max(1u, std::thread::hardware_concurrency());
+    const size_t helpers = std::min(std::min(max_threads, hw), n_tasks) - 1;
+    WorkerPool& p        = pool();
+    std::unique_lock<std::mutex> caller(p.one_caller, std::try_to_lock);
+    if (helpers == 0 || !caller.owns_lock())
+    {
+        for (size_t i = 0; i < n_tasks; i++) task(i);
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lock(p.m);
+        p.ensure_workers(helpers);
+        p.task    = &task;
+        p.n_tasks = n_tasks;
+        p.wanted  = helpers;
+        p.joined  = 0;
+        p.error   = nullptr;
+        p.next.store(0, std::memory_order_relaxed);
+        p.job++;
+    }
+    p.wake.notify_all();
+    p.run_tasks(task, n_tasks);
+    std::exception_ptr err;
+    {
+        // every index has been claimed; wait for the workers that are still inside one, and stop latecomers from joining
+        std::unique_lock<std::mutex> lock(p.m);
+        p.wanted = p.joined;
+        p.idle.wait(lock, [&] { return p.inside == 0; });
+        p.task = nullptr;
+        err    = p.error;
+    }
+    if (err) std::rethrow_exception(err);
+}
+} // namespace gwhost
 
 // ---- pinned host staging cache (alignment_impl.hpp) ----------------------------------------------------------------
 namespace claraparabricks

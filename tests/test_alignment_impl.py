@@ -65,3 +65,17 @@ def test_line_wrapped_output_and_empty_alignment(driver):
     assert impl[13] == "ACG/|| /AC-/TA/||/TA//"
     empty = rows[4]
     assert empty[0] == "AlignmentImpl" and empty[7] == "" and empty[8] == "" and empty[9] == "0"
+
+
+def test_worker_pool_runs_every_task_once(tmp_path):
+    """gwhost::parallel_tasks (the pool behind the un-reversal of get_consensus()): tests/cpp/parallel_tasks_driver.cpp."""
+    from genomeworks_amd import build
+    build.build_host()
+    exe = str(tmp_path / "parallel_tasks_driver")
+    lib = os.path.join(ROOT, "genomeworks_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "genomeworks_amd", "host"), "-o", exe,
+                    os.path.join(ROOT, "tests", "cpp", "parallel_tasks_driver.cpp"), "-L", lib, "-lgenomeworks_amd", "-lgwhip",
+                    "-L", os.path.join(ROCM, "lib"), "-lamdhip64", "-Wl,-rpath," + lib, "-Wl,-rpath," + os.path.join(ROCM, "lib"),
+                    "-pthread"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
