@@ -47,7 +47,7 @@ static_assert(kReadLds + kCodeTileLds >= 3072 * 2, "the incremental topsort keep
 // the band starts of those rows, and a sliding window of the read. 4 blocks per CU still fit (4 x 35 KB).
 constexpr int kBsRingBytes   = 2048; // band starts of the ring rows (64 x 4 B) + 64 staged rows of the HBM row table (64 x 24 B)
 constexpr int kReadWinBytes  = 4096;
-constexpr int kMwLds         = 512;  // arguments, progress and carry words of the multi-wave forward pass (poa_device.h)
+constexpr int kMwLds         = 768;  // arguments (128 B) and hand-over entries of the multi-wave forward pass (poa_device.h)
 constexpr size_t kReservedCuLds = 128 * 1024; // LDS of a multi-wave block (160 KB per CU: nothing else of this kernel family, >= 35 KB per block, fits beside it)
 
 struct KernelArgs

@@ -1259,11 +1259,16 @@ template <typename ScoreT> struct MwArgs
 };
 struct MwShared // in LDS, behind the regions of the single-wave layout
 {
-    int32_t done[kSkWaves];     // per wave: last row finished or skipped
-    int32_t carry[kSkWaves][8]; // per wave: the last cell of its block in row r at [r & 7] (a wave is never more than kSkLead + 1 rows ahead of its reader)
-    unsigned long long prof;    // profiling: the selected counter, summed over the waves
-    int32_t fail;               // a wavefront gave up on a bounded wait (protocol error): the window reports a failure status
+    // per wave and row & 7: {the last cell of the wave's block in row r, r}, written with ONE 8-byte store when the wave has
+    // finished (or skipped) row r -- behind the row's ring stores, one wavefront's LDS operations execute in order. A wave is
+    // never more than kSkLead + 1 rows ahead of its reader, so entry r & 7 says r until the reader is past row r; "wave w has
+    // finished row r" is hand[w][r & 7][1] >= r. (Round 4: a progress word per wave next to the carries cost every row a
+    // second LDS store and every reader a second load.)
+    int32_t hand[kSkWaves][8][2];
+    unsigned long long prof; // profiling: the selected counter, summed over the waves
+    int32_t fail;            // a wavefront gave up on a bounded wait (protocol error): the window reports a failure status
 };
+static_assert(sizeof(MwShared) <= 640, "kMwLds (gwhip_poa.hip) reserves 128 bytes for MwArgs and 640 for MwShared");
 
 __device__ __forceinline__ int32_t lds_poll(const int32_t* p)
 {
@@ -1279,7 +1284,7 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
     // skipped, 3 block barriers (x 1000), 4 cycles in the pass, 5 cycles waiting for the left neighbour, 6 cycles waiting
     // for ring space, 7 rows on the general path, 8 cycles in the row bodies (waits included), 9 polls, 10 cycles waiting
     // for the left neighbour at the start of a row, 11 cycles in the bodies of first-block rows, 12 their number, 13 cycles
-    // in the row-table batches
+    // in the row-table batches, 14 cycles in the block barriers of far rows
     // (PROF = false: the helper wavefronts of a production kernel, whose copy of the arguments comes out of LDS and could
     // not be folded: no counter code in their row loop. Wave 0 passes a compile-time 0 in production kernels.)
     const int32_t sksel = PROF ? (A.dbg >> 12) & 15 : 0;
@@ -1289,16 +1294,20 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
     const int32_t graph_count = A.graph_count, read_length = A.read_length, band_width = A.band_width;
     const int32_t max_column = A.max_column, gap_score = A.gap_score;
     const int32_t min_score  = Limits<ScoreT>::min / 2;
-    const int32_t stride     = band_width + kRightPad;
+    int32_t stride           = band_width + kRightPad;
+    asm volatile("" : "+s"(stride)); // one scalar value: the row pointers advance by it with one add each, not by band_width and the pad
     const int32_t ring_rows  = A.ring_rows;
     const int32_t near_rows  = ring_rows - kSkLead - 1; // a predecessor closer than this is read from the ring
     // explicit global pointers: the arguments come out of an LDS struct, and behind a pointer of unknown address space
     // every access would be a flat instruction, which the row loop must not contain (it waits on both memory counters)
     typedef __attribute__((address_space(1))) ScoreT GScore;
     typedef __attribute__((address_space(1))) uint8_t GByte;
-    GScore* scores           = (GScore*)A.scores;
-    GByte* codes             = (GByte*)A.codes;
-    const GByte* read        = (const GByte*)A.read;
+    // (the helper wavefronts' copy of A comes out of LDS, i.e. out of vector registers: made scalar here, once)
+    GScore* scores           = (GScore*)wave_first64((uint64_t)A.scores);
+    GByte* codes             = (GByte*)wave_first64((uint64_t)A.codes);
+    const GByte* read        = (const GByte*)wave_first64((uint64_t)A.read);
+    // match / mismatch in vector registers for the whole pass: the selects of the row loop take them as they are
+    const int32_t match_v = (int32_t)pin_vgpr((uint32_t)A.match_score), mismatch_v = (int32_t)pin_vgpr((uint32_t)A.mismatch_score);
     const int left = (wave + kSkWaves - 1) % kSkWaves, right = (wave + 1) % kSkWaves;
 
     // ---- this wave's block: per-lane values that only change when the wave moves on to its next block ----
@@ -1374,80 +1383,99 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
     adopt_batch(1);
     load_batch(65, nxt);
 
-    // ---- the neighbours' progress: done[w] = last row wave w has finished or skipped; carry[w][r & 3] = its last cell of row r ----
-    typedef __attribute__((address_space(3))) const volatile int32_t* LdsWord;
-    const LdsWord left_word  = (LdsWord)&shared->done[left];
-    const LdsWord right_word = (LdsWord)&shared->done[right];
-    const LdsWord left_carry_words = (LdsWord)&shared->carry[left][0];
-    const uint32_t my_word   = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&shared->done[wave];
-    const uint32_t my_carry  = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&shared->carry[wave][0];
-    auto publish = [&](int32_t row, int32_t carry) { // behind the row's ring stores: LDS runs one wave's operations in order
-        const uint32_t ca = my_carry + 4u * (uint32_t)(row & 7);
-        asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, -1" ::"v"(ca), "v"(carry), "v"(my_word), "v"(row)
-                     : "memory");
+    // ---- the neighbours' progress (MwShared::hand): entry [w][r & 7] = {wave w's last cell of row r, r} ----
+    const uint32_t left_hand  = lds_addr(&shared->hand[left][0][0]);
+    const uint32_t right_hand = lds_addr(&shared->hand[right][0][0]);
+    const uint32_t my_hand    = lds_addr(&shared->hand[wave][0][0]);
+    auto hand_load = [&](uint32_t base, int32_t row) -> uint2 { // one 8-byte LDS load (volatile: polled)
+        const uint32_t addr = base + 8u * (uint32_t)(row & 7);
+        const uint64_t v    = *reinterpret_cast<const volatile __attribute__((address_space(3))) uint64_t*>(addr);
+        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
     };
-    int32_t left_done = 0, right_done = 0; // cached copies
+    auto hand_wait = [&]() {};
+    auto publish = [&](int32_t row, int32_t carry) { // behind the row's ring stores: LDS runs one wave's operations in order
+        const uint32_t ha = my_hand + 8u * (uint32_t)(row & 7);
+        u32x2 pr;
+        pr.x = (uint32_t)carry;
+        pr.y = (uint32_t)row;
+        asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(ha), "v"(pr) : "memory");
+    };
+    int32_t left_done = 0, right_done = 0; // cached: the neighbour has finished at least this row
     // Waits are bounded: a protocol error must not end as a wavefront spinning forever. After the first timeout a wave
-    // stops waiting altogether and raises MwShared::fail; wave 0 turns that into a failure status of the window (nw_banded
-    // returns kNwPipelineFailed -> StatusType::generic_error): never a silent result.
-    bool gave_up = false;
+    // stops waiting altogether (both cached values jump to the largest row) and raises MwShared::fail; wave 0 turns that into
+    // a failure status of the window (nw_banded returns kNwPipelineFailed -> StatusType::generic_error): never a silent result.
+    auto give_up = [&]() {
+        shared->fail = 1; // (every lane, the same word: no divergent branch next to the cached values, which must stay scalar)
+        left_done  = INT32_MAX;
+        right_done = INT32_MAX;
+    };
     auto wait_left = [&](int32_t row) {
         const uint64_t t_w = sksel == 5 ? clock64() : 0;
         int32_t spins = 0;
-        while (left_done < row && !gave_up)
+        while (left_done < row)
         {
             if (sksel == 9) skacc++;
-            left_done = wave_first(*left_word);
+            const uint2 e = hand_load(left_hand, row);
+            hand_wait();
+            left_done = max(left_done, wave_first((int32_t)e.y));
             if (left_done < row)
             {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) gave_up = true;
+                if (++spins > (1 << 22)) give_up();
             }
         }
-        asm volatile("" ::: "memory");
         if (sksel == 5) skacc += clock64() - t_w;
     };
     auto wait_right = [&](int32_t row) {
         const uint64_t t_w = sksel == 6 ? clock64() : 0;
         int32_t spins = 0;
-        while (right_done < row && !gave_up)
+        while (right_done < row)
         {
             if (sksel == 9) skacc++;
-            right_done = wave_first(*right_word);
+            const uint2 e = hand_load(right_hand, row);
+            hand_wait();
+            right_done = max(right_done, wave_first((int32_t)e.y));
             if (right_done < row)
             {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) gave_up = true;
+                if (++spins > (1 << 22)) give_up();
             }
         }
-        asm volatile("" ::: "memory");
         if (sksel == 6) skacc += clock64() - t_w;
+    };
+    auto left_carry = [&](int32_t row) -> int32_t { // of a row the left neighbour has finished
+        const uint2 e = hand_load(left_hand, row);
+        hand_wait();
+        return wave_first((int32_t)e.x);
     };
 
     // per-row state kept incrementally: the ring slot of row r, its byte offset, the row's HBM score / code rows
     const uint32_t ring_lds = lds_addr(ring);
     const int32_t row_bytes = stride * (int32_t)sizeof(ScoreT);
     const int32_t ring_span = ring_rows * row_bytes;
-    int32_t slot_r      = 1 % ring_rows;
-    uint32_t ring_off_r = (uint32_t)(slot_r * row_bytes);
+    uint32_t ring_off_r = (uint32_t)((1 % ring_rows) * row_bytes);
     GScore* scores_row  = scores + stride;
     GByte* codes_row    = codes ? codes + stride : codes;
     auto next_row = [&]() {
-        slot_r     = slot_r + 1 == ring_rows ? 0 : slot_r + 1;
-        ring_off_r = slot_r == 0 ? 0u : ring_off_r + (uint32_t)row_bytes;
+        ring_off_r = ring_off_r + (uint32_t)row_bytes;
+        ring_off_r = ring_off_r == (uint32_t)ring_span ? 0u : ring_off_r;
         scores_row += stride;
         codes_row += stride;
     };
-    for (int32_t r = 1; r <= graph_count; r++, next_row())
+    // (two loops, the outer one over the 64-row batches of the register row table: the row loop carries no batch test)
+    for (int32_t r0 = 1; r0 <= graph_count; r0 += 64)
     {
-        const int32_t ridx = (r - 1) & 63;
-        if (ridx == 0 && r > 1)
-        {
-            const uint64_t t_b = sksel == 13 ? clock64() : 0;
-            adopt_batch(r);
-            load_batch(r + 64, nxt);
-            if (sksel == 13) skacc += clock64() - t_b;
-        }
+    if (r0 > 1)
+    {
+        const uint64_t t_b = sksel == 13 ? clock64() : 0;
+        adopt_batch(r0);
+        load_batch(r0 + 64, nxt);
+        if (sksel == 13) skacc += clock64() - t_b;
+    }
+    const int32_t r_last = min(r0 + 63, graph_count);
+    for (int32_t r = r0; r <= r_last; r++, next_row())
+    {
+        const int32_t ridx = r - r0;
         const uint32_t m0        = (uint32_t)__builtin_amdgcn_readlane(m0v, ridx);
         const uint32_t m1        = (uint32_t)__builtin_amdgcn_readlane(m1v, ridx);
         const uint32_t kb        = (uint32_t)__builtin_amdgcn_readlane(kbv, ridx);
@@ -1456,8 +1484,9 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
         const uint32_t base      = m0 & 0xffu;
         const int32_t pred_count = (int32_t)((m0 >> 8) & 0x7fu);
         const bool general       = (m0 & 0x8000u) != 0;
+        auto slot_now  = [&]() -> int32_t { return (int32_t)(ring_off_r / (uint32_t)row_bytes); }; // general rows only
         auto slot_back = [&](int32_t d) -> int32_t { // slot of row r - d, d < ring_rows
-            const int32_t sl = slot_r - d;
+            const int32_t sl = slot_now() - d;
             return sl < 0 ? sl + ring_rows : sl;
         };
         // A predecessor that is not safely in the ring comes from the HBM matrix, written by other wavefronts: every wave
@@ -1480,8 +1509,10 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                     far                = far || (r - prow >= near_rows);
                 }
             }
+            const uint64_t t_bar = (far && sksel == 14) ? clock64() : 0;
             if (far) block_barrier();
             if (far && sksel == 3) skacc += 1000;
+            if (far && sksel == 14) skacc += clock64() - t_bar;
         }
 
         if ((int32_t)(kb >> 19) != blk) // the band has passed this wave's block: on to the next one
@@ -1511,14 +1542,12 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
         int32_t rel0_val = min_score;
 
         // match / mismatch costs of the row's base against the lane's four read characters
-        const int32_t cp0 = ((rd4 & 0xff) == base) ? A.match_score : A.mismatch_score;
-        const int32_t cp1 = (((rd4 >> 8) & 0xff) == base) ? A.match_score : A.mismatch_score;
-        const int32_t cp2 = (((rd4 >> 16) & 0xff) == base) ? A.match_score : A.mismatch_score;
-        const int32_t cp3 = ((rd4 >> 24) == base) ? A.match_score : A.mismatch_score;
+        const int32_t cp0 = ((rd4 & 0xff) == base) ? match_v : mismatch_v;
+        const int32_t cp1 = (((rd4 >> 8) & 0xff) == base) ? match_v : mismatch_v;
+        const int32_t cp2 = (((rd4 >> 16) & 0xff) == base) ? match_v : mismatch_v;
+        const int32_t cp3 = ((rd4 >> 24) == base) ? match_v : mismatch_v;
         // the row's finish, shared by both bodies: prefix maximum in u space (u = v - (c + k) * gap, an offset common to the
         // whole row, so the carry is converted with the column it belongs to), the hand-over from the left, H and the stores
-        int32_t probe_carry = 0; // the left neighbour's carry of this row, if an early read has it
-        bool have_carry     = false;
         auto finish_row = [&](int32_t s0, int32_t s1, int32_t s2, int32_t s3, int32_t fe_if_first) {
             int32_t u0 = s0 - cg0, u1 = s1 - cg1, u2 = s2 - cg2, u3 = s3 - cg3;
             if (first_block) // lanes left of the band start carry no cells (lanes right of its end feed nobody)
@@ -1533,8 +1562,8 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                 carry_u = fe_if_first - (bs - 1) * gap_score; // the carry-in is the element of column bs - 1
             else
             {
-                if (left_done < r) wait_left(r); // the probe came too early (or there was none)
-                const int32_t hl = have_carry ? probe_carry : wave_first(left_carry_words[r & 7]);
+                if (left_done < r) wait_left(r);
+                const int32_t hl = left_carry(r);
                 carry_u          = hl - (256 * blk - 1) * gap_score; // the left neighbour's cell of column 256 blk
             }
             const int32_t excl = max(wave_shr1(incl, INT32_MIN), carry_u);
@@ -1588,18 +1617,14 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                     qc = lds_ld_qv<ScoreT>(a2 + esz);
                     vc = (uint32_t)(tg + e2) <= (uint32_t)wlim && c_in_read;
                 }
-                // the left neighbour's progress word and its carry of this row are requested now, looked at after the arithmetic
-                int32_t probe_done = left_done, probe_c = 0;
-                if constexpr (!FIRST)
-                {
-                    if (left_done < r) probe_done = *left_word;
-                    probe_c = left_carry_words[r & 7]; // (behind the progress word: valid if that one says r or more)
-                }
+                // the left neighbour's entry of this row is requested now, looked at after the arithmetic
+                uint2 probe = make_uint2(0u, 0u);
+                if constexpr (!FIRST) probe = hand_load(left_hand, r);
                 // match / mismatch costs of the row's base against the lane's four read characters
-                const int32_t cp0 = ((rd4 & 0xff) == base) ? A.match_score : A.mismatch_score;
-                const int32_t cp1 = (((rd4 >> 8) & 0xff) == base) ? A.match_score : A.mismatch_score;
-                const int32_t cp2 = (((rd4 >> 16) & 0xff) == base) ? A.match_score : A.mismatch_score;
-                const int32_t cp3 = ((rd4 >> 24) == base) ? A.match_score : A.mismatch_score;
+                const int32_t cp0 = ((rd4 & 0xff) == base) ? match_v : mismatch_v;
+                const int32_t cp1 = (((rd4 >> 8) & 0xff) == base) ? match_v : mismatch_v;
+                const int32_t cp2 = (((rd4 >> 16) & 0xff) == base) ? match_v : mismatch_v;
+                const int32_t cp3 = ((rd4 >> 24) == base) ? match_v : mismatch_v;
                 int32_t D[4], V[4], s[4];
                 D[0] = Sa + cp0; D[1] = (int32_t)qa.x + cp1; D[2] = (int32_t)qa.y + cp2; D[3] = (int32_t)qa.z + cp3;
                 V[0] = (int32_t)qa.x + gap_score; V[1] = (int32_t)qa.y + gap_score; V[2] = (int32_t)qa.z + gap_score; V[3] = (int32_t)qa.w + gap_score;
@@ -1680,16 +1705,16 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                 }
                 else
                 {
-                    if (left_done < r) left_done = wave_first(probe_done);
-                    int32_t hl;
-                    if (left_done >= r)
-                        hl = wave_first(probe_c);
-                    else // the probe came too early
+                    hand_wait();
+                    const int32_t probe_row = wave_first((int32_t)probe.y);
+                    int32_t hl              = wave_first((int32_t)probe.x);
+                    if (probe_row < r) // the probe came too early
                     {
-                        wait_left(r);
-                        hl = wave_first(left_carry_words[r & 7]);
+                        if (left_done < r) wait_left(r);
+                        hl = left_carry(r);
                     }
-                    carry_u = hl - blk_carry_gap; // the left neighbour's cell of column 256 blk
+                    left_done = max(left_done, r);
+                    carry_u   = hl - blk_carry_gap; // the left neighbour's cell of column 256 blk
                 }
                 const int32_t excl = max(wave_shr1(incl, INT32_MIN), carry_u);
                 const int32_t Hk[4] = {(int32_t)(ScoreT)(max(m0_, excl) + cg0), (int32_t)(ScoreT)(max(m1_, excl) + cg1),
@@ -1711,12 +1736,21 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
                 {
                     typedef typename QuadVec<ScoreT>::type V4;
                     const V4 out = {(ScoreT)Hk[0], (ScoreT)Hk[1], (ScoreT)Hk[2], (ScoreT)Hk[3]};
-                    // explicit LDS store: the progress word below is ordered behind it by the LDS queue, not by a wait
+                    // explicit LDS store: the hand-over entry below is ordered behind it by the LDS queue, not by a wait
                     *reinterpret_cast<__attribute__((address_space(3))) V4*>(ring_lds + ring_off_r + (uint32_t)(kRelShift + 1) * esz + (uint32_t)tg4) = out;
                     // (streaming store: the matrix is read again only by far predecessors, the sink scan and recomputed steps,
-                    // and 1 TB of it per long-read set should not push the graphs and the trace codes out of the L2)
-                    __builtin_nontemporal_store(out, reinterpret_cast<__attribute__((address_space(1))) V4*>(scores_row + kRelShift + 1 + tg));
-                    if (codes) *reinterpret_cast<__attribute__((address_space(1))) uint32_t*>(codes_row + kRelShift + 1 + tg) = code4;
+                    // and 1 TB of it per long-read set should not push the graphs and the trace codes out of the L2).
+                    // Row base in a scalar register pair + the lane's 32-bit offset (tg >= 0 here): no 64-bit vector address
+                    // arithmetic per row.
+                    if constexpr (sizeof(ScoreT) == 4)
+                        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" ::"v"((uint32_t)tg4), "v"(out), "s"(scores_row),
+                                     "n"((kRelShift + 1) * 4)
+                                     : "memory");
+                    else
+                        __builtin_nontemporal_store(out, reinterpret_cast<__attribute__((address_space(1))) V4*>(scores_row + kRelShift + 1 + tg));
+                    if (codes)
+                        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"((uint32_t)tg), "v"(code4), "s"(codes_row), "n"(kRelShift + 1)
+                                     : "memory");
                 }
                 if constexpr (FIRST)
                 {
@@ -1858,21 +1892,22 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
         {
             const int32_t rel = tg + 1;
             // explicit LDS stores: the progress word below is ordered behind them by the LDS queue, not by a wait
+            const int32_t slot_r = slot_now();
             lds_st_quad<ScoreT>(ring + slot_r * stride + rel + kRelShift, (ScoreT)H0, (ScoreT)H1, (ScoreT)H2, (ScoreT)H3);
             global_st_quad<ScoreT>(scores + (int64_t)r * stride + rel + kRelShift, (ScoreT)H0, (ScoreT)H1, (ScoreT)H2, (ScoreT)H3);
             if (codes) *reinterpret_cast<__attribute__((address_space(1))) uint32_t*>(codes + (int64_t)r * stride + rel + kRelShift) = code4;
         }
         if (first_block && lane == 0)
         {
-            *(__attribute__((address_space(3))) ScoreT*)(ring + slot_r * stride + kRelShift) = (ScoreT)rel0_val;
+            *(__attribute__((address_space(3))) ScoreT*)(ring + slot_now() * stride + kRelShift) = (ScoreT)rel0_val;
             scores[(int64_t)r * stride + kRelShift]                                          = (ScoreT)rel0_val;
         }
         publish(r, __builtin_amdgcn_readlane(H3, kWave - 1));
         if (sksel == 8 || (sksel == 11 && first_block)) skacc += clock64() - t_rb;
     }
+    }
     if (sksel == 4) skacc += clock64() - t_pass;
     if (sksel && lane == 0) __hip_atomic_fetch_add(&shared->prof, (unsigned long long)skacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (gave_up && lane == 0) shared->fail = 1;
     block_barrier(); // the score and code matrices are complete in HBM (wave 0's traceback reads them)
     if (sksel && prof_out && lane == 0) *prof_out += shared->prof;
 }
@@ -2057,8 +2092,8 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             A.gap_score = gap_score; A.mismatch_score = mismatch_score; A.match_score = match_score;
             A.ring_rows = sk_rows; A.read = read; A.scores = scores; A.codes = codes; A.dbg = dbg;
             if (lane == 0) *mw_args = A;
-            if (lane < kSkWaves) mw_shared->done[lane] = 0;
-            if (lane < kSkWaves * 8) (&mw_shared->carry[0][0])[lane] = 0;
+            (&mw_shared->hand[0][0][0])[lane]      = 0; // kSkWaves x 8 entries of two words: row 0 is "finished" everywhere
+            (&mw_shared->hand[0][0][0])[lane + 64] = 0;
             if (lane == 0) { mw_shared->prof = 0; mw_shared->fail = 0; }
             block_barrier(); // the helper wavefronts wait here for their arguments
             generic_forward_skew<ScoreT, IdT, RowT>(A, g, rowinfo, b.ring, mw_shared, 0, lane, pc.acc ? &pc.acc[kPhOther] : nullptr);
