@@ -1265,10 +1265,19 @@ struct MwShared // in LDS, behind the regions of the single-wave layout
     // finished row r" is hand[w][r & 7][1] >= r. (Round 4: a progress word per wave next to the carries cost every row a
     // second LDS store and every reader a second load.)
     int32_t hand[kSkWaves][8][2];
+    // per wave: the last row it SKIPPED (the band does not touch its block there). Skipped rows leave the entries alone: a wave
+    // that works row r and then runs through skipped rows r + 1 .. r + 8 -- nothing holds it back there -- would otherwise
+    // overwrite row r's entry while its right neighbour may still be rows behind (found by the protocol model in
+    // tests/test_long_read_handover_model.py, never seen on the GPU). "Wave w has finished row r" is therefore
+    // max(hand[w][r & 7][1], skipped[w]) >= r; a carry is only ever asked of a row its wave worked on.
+    int32_t skipped[kSkWaves];
     unsigned long long prof; // profiling: the selected counter, summed over the waves
     int32_t fail;            // a wavefront gave up on a bounded wait (protocol error): the window reports a failure status
 };
 static_assert(sizeof(MwShared) <= 640, "kMwLds (gwhip_poa.hip) reserves 128 bytes for MwArgs and 640 for MwShared");
+// Entry r & 7 is rewritten by row r + 8, which its wave finishes only after the reader has finished row r + 8 - kSkLead - 1
+// (the ring-space rule): that must not be before row r (modelled in tests/test_long_read_handover_model.py).
+static_assert(kSkLead + 1 <= 8, "a hand-over entry must survive until its reader is past the row");
 
 __device__ __forceinline__ int32_t lds_poll(const int32_t* p)
 {
@@ -1409,15 +1418,22 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
         left_done  = INT32_MAX;
         right_done = INT32_MAX;
     };
+    typedef __attribute__((address_space(3))) const volatile int32_t* LdsWord;
+    const LdsWord left_skipped  = (LdsWord)&shared->skipped[left];
+    const LdsWord right_skipped = (LdsWord)&shared->skipped[right];
+    const uint32_t my_skipped   = lds_addr(&shared->skipped[wave]);
+    auto publish_skip = [&](int32_t row) {
+        asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(my_skipped), "v"(row) : "memory");
+    };
     auto wait_left = [&](int32_t row) {
         const uint64_t t_w = sksel == 5 ? clock64() : 0;
         int32_t spins = 0;
         while (left_done < row)
         {
             if (sksel == 9) skacc++;
-            const uint2 e = hand_load(left_hand, row);
-            hand_wait();
-            left_done = max(left_done, wave_first((int32_t)e.y));
+            const uint2 e    = hand_load(left_hand, row);
+            const int32_t sk = *left_skipped;
+            left_done        = max(left_done, max(wave_first((int32_t)e.y), wave_first(sk)));
             if (left_done < row)
             {
                 __builtin_amdgcn_s_sleep(1);
@@ -1432,9 +1448,9 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
         while (right_done < row)
         {
             if (sksel == 9) skacc++;
-            const uint2 e = hand_load(right_hand, row);
-            hand_wait();
-            right_done = max(right_done, wave_first((int32_t)e.y));
+            const uint2 e    = hand_load(right_hand, row);
+            const int32_t sk = *right_skipped;
+            right_done       = max(right_done, max(wave_first((int32_t)e.y), wave_first(sk)));
             if (right_done < row)
             {
                 __builtin_amdgcn_s_sleep(1);
@@ -1520,9 +1536,9 @@ __device__ __forceinline__ void generic_forward_skew(const MwArgs<ScoreT>& A, co
             blk = (int32_t)(kb >> 19);
             enter_block(blk);
         }
-        if (kind == 7) // the band has not reached this block yet
+        if (kind == 7) // the band has not reached this block yet, or has passed it
         {
-            publish(r, 0);
+            publish_skip(r); // (not an entry of MwShared::hand: see there)
             if (sksel == 2) skacc++;
             continue;
         }
@@ -2094,6 +2110,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
             if (lane == 0) *mw_args = A;
             (&mw_shared->hand[0][0][0])[lane]      = 0; // kSkWaves x 8 entries of two words: row 0 is "finished" everywhere
             (&mw_shared->hand[0][0][0])[lane + 64] = 0;
+            if (lane < kSkWaves) mw_shared->skipped[lane] = 0;
             if (lane == 0) { mw_shared->prof = 0; mw_shared->fail = 0; }
             block_barrier(); // the helper wavefronts wait here for their arguments
             generic_forward_skew<ScoreT, IdT, RowT>(A, g, rowinfo, b.ring, mw_shared, 0, lane, pc.acc ? &pc.acc[kPhOther] : nullptr);
