@@ -158,6 +158,12 @@ int gw_poa_get_consensus(gw_poa_batch* b, int32_t* n_out)
     poa::StatusType r = b->impl ? b->impl->get_consensus_in_place(b->consensus, b->coverage, b->status)
                                 : (b->consensus.clear(), b->coverage.clear(), b->status.clear(),
                                    b->batch->get_consensus(b->consensus, b->coverage, b->status));
+    if (r != poa::StatusType::success) // nothing was fetched: the handle must not keep showing the previous call's results
+    {
+        b->consensus.clear();
+        b->coverage.clear();
+        b->status.clear();
+    }
     if (n_out) *n_out = static_cast<int32_t>(b->consensus.size());
     return static_cast<int>(r);
     GW_CATCH(-1)
