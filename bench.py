@@ -443,12 +443,14 @@ def bench_default_aligner(local_rank, sync, cpu_all_cores=None):
     100 000 bases; :69-143 BM_SingleBatchAlignment: 1024 pairs x 2048 bases) and on 2 000 pairs x 1 kbp. Timed region as
     there: align_all() + sync_alignments() with the pairs queued. Rank 0 only."""
     from genomeworks_amd import cudaaligner, synthetic
-    shapes = [(1, 100), (1, 1000), (1, 10000), (1, 100000), (1024, 2048), (2000, 1000)]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_io as G  # the checker: committed oracle goldens of every shape (tests/golden/make_default_aligner_goldens.py)
+    gold = G.default_aligner_goldens()
+    shapes = G.aligner_gen.SHAPES
     rows = []
     cpu = cpu_all_cores
     for n, size in shapes:
-        pairs = synthetic.generate_pairs(1, n, size, size // 30, size // 30, size // 30)
-        pairs = [(q, t[:size]) for q, t in pairs]
+        pairs = G.aligner_gen.shape_pairs(n, size)
         al = cudaaligner.CudaAlignerBatch(size, size, n, max_device_memory_allocator_caching_size=32 << 30, device_id=local_rank)
         best = None
         for _ in range(3):
@@ -460,17 +462,24 @@ def bench_default_aligner(local_rank, sync, cpu_all_cores=None):
             assert al.sync() == n
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
+            # every pair's state sequence of the LAST timed run against the oracle's (outside the clock)
+            res = al.get_alignments()
             k_ms = min(al.relaunch_timed() for _ in range(3))   # the kernels alone, HIP events on the aligner's stream
             al.reset()
         del al
+        g = gold["%dx%d" % (n, size)]
+        sha = G.aligner_gen.digest(G.aligner_gen.pair_record(r.status, r.alignment) for r in res)
         cells = sum(len(q) * len(t) for q, t in pairs)
         rows.append({"pairs": n, "length": size, "ms": round(best * 1e3, 3), "pairs_per_s": round(n / best, 1),
-                     "full_matrix_gcups": round(cells / best / 1e9, 2), "kernel_ms": round(k_ms, 3)})
+                     "full_matrix_gcups": round(cells / best / 1e9, 2), "kernel_ms": round(k_ms, 3),
+                     "states_sha256": sha, "equals_oracle_golden": bool(sha == g["states_sha256"])})
+        del res
     head = rows[-1]
     achieved = 2000 * 1000 * 1000 * BYTES_PER_MYERS_CELL / (head["kernel_ms"] * 1e-3) / 1e9
     out = {"workload": "default aligner (Hirschberg + Myers bit vectors, one wavefront per pair, the tree grown level by level for queries of up to 2 048 bases): reference benchmark shapes",
            "metric": "pairs/s, align_all() + sync_alignments(), 2 000 pairs x 1 kbp (about 10 % divergence)",
            "value": head["pairs_per_s"], "unit": "pairs/s", "ms": head["ms"], "shapes": rows,
+           "all_equal_oracle_golden": all(r["equals_oracle_golden"] for r in rows),
            "kernel_only": {"pairs_per_s": round(2000 / (head["kernel_ms"] * 1e-3), 1), "ms": head["kernel_ms"]},
            "roofline": {"bound": "hbm", "kernel": "hirschberg_levels_kernel (+ hirschberg_wave_kernel for what it leaves)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": sub_traffic("default_aligner"), "algorithmic_bytes_per_cell": BYTES_PER_MYERS_CELL,
@@ -537,6 +546,9 @@ def bench_reference_shapes(windows, local_rank, sync, steps):
     (cudapoa/benchmarks/single_batch.hpp:52-54,86-93); BM_MultiBatchTest -- 1, 2, 4, 8 concurrent batches on host
     threads sharing one device (multi_batch.hpp:41-61,72-177), here through process_windows_multi_device."""
     from genomeworks_amd import cudapoa
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_io as G  # the checker: the full-band golden (tests/golden/make_full_band_goldens.py) and the config-3 golden
+    fgold, fsum = G.full_band_goldens(), G.full_band_summary()
     b = cudapoa.CudaPoaBatch(200, 1024, 16 << 30, output_type="consensus", band_mode="full_band", device_id=local_rank,
                              max_nodes_per_graph=3072, matrix_sequence_dimension=1024)
     for w in windows:
@@ -553,10 +565,19 @@ def bench_reference_shapes(windows, local_rank, sync, steps):
     sync()
     dt = (time.perf_counter() - t0) / steps
     k_ms, _o = b.relaunch_timed()
+    cons, cov, status = b.get_consensus()  # of the last launch
     del b
+    fp = G.band_mode_fingerprints(cons, cov, status)
     single = {"shape": "BM_SingleBatchTest: %d windows, BatchConfig(1024, 200) full band, consensus" % len(windows),
               "ms": round(dt * 1e3, 2), "gcups": round(cells / dt / 1e9, 2), "windows_per_s": round(len(windows) / dt, 1),
-              "cells": cells, "kernel_ms": round(k_ms, 2)}
+              "cells": cells, "kernel_ms": round(k_ms, 2),
+              "roofline": {"bound": "hbm", "kernel": "poa_window_kernel<int16,int16,full_band>", "achieved": round(cells * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9, 2),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(cells * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                           "algorithmic_bytes_per_cell": BYTES_PER_CELL, "kernel_ms": round(k_ms, 3)},
+              "windows_equal_oracle_golden": int((fp == fgold["fingerprint"]).sum()) if len(windows) == fsum["windows"] else None,
+              "equals_oracle_golden": bool(len(windows) == fsum["windows"] and G.band_gen.cell_digest(fp) == fsum["fingerprint_sha256"]
+                                           and cells == fsum["cells"])}
+    golden3 = config3_golden_digest()
     multi = []
     twice = windows + windows
     for nb in (1, 2, 4, 8):
@@ -566,7 +587,9 @@ def bench_reference_shapes(windows, local_rank, sync, steps):
                                                    max_nodes_per_graph=3072)
         dt = out["seconds"]
         assert all(s == 0 for s in out["status"])
-        multi.append({"batches": nb, "ms": round(dt * 1e3, 1), "windows_per_s": round(len(twice) / dt, 1), "launches": out["launches"]})
+        halves = [consensus_digest(out["consensus"][k * len(windows):(k + 1) * len(windows)]) for k in range(2)]
+        multi.append({"batches": nb, "ms": round(dt * 1e3, 1), "windows_per_s": round(len(twice) / dt, 1), "launches": out["launches"],
+                      "equals_oracle_golden": bool(len(windows) == WINDOWS and golden3 is not None and all(h == golden3 for h in halves))})
     return {"single_batch_full_band": single,
             "multi_batch": {"shape": "BM_MultiBatchTest pattern: %d windows (the 1024 config-3 windows twice), static band 256, "
                                      "N batches on host threads sharing the device, about 260 windows per batch fill; "

@@ -73,3 +73,30 @@ def band_mode_goldens():
 def band_mode_fingerprints(consensus, coverage, status):
     """The golden's per-window fingerprint from a batch's get_consensus() output."""
     return np.array([band_gen.fingerprint(int(status[i]), consensus[i], coverage[i]) for i in range(len(status))], np.uint64)
+
+
+# ---- the 17th cell: full band, BatchConfig(1024, 200) (tests/golden/make_full_band_goldens.py) ----
+_fspec = importlib.util.spec_from_file_location("make_full_band_goldens", os.path.join(GOLDEN, "make_full_band_goldens.py"))
+full_gen = importlib.util.module_from_spec(_fspec)
+_fspec.loader.exec_module(full_gen)
+
+
+def full_band_summary():
+    with open(os.path.join(GOLDEN, "full_band_goldens.json")) as f:
+        return json.load(f)
+
+
+def full_band_goldens():
+    """-> dict(fingerprint[window] uint64, cells[window], status[window])"""
+    return dict(np.load(os.path.join(GOLDEN, "full_band_goldens.npz")))
+
+
+# ---- default aligner on the benchmark shapes (tests/golden/make_default_aligner_goldens.py) ----
+_aspec = importlib.util.spec_from_file_location("make_default_aligner_goldens", os.path.join(GOLDEN, "make_default_aligner_goldens.py"))
+aligner_gen = importlib.util.module_from_spec(_aspec)
+_aspec.loader.exec_module(aligner_gen)
+
+
+def default_aligner_goldens():
+    with open(os.path.join(GOLDEN, "default_aligner_goldens.json")) as f:
+        return json.load(f)

@@ -125,3 +125,29 @@ def test_band_mode_table_file_matches_summary_and_oracle_sample():
     assert s["cells"]["static_band/256"]["cells"] == G.summary()["config3"]["cells"]
     for w in (0, 511, 1023):
         assert G.band_gen.fingerprint(rows[w]["status"], rows[w]["consensus"], rows[w]["coverage"]) == int(g["fingerprint"][mi, wi, w])
+
+
+def test_full_band_file_matches_summary_and_oracle_sample():
+    """tests/golden/full_band_goldens.{npz,json}: BatchConfig(1024, 200) = full band on the 1024 metric windows."""
+    from genomeworks_amd import synthetic
+    s, g = G.full_band_summary(), G.full_band_goldens()
+    assert s["windows"] == 1024 and g["fingerprint"].shape == (1024,)
+    assert int(g["cells"].sum()) == s["cells"] and G.band_gen.cell_digest(g["fingerprint"]) == s["fingerprint_sha256"]
+    assert s["oracle_int16_overflow_events"] == 0 and int((g["status"] == 0).sum()) == 1024
+    with O.Workspace(G.full_gen.full_band_cfg()) as ws:
+        for w in (5, 700):
+            ref = ws.process([r.decode() for r in synthetic.generate_window(s["first_seed"] + w)])
+            assert ref["status"] == int(g["status"][w]) and ref["cells"] == int(g["cells"][w])
+            assert G.band_gen.fingerprint(ref["status"], ref.get("consensus", ""), ref.get("coverage", [])) == int(g["fingerprint"][w])
+
+
+def test_default_aligner_golden_file_matches_oracle_sample():
+    """tests/golden/default_aligner_goldens.json: the oracle still reproduces the short single-pair shapes and the first pairs
+    of the batch shapes (the 100 kbp pair takes the oracle 30 s and is left to the generator)."""
+    gold = G.default_aligner_goldens()
+    assert sorted(gold) == sorted("%dx%d" % s for s in G.aligner_gen.SHAPES)
+    for n, size in [(1, 100), (1, 1000), (1, 10000)]:
+        (q, t), = G.aligner_gen.shape_pairs(n, size)
+        ref = A.hirschberg(q, t, size)
+        assert G.aligner_gen.digest([G.aligner_gen.pair_record(ref["status"], ref["states"])]) == gold["%dx%d" % (n, size)]["states_sha256"]
+        assert ref["edit_distance"] == gold["%dx%d" % (n, size)]["edit_distance_sum"]

@@ -257,8 +257,29 @@ def test_default_aligner_span_path_equals_the_depth_first_kernel(monkeypatch):
         for k, (a, b) in enumerate(zip(out["span"], out["depth_first"])):
             assert a == b, (max_len, k)
         for (st, states), (q, t) in zip(out["span"], pairs):
-            if max_len <= 6400:
-                assert states == A.hirschberg(q, t, max_len)["states"]
+            assert states == A.hirschberg(q, t, max_len)["states"]
+
+
+def test_default_aligner_benchmark_shapes_equal_the_golden():
+    """Every shape bench.py publishes for the default aligner (the reference's BM_SingleAlignment pairs of 100 .. 100 000
+    bases, BM_SingleBatchAlignment 1024 x 2048 bases, cudaaligner/benchmarks/main.cpp:39-143, and 2 000 x 1 kbp) against the
+    committed oracle goldens (tests/golden/make_default_aligner_goldens.py: sha256 over every pair's status and state sequence;
+    edit-distance sums) -- the 10 kbp and 100 kbp single pairs run through the span path."""
+    import golden_io as G
+    from genomeworks_amd import cudaaligner
+    gold = G.default_aligner_goldens()
+    for n, size in G.aligner_gen.SHAPES:
+        pairs = G.aligner_gen.shape_pairs(n, size)
+        al = cudaaligner.CudaAlignerBatch(size, size, n, max_device_memory_allocator_caching_size=16 << 30)
+        for q, t in pairs:
+            assert al.add_alignment(q, t) == 0
+        al.align_all()
+        res = al.get_alignments()
+        g = gold["%dx%d" % (n, size)]
+        assert len(res) == n and all(r.status == 0 for r in res)
+        assert sum(sum(1 for x in r.alignment if x != 0) for r in res) == g["edit_distance_sum"], (n, size)
+        assert sum(len(r.alignment) for r in res) == g["states_total"], (n, size)
+        assert G.aligner_gen.digest(G.aligner_gen.pair_record(r.status, r.alignment) for r in res) == g["states_sha256"], (n, size)
 
 
 def test_default_aligner_level_by_level_kernel_agrees(monkeypatch):

@@ -677,3 +677,28 @@ def test_spoa_accurate_topological_order_bit_exact(band_mode, monkeypatch):
                 else:
                     assert mstatus[i] == 0 and msa[i] == ref["msa"]
     assert len(pcons) == len(cons)  # the default order still runs in the same process (the flag is read per batch)
+
+
+def test_full_band_benchmark_shape_equals_the_golden():
+    """The 17th cell of the band-mode table: the reference benchmarks' own BatchConfig(1024, 200) = FULL band
+    (cudapoa/benchmarks/single_batch.hpp:52, multi_batch.hpp:49; kernel cudapoa_nw.cuh:149-454) on ALL 1024 metric windows
+    against the committed oracle golden (tests/golden/make_full_band_goldens.py): status, consensus and coverage of every
+    window, the batch's cell count, and a relaunch on the dirty buffers."""
+    import golden_io as G
+    from genomeworks_amd import cudapoa
+    s, g = G.full_band_summary(), G.full_band_goldens()
+    windows = config3(s["windows"], s["first_seed"])
+    b = cudapoa.CudaPoaBatch(200, 1024, 16 << 30, output_type="consensus", band_mode="full_band", max_nodes_per_graph=3072,
+                             matrix_sequence_dimension=1024)
+    for w in windows:
+        st, _ = b.add_poa_group(w)
+        assert st == 0
+    for launch in range(2):
+        b.generate_poa() if launch == 0 else b.relaunch()
+        cons, cov, status = b.get_consensus()
+        fp = G.band_mode_fingerprints(cons, cov, status)
+        bad = np.nonzero(fp != g["fingerprint"])[0]
+        assert len(bad) == 0, (launch, bad[:10])
+        assert [int(x) for x in status] == [int(x) for x in g["status"]]
+        assert b.total_cells() == s["cells"]
+        assert G.band_gen.cell_digest(fp) == s["fingerprint_sha256"]
