@@ -138,7 +138,13 @@ def pmc_profile():
     global _PMC_PROFILE
     if _PMC_PROFILE is None:
         try:
-            _PMC_PROFILE = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_profile.json")))
+            _PMC_PROFILE = {}
+            for name in ("r05_pmc_profile.json", "r04_pmc_profile.json"):
+                path = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(path):
+                    _PMC_PROFILE = json.load(open(path))
+                    _PMC_PROFILE["file"] = "profiles/" + name
+                    break
         except (OSError, ValueError):
             _PMC_PROFILE = {}
     return _PMC_PROFILE
@@ -171,7 +177,8 @@ def roofline_issue(key):
            "cycles_per_instruction": e["issue"]["cycles_per_instruction"],
            "lone_wave_cycles_per_instruction": e["issue"]["lone_wave_cycles_per_instruction"],
            "frac": e["issue"]["frac_of_lone_wave_issue_bound"], "wait_share": e.get("wait_share"),
-           "source": "profiles/r04_pmc_profile.json (commit %s, tag %s)" % (p.get("commit"), p.get("tag"))}
+           "lone_wave_cycles_per_instruction_source": "constant from a round-3 microbenchmark (profiles/r03_microbench_instruction_size.json)",
+           "source": "%s (commit %s, tag %s)" % (p.get("file"), p.get("commit"), p.get("tag"))}
     if "lds" in e:
         out["lds_bank_conflict_share_of_lds_active"] = e["lds"]["bank_conflict_share_of_lds_active"]
         out["lds_bank_conflict_share_of_wave_cycles"] = e["lds"].get("bank_conflict_share_of_wave_cycles")
@@ -481,7 +488,7 @@ def bench_default_aligner(local_rank, sync, cpu_all_cores=None):
            "value": head["pairs_per_s"], "unit": "pairs/s", "ms": head["ms"], "shapes": rows,
            "all_equal_oracle_golden": all(r["equals_oracle_golden"] for r in rows),
            "kernel_only": {"pairs_per_s": round(2000 / (head["kernel_ms"] * 1e-3), 1), "ms": head["kernel_ms"]},
-           "roofline": {"bound": "hbm", "kernel": "hirschberg_levels_kernel (+ hirschberg_wave_kernel for what it leaves)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "roofline": {"bound": "hbm", "kernel": "hirschberg_levels_kernel (+ hirschberg_wave_kernel for what it leaves; the 10 kbp / 100 kbp single pairs: hb_span_rows_mw / split / parts / join kernels)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": sub_traffic("default_aligner"), "algorithmic_bytes_per_cell": BYTES_PER_MYERS_CELL,
                         "note": "|q| x |t| cells of the full matrix at the bit-vector cost of 12 B per 32-cell word column; the divide "
                                 "and conquer computes every cell about twice and keeps its state in registers and LDS, so HBM "
@@ -702,6 +709,19 @@ def main():
     (ok_all,) = reduce_scalars(dist, torch, [ok_here], "MIN")
     equals_golden = (ok_all == 1.0) if checkable else None
 
+    # ---- extension, reported next to the metric and never as the metric: the same step with the library's
+    # get_consensus_in_place (results into the storage of the previous call; cudapoa::Batch has no such entry point) ----
+    batch.generate_poa()
+    batch.get_consensus_native(in_place=True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.generate_poa()
+        batch.get_consensus_native(in_place=True)
+    sync()
+    in_place = time.perf_counter() - t0
+    (in_place,) = reduce_scalars(dist, torch, [in_place], "MAX")
+
     # ---- the same kernels on inputs resident in HBM (no H2D) ----
     batch.relaunch()
     batch.get_consensus_native()
@@ -813,8 +833,10 @@ def main():
             "dtype": "int16", "data": "synthetic",
             "equals_oracle_golden": equals_golden, "consensus_sha256": my_digest,
             "windows_per_s": round(world * args.windows * args.steps / elapsed, 1),
-            "timed_region": "generate_poa() [H2D from pinned host + graph-build kernel + consensus kernel] + get_consensus() "
-                            "[D2H + host un-reversal], steady state on one Batch (cudapoa/benchmarks/single_batch.hpp:86-93)",
+            "timed_region": "generate_poa() [H2D from pinned host + graph-build kernel + consensus kernel] + the PUBLIC "
+                            "Batch::get_consensus() into three fresh vectors per step [D2H + host un-reversal; the previous step's "
+                            "results destroyed], steady state on one Batch: the body of SingleBatch::process_consensus(), "
+                            "cudapoa/benchmarks/single_batch.hpp:86-93",
             "config": {"workload": "BASELINE configs[2]: cudapoa single-batch consensus, %d windows x 32 reads, "
                                    "backbone 960 bp, <=48 sub/24 ins/24 del, BatchConfig(1024,32,256,static_band), "
                                    "scores 8/-6/-8" % args.windows,
@@ -830,8 +852,18 @@ def main():
                             "ms_per_step": round(resident / args.steps * 1e3, 3),
                             "gcups": round(total_cells * args.steps / resident / 1e9, 3),
                             "windows_per_s": round(world * args.windows * args.steps / resident, 1)},
+            "extension_get_consensus_in_place": {
+                "what": "the same step with gw_poa_get_consensus_in_place (result storage of the previous call reused; not part of "
+                        "cudapoa::Batch, not the metric)",
+                "ms_per_step": round(in_place / args.steps * 1e3, 3),
+                "gcups": round(total_cells * args.steps / in_place / 1e9, 3)},
             "cold_first_pass_ms": round(t_cold * 1e3, 3),
         }
+        if world > 1:
+            out["scaling_note"] = ("weak scaling by construction: every rank runs the same 1024-window batch (one window is one "
+                                   "chain of 31 dependent alignments, and a launch lasts as long as its slowest window, so one "
+                                   "1024-window batch does not split: see strong_scaling); the comparable strong-scaling record "
+                                   "is strong_scaling_8x (8 x 1024 windows index-split over the ranks)")
         if cpu is not None:  # timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu
         if strong is not None:

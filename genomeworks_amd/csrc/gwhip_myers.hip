@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstdlib>
 #include <string>
@@ -2083,6 +2084,28 @@ __device__ __forceinline__ int32_t hb_wave_run(const HbWaveIn& in, int8_t* path,
     return ok ? len : -1;
 }
 
+// Span path (defined below the depth-first kernel): sizes of its workspace behind the wave region, and whether it is there. A
+// caller that sized the workspace with gwhip_hirschberg_myers_workspace_bytes (same n, same max_query_length) always has it;
+// with a smaller workspace the span kernels do nothing and the depth-first kernel keeps the pair.
+static_assert(kSpanMaxPairs <= 64, "the span path's region geometry reads one pair per lane of one wavefront (region 0)");
+__host__ __device__ inline int32_t hb_span_levels(int32_t max_query)
+{
+    int32_t L = 0;
+    while (((int64_t)kSpanPartQuery << L) < (int64_t)max_query) ++L;
+    return L;
+}
+__host__ __device__ inline int64_t hb_span_words(int32_t qw, int32_t t, int32_t max_query)
+{
+    const int32_t L = hb_span_levels(max_query);
+    if (L == 0) return 0;
+    const int64_t P = (int64_t)1 << L, rows = (int64_t)t + P + 1;
+    return 8 * P + P + 2 * rows + 6 * rows + ((int64_t)32 * qw + t + 64 + 3) / 4 + 16;
+}
+__device__ __forceinline__ bool hb_span_fits(const HirschbergArgs& a, int32_t qw_max, int32_t t_max, int64_t max_elems)
+{
+    return a.wave_offsets[0] + 64 * hb_lane_words(qw_max, t_max, max_elems) + (int64_t)a.n * hb_span_words(qw_max, t_max, a.max_query_length) <=
+           a.ws_capacity_words;
+}
 __global__ __launch_bounds__(64) void hirschberg_wave_kernel(HirschbergArgs a)
 {
     extern __shared__ uint32_t hw_lds[];
@@ -2113,7 +2136,8 @@ __global__ __launch_bounds__(64) void hirschberg_wave_kernel(HirschbergArgs a)
     int8_t* path              = a.results + a.starts[2 * idx];
     // pairs the level-by-level kernel has already aligned (it ran first on this stream) are not touched again
     if (a.levels_first && lv_eligible(query_size, target_size, a.max_query_length) && a.result_lengths[idx] != kLvFlagRedo) return;
-    if (a.span_levels > 0 && query_size > kSpanPartQuery) return; // the span path (below) aligns this pair
+    // the span path (below) aligns this pair -- unless its workspace is not there, in which case it stays here
+    if (a.span_levels > 0 && query_size > kSpanPartQuery && hb_span_fits(a, qw_max, t_max, max_elems)) return;
     const int64_t region      = a.wave_offsets[region_index];
     const int64_t per_pair    = hb_lane_words(qw_max, t_max, max_elems);
     if (region + 64 * per_pair > a.ws_capacity_words)
@@ -2167,19 +2191,6 @@ __global__ __launch_bounds__(64) void hirschberg_wave_kernel(HirschbergArgs a)
 // lengths, the rows / leaf matrices of all parts side by side (part j of a level owns [tb_j + j, te_j + j]: parts tile the
 // target), and a staging buffer for the pieces (part j owns [qb_j + tb_j, qe_j + te_j)).
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ inline int32_t hb_span_levels(int32_t max_query)
-{
-    int32_t L = 0;
-    while (((int64_t)kSpanPartQuery << L) < (int64_t)max_query) ++L;
-    return L;
-}
-__host__ __device__ inline int64_t hb_span_words(int32_t qw, int32_t t, int32_t max_query)
-{
-    const int32_t L = hb_span_levels(max_query);
-    if (L == 0) return 0;
-    const int64_t P = (int64_t)1 << L, rows = (int64_t)t + P + 1;
-    return 8 * P + P + 2 * rows + 6 * rows + ((int64_t)32 * qw + t + 64 + 3) / 4 + 16;
-}
 struct SpanGeom
 {
     LvPart* parts[2];
@@ -2237,11 +2248,6 @@ __device__ __forceinline__ void hb_span_pair_tables(const HirschbergArgs& a, int
 __device__ __forceinline__ bool hb_span_pair(const HirschbergArgs& a, int32_t idx)
 {
     return a.span_levels > 0 && (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]) > kSpanPartQuery;
-}
-__device__ __forceinline__ bool hb_span_fits(const HirschbergArgs& a, int32_t qw_max, int32_t t_max, int64_t max_elems)
-{
-    return a.wave_offsets[0] + 64 * hb_lane_words(qw_max, t_max, max_elems) + (int64_t)a.n * hb_span_words(qw_max, t_max, a.max_query_length) <=
-           a.ws_capacity_words;
 }
 // a part that is split at the next level: long enough, and both sides non-empty (an empty side is a terminal: a run of gaps)
 __device__ __forceinline__ bool hb_span_splits(const LvPart& p) { return p.qe - p.qb > kSpanPartQuery && p.te > p.tb; }
@@ -2531,11 +2537,7 @@ __global__ __launch_bounds__(256) void hb_span_join_kernel(HirschbergArgs a)
     hb_region_geometry(a, lane, qw_max, t_max);
     if (!hb_span_pair(a, idx)) return;
     const int64_t max_elems = (int64_t)ceil_div(max(a.max_query_length, 1), kWord) * (kHbSwitchToMyers + 1);
-    if (!hb_span_fits(a, qw_max, t_max, max_elems))
-    {
-        if (threadIdx.x == 0) a.result_lengths[idx] = 0;
-        return;
-    }
+    if (!hb_span_fits(a, qw_max, t_max, max_elems)) return; // the depth-first kernel aligned the pair
     const SpanGeom g        = hb_span_geom(a, idx, qw_max, t_max, max_elems);
     const LvPart* parts     = g.parts[g.levels & 1];
     int8_t* path            = a.results + a.starts[2 * idx];
@@ -3440,16 +3442,16 @@ int gwhip_hirschberg_myers(const gwhip_hirschberg_args* args, gwhip_stream_t str
     const size_t wave_lds     = (size_t)(4 * kHbStackEntries + 6 * 64 * part_chunks + 3 * kHwLeafElems) * sizeof(uint32_t);
     // LDS a block may ask for on this device (queried once per device: 160 KB on gfx950) minus a margin for the kernels' static
     // LDS; a launch that would not fit falls through to the kernels below instead of failing
-    static int lds_limit_of_device[64] = {};
+    static std::atomic<int> lds_limit_of_device[64]; // zero-initialised; filled by whichever host thread asks first (same value)
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && lds_limit_of_device[dev] == 0)
+    if (dev >= 0 && dev < 64 && lds_limit_of_device[dev].load(std::memory_order_relaxed) == 0)
     {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 64 * 1024;
-        lds_limit_of_device[dev] = v;
+        lds_limit_of_device[dev].store(v, std::memory_order_relaxed);
     }
-    const size_t lds_limit    = (size_t)((dev >= 0 && dev < 64) ? lds_limit_of_device[dev] : 64 * 1024) - 10 * 1024;
+    const size_t lds_limit    = (size_t)((dev >= 0 && dev < 64) ? lds_limit_of_device[dev].load(std::memory_order_relaxed) : 64 * 1024) - 10 * 1024;
     bool use_wave             = n <= 262144 && wave_lds <= lds_limit;
     {
         const char* hw = std::getenv("GWHIP_HIRSCHBERG_WAVE");

@@ -218,9 +218,11 @@ class CudaAlignerBatch:
             states = np.zeros(max(ns, 1), np.int8)
             self._L.gw_alignment_states(self._h, i, states.ctypes.data, ns)
             q, t = self._pairs[i] if i < len(self._pairs) else ("", "")
-            out.append(CudaAlignment(q, t, cigar, cigar_x, self._L.gw_alignment_status(self._h, i),
-                                     bool(self._L.gw_alignment_is_optimal(self._h, i)),
-                                     self._L.gw_alignment_edit_distance(self._h, i), [int(x) for x in states[:ns]]))
+            st, opt, ed = (self._L.gw_alignment_status(self._h, i), self._L.gw_alignment_is_optimal(self._h, i),
+                           self._L.gw_alignment_edit_distance(self._h, i))
+            if ns < 0 or st < 0 or opt < 0 or ed < 0:  # the C ABI reports a bad index / a thrown accessor as -1 + error string
+                raise RuntimeError("alignment %d: %s" % (i, self._L.gw_last_error().decode()))
+            out.append(CudaAlignment(q, t, cigar, cigar_x, st, bool(opt), ed, [int(x) for x in states[:ns]]))
         return out
 
     def reset(self):

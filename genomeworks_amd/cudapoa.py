@@ -58,6 +58,7 @@ def _bind(L):
                  "gw_poa_relaunch"):
         getattr(L, name).argtypes = [vp]
     L.gw_poa_get_consensus.argtypes = [vp, C.POINTER(i32)]
+    L.gw_poa_get_consensus_in_place.argtypes = [vp, C.POINTER(i32)]
     L.gw_poa_consensus_str.restype = C.POINTER(C.c_char)
     L.gw_poa_consensus_str.argtypes = [vp, i32, C.POINTER(i32)]
     L.gw_poa_consensus_coverage.restype = C.POINTER(C.c_uint16)
@@ -206,10 +207,12 @@ class CudaPoaBatch:
         names = ("row_table", "nw_forward", "sink_traceback", "graph_merge", "topsort", "other")
         return [dict(zip(names, [int(out[6 * w + k]) for k in range(6)])) for w in range(got)]
 
-    def get_consensus_native(self):
-        """D2H + host unpack inside the library, without marshalling the strings to Python. Returns window count."""
+    def get_consensus_native(self, in_place=False):
+        """Batch::get_consensus inside the library -- fresh result vectors through the public call, as the reference's
+        benchmark does (single_batch.hpp:86-93) -- without marshalling the strings to Python. in_place=True: the library's
+        extension that reuses the previous call's storage. Returns window count."""
         n = C.c_int32(0)
-        err = self._L.gw_poa_get_consensus(self._h, C.byref(n))
+        err = (self._L.gw_poa_get_consensus_in_place if in_place else self._L.gw_poa_get_consensus)(self._h, C.byref(n))
         if err != 0:
             raise RuntimeError("get_consensus failed: %d" % err)
         return n.value

@@ -151,22 +151,75 @@ int gw_poa_reset(gw_poa_batch* b)
     GW_CATCH(-1)
 }
 
+// What a source-compatible caller of cudapoa::Batch does (cudapoa/benchmarks/single_batch.hpp:86-93): three fresh vectors,
+// the public virtual get_consensus(), and the previous call's results destroyed. The handle keeps the new vectors for the
+// accessors below. On any failure (status or exception) the handle shows no results at all.
 int gw_poa_get_consensus(gw_poa_batch* b, int32_t* n_out)
 {
-    GW_TRY
-    // the handle owns the results of the last call: their storage is reused (no heap traffic in a steady-state loop)
-    poa::StatusType r = b->impl ? b->impl->get_consensus_in_place(b->consensus, b->coverage, b->status)
-                                : (b->consensus.clear(), b->coverage.clear(), b->status.clear(),
-                                   b->batch->get_consensus(b->consensus, b->coverage, b->status));
-    if (r != poa::StatusType::success) // nothing was fetched: the handle must not keep showing the previous call's results
+    if (n_out) *n_out = 0;
+    try
     {
-        b->consensus.clear();
-        b->coverage.clear();
-        b->status.clear();
+        std::vector<std::string> consensus;
+        std::vector<std::vector<uint16_t>> coverage;
+        std::vector<poa::StatusType> status;
+        poa::StatusType r = b->batch->get_consensus(consensus, coverage, status);
+        if (r != poa::StatusType::success)
+        {
+            consensus.clear();
+            coverage.clear();
+            status.clear();
+        }
+        b->consensus = std::move(consensus); // the old vectors die here, as the benchmark's do at the end of its scope
+        b->coverage  = std::move(coverage);
+        b->status    = std::move(status);
+        if (n_out) *n_out = static_cast<int32_t>(b->consensus.size());
+        return static_cast<int>(r);
     }
-    if (n_out) *n_out = static_cast<int32_t>(b->consensus.size());
-    return static_cast<int>(r);
-    GW_CATCH(-1)
+    catch (const std::exception& e)
+    {
+        gwhost::set_last_error(e.what());
+    }
+    catch (...)
+    {
+        gwhost::set_last_error("unknown exception");
+    }
+    b->consensus.clear();
+    b->coverage.clear();
+    b->status.clear();
+    return -1;
+}
+
+// EXTENSION (not part of cudapoa::Batch): the same fetch into the strings and vectors of the handle's previous call, whose
+// storage is reused -- no heap traffic in a steady-state loop. bench.py reports it next to the metric, never as the metric.
+int gw_poa_get_consensus_in_place(gw_poa_batch* b, int32_t* n_out)
+{
+    if (n_out) *n_out = 0;
+    try
+    {
+        poa::StatusType r = b->impl ? b->impl->get_consensus_in_place(b->consensus, b->coverage, b->status)
+                                    : (b->consensus.clear(), b->coverage.clear(), b->status.clear(),
+                                       b->batch->get_consensus(b->consensus, b->coverage, b->status));
+        if (r != poa::StatusType::success) // nothing was fetched: the handle must not keep showing the previous call's results
+        {
+            b->consensus.clear();
+            b->coverage.clear();
+            b->status.clear();
+        }
+        if (n_out) *n_out = static_cast<int32_t>(b->consensus.size());
+        return static_cast<int>(r);
+    }
+    catch (const std::exception& e)
+    {
+        gwhost::set_last_error(e.what());
+    }
+    catch (...)
+    {
+        gwhost::set_last_error("unknown exception");
+    }
+    b->consensus.clear(); // a throwing fetch leaves the vectors resized and partly overwritten: show nothing
+    b->coverage.clear();
+    b->status.clear();
+    return -1;
 }
 
 // Accessors of the last get_*() call: an index outside it sets the error string and returns null / -1 (no exception

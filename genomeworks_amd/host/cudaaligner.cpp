@@ -233,6 +233,10 @@ StatusType BandedAligner::align_all()
     const size_t o_cells = take(static_cast<size_t>(n) * 8);
     // a previous align_all() without a sync in between may still be uploading from / computing on what this replaces
     if (uploads_in_flight_) GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+    // from here until launch() the object describes NO finished run: if an allocation below throws, a later
+    // sync_alignments() must not read the previous run's offsets against the fresh, never-written result block
+    launched_ = false;
+    n_head_   = 0;
     free_device();
     device_block_bytes_ = off;
     device_block_       = allocator_.allocate(device_block_bytes_, {stream_});

@@ -573,7 +573,7 @@ void reversed_copy_u16(uint16_t* dst, const uint16_t* src, size_t n)
 
 // D2H of consensus + coverage, then un-reversal into count = poa_count_ slots (strings / vectors whose storage is reused
 // when they have any); statuses of failed windows are logged in window order.
-void PoaBatch::fetch_consensus(std::string* consensus, std::vector<uint16_t>* coverage, StatusType* output_status)
+void PoaBatch::fetch_consensus(std::string* consensus, std::vector<uint16_t>* coverage, StatusType* output_status, bool presize)
 {
     scoped_device_switch dev(device_id_);
     // D2H of the windows actually in the batch (the reference copies the whole capacity: SURVEY Appendix C.4). The two
@@ -590,9 +590,24 @@ void PoaBatch::fetch_consensus(std::string* consensus, std::vector<uint16_t>* co
             GW_CU_CHECK_ERR(hipMemcpyAsync(h_coverage_, d_coverage_, n * sizeof(uint16_t), hipMemcpyDeviceToHost, stream_));
         }
     }
-    GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
     const size_t count = static_cast<size_t>(poa_count_);
     const size_t row   = static_cast<size_t>(batch_size_.max_consensus_size);
+    if (presize)
+    {
+        // Fresh (empty) strings and vectors of the caller: their heap blocks are requested NOW, while the kernels and the
+        // copies above are still in flight and this thread would only wait -- a consensus is about as long as the window's
+        // longest read (an estimate: the resize below corrects it either way).
+        for (size_t poa = 0; poa < count; poa++)
+        {
+            const gwhip_window_details& wd = h_windows_[poa];
+            int32_t longest = 0;
+            for (int32_t k = 0; k < static_cast<int32_t>(wd.num_seqs); k++) longest = std::max(longest, h_seq_lens_[wd.seq_len_buffer_offset + k]);
+            const size_t hint = std::min(row, static_cast<size_t>(longest) + static_cast<size_t>(longest) / 16 + 16);
+            consensus[poa].reserve(hint);
+            coverage[poa].reserve(hint);
+        }
+    }
+    GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
     // The staging block is pinned memory, which the host reads slowly (measured: 3 GB/s in 8-byte steps from the far end of a
     // row, 5 GB/s with memcpy): a row goes to a small cached buffer in one forward memcpy and is reversed from there.
     constexpr size_t kLocalRow = 4096;
@@ -650,7 +665,7 @@ StatusType PoaBatch::get_consensus(std::vector<std::string>& consensus, std::vec
     consensus.resize(base_c + count);
     coverage.resize(base_v + count);
     output_status.resize(base_s + count, StatusType::success);
-    fetch_consensus(consensus.data() + base_c, coverage.data() + base_v, output_status.data() + base_s);
+    fetch_consensus(consensus.data() + base_c, coverage.data() + base_v, output_status.data() + base_s, true);
     return StatusType::success;
 }
 
@@ -662,7 +677,7 @@ StatusType PoaBatch::get_consensus_in_place(std::vector<std::string>& consensus,
     consensus.resize(count); // strings and vectors of an earlier call keep their storage
     coverage.resize(count);
     output_status.resize(count);
-    fetch_consensus(consensus.data(), coverage.data(), output_status.data());
+    fetch_consensus(consensus.data(), coverage.data(), output_status.data(), false);
     return StatusType::success;
 }
 
@@ -699,18 +714,13 @@ StatusType PoaBatch::get_msa(std::vector<std::vector<std::string>>& msa, std::ve
                 rows.emplace_back(reinterpret_cast<const char*>(&h_msa_[(poa * max_sequences_per_poa_ + static_cast<size_t>(i)) * row]));
         }
     };
+    // long-read MSAs are hundreds of megabytes of rows: the windows go over the library's worker pool in chunks (joined and
+    // exception-safe: a bad_alloc in one chunk is rethrown here once every chunk has finished)
     const size_t bytes     = count * static_cast<size_t>(max_sequences_per_poa_) * row;
     const size_t n_threads = bytes >= (size_t(8) << 20) ? std::min<size_t>(8, std::max<size_t>(1, count)) : 1;
-    if (n_threads == 1)
-        unpack(0, count);
-    else
-    {
-        std::vector<std::thread> workers;
-        const size_t chunk = (count + n_threads - 1) / n_threads;
-        for (size_t t = 1; t < n_threads; t++) workers.emplace_back(unpack, std::min(count, t * chunk), std::min(count, (t + 1) * chunk));
-        unpack(0, std::min(count, chunk));
-        for (std::thread& w : workers) w.join();
-    }
+    const size_t per_task  = std::max<size_t>(1, (count + 4 * n_threads - 1) / (4 * n_threads));
+    gwhost::parallel_tasks((count + per_task - 1) / per_task, n_threads,
+                           [&](size_t t) { unpack(t * per_task, std::min(count, (t + 1) * per_task)); });
     for (size_t poa = 0; poa < count; poa++)
         if (output_status[base_s + poa] != StatusType::success)
         {

@@ -395,10 +395,14 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
     std::mutex start_mutex;
     std::chrono::steady_clock::time_point compute_begin{}, fill_begin{};
     std::atomic<int32_t> created{0}, create_arrived{0};
+    std::atomic<bool> spawn_failed{false}; // a worker thread could not be started: the barriers below must not wait for it
     std::vector<std::exception_ptr> errors(classes);
     std::vector<std::thread> threads;
     JoinAll join_on_exit{threads};
     const auto t_begin = std::chrono::steady_clock::now();
+    threads.reserve(classes);
+    try
+    {
     for (size_t k = 0; k < classes; ++k)
     {
         if (plan.groups[k].empty()) continue;
@@ -412,7 +416,7 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                     std::lock_guard<std::mutex> g(start_mutex);
                     compute_begin = std::chrono::steady_clock::now();
                 }
-                while (filled.load() < static_cast<int32_t>(active_classes)) std::this_thread::yield();
+                while (filled.load() < static_cast<int32_t>(active_classes) && !spawn_failed.load()) std::this_thread::yield();
             };
             bool counted_created = false;
             auto arrive_created  = [&](bool ok) { // this worker's Batch exists (or its creation failed): barrier before any filling
@@ -424,7 +428,7 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                     std::lock_guard<std::mutex> g(start_mutex);
                     fill_begin = std::chrono::steady_clock::now();
                 }
-                while (create_arrived.load() < static_cast<int32_t>(active_classes)) std::this_thread::yield();
+                while (create_arrived.load() < static_cast<int32_t>(active_classes) && !spawn_failed.load()) std::this_thread::yield();
             };
             try
             {
@@ -486,7 +490,7 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                         arrive();
                         if (first_launch) // submission order of the classes' first launches
                         {
-                            while (launch_turn.load() < launch_rank[k]) std::this_thread::yield();
+                            while (launch_turn.load() < launch_rank[k] && !spawn_failed.load()) std::this_thread::yield();
                             // (the gate's event was recorded before its class passed the turn on)
                             if (gate_on[k] >= 0) GW_CU_CHECK_ERR(hipStreamWaitEvent(stream, class_done[static_cast<size_t>(gate_on[k])], 0));
                         }
@@ -553,11 +557,19 @@ void process_windows_size_classes(MultiDeviceOutput& out, const std::vector<std:
                 arrive_created(false); // releases the creation barrier on the error path too
                 arrive();
                 // a class that failed before its first launch still passes the turn on
-                while (launch_turn.load() < launch_rank[k]) std::this_thread::yield();
+                while (launch_turn.load() < launch_rank[k] && !spawn_failed.load()) std::this_thread::yield();
                 int32_t mine_turn = launch_rank[k];
                 launch_turn.compare_exchange_strong(mine_turn, launch_rank[k] + 1);
             }
         });
+    }
+    }
+    catch (...)
+    {
+        // std::thread could not start a worker (std::system_error): the started ones must not spin at the barriers for it;
+        // JoinAll joins them on the way out and the error surfaces
+        spawn_failed.store(true);
+        throw;
     }
     for (std::thread& t : threads) t.join();
     const auto t_end = std::chrono::steady_clock::now();

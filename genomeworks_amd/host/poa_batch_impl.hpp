@@ -62,7 +62,7 @@ private:
     void launch(void* event_after_graph_build = nullptr, uint64_t* phase_cycles = nullptr);
     gwhip_poa_args kernel_args() const;
     void log_kernel_error(StatusType error_type, std::vector<StatusType>& output_status);
-    void fetch_consensus(std::string* consensus, std::vector<uint16_t>* coverage, StatusType* output_status);
+    void fetch_consensus(std::string* consensus, std::vector<uint16_t>* coverage, StatusType* output_status, bool presize);
     size_t plan(int32_t n_poas, size_t* offsets) const;
 
     int32_t max_sequences_per_poa_ = 0;

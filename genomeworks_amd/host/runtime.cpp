@@ -30,6 +30,7 @@ namespace gwhost
 {
 namespace
 {
+thread_local bool inside_pool_job = false; // this thread is running tasks of a parallel_tasks call (caller or worker)
 struct WorkerPool
 {
     std::mutex m;                 // guards the fields below
@@ -73,7 +74,9 @@ struct WorkerPool
             const std::function<void(size_t)>* t = task;
             const size_t n                       = n_tasks;
             lock.unlock();
+            inside_pool_job = true;
             run_tasks(*t, n);
+            inside_pool_job = false;
             lock.lock();
             if (--inside == 0) idle.notify_all();
         }
@@ -98,14 +101,46 @@ void parallel_tasks(size_t n_tasks, size_t max_threads, const std::function<void
 {
     if (n_tasks == 0) return;
     const size_t hw      = std::max(1u, std::thread::hardware_concurrency());
-    const size_t helpers = std::min(std::min(max_threads, hw), n_tasks) - 1;
-    WorkerPool& p        = pool();
-    std::unique_lock<std::mutex> caller(p.one_caller, std::try_to_lock);
-    if (helpers == 0 || !caller.owns_lock())
+    const size_t helpers = std::min(std::min(std::max<size_t>(max_threads, 1), hw), n_tasks) - 1;
+    // a task that calls parallel_tasks itself (on the caller's thread or on a pool worker) runs its tasks serially: the pool
+    // is busy with the outer call, and try_lock on a mutex this thread already holds would be undefined behaviour
+    struct InsideFlag
     {
-        for (size_t i = 0; i < n_tasks; i++) task(i);
+        bool& f;
+        bool prev;
+        explicit InsideFlag(bool& flag) : f(flag), prev(flag) { f = true; }
+        ~InsideFlag() { f = prev; }
+    };
+    auto serial = [&]() {
+        // same contract as the pooled path: every task runs, the first exception is rethrown afterwards
+        InsideFlag in(inside_pool_job);
+        std::exception_ptr first;
+        for (size_t i = 0; i < n_tasks; i++)
+        {
+            try
+            {
+                task(i);
+            }
+            catch (...)
+            {
+                if (!first) first = std::current_exception();
+            }
+        }
+        if (first) std::rethrow_exception(first);
+    };
+    if (helpers == 0 || inside_pool_job)
+    {
+        serial();
         return;
     }
+    WorkerPool& p = pool();
+    std::unique_lock<std::mutex> caller(p.one_caller, std::try_to_lock);
+    if (!caller.owns_lock())
+    {
+        serial();
+        return;
+    }
+    InsideFlag in(inside_pool_job);
     {
         std::lock_guard<std::mutex> lock(p.m);
         p.ensure_workers(helpers);

@@ -89,9 +89,14 @@ int32_t gw_poa_batch_id(gw_poa_batch* b);
 int gw_poa_reset(gw_poa_batch* b);
 int32_t gw_poa_max_poas(gw_poa_batch* b);
 
-/* Batch::get_consensus: runs the D2H copy + un-reversal; results stay owned by the handle.
-   Returns the StatusType of the call (output_type_unavailable = 9), -1 on exception. */
+/* Batch::get_consensus (cudapoa/include/.../batch.hpp:83-86) the way the reference's benchmark calls it
+   (cudapoa/benchmarks/single_batch.hpp:86-93): three fresh vectors through the public virtual call; the handle then owns
+   them (the previous call's are destroyed). Returns the StatusType of the call (output_type_unavailable = 9), -1 on
+   exception; on any failure the handle holds no results. */
 int gw_poa_get_consensus(gw_poa_batch* b, int32_t* n_out);
+/* EXTENSION, no counterpart in cudapoa::Batch: fetch into the storage of the handle's previous results (no heap traffic in
+   a steady-state loop). Same return convention. */
+int gw_poa_get_consensus_in_place(gw_poa_batch* b, int32_t* n_out);
 const char* gw_poa_consensus_str(gw_poa_batch* b, int32_t poa, int32_t* length);
 const uint16_t* gw_poa_consensus_coverage(gw_poa_batch* b, int32_t poa, int32_t* length);
 int32_t gw_poa_output_status(gw_poa_batch* b, int32_t poa);

@@ -59,6 +59,30 @@ int main()
         gwhost::parallel_tasks(64, 8, [&](size_t) { again++; });
         if (again != 64) return fail("pool unusable after an exception");
     }
+    // the serial paths keep the same contract: one thread (no helpers), max_threads == 0 (clamped to 1, must not spawn
+    // without bound), and a call nested inside a task (on the caller's thread and on a pool worker)
+    for (size_t threads : {size_t(0), size_t(1)})
+    {
+        std::atomic<int> ran{0};
+        bool caught = false;
+        try
+        {
+            gwhost::parallel_tasks(100, threads, [&](size_t i) {
+                ran++;
+                if (i == 3) throw std::runtime_error("task 3");
+            });
+        }
+        catch (const std::runtime_error&)
+        {
+            caught = true;
+        }
+        if (!caught || ran != 100) return fail("serial path: caught " + std::to_string(caught) + ", ran " + std::to_string(ran));
+    }
+    {
+        std::atomic<int> inner{0};
+        gwhost::parallel_tasks(16, 8, [&](size_t) { gwhost::parallel_tasks(10, 8, [&](size_t) { inner++; }); });
+        if (inner != 160) return fail("nested calls: " + std::to_string(inner));
+    }
     std::printf("ok\n");
     return 0;
 }

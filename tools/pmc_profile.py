@@ -18,7 +18,9 @@ tag = sys.argv[2] if len(sys.argv) > 2 else "session"
 out_dir = sys.argv[3] if len(sys.argv) > 3 else "."
 commit = sys.argv[4] if len(sys.argv) > 4 else os.environ.get("GW_COMMIT", "unknown")
 
-LONE_WAVE_CYCLES_PER_INST = 4.1  # profiles/r03_microbench_instruction_size.json
+# a CONSTANT, not a counter: the issue rate of a lone wavefront measured once by a microbenchmark in the production launch geometry
+# (profiles/r03_microbench_instruction_size.json: 4.1-4.2 cycles per 4-byte instruction); every record says so
+LONE_WAVE_CYCLES_PER_INST = 4.1
 
 
 def entry(match, what="mean", note=None):
@@ -58,6 +60,7 @@ def entry(match, what="mean", note=None):
             e["issue"] = {"instructions_per_wave": round(per_wave, 1), "cycles_per_wave": round(wc * 4 / waves, 1),
                           "cycles_per_instruction": round(wc * 4 / waves / per_wave, 2),
                           "lone_wave_cycles_per_instruction": LONE_WAVE_CYCLES_PER_INST,
+                          "lone_wave_cycles_per_instruction_source": "constant from the round-3 microbenchmark profiles/r03_microbench_instruction_size.json, not measured in this session",
                           "frac_of_lone_wave_issue_bound": round(per_wave * LONE_WAVE_CYCLES_PER_INST / (wc * 4 / waves), 4)}
     bc, ia = tot("SQ_LDS_BANK_CONFLICT"), tot("SQ_LDS_IDX_ACTIVE")
     if bc is not None and ia:
@@ -76,8 +79,9 @@ out = {"tag": tag, "commit": commit,
 for key, e in (("headline", entry(lambda k: "poa_window_kernel<short, short, signed char, 1, false, tru" in k)),
                ("configs[1]", entry(lambda k: "myers_banded_group_kernel" in k)),
                ("configs[4]", entry(lambda k: "myers_banded_kernel<true>" in k)),
-               ("default_aligner", entry(lambda k: "hirschberg_levels_kernel" in k or "hirschberg_wave_kernel" in k or "hirschberg_span" in k, "mean",
-                                         "all Hirschberg kernels of the sub-record's shapes (1 .. 2000 pairs), mean over their launches")),
+               ("default_aligner", entry(lambda k: "hirschberg_levels_kernel" in k or "hirschberg_wave_kernel" in k or "hb_span_" in k, "sum",
+                                         "all Hirschberg kernels of the sub-record's shapes (1 .. 2000 pairs; the hb_span_* kernels are the long "
+                                         "single pairs' span path), summed over their launches")),
                ("configs[3]", entry(lambda k: "poa_window_kernel<" in k and "2, true, false" in k, "sum",
                                     "sum over the launches of the set's size classes"))):
     if e:
