@@ -17,7 +17,7 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
 KERNEL_SRCS = ["csrc/gwhip_poa.hip", "csrc/gwhip_poa_part0.hip", "csrc/gwhip_poa_part1.hip", "csrc/gwhip_poa_part2.hip",
-               "csrc/gwhip_poa_part3.hip", "csrc/gwhip_poa_part4.hip", "csrc/gwhip_poa_part5.hip", "csrc/gwhip_poa_part6.hip", "csrc/gwhip_poa_hooks.hip", "csrc/gwhip_myers.hip", "csrc/gwhip_ukkonen.hip"]
+               "csrc/gwhip_poa_part3.hip", "csrc/gwhip_poa_part4.hip", "csrc/gwhip_poa_part5.hip", "csrc/gwhip_poa_part6.hip", "csrc/gwhip_poa_part7.hip", "csrc/gwhip_poa_hooks.hip", "csrc/gwhip_myers.hip", "csrc/gwhip_ukkonen.hip"]
 HOST_SRCS = ["host/capi.cpp", "host/cudapoa_batch.cpp", "host/cudapoa_utils.cpp", "host/cudaaligner.cpp", "host/aligner_global.cpp", "host/device_pool.cpp",
              "host/alignment_impl.cpp", "host/runtime.cpp", "host/logging.cpp", "host/overlap_alignment.cpp", "host/multi_device.cpp"]
 

@@ -16,10 +16,10 @@
 namespace gwhip
 {
 
-// This file is compiled eight times: as it stands (everything but the graph-build kernel's instantiations) and, through
-// gwhip_poa_part{0..6}.hip, with GWHIP_POA_PART defined -- parts 0..3 once per (score type, id type) pair, parts 4 and 5 for
+// This file is compiled nine times: as it stands (everything but the graph-build kernel's instantiations) and, through
+// gwhip_poa_part{0..7}.hip, with GWHIP_POA_PART defined -- parts 0..3 once per (score type, id type) pair, parts 4 and 5 for
 // the packed passes of band 128 and of bands 384 / 512 (launch_packed_variant below), part 6 for the traceback-buffer kernels
-// with 16-bit scores, ids and traces. Those translation units hold nothing but
+// with 16-bit scores, ids and traces, part 7 for the full band with 16-bit scores. Those translation units hold nothing but
 // their poa_window_kernel instantiations and their launcher, so the heavy compilations run in parallel.
 #ifndef GWHIP_POA_PART
 thread_local std::string g_last_error;
@@ -114,12 +114,14 @@ __device__ GraphView<IdT> carve_graph(uint8_t* slab, const PoaLayout& L)
 // for alignment_band_width 128 (the packed pass with the band in lanes 0..31 next to the 256-column one an adaptive band may
 // widen to: a separate instantiation, so that the metric configuration's kernel carries none of its code -- with both in one
 // kernel the headline lost 1 %); 3 = production for alignment_band_width 384 / 512 (the two-pass packed pass,
-// poa_forward_moves_wide.h); 4 = debug for those widths.
+// poa_forward_moves_wide.h); 4 = debug for those widths; 5 / 6 = production / debug of the FULL band with int16 scores (the
+// packed pass of poa_forward_moves_full.h in front of the generic nw_full; gwhip_poa_part7.hip).
 template <typename ScoreT, typename IdT, typename TraceT, int BM, bool MSA, bool LDS_TABLES, int NW, int VARIANT>
 __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
 {
-    constexpr bool DBG = VARIANT == 1 || VARIANT == 4;
+    constexpr bool DBG = VARIANT == 1 || VARIANT == 4 || VARIANT == 6;
     constexpr int PV   = VARIANT == 0 ? 0 : (VARIANT <= 2 ? 1 : 2); // packed passes of nw_banded
+    constexpr bool kFullPacked = (VARIANT == 5 || VARIANT == 6) && BM == GWHIP_FULL_BAND && LDS_TABLES && std::is_same<ScoreT, int16_t>::value;
     const int32_t debug_flags = DBG ? a.debug_flags : 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane       = threadIdx.x & (kWave - 1);
@@ -155,8 +157,15 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
 
     constexpr bool TB = (BM == GWHIP_STATIC_BAND_TRACEBACK || BM == GWHIP_ADAPTIVE_BAND_TRACEBACK);
     ScoreT* scores;
+    uint8_t* full_moves = nullptr; // full band, int16 scores: one move byte per cell behind the window's score matrix
     if (BM == GWHIP_FULL_BAND)
-        scores = reinterpret_cast<ScoreT*>(a.full_scores) + (size_t)wd.scores_offset * (size_t)c.max_nodes_per_graph;
+    {
+        // the window's region: scores_width x max_nodes score cells (+ as many move bytes with int16 scores, full_score_bytes)
+        const size_t cell_bytes = sizeof(ScoreT) + (sizeof(ScoreT) == 2 ? 1 : 0);
+        uint8_t* region         = a.full_scores + (size_t)wd.scores_offset * (size_t)c.max_nodes_per_graph * cell_bytes;
+        scores                  = reinterpret_cast<ScoreT*>(region);
+        if (sizeof(ScoreT) == 2) full_moves = region + (size_t)wd.scores_width * (size_t)c.max_nodes_per_graph * sizeof(ScoreT);
+    }
     else
         scores = reinterpret_cast<ScoreT*>(slab + a.L.scores);
     TraceT* traceback = TB ? reinterpret_cast<TraceT*>(slab + a.L.trace) : nullptr;
@@ -335,8 +344,14 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
         }
         else
         {
-            alen = nw_full<ScoreT, IdT, RowT>(g, rowinfo, node_count, sequence, seq_len, scores, wd.scores_width, ring, kRingBytes,
-                                        alignment_graph, alignment_read, c.gap_score, c.mismatch_score, c.match_score, cells);
+            bool full_handled = false;
+            if constexpr (kFullPacked)
+                alen = nw_full_packed<IdT>(g, rowinfo, node_count, sequence, seq_len, reinterpret_cast<int16_t*>(scores), wd.scores_width, full_moves,
+                                           smem, kRingBytes, reinterpret_cast<const uint64_t*>(lds_code_tile), alignment_graph, alignment_read,
+                                           c.gap_score, c.mismatch_score, c.match_score, cells, debug_flags, full_handled);
+            if (!full_handled)
+                alen = nw_full<ScoreT, IdT, RowT>(g, rowinfo, node_count, sequence, seq_len, scores, wd.scores_width, ring, kRingBytes,
+                                            alignment_graph, alignment_read, c.gap_score, c.mismatch_score, c.match_score, cells);
         }
         // SizeT alignment_length in the reference: the value is narrowed to SizeT (cudapoa_kernels.cuh:268)
         alen = (int32_t)(IdT)alen;
@@ -622,7 +637,8 @@ static size_t full_score_bytes(const gwhip_poa_config& c, int32_t windows, uint6
     if (c.band_mode != GWHIP_FULL_BAND) return 0;
     uint64_t per_window_width = (uint64_t)((c.max_sequence_size + 1 + kCellsPerLane + 3) & ~3);
     uint64_t width_sum        = sum_scores_width ? sum_scores_width : per_window_width * (uint64_t)windows;
-    return (size_t)(width_sum * (uint64_t)c.max_nodes_per_graph * (c.score32 ? 4u : 2u)) + 256;
+    // int16 scores: + one move byte per cell (poa_forward_moves_full.h); the kernel carves a window's region the same way
+    return (size_t)(width_sum * (uint64_t)c.max_nodes_per_graph * (c.score32 ? 4u : 3u)) + 256;
 }
 
 static bool validate(const gwhip_poa_args* args)
@@ -648,6 +664,13 @@ hipError_t launch_packed_variant(const KernelArgs& ka, dim3 grid, size_t lds, hi
     hipLaunchKernelGGL((poa_window_kernel<int16_t, int16_t, int8_t, BM, MSA, true, 1, VARIANT>), grid, dim3(kWave), lds, stream, ka);
     return hipGetLastError();
 }
+#if GWHIP_POA_PART == 7
+// full band, int16 scores: the packed pass of poa_forward_moves_full.h (production and debug)
+template hipError_t launch_packed_variant<GWHIP_FULL_BAND, false, 5>(const KernelArgs&, dim3, size_t, hipStream_t);
+template hipError_t launch_packed_variant<GWHIP_FULL_BAND, true, 5>(const KernelArgs&, dim3, size_t, hipStream_t);
+template hipError_t launch_packed_variant<GWHIP_FULL_BAND, false, 6>(const KernelArgs&, dim3, size_t, hipStream_t);
+template hipError_t launch_packed_variant<GWHIP_FULL_BAND, true, 6>(const KernelArgs&, dim3, size_t, hipStream_t);
+#elif GWHIP_POA_PART == 4 || GWHIP_POA_PART == 5
 #if GWHIP_POA_PART == 4
 #define GW_PACKED_VARIANTS(BM, MSA) template hipError_t launch_packed_variant<BM, MSA, 2>(const KernelArgs&, dim3, size_t, hipStream_t);
 #else
@@ -660,6 +683,7 @@ GW_PACKED_VARIANTS(GWHIP_STATIC_BAND, true)
 GW_PACKED_VARIANTS(GWHIP_ADAPTIVE_BAND, false)
 GW_PACKED_VARIANTS(GWHIP_ADAPTIVE_BAND, true)
 #undef GW_PACKED_VARIANTS
+#endif
 #endif
 
 template <typename ScoreT, typename IdT, typename TraceT, bool MSA, bool LDS_TABLES>
@@ -706,6 +730,14 @@ static hipError_t launch_window_kernel(const KernelArgs& ka_in, hipStream_t stre
                 if (pe != hipSuccess) return pe;                                                                   \
                 launched = true;                                                                                   \
             }                                                                                                      \
+        }                                                                                                          \
+        if constexpr (BM == GWHIP_FULL_BAND && LDS_TABLES && std::is_same<ScoreT, int16_t>::value && std::is_same<IdT, int16_t>::value && \
+                      std::is_same<TraceT, int8_t>::value)                                                         \
+        {                                                                                                          \
+            hipError_t pe = debug ? launch_packed_variant<GWHIP_FULL_BAND, MSA, 6>(ka, grid, lds_req, stream)      \
+                                  : launch_packed_variant<GWHIP_FULL_BAND, MSA, 5>(ka, grid, lds_req, stream);     \
+            if (pe != hipSuccess) return pe;                                                                       \
+            launched = true;                                                                                       \
         }                                                                                                          \
         if (launched) {}                                                                                           \
         else if (debug)                                                                                            \
@@ -824,7 +856,8 @@ void gwhip_poa_bytes_per_window(const gwhip_poa_config* cfg, int64_t* per_poa, i
     {
         // worst-case per-window score row: align4(max_sequence_size + 1 + 4) (cudapoa_batch.cuh:502)
         *per_poa    = (int64_t)L.per_window;
-        *per_matrix = (int64_t)((cfg->max_sequence_size + 1 + kCellsPerLane + 3) & ~3) * (int64_t)cfg->max_nodes_per_graph * L.score_bytes;
+        *per_matrix = (int64_t)((cfg->max_sequence_size + 1 + kCellsPerLane + 3) & ~3) * (int64_t)cfg->max_nodes_per_graph *
+                      (cfg->score32 ? 4 : 3); // int16 scores: + one move byte per cell (full_score_bytes)
     }
     else
     {

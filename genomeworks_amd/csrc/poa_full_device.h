@@ -196,3 +196,5 @@ __device__ __forceinline__ int32_t nw_full(const GraphView<IdT>& g, RowT* rowinf
 }
 
 } // namespace gwhip
+
+#include "poa_forward_moves_full.h" // the packed pass for int16 scores (round 5); nw_full above stays the generic routine

@@ -702,3 +702,59 @@ def test_full_band_benchmark_shape_equals_the_golden():
         assert [int(x) for x in status] == [int(x) for x in g["status"]]
         assert b.total_cells() == s["cells"]
         assert G.band_gen.cell_digest(fp) == s["fingerprint_sha256"]
+
+
+def test_full_band_packed_pass_equals_the_generic_routine_and_the_oracle(monkeypatch):
+    """The packed full-band pass (poa_forward_moves_full.h; 1 .. 4 register passes of 256 columns per row, predecessors from
+    registers / the 4-row LDS ring / the HBM matrix, move bytes + sheared-tile walk; debug instantiation VARIANT 6) against
+    the generic nw_full (GWHIP_DEBUG bit 8) and against its own row kinds demoted into each other (bits 9, 10, 11, 30), on
+    config-3 windows and on windows whose reads end in every pass (lengths around 256 / 512 / 768 / 1023, a read of exactly
+    1024 bases that the pass hands to the generic routine, single-base and very short reads, heavy indels: branchy graphs
+    with 4+ predecessors) -- identical consensus, coverage, status and cell counts, and equal to the oracle's."""
+    import random
+    from genomeworks_amd import synthetic
+    rng = random.Random(20250926)
+    windows = config3(48)
+    for k in range(64):
+        blen = rng.choice([3, 40, 130, 250, 256, 257, 300, 500, 512, 513, 640, 766, 769, 900, 1000, 1019])
+        reads = rng.choice([2, 3, 8, 17, 32])
+        mut, ins, dele = rng.choice([(0, 0, 0), (5, 2, 2), (40, 20, 20), (90, 40, 40), (10, 60, 5), (10, 5, 60)])
+        mut, ins, dele = (min(x, max(1, blen // 4)) for x in (mut, ins, dele))
+        w = [r.decode() for r in synthetic.generate_window(9100 + k, blen, reads, mut, ins, dele)]
+        if k % 4 == 0:
+            w = [("GATTACA"[: rng.randrange(8)] + r)[rng.randrange(5):] for r in w]
+        if k % 9 == 0:   # reads much shorter than the backbone: fewer passes than the widest read of the window
+            w = w[:1] + [r[: max(1, len(r) // rng.choice([2, 3, 5]))] for r in w[1:]]
+        if k % 16 == 5:  # a read of exactly max_sequence_size (1024): the packed pass declines it
+            w.append((w[-1] * (1024 // max(1, len(w[-1])) + 1))[:1024])
+        if k % 16 == 6:  # 1023: the longest read the pass takes (four full passes but one column)
+            w.append((w[-1] * (1023 // max(1, len(w[-1])) + 1))[:1023])
+        windows.append([r for r in w if 0 < len(r) <= 1024][:32])
+    out = {}
+    arms = (("production", None), ("registers_through_ring", str(1 << 10)), ("ring_through_general", str(1 << 9)),
+            ("registers_through_general", str(1 << 11)), ("many_predecessors_general", str(1 << 30)),
+            ("everything_general", str((1 << 9) | (1 << 11) | (1 << 30))), ("generic_nw_full", str(1 << 8)))
+    for name, flag in arms:
+        if flag is None:
+            monkeypatch.delenv("GWHIP_DEBUG", raising=False)
+        else:
+            monkeypatch.setenv("GWHIP_DEBUG", flag)
+        b = run_gpu(windows, "full_band", mem=16 << 30)
+        out[name] = (b.get_consensus(), b.total_cells())
+    monkeypatch.delenv("GWHIP_DEBUG", raising=False)
+    for name, _ in arms[1:]:
+        (c0, v0, s0), n0 = out["production"]
+        (c1, v1, s1), n1 = out[name]
+        bad = [i for i in range(len(windows)) if (c0[i], v0[i], s0[i]) != (c1[i], v1[i], s1[i])]
+        assert not bad and n0 == n1, (name, bad[:8], n0, n1)
+    (cons, cov, status), cells = out["production"]
+    cells_ref = 0
+    with O.Workspace(oracle_cfg("full_band")) as ws:
+        for i, w in enumerate(windows):
+            ref = ws.process(w)
+            cells_ref += ref["cells"]
+            assert status[i] == ref["status"], i
+            if ref["status"] == 0:
+                assert cons[i] == ref["consensus"] and cov[i] == list(ref["coverage"]), i
+        assert ws.overflow_events() == 0
+    assert cells == cells_ref
