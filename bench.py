@@ -400,12 +400,14 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu,
     return rec
 
 
-def cpu_baseline_pairs_all_cores(pairs, max_bandwidth, seconds):
+def cpu_baseline_pairs_all_cores(pairs, max_bandwidth, seconds, max_cores=None):
     """The aligner CPU baseline on ALL host cores: one forked process per core, each running the reference's own
     needleman_wunsch_cpu (oracle/_ref, kind "reference"; the C port of the banded kernel if that library is absent) over
     its share of the pairs for `seconds`. Runs before the process's first device call."""
     import multiprocessing as mp
     cores = max(1, os.cpu_count() or 1)
+    if max_cores is not None:  # (the reference's CPU aligner keeps a full int matrix per pair: 268 MB at 8 192 bases)
+        cores = max(1, min(cores, max_cores))
     _CPU_SHARED.update(pairs=pairs, cores=cores, seconds=seconds, max_bandwidth=max_bandwidth)
     try:
         with mp.get_context("fork").Pool(cores) as pool:
@@ -498,6 +500,74 @@ def bench_default_aligner(local_rank, sync, cpu_all_cores=None):
     if cpu is not None:
         out["cpu_baseline"] = cpu
     return out
+
+
+def bench_aligner_matrix(local_rank, sync, cpu_by_size=None):
+    """Six cells of the reference's aligner benchmark matrix (cudaaligner/benchmarks/main.cpp:69-143, registered :150-168:
+    AlignerGlobalUkkonen / AlignerGlobalMyers / AlignerGlobalMyersBanded / AlignerGlobalHirschbergMyers x alignments per batch
+    x genome size): all four classes at 1024 pairs x 2048 bases, Ukkonen and Hirschberg + Myers at 256 x 8192. Timed region as
+    there: align_all() + sync_alignments() with the pairs queued; the kernels alone by HIP events. Every cell's state
+    sequences are compared with the committed oracle golden of that class (tests/golden/make_aligner_matrix_goldens.py)."""
+    import ctypes as C
+    import numpy as np
+    from genomeworks_amd import _native, cudaaligner
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_io as G  # the checker
+    gold = G.aligner_matrix_goldens()
+    rows = []
+    for algorithm, n, size in G.matrix_gen.CELLS:
+        pairs = G.aligner_gen.shape_pairs(n, size)
+        if algorithm == "myers_banded":
+            al = cudaaligner.CudaAlignerBatch(max_bandwidth=G.matrix_gen.BANDED_MAX_BANDWIDTH, max_device_memory_allocator_caching_size=64 << 30,
+                                              device_id=local_rank)
+        else:
+            al = cudaaligner.CudaAlignerBatch(size, size, n, algorithm=algorithm, max_device_memory_allocator_caching_size=64 << 30,
+                                              device_id=local_rank)
+        best = None
+        for _ in range(3):
+            for q, t in pairs:
+                assert al.add_alignment(q, t) == 0
+            sync()
+            t0 = time.perf_counter()
+            al.align_all()
+            assert al.sync() == n
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            res = al.get_alignments()  # of the last timed run (outside the clock)
+            k_ms = min(al.relaunch_timed() for _ in range(3))
+            band_cells = al.band_cells() if algorithm == "myers_banded" else None
+            al.reset()
+        del al
+        g = gold[G.matrix_gen.cell_key(algorithm, n, size)]
+        sha = G.aligner_gen.digest(G.aligner_gen.pair_record(r.status, r.alignment) for r in res)
+        del res
+        full_cells = sum(len(q) * len(t) for q, t in pairs)
+        if algorithm == "ukkonen":
+            # the band Ukkonen's class stores (int16 per slot, every slot written once): what gwhip_ukkonen_workspace_bytes sizes
+            starts = np.cumsum([0] + [x for q, t in pairs for x in (len(q), len(t))]).astype(np.int64)
+            Gw = _native.gwhip()
+            Gw.gwhip_ukkonen_workspace_bytes.restype = C.c_size_t
+            Gw.gwhip_ukkonen_workspace_bytes.argtypes = [C.c_int32, C.c_void_p, C.c_int32]
+            alg_bytes, what = float(Gw.gwhip_ukkonen_workspace_bytes(n, starts.ctypes.data, 100)), "band slots x 2 B (each written once)"
+        elif algorithm == "myers_banded":
+            alg_bytes, what = band_cells * BYTES_PER_MYERS_CELL, "band cells x 0.375 B (pv, mv, score per 32-cell word column)"
+        else:
+            alg_bytes, what = full_cells * BYTES_PER_MYERS_CELL, "|q| x |t| cells x 0.375 B (pv, mv, score per 32-cell word column)"
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        row = {"algorithm": algorithm, "pairs": n, "length": size, "ms": round(best * 1e3, 3), "pairs_per_s": round(n / best, 1),
+               "full_matrix_gcups": round(full_cells / best / 1e9, 2), "kernel_ms": round(k_ms, 3),
+               "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(alg_bytes), "algorithmic_bytes_are": what,
+                            "kernel_ms": round(k_ms, 3), "traffic": sub_traffic("aligner_matrix/" + G.matrix_gen.cell_key(algorithm, n, size))},
+               "roofline_issue": roofline_issue("aligner_matrix/" + G.matrix_gen.cell_key(algorithm, n, size)),
+               "states_sha256": sha, "equals_oracle_golden": bool(sha == g["states_sha256"])}
+        if cpu_by_size and size in cpu_by_size and cpu_by_size[size] is not None:
+            row["cpu_baseline"] = cpu_by_size[size]
+        rows.append(row)
+    return {"workload": "cells of the reference's aligner benchmark matrix (BM_SingleBatchAlignment: every aligner class x alignments per "
+                        "batch x genome size; genome pairs at about 10 % divergence)",
+            "metric": "pairs/s, align_all() + sync_alignments()", "all_equal_oracle_golden": all(r["equals_oracle_golden"] for r in rows),
+            "rows": rows}
 
 
 def bench_band_modes(windows, local_rank, sync):
@@ -611,9 +681,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--windows", type=int, default=WINDOWS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sub-configs", default="aligner,default_aligner,long_reads,reference_shapes,band_modes",
+    ap.add_argument("--sub-configs", default="aligner,default_aligner,aligner_matrix,long_reads,reference_shapes,band_modes",
                     help="comma list of the sub-records to measure next to the metric config: aligner, default_aligner, "
-                         "long_reads, reference_shapes, band_modes, none")
+                         "aligner_matrix, long_reads, reference_shapes, band_modes, none")
     ap.add_argument("--long-read-windows", type=int, default=598)
     args = ap.parse_args()
     subs = set(x for x in args.sub_configs.split(",") if x and x != "none")
@@ -648,6 +718,11 @@ def main():
         if "default_aligner" in subs:
             p1k = synthetic.generate_pairs(1, 2000, 1000, 33, 33, 33)
             cpu_pairs["default_aligner"] = cpu_baseline_pairs_all_cores([(q, t[:1000]) for q, t in p1k], 1024, 3.0)
+        if "aligner_matrix" in subs:  # the reference's own needleman_wunsch_cpu on the matrix's two genome sizes
+            for size, count in ((2048, 1024), (8192, 256)):
+                pm = synthetic.generate_pairs(1, count, size, size // 30, size // 30, size // 30)
+                cpu_pairs["matrix_%d" % size] = cpu_baseline_pairs_all_cores([(q, t[:size]) for q, t in pm], 1024, 3.0,
+                                                                             max_cores=None if size <= 2048 else 32)
 
     import torch
     if not torch.cuda.is_available():
@@ -803,6 +878,9 @@ def main():
     if "default_aligner" in subs and rank == 0:
         sub["default_aligner"] = bench_default_aligner(local_rank, sync if world == 1 else (lambda: torch.cuda.synchronize()),
                                                        cpu_pairs.get("default_aligner"))
+    if "aligner_matrix" in subs and rank == 0:
+        sub["aligner_matrix"] = bench_aligner_matrix(local_rank, sync if world == 1 else (lambda: torch.cuda.synchronize()),
+                                                     {2048: cpu_pairs.get("matrix_2048"), 8192: cpu_pairs.get("matrix_8192")})
     if "band_modes" in subs and world == 1:
         sub["band_modes"] = bench_band_modes(windows, local_rank, sync)
     if "reference_shapes" in subs and world == 1:

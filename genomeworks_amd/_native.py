@@ -37,7 +37,9 @@ class MyersArgs(C.Structure):
                 ("result_starts", C.c_void_p), ("result_metadata", C.c_void_p), ("results_capacity", C.c_int64),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("total_sequence_length", C.c_int64),
                 ("scheduling_index", C.c_void_p), ("band_cells", C.c_void_p), ("run_counts_out", C.c_void_p),
-                ("max_query_length", C.c_int32), ("max_bandwidth_hint", C.c_int32)]
+                ("max_query_length", C.c_int32), ("max_bandwidth_hint", C.c_int32),
+                # chunked batches (include/gwhip.h); all zero = one call for the whole batch
+                ("index_base", C.c_int32), ("first_sequence_offset", C.c_int64), ("result_starts_base", C.c_void_p)]
 
 
 class PoaBatchConfig(C.Structure):

@@ -517,6 +517,8 @@ struct KernelArgs
     int32_t lds_pattern_words;  // LDS_STATE kernels: per-lane words of the pattern table / of one column-state array
     int32_t lds_band_words;
     int32_t debug_skip;         // profiling ablations (GWHIP_MYERS_SKIP): 1 = no backtrace, 2 = no forward stripes, 4 = no pattern build
+    int32_t index_base;         // chunked batches (gwhip_myers_args::index_base): added to the pair index kept in metadata
+    int64_t slot_base;          // sequence offset of the (chunk's) first pair: the per-pair result slots are indexed relative to it
 };
 
 // per-alignment body of myers_banded_kernel (myers_gpu.cu:897-1021).
@@ -548,15 +550,15 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
     const int32_t query_size  = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
     const int32_t target_size = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
     const int32_t max_bw     = a.max_bandwidths[idx];
-    int8_t* path             = a.slot_ops + a.starts[2 * idx];
-    int32_t* counts          = a.slot_counts + a.starts[2 * idx];
+    int8_t* path             = a.slot_ops + (a.starts[2 * idx] - a.slot_base);
+    int32_t* counts          = a.slot_counts + (a.starts[2 * idx] - a.slot_base);
     const int32_t dlen       = abs(target_size - query_size);
     uint64_t cells           = 0;
 
     if (max_bw - 1 < dlen && query_size != 0 && target_size != 0)
     {
         a.run_counts[idx] = -1;
-        a.metadata[idx]   = (uint32_t)idx;
+        a.metadata[idx]   = (uint32_t)(idx + a.index_base);
         return;
     }
     if (target_size == 0 || query_size == 0)
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
             counts[0]         = query_size + target_size;
             a.run_counts[idx] = 1;
         }
-        a.metadata[idx] = (uint32_t)idx | (1u << 31);
+        a.metadata[idx] = (uint32_t)(idx + a.index_base) | (1u << 31);
         return;
     }
 
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
     if (region + 64 * (3 * me_max + pw_max) > a.ws_capacity_words) // workspace was sized for a different order
     {
         a.run_counts[idx] = -1;
-        a.metadata[idx]   = (uint32_t)idx;
+        a.metadata[idx]   = (uint32_t)(idx + a.index_base);
         return;
     }
     uint32_t* base          = a.ws + region + (threadIdx.x & 63);
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
     if (band_width != 0 && (a.debug_skip & 1))
     {
         a.run_counts[idx] = 0;
-        a.metadata[idx]   = (uint32_t)idx;
+        a.metadata[idx]   = (uint32_t)(idx + a.index_base);
     }
     else if (band_width != 0)
     {
@@ -691,12 +693,12 @@ __global__ __launch_bounds__(64) void myers_banded_kernel(KernelArgs a)
                                                  LaneArray{myers_lds + (threadIdx.x & 63)}, a.lds_pattern_words + 3 * a.lds_band_words + 16);
         else
             a.run_counts[idx] = backtrace_banded(path, counts, b, diagonal_begin, diagonal_end, abs(band_width), target_size);
-        a.metadata[idx]   = (uint32_t)idx | (band_width > 0 ? (1u << 31) : 0u);
+        a.metadata[idx]   = (uint32_t)(idx + a.index_base) | (band_width > 0 ? (1u << 31) : 0u);
     }
     else
     {
         a.run_counts[idx] = -1;
-        a.metadata[idx]   = (uint32_t)idx;
+        a.metadata[idx]   = (uint32_t)(idx + a.index_base);
     }
     if (a.band_cells) a.band_cells[idx] = cells;
 }
@@ -968,8 +970,8 @@ __global__ __launch_bounds__(WAVES * 64) void myers_banded_group_kernel(KernelAr
     const int32_t query_size  = (int32_t)(a.starts[2 * idx + 1] - a.starts[2 * idx]);
     const int32_t target_size = (int32_t)(a.starts[2 * idx + 2] - a.starts[2 * idx + 1]);
     const int32_t max_bw     = a.max_bandwidths[idx];
-    int8_t* path             = a.slot_ops + a.starts[2 * idx];
-    int32_t* counts          = a.slot_counts + a.starts[2 * idx];
+    int8_t* path             = a.slot_ops + (a.starts[2 * idx] - a.slot_base);
+    int32_t* counts          = a.slot_counts + (a.starts[2 * idx] - a.slot_base);
     const int32_t dlen       = abs(target_size - query_size);
     uint64_t cells           = 0;
 
@@ -978,7 +980,7 @@ __global__ __launch_bounds__(WAVES * 64) void myers_banded_group_kernel(KernelAr
         if (leader)
         {
             a.run_counts[idx] = -1;
-            a.metadata[idx]   = (uint32_t)idx;
+            a.metadata[idx]   = (uint32_t)(idx + a.index_base);
         }
         return;
     }
@@ -994,7 +996,7 @@ __global__ __launch_bounds__(WAVES * 64) void myers_banded_group_kernel(KernelAr
                 counts[0]         = query_size + target_size;
                 a.run_counts[idx] = 1;
             }
-            a.metadata[idx] = (uint32_t)idx | (1u << 31);
+            a.metadata[idx] = (uint32_t)(idx + a.index_base) | (1u << 31);
         }
         return;
     }
@@ -1007,7 +1009,7 @@ __global__ __launch_bounds__(WAVES * 64) void myers_banded_group_kernel(KernelAr
         if (leader)
         {
             a.run_counts[idx] = -1;
-            a.metadata[idx]   = (uint32_t)idx;
+            a.metadata[idx]   = (uint32_t)(idx + a.index_base);
         }
         return;
     }
@@ -1149,7 +1151,7 @@ __global__ __launch_bounds__(WAVES * 64) void myers_banded_group_kernel(KernelAr
         if (leader)
         {
             a.run_counts[idx] = 0;
-            a.metadata[idx]   = (uint32_t)idx;
+            a.metadata[idx]   = (uint32_t)(idx + a.index_base);
         }
     }
     else if (band_width != 0)
@@ -1161,13 +1163,13 @@ __global__ __launch_bounds__(WAVES * 64) void myers_banded_group_kernel(KernelAr
         if (leader)
         {
             a.run_counts[idx] = runs;
-            a.metadata[idx]   = (uint32_t)idx | (band_width > 0 ? (1u << 31) : 0u);
+            a.metadata[idx]   = (uint32_t)(idx + a.index_base) | (band_width > 0 ? (1u << 31) : 0u);
         }
     }
     else if (leader)
     {
         a.run_counts[idx] = -1;
-        a.metadata[idx]   = (uint32_t)idx;
+        a.metadata[idx]   = (uint32_t)(idx + a.index_base);
     }
     if (leader && a.band_cells) a.band_cells[idx] = cells;
 }
@@ -1213,11 +1215,11 @@ __global__ __launch_bounds__(kScanBlock) void scan_block_totals_kernel(const int
 }
 
 template <typename T>
-__global__ __launch_bounds__(1024) void scan_totals_kernel(T* block_totals, int32_t n_blocks, T* grand_total)
+__global__ __launch_bounds__(1024) void scan_totals_kernel(T* block_totals, int32_t n_blocks, T* grand_total, const T* base = nullptr)
 {
     __shared__ T part[1024];
     __shared__ T carry;
-    if (threadIdx.x == 0) carry = 0;
+    if (threadIdx.x == 0) carry = base ? *base : 0; // chunked batches: the runs of the chunks before this one
     __syncthreads();
     for (int32_t base = 0; base < n_blocks; base += 1024)
     {
@@ -1267,7 +1269,7 @@ __global__ __launch_bounds__(256) void compact_kernel(KernelArgs a, int8_t* resu
     const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.n) return;
     const int32_t nr  = max(a.run_counts[idx], 0);
-    const int64_t src = a.starts[2 * idx];
+    const int64_t src = a.starts[2 * idx] - a.slot_base;
     const int32_t dst = result_starts[idx];
     int32_t k         = 0;
     for (; k + 4 <= nr; k += 4)
@@ -3185,7 +3187,8 @@ size_t gwhip_myers_banded_workspace_bytes_ordered(int32_t n_alignments, const in
                                                   const int32_t* max_bandwidths_host, const int32_t* scheduling_index_host)
 {
     if (n_alignments <= 0) return 256;
-    const WsPlan p = plan_fixed(n_alignments, sequence_starts_host[2 * (size_t)n_alignments]);
+    // (the result slots are indexed relative to the first pair's offset: a chunk of a larger batch passes its own slice)
+    const WsPlan p = plan_fixed(n_alignments, sequence_starts_host[2 * (size_t)n_alignments] - sequence_starts_host[0]);
     int64_t words  = 0;
     for (int32_t w0 = 0; w0 < n_alignments; w0 += 64) // one interleaved region per wave of 64 slots
     {
@@ -3243,6 +3246,8 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
     ka.order          = args->scheduling_index ? args->scheduling_index : identity;
     ka.ws             = reinterpret_cast<uint32_t*>(ws + p.off_ws);
     ka.metadata       = args->result_metadata;
+    ka.index_base     = args->index_base;
+    ka.slot_base      = args->first_sequence_offset;
 
     ka.ws_capacity_words = ((int64_t)args->workspace_bytes - (int64_t)p.off_ws) / 4;
     {
@@ -3254,7 +3259,8 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
         hipLaunchKernelGGL(ws_sizes_kernel, dim3(std::max(id_blocks, (n_waves + kScanBlock - 1) / kScanBlock)), dim3(kScanBlock), 0, stream,
                            args->sequence_starts, args->max_bandwidths, ka.order, offsets, identity, n);
         hipLaunchKernelGGL(ws_block_totals_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, offsets, block_totals, n_waves);
-        hipLaunchKernelGGL(scan_totals_kernel<int64_t>, dim3(1), dim3(1024), 0, stream, block_totals, n_blocks, offsets + n_waves);
+        hipLaunchKernelGGL(scan_totals_kernel<int64_t>, dim3(1), dim3(1024), 0, stream, block_totals, n_blocks, offsets + n_waves,
+                           (const int64_t*)nullptr);
         hipLaunchKernelGGL(ws_apply_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, offsets, block_totals, n_waves);
     }
     // LDS flavour when every pair's pattern table and column state fit one wave's share (<= 1 KiB per lane)
@@ -3331,7 +3337,8 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
         int32_t* block_totals  = reinterpret_cast<int32_t*>(ws + p.off_scan);
         const int32_t n_blocks = (n + kScanChunk - 1) / kScanChunk;
         hipLaunchKernelGGL(scan_block_totals_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, ka.run_counts, block_totals, n);
-        hipLaunchKernelGGL(scan_totals_kernel<int32_t>, dim3(1), dim3(1024), 0, stream, block_totals, n_blocks, args->result_starts + n);
+        hipLaunchKernelGGL(scan_totals_kernel<int32_t>, dim3(1), dim3(1024), 0, stream, block_totals, n_blocks, args->result_starts + n,
+                           args->result_starts_base);
         hipLaunchKernelGGL(scan_apply_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, ka.run_counts, block_totals, args->result_starts, n);
     }
     hipLaunchKernelGGL(compact_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ka, args->results, args->result_counts,

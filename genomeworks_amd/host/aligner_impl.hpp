@@ -51,7 +51,10 @@ public:
 private:
     void reset_data();
     void free_device();
-    void launch(void* event_before = nullptr, void* event_after = nullptr);
+    struct Chunk;
+    void launch(void* event_before = nullptr, void* event_after = nullptr); ///< every chunk's kernels again + fetch_head()
+    void launch_chunk(const Chunk& c);
+    void fetch_head();
 
     cudaStream_t stream_;
     int32_t device_id_;
@@ -71,7 +74,6 @@ private:
     size_t largest_wave_ws_          = 0;
     int32_t longest_query_           = 0;
     int32_t widest_band_             = 0;
-    size_t workspace_bytes_          = 0;
     bool launched_                   = false;
     bool uploads_in_flight_          = false;
     int64_t total_length_h_          = 0;
@@ -82,8 +84,19 @@ private:
 
     char* device_block_        = nullptr; ///< inputs and outputs (allocated first: the uploads start before the batch is sorted)
     size_t device_block_bytes_ = 0;
-    char* workspace_block_     = nullptr; ///< the kernels' workspace (sized once the processing order is known)
-    size_t workspace_block_bytes_ = 0;
+    /// A batch is processed as one chunk, or -- large batches -- as several chunks of consecutive pairs whose uploads run on a
+    /// stream of their own: the upload of chunk k + 1 overlaps the kernels of chunk k (include/gwhip.h, gwhip_myers_args).
+    /// Every chunk has its own workspace (sized once its processing order is known).
+    struct Chunk
+    {
+        int32_t lo = 0, hi = 0;
+        char* workspace        = nullptr;
+        size_t workspace_bytes = 0, block_bytes = 0;
+        void* uploaded         = nullptr; ///< hipEvent_t on the upload stream (null: uploaded on the aligner's own stream)
+    };
+    std::vector<Chunk> chunks_;
+    void* upload_stream_ = nullptr;       ///< hipStream_t, created with the first chunked batch
+    std::vector<void*> upload_events_;    ///< hipEvent_t pool (timing disabled)
     char* d_seq_               = nullptr;
     int64_t* d_starts_         = nullptr;
     int32_t* d_bw_             = nullptr;
@@ -93,7 +106,6 @@ private:
     int32_t* d_result_starts_  = nullptr;
     uint32_t* d_metadata_      = nullptr;
     uint64_t* d_cells_         = nullptr;
-    char* d_workspace_         = nullptr;
 };
 
 } // namespace cudaaligner

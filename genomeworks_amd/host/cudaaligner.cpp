@@ -82,6 +82,12 @@ BandedAligner::~BandedAligner()
 {
     scoped_device_switch dev(device_id_);
     (void)hipStreamSynchronize(stream_);
+    if (upload_stream_ != nullptr)
+    {
+        (void)hipStreamSynchronize(static_cast<hipStream_t>(upload_stream_));
+        (void)hipStreamDestroy(static_cast<hipStream_t>(upload_stream_));
+    }
+    for (void* e : upload_events_) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
     free_device();
     if (head_ != nullptr) pinned_release(head_, head_cap_);
 }
@@ -103,12 +109,9 @@ void BandedAligner::free_device()
         device_block_       = nullptr;
         device_block_bytes_ = 0;
     }
-    if (workspace_block_ != nullptr)
-    {
-        allocator_.deallocate(workspace_block_, workspace_block_bytes_);
-        workspace_block_       = nullptr;
-        workspace_block_bytes_ = 0;
-    }
+    for (Chunk& c : chunks_)
+        if (c.workspace != nullptr) allocator_.deallocate(c.workspace, c.block_bytes);
+    chunks_.clear();
 }
 
 void BandedAligner::reset_data()
@@ -127,6 +130,7 @@ void BandedAligner::reset()
 {
     scoped_device_switch dev(device_id_);
     (void)hipStreamSynchronize(stream_);
+    if (upload_stream_ != nullptr) (void)hipStreamSynchronize(static_cast<hipStream_t>(upload_stream_));
     uploads_in_flight_ = false;
     reset_data();
     free_device();
@@ -249,70 +253,126 @@ StatusType BandedAligner::align_all()
     d_result_starts_    = reinterpret_cast<int32_t*>(device_block_ + o_rs);
     d_metadata_         = reinterpret_cast<uint32_t*>(device_block_ + o_meta);
     d_cells_            = reinterpret_cast<uint64_t*>(device_block_ + o_cells);
-    GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq_, seq_h_.data(), static_cast<size_t>(total_len), hipMemcpyHostToDevice, stream_));
-    GW_CU_CHECK_ERR(hipMemcpyAsync(d_starts_, seq_starts_h_.data(), seq_starts_h_.size() * 8, hipMemcpyHostToDevice, stream_));
-    GW_CU_CHECK_ERR(hipMemcpyAsync(d_bw_, max_bandwidths_h_.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, stream_));
-    uploads_in_flight_ = true;
-    trace.mark("align_all: device block, uploads enqueued");
-    // longest pairs first (aligner_global_myers_banded.cpp:306-309): lanes of one wave get similar work
+
+    // Chunks of consecutive pairs for large batches (a million short reads: the upload is 2 / 3 of the call): the upload of
+    // chunk k + 1 runs on a stream of its own under the kernels of chunk k. The pairs' results do not depend on how the
+    // batch is cut (scheduling order and workspace are per chunk, the packed runs are appended in input order).
+    int32_t n_chunks = (n >= 131072 && total_len >= (int64_t(32) << 20)) ? 6 : 1; // (2 .. 24 measured: profiles/r05_d_aligner_chunk_sweep.txt)
+    if (const char* e = std::getenv("GW_ALIGNER_CHUNKS")) n_chunks = std::max(1, std::min(std::atoi(e), std::max(1, n / 64)));
+    chunks_.resize(static_cast<size_t>(n_chunks));
+    for (int32_t k = 0; k < n_chunks; ++k)
+    {
+        chunks_[static_cast<size_t>(k)].lo = static_cast<int32_t>(static_cast<int64_t>(n) * k / n_chunks);
+        chunks_[static_cast<size_t>(k)].hi = static_cast<int32_t>(static_cast<int64_t>(n) * (k + 1) / n_chunks);
+    }
+    hipStream_t up = stream_;
+    if (n_chunks > 1)
+    {
+        if (upload_stream_ == nullptr)
+        {
+            hipStream_t s = nullptr;
+            GW_CU_CHECK_ERR(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            upload_stream_ = s;
+        }
+        while (upload_events_.size() < static_cast<size_t>(n_chunks) + 1)
+        {
+            hipEvent_t e = nullptr;
+            GW_CU_CHECK_ERR(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            upload_events_.push_back(e);
+        }
+        up = static_cast<hipStream_t>(upload_stream_);
+        // the fresh block may be memory that earlier work on the aligner's stream still uses: the uploads start behind it
+        hipEvent_t begin = static_cast<hipEvent_t>(upload_events_[static_cast<size_t>(n_chunks)]);
+        GW_CU_CHECK_ERR(hipEventRecord(begin, stream_));
+        GW_CU_CHECK_ERR(hipStreamWaitEvent(up, begin, 0));
+    }
     PinnedVector<int32_t> order;
     order.resize(static_cast<size_t>(n));
-    {
+    auto enqueue_inputs = [&](const Chunk& c) {
+        const int64_t b0 = seq_starts_h_[2 * static_cast<size_t>(c.lo)], b1 = seq_starts_h_[2 * static_cast<size_t>(c.hi)];
+        const size_t m   = static_cast<size_t>(c.hi - c.lo);
+        if (b1 > b0) GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq_ + b0, seq_h_.data() + b0, static_cast<size_t>(b1 - b0), hipMemcpyHostToDevice, up));
+        GW_CU_CHECK_ERR(hipMemcpyAsync(d_starts_ + 2 * static_cast<size_t>(c.lo), seq_starts_h_.data() + 2 * static_cast<size_t>(c.lo), (2 * m + 1) * 8,
+                                       hipMemcpyHostToDevice, up));
+        GW_CU_CHECK_ERR(hipMemcpyAsync(d_bw_ + c.lo, max_bandwidths_h_.data() + c.lo, m * 4, hipMemcpyHostToDevice, up));
+    };
+    // longest pairs first within a chunk (aligner_global_myers_banded.cpp:306-309): lanes of one wave get similar work;
+    // indices are chunk-local
+    auto sort_chunk = [&](const Chunk& c) {
+        const int32_t m = c.hi - c.lo;
+        int32_t* ord    = order.data() + c.lo;
+        auto len_of     = [&](int32_t i) { return seq_starts_h_[2 * static_cast<size_t>(c.lo + i) + 2] - seq_starts_h_[2 * static_cast<size_t>(c.lo + i)]; };
         int64_t longest = 0;
-        for (int32_t i = 0; i < n; ++i) longest = std::max(longest, seq_starts_h_[2 * i + 2] - seq_starts_h_[2 * i]);
-        if (n >= 4096 && longest < (int64_t(1) << 22))
+        for (int32_t i = 0; i < m; ++i) longest = std::max(longest, len_of(i));
+        if (m >= 4096 && longest < (int64_t(1) << 22))
         {
-            // a stable counting sort by descending pair length: linear in n (a million short pairs sort in a few ms)
+            // a stable counting sort by descending pair length: linear in m (a million short pairs sort in a few ms)
             std::vector<int32_t> first(static_cast<size_t>(longest) + 2, 0);
-            for (int32_t i = 0; i < n; ++i) first[static_cast<size_t>(longest - (seq_starts_h_[2 * i + 2] - seq_starts_h_[2 * i])) + 1]++;
+            for (int32_t i = 0; i < m; ++i) first[static_cast<size_t>(longest - len_of(i)) + 1]++;
             for (size_t k = 1; k < first.size(); ++k) first[k] += first[k - 1];
-            for (int32_t i = 0; i < n; ++i) order[static_cast<size_t>(first[static_cast<size_t>(longest - (seq_starts_h_[2 * i + 2] - seq_starts_h_[2 * i]))]++)] = i;
+            for (int32_t i = 0; i < m; ++i) ord[static_cast<size_t>(first[static_cast<size_t>(longest - len_of(i))]++)] = i;
         }
         else
         {
-            std::iota(order.data(), order.data() + n, 0);
-            std::stable_sort(order.data(), order.data() + n, [&](int32_t a, int32_t b) {
-                return (seq_starts_h_[2 * a + 2] - seq_starts_h_[2 * a]) > (seq_starts_h_[2 * b + 2] - seq_starts_h_[2 * b]);
-            });
+            std::iota(ord, ord + m, 0);
+            std::stable_sort(ord, ord + m, [&](int32_t a, int32_t b) { return len_of(a) > len_of(b); });
         }
+    };
+    enqueue_inputs(chunks_[0]);
+    uploads_in_flight_ = true;
+    trace.mark("align_all: device block, first uploads enqueued");
+    for (int32_t k = 0; k < n_chunks; ++k)
+    {
+        Chunk& c = chunks_[static_cast<size_t>(k)];
+        const size_t m = static_cast<size_t>(c.hi - c.lo);
+        sort_chunk(c);
+        // (the copy below reads the vector's storage, which order_h_ takes over at the end)
+        GW_CU_CHECK_ERR(hipMemcpyAsync(d_order_ + c.lo, order.data() + c.lo, m * 4, hipMemcpyHostToDevice, up));
+        if (n_chunks > 1)
+        {
+            c.uploaded = upload_events_[static_cast<size_t>(k)];
+            GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(c.uploaded), up));
+            if (k + 1 < n_chunks) enqueue_inputs(chunks_[static_cast<size_t>(k) + 1]); // keeps the copy engine busy while this chunk is sized
+        }
+        c.workspace_bytes = gwhip_myers_banded_workspace_bytes_ordered(static_cast<int32_t>(m), seq_starts_h_.data() + 2 * static_cast<size_t>(c.lo),
+                                                                       max_bandwidths_h_.data() + c.lo, order.data() + c.lo);
+        c.block_bytes     = up256(c.workspace_bytes);
+        c.workspace       = allocator_.allocate(c.block_bytes, {stream_});
+        if (c.uploaded != nullptr) GW_CU_CHECK_ERR(hipStreamWaitEvent(stream_, static_cast<hipEvent_t>(c.uploaded), 0));
+        launch_chunk(c);
     }
-    trace.mark("align_all: length sort");
-    workspace_bytes_ = gwhip_myers_banded_workspace_bytes_ordered(n, seq_starts_h_.data(), max_bandwidths_h_.data(), order.data());
-    trace.mark("align_all: workspace sizing");
-    workspace_block_bytes_ = up256(workspace_bytes_);
-    workspace_block_       = allocator_.allocate(workspace_block_bytes_, {stream_});
-    d_workspace_           = workspace_block_;
-    order_h_               = std::move(order);
-    GW_CU_CHECK_ERR(hipMemcpyAsync(d_order_, order_h_.data(), static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, stream_));
-    launch();
-    trace.mark("align_all: order upload and kernels enqueued");
-    launched_          = true;
+    order_h_ = std::move(order);
+    trace.mark("align_all: chunks sorted, sized, uploaded and launched");
+    fetch_head();
+    launched_ = true;
     return StatusType::success;
 }
 
-void BandedAligner::launch(void* event_before, void* event_after)
+void BandedAligner::launch_chunk(const Chunk& c)
 {
     gwhip_myers_args a{};
-    a.n_alignments          = num_alignments();
+    const size_t lo         = static_cast<size_t>(c.lo);
+    a.n_alignments          = c.hi - c.lo;
     a.sequences             = d_seq_;
-    a.sequence_starts       = d_starts_;
-    a.max_bandwidths        = d_bw_;
+    a.sequence_starts       = d_starts_ + 2 * lo;
+    a.max_bandwidths        = d_bw_ + lo;
     a.results               = d_results_;
     a.result_counts         = d_result_counts_;
-    a.result_starts         = d_result_starts_;
-    a.result_metadata       = d_metadata_;
+    a.result_starts         = d_result_starts_ + lo;
+    a.result_metadata       = d_metadata_ + lo;
     a.results_capacity      = seq_starts_h_.back();
-    a.workspace             = d_workspace_;
-    a.workspace_bytes       = workspace_bytes_;
-    a.total_sequence_length = seq_starts_h_.back();
-    a.scheduling_index      = d_order_;
-    a.band_cells            = d_cells_;
+    a.workspace             = c.workspace;
+    a.workspace_bytes       = c.workspace_bytes;
+    a.total_sequence_length = seq_starts_h_[2 * static_cast<size_t>(c.hi)] - seq_starts_h_[2 * lo];
+    a.first_sequence_offset = seq_starts_h_[2 * lo];
+    a.index_base            = c.lo;
+    a.result_starts_base    = c.lo > 0 ? d_result_starts_ + lo : nullptr; // written by the chunk before this one
+    a.scheduling_index      = d_order_ + lo;
+    a.band_cells            = d_cells_ + lo;
     // hints for the LDS-cached kernel variant: longest query and widest band of this batch
     a.max_query_length   = longest_query_;
     a.max_bandwidth_hint = widest_band_;
-    if (event_before != nullptr) GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(event_before), stream_));
-    const int rc            = gwhip_myers_banded(&a, stream_);
-    if (event_after != nullptr) GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(event_after), stream_));
+    const int rc         = gwhip_myers_banded(&a, stream_);
     if (rc != 0)
     {
         char buf[512];
@@ -320,10 +380,22 @@ void BandedAligner::launch(void* event_before, void* event_after)
         GW_LOG_ERROR(buf);
         GW_CU_CHECK_ERR(static_cast<hipError_t>(rc));
     }
+}
+
+void BandedAligner::launch(void* event_before, void* event_after)
+{
+    if (event_before != nullptr) GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(event_before), stream_));
+    for (const Chunk& c : chunks_) launch_chunk(c);
+    if (event_after != nullptr) GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(event_after), stream_));
+    fetch_head();
+}
+
+void BandedAligner::fetch_head()
+{
     // result offsets and metadata follow the kernels to the host (pinned), as the reference's align_all() does with its
     // result_starts (aligner_global_myers_banded.cpp:372-374): sync_alignments() and get_alignments_device() read
     // them after the stream has drained
-    const size_t un = static_cast<size_t>(a.n_alignments);
+    const size_t un = static_cast<size_t>(num_alignments());
     if (head_ == nullptr || head_cap_ < (2 * un + 1) * 4) // (sync_alignments() hands the buffer to the views' block)
     {
         if (head_ != nullptr) pinned_release(head_, head_cap_);
@@ -331,7 +403,8 @@ void BandedAligner::launch(void* event_before, void* event_after)
     }
     GW_CU_CHECK_ERR(hipMemcpyAsync(head_, d_result_starts_, (un + 1) * 4, hipMemcpyDeviceToHost, stream_));
     GW_CU_CHECK_ERR(hipMemcpyAsync(head_ + (un + 1) * 4, d_metadata_, un * 4, hipMemcpyDeviceToHost, stream_));
-    n_head_ = a.n_alignments;
+    n_head_ = static_cast<int32_t>(un);
+
 }
 
 void BandedAligner::relaunch_resident()

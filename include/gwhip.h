@@ -188,6 +188,20 @@ typedef struct gwhip_myers_args
     int32_t max_query_length;        /* optional hints (0 = unknown): longest query and largest max_bandwidth of the batch; */
     int32_t max_bandwidth_hint;      /* when both are known and small enough, the column state and the query patterns
                                         of every pair are kept in LDS instead of being re-read from the HBM workspace */
+    /* A large batch processed in CHUNKS of consecutive pairs, so that the upload of chunk k + 1 overlaps the kernels of chunk k
+       (host/cudaaligner.cpp): every chunk is one call with the arrays advanced to its first pair -- sequence_starts + 2 lo
+       (absolute offsets into `sequences`, which stays the batch's base), max_bandwidths + lo, result_starts + lo,
+       result_metadata + lo, band_cells + lo, a scheduling_index of chunk-local indices -- and
+         total_sequence_length  = sequence_starts[2 hi] - sequence_starts[2 lo] (sizes the workspace's per-pair result slots),
+         first_sequence_offset  = sequence_starts[2 lo] (host-known),
+         index_base             = lo (added to the pair index kept in result_metadata),
+         result_starts_base     = device pointer to the number of runs before the chunk: result_starts + lo of the batch's
+                                  array, whose entry the previous chunk's call has written (NULL for the first chunk).
+       `results` / `result_counts` stay the batch's packed arrays: the chunks append in input order. All zero / NULL = one call
+       for the whole batch. */
+    int32_t index_base;
+    int64_t first_sequence_offset;
+    const int32_t* result_starts_base;
 } gwhip_myers_args;
 
 size_t gwhip_myers_banded_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host,

@@ -100,3 +100,14 @@ _aspec.loader.exec_module(aligner_gen)
 def default_aligner_goldens():
     with open(os.path.join(GOLDEN, "default_aligner_goldens.json")) as f:
         return json.load(f)
+
+
+# ---- cells of the aligner benchmark matrix (tests/golden/make_aligner_matrix_goldens.py) ----
+_mspec = importlib.util.spec_from_file_location("make_aligner_matrix_goldens", os.path.join(GOLDEN, "make_aligner_matrix_goldens.py"))
+matrix_gen = importlib.util.module_from_spec(_mspec)
+_mspec.loader.exec_module(matrix_gen)
+
+
+def aligner_matrix_goldens():
+    with open(os.path.join(GOLDEN, "aligner_matrix_goldens.json")) as f:
+        return json.load(f)

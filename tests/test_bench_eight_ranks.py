@@ -30,7 +30,7 @@ class FakeBatch:
     def relaunch_timed(self):
         return 1.0, 0.1
 
-    def get_consensus_native(self):
+    def get_consensus_native(self, in_place=False):
         return len(self.idx)
 
     def total_cells(self):

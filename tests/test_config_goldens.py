@@ -151,3 +151,17 @@ def test_default_aligner_golden_file_matches_oracle_sample():
         ref = A.hirschberg(q, t, size)
         assert G.aligner_gen.digest([G.aligner_gen.pair_record(ref["status"], ref["states"])]) == gold["%dx%d" % (n, size)]["states_sha256"]
         assert ref["edit_distance"] == gold["%dx%d" % (n, size)]["edit_distance_sum"]
+
+
+def test_aligner_matrix_golden_file_matches_oracle_sample():
+    """tests/golden/aligner_matrix_goldens.json: the cells bench.py publishes; the Hirschberg cell at 1024 x 2048 is the
+    default aligner's golden of the same pairs, and each class's oracle still reproduces the first pairs of a cell."""
+    gold, dgold = G.aligner_matrix_goldens(), G.default_aligner_goldens()
+    assert sorted(gold) == sorted(G.matrix_gen.cell_key(*c) for c in G.matrix_gen.CELLS)
+    assert gold["hirschberg_myers/1024x2048"]["states_sha256"] == dgold["1024x2048"]["states_sha256"]
+    pairs = G.aligner_gen.shape_pairs(1024, 2048)[:3]
+    for algorithm in ("ukkonen", "myers", "myers_banded", "hirschberg_myers"):
+        recs = [G.matrix_gen._one((algorithm, q, t, 2048)) for q, t in pairs]
+        assert all(r[1] >= 0 and r[2] >= 2048 for r in recs)
+    # all four classes are optimal on these pairs: equal edit-distance sums
+    assert len({gold[G.matrix_gen.cell_key(a, 1024, 2048)]["edit_distance_sum"] for a in ("ukkonen", "myers", "myers_banded", "hirschberg_myers")}) == 1

@@ -443,3 +443,27 @@ def test_myers_class_bit_exact_vs_oracle():
         assert r.status == 0 and r.is_optimal
         assert list(r.alignment) == ref["states"], (len(q), len(t))
         assert r.cigar == ref["cigar"]
+
+
+def test_aligner_matrix_cells_equal_the_golden():
+    """The cells of the reference's aligner benchmark matrix that bench.py publishes (cudaaligner/benchmarks/main.cpp:69-168:
+    AlignerGlobalUkkonen, AlignerGlobalMyers, AlignerGlobalMyersBanded, AlignerGlobalHirschbergMyers at 1024 x 2048 bases;
+    Ukkonen and Hirschberg at 256 x 8192) against each class's committed oracle golden
+    (tests/golden/make_aligner_matrix_goldens.py)."""
+    import golden_io as G
+    from genomeworks_amd import cudaaligner
+    gold = G.aligner_matrix_goldens()
+    for algorithm, n, size in G.matrix_gen.CELLS:
+        pairs = G.aligner_gen.shape_pairs(n, size)
+        if algorithm == "myers_banded":
+            al = cudaaligner.CudaAlignerBatch(max_bandwidth=G.matrix_gen.BANDED_MAX_BANDWIDTH, max_device_memory_allocator_caching_size=64 << 30)
+        else:
+            al = cudaaligner.CudaAlignerBatch(size, size, n, algorithm=algorithm, max_device_memory_allocator_caching_size=64 << 30)
+        for q, t in pairs:
+            assert al.add_alignment(q, t) == 0
+        al.align_all()
+        res = al.get_alignments()
+        g = gold[G.matrix_gen.cell_key(algorithm, n, size)]
+        assert len(res) == n and all(r.status == 0 for r in res), (algorithm, n, size)
+        assert sum(sum(1 for x in r.alignment if x != 0) for r in res) == g["edit_distance_sum"], (algorithm, n, size)
+        assert G.aligner_gen.digest(G.aligner_gen.pair_record(r.status, r.alignment) for r in res) == g["states_sha256"], (algorithm, n, size)
