@@ -654,23 +654,26 @@ def bench_reference_shapes(windows, local_rank, sync, steps):
               "windows_equal_oracle_golden": int((fp == fgold["fingerprint"]).sum()) if len(windows) == fsum["windows"] else None,
               "equals_oracle_golden": bool(len(windows) == fsum["windows"] and G.band_gen.cell_digest(fp) == fsum["fingerprint_sha256"]
                                            and cells == fsum["cells"])}
-    golden3 = config3_golden_digest()
     multi = []
     twice = windows + windows
+    gold_fp = fgold["fingerprint"]
     for nb in (1, 2, 4, 8):
         sync()
-        out = cudapoa.process_windows_multi_device(twice, 32, 1024, devices=(local_rank,), batches_per_device=nb,
-                                                   memory_per_device=int(nb * 1.0e9), band_mode="static_band",
-                                                   max_nodes_per_graph=3072)
+        # BatchConfig(1024, 200) = full band, as the reference's multi-batch benchmark (multi_batch.hpp:49); about 260 windows
+        # per batch fill (11 MB of device memory per window)
+        out = cudapoa.process_windows_multi_device(twice, 200, 1024, devices=(local_rank,), batches_per_device=nb,
+                                                   memory_per_device=int(nb * 3.0e9), band_mode="full_band",
+                                                   max_nodes_per_graph=3072, matrix_sequence_dimension=1024)
         dt = out["seconds"]
         assert all(s == 0 for s in out["status"])
-        halves = [consensus_digest(out["consensus"][k * len(windows):(k + 1) * len(windows)]) for k in range(2)]
+        fp2 = G.band_mode_fingerprints(out["consensus"], out["coverage"], out["status"])
+        ok = bool(len(windows) == fsum["windows"] and (fp2[:len(windows)] == gold_fp).all() and (fp2[len(windows):] == gold_fp).all())
         multi.append({"batches": nb, "ms": round(dt * 1e3, 1), "windows_per_s": round(len(twice) / dt, 1), "launches": out["launches"],
-                      "equals_oracle_golden": bool(len(windows) == WINDOWS and golden3 is not None and all(h == golden3 for h in halves))})
+                      "gcups": round(2 * cells / dt / 1e9, 1), "equals_oracle_golden": ok})
     return {"single_batch_full_band": single,
-            "multi_batch": {"shape": "BM_MultiBatchTest pattern: %d windows (the 1024 config-3 windows twice), static band 256, "
-                                     "N batches on host threads sharing the device, about 260 windows per batch fill; "
-                                     "wall time of the workers: batch creation, filling, kernels, result unpacking" % len(twice),
+            "multi_batch": {"shape": "BM_MultiBatchTest pattern: %d windows (the 1024 config-3 windows twice), BatchConfig(1024, 200) full "
+                                     "band as in the reference, N batches on host threads sharing the device, about 260 windows per "
+                                     "batch fill; wall time of the workers: batch creation, filling, kernels, result unpacking" % len(twice),
                             "runs": multi}}
 
 

@@ -3215,6 +3215,25 @@ size_t gwhip_myers_banded_workspace_bytes(int32_t n_alignments, const int64_t* s
     return gwhip_myers_banded_workspace_bytes_ordered(n_alignments, sequence_starts_host, max_bandwidths_host, nullptr);
 }
 
+int gwhip_myers_occupancy(int device, int* blocks_per_cu)
+{
+    if (!blocks_per_cu)
+    {
+        g_last_error = "gwhip_myers_occupancy: null output";
+        return (int)hipErrorInvalidValue;
+    }
+    int prev = 0;
+    hipError_t e = hipGetDevice(&prev);
+    if (e == hipSuccess && prev != device) e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(e, "gwhip_myers_occupancy: device");
+    int blocks = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void*>(&myers_banded_kernel<false>), 64, 0);
+    if (prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return fail(e, "gwhip_myers_occupancy: occupancy query");
+    *blocks_per_cu = blocks;
+    return 0;
+}
+
 int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;

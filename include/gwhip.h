@@ -211,6 +211,11 @@ size_t gwhip_myers_banded_workspace_bytes(int32_t n_alignments, const int64_t* s
 size_t gwhip_myers_banded_workspace_bytes_ordered(int32_t n_alignments, const int64_t* sequence_starts_host,
                                                   const int32_t* max_bandwidths_host, const int32_t* scheduling_index_host);
 int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream);
+/* myers_banded_gpu_get_blocks_per_sm() (myers_gpu.cuh:53; the reference sizes its persistent launch with it,
+   aligner_global_myers_banded.cpp:137-140): resident blocks of the one-lane-per-pair kernel per compute unit on `device`.
+   Our launches are one block per wave of pairs, not persistent, so the host classes do not need it; exported for callers that
+   size their batches by it. Returns a hipError_t as int. */
+int gwhip_myers_occupancy(int device, int* blocks_per_cu);
 
 /* ---- cudaaligner: default aligner, Hirschberg + Myers (hirschberg_myers_gpu.cuh:45, hirschberg_myers_gpu.cu:684-701) ---- */
 typedef struct gwhip_hirschberg_args

@@ -291,3 +291,36 @@ def test_incremental_topsort_with_lds_state_model_equals_kahn(lane_order):
     assert st["refills"] > st["reads"], st                 # the window did slide
     assert st["block_nodes"] > 3 * st["real_steps"], st    # most pops are replayed, not recomputed
     assert st["hbm_steps"] * 2 < st["real_steps"], st      # and most ordinary steps need no HBM round trip
+
+
+def test_banded_int16_scores_cannot_wrap_inside_the_type_selection_bounds():
+    """VERDICT r4 item 9 / ADVICE r3: is there an in-spec window whose banded int16 scores wrap (the kernels would end it with
+    generic_error, INTEGRATION.md section 5, where the reference returns a wrapped result)? A search at the edge of the type
+    selection -- the deepest graphs that still select int16 (max_nodes_per_graph 4352 at max_sequence_size 1024, scores
+    8 / -6 / -8: cudapoa_limits.hpp:34-59), filled by mutually unrelated reads so that every alignment is as bad as alignments
+    get -- finds none, and there is a bound behind it: a banded row whose band starts past column 0 takes min / 2 = -16384 as
+    its left boundary AFRESH in every row (cudapoa_nw_banded.cuh:158-175), so no cell of the band lies below
+    -16384 + min(mismatch, gap) + (band_width - 1) * gap (= -18 430 at band 256, -28 670 at the widest adaptive band of 1536
+    columns), and the rows whose band starts at column 0 are the first band_width / 2 / gradient rows, whose cells lie above
+    (rows + columns) * gap. A wrap needs scores outside the range the API documents (|gap| >= 11 at 1536 columns)."""
+    import random
+    cfg = O.make_cfg(1024, 32, 256, 1)
+    cfg.max_nodes_per_graph = 4352
+    cfg.matrix_sequence_dimension = 264
+    cfg.max_banded_pred_distance = 512
+    O.lib().poa_cfg_select_types(cfg)
+    assert cfg.score32 == 0  # still the int16 kernels
+    rng = random.Random(5)
+    with O.Workspace(cfg) as ws:
+        for n, length in ((12, 1000), (8, 1024), (14, 900)):
+            reads = ["".join(rng.choice("ACGT") for _ in range(length)) for _ in range(n)]
+            ref = ws.process(reads)
+            assert ref["status"] == 0 and ref["node_count"] > 2500
+        assert ws.overflow_events() == 0
+    acfg = O.make_cfg(1024, 32, 256, 2)   # adaptive band: widens for these gradients
+    acfg.max_nodes_per_graph = 4352
+    O.lib().poa_cfg_select_types(acfg)
+    with O.Workspace(acfg) as ws:
+        reads = ["".join(rng.choice("ACGT") for _ in range(1000)) for _ in range(10)]
+        ws.process(reads)
+        assert ws.overflow_events() == 0
