@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
             if constexpr (kFullPacked)
                 alen = nw_full_packed<IdT>(g, rowinfo, node_count, sequence, seq_len, reinterpret_cast<int16_t*>(scores), wd.scores_width, full_moves,
                                            smem, kRingBytes, reinterpret_cast<const uint64_t*>(lds_code_tile), alignment_graph, alignment_read,
-                                           c.gap_score, c.mismatch_score, c.match_score, cells, debug_flags, full_handled);
+                                           c.gap_score, c.mismatch_score, c.match_score, cells, debug_flags, full_handled, pc);
             if (!full_handled)
                 alen = nw_full<ScoreT, IdT, RowT>(g, rowinfo, node_count, sequence, seq_len, scores, wd.scores_width, ring, kRingBytes,
                                             alignment_graph, alignment_read, c.gap_score, c.mismatch_score, c.match_score, cells);

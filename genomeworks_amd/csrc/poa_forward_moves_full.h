@@ -121,7 +121,12 @@ __device__ __forceinline__ void full_forward_moves(const GraphView<IdT>& g, RowI
         V23 = pk_add(q23, GAP2);
     };
     auto pack_moves = [&](uint32_t m01, uint32_t m23) -> uint32_t { return __builtin_amdgcn_perm(m23, m01, 0x06040200u); };
-    // the finished row (P*) of row r with H[r][0] = c0: HBM score row, ring slot r & 3, move bytes
+    // timing ablations (GWHIP_DEBUG, debug instantiation only; results are garbage): bit 26 no score-row stores, bit 27 no
+    // move-row stores
+    const bool st_scores = !(dbg & (1 << 26)), st_moves = !(dbg & (1 << 27));
+    // the finished row (P*) of row r with H[r][0] = c0: HBM score row, ring slot r & 3, move bytes. Both HBM stores are
+    // streaming stores (round 5, same-box A/B on the 1024 windows: 59.0 -> 55.2 ms; the matrices of a full-band batch are 10 GB,
+    // far beyond every cache level, and the walk reads a sliver of the move rows)
     auto store_row = [&](int32_t r, int32_t c0, const uint32_t (&mv)[NP]) {
         score_ptr += stride2;
         move_ptr += stride;
@@ -129,15 +134,15 @@ __device__ __forceinline__ void full_forward_moves(const GraphView<IdT>& g, RowI
 #pragma unroll
         for (int p = 0; p < NP - 1; p++)
         {
-            *reinterpret_cast<uint2*>(score_ptr + 512 * p) = make_uint2(P01[p], P23[p]);
+            if (st_scores) gstore_nt_u64(score_ptr + 512 * p, P01[p], P23[p]);
             lds_store_u64(sbase + a1[p], P01[p], P23[p]);
-            *reinterpret_cast<uint32_t*>(move_ptr + 256 * p) = mv[p];
+            if (st_moves) __builtin_nontemporal_store(mv[p], reinterpret_cast<uint32_t*>(move_ptr + 256 * p));
         }
         lds_store_u64(sbase + a1[NP - 1], P01[NP - 1], P23[NP - 1]);
         if (act)
         {
-            *reinterpret_cast<uint2*>(score_ptr + 512 * (NP - 1))   = make_uint2(P01[NP - 1], P23[NP - 1]);
-            *reinterpret_cast<uint32_t*>(move_ptr + 256 * (NP - 1)) = mv[NP - 1];
+            if (st_scores) gstore_nt_u64(score_ptr + 512 * (NP - 1), P01[NP - 1], P23[NP - 1]);
+            if (st_moves) __builtin_nontemporal_store(mv[NP - 1], reinterpret_cast<uint32_t*>(move_ptr + 256 * (NP - 1)));
         }
         gstore_u16_lane0_below(score_ptr, (uint32_t)c0); // column 0
         c0ring  = lane == (int)((uint32_t)r & (kWdSlots - 1)) ? c0 : c0ring;
@@ -408,7 +413,7 @@ __device__ __forceinline__ int32_t nw_full_packed(const GraphView<IdT>& g, RowIn
                                                   int32_t read_length, int16_t* scores, int32_t scores_width, uint8_t* moves, uint8_t* ring,
                                                   int32_t ring_bytes, const uint64_t* xpred, int32_t* alignment_graph, int32_t* alignment_read,
                                                   int32_t gap_score, int32_t mismatch_score, int32_t match_score, uint64_t& cells, int32_t dbg,
-                                                  bool& handled)
+                                                  bool& handled, PhaseClock& pc)
 {
     const int lane = threadIdx.x & (kWave - 1);
     handled        = false;
@@ -434,6 +439,7 @@ __device__ __forceinline__ int32_t nw_full_packed(const GraphView<IdT>& g, RowIn
     else
         full_forward_moves<IdT, 1>(g, rowinfo, graph_count, read, read_length, scores, scores_width, moves, ring, xpred, gap_score, mismatch_score, match_score, dbg);
     wave_sync(); // matrices complete and visible to every lane
+    pc.tick(kPhForward);
 
     // sink selection (:320-337): first row with the strictly greatest H(row, L) among sink rows
     int32_t best = Limits<int16_t>::min, best_i = 0;

@@ -139,11 +139,11 @@ __device__ __forceinline__ void banded_forward_moves_wide(const GraphView<IdT>& 
         score_ptr += stride * 2;
         move_ptr += stride;
         const uint32_t sbase = ring_base + (((uint32_t)r & (kWdSlots - 1)) * kWdSlotBytes);
-        *reinterpret_cast<uint2*>(score_ptr) = make_uint2(PA01, PA23);
+        gstore_nt_u64(score_ptr, PA01, PA23);
         lds_store_u64(sbase + a1A, PA01, PA23);
         if (BW == 512 || bandB_lane)
         {
-            *reinterpret_cast<uint2*>(score_ptr + 512) = make_uint2(PB01, PB23);
+            gstore_nt_u64(score_ptr + 512, PB01, PB23);
             lds_store_u64(sbase + a1B, PB01, PB23);
         }
         if constexpr (BS0)
@@ -265,12 +265,12 @@ __device__ __forceinline__ void banded_forward_moves_wide(const GraphView<IdT>& 
         move_ptr += stride;
         const uint32_t sbase  = ring_base + (((uint32_t)r & (kWdSlots - 1)) * kWdSlotBytes);
         const uint32_t rel0pk = ((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)rel0_val << 16);
-        *reinterpret_cast<uint2*>(score_ptr) = make_uint2(PA01, PA23);
+        gstore_nt_u64(score_ptr, PA01, PA23);
         lds_store_u64(sbase + a1A, PA01, PA23);
         *reinterpret_cast<uint32_t*>(move_ptr) = 0u;
         if (BW == 512 || bandB_lane)
         {
-            *reinterpret_cast<uint2*>(score_ptr + 512) = make_uint2(PB01, PB23);
+            gstore_nt_u64(score_ptr + 512, PB01, PB23);
             lds_store_u64(sbase + a1B, PB01, PB23);
             *reinterpret_cast<uint32_t*>(move_ptr + 256) = 0u;
         }

@@ -90,11 +90,13 @@ private:
     struct Chunk
     {
         int32_t lo = 0, hi = 0;
+        int64_t first_offset = 0, span = 0; ///< sequence offset of the first pair, bytes of the chunk's sequences
         char* workspace        = nullptr;
         size_t workspace_bytes = 0, block_bytes = 0;
         void* uploaded         = nullptr; ///< hipEvent_t on the upload stream (null: uploaded on the aligner's own stream)
     };
     std::vector<Chunk> chunks_;
+    int64_t launched_total_length_ = 0;   ///< bases of the launched batch (the host arrays move to the views at sync_alignments())
     void* upload_stream_ = nullptr;       ///< hipStream_t, created with the first chunked batch
     std::vector<void*> upload_events_;    ///< hipEvent_t pool (timing disabled)
     char* d_seq_               = nullptr;

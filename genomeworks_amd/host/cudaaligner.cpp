@@ -264,7 +264,11 @@ StatusType BandedAligner::align_all()
     {
         chunks_[static_cast<size_t>(k)].lo = static_cast<int32_t>(static_cast<int64_t>(n) * k / n_chunks);
         chunks_[static_cast<size_t>(k)].hi = static_cast<int32_t>(static_cast<int64_t>(n) * (k + 1) / n_chunks);
+        Chunk& c       = chunks_[static_cast<size_t>(k)];
+        c.first_offset = seq_starts_h_[2 * static_cast<size_t>(c.lo)];
+        c.span         = seq_starts_h_[2 * static_cast<size_t>(c.hi)] - c.first_offset;
     }
+    launched_total_length_ = total_len;
     hipStream_t up = stream_;
     if (n_chunks > 1)
     {
@@ -360,11 +364,11 @@ void BandedAligner::launch_chunk(const Chunk& c)
     a.result_counts         = d_result_counts_;
     a.result_starts         = d_result_starts_ + lo;
     a.result_metadata       = d_metadata_ + lo;
-    a.results_capacity      = seq_starts_h_.back();
+    a.results_capacity      = launched_total_length_;
     a.workspace             = c.workspace;
     a.workspace_bytes       = c.workspace_bytes;
-    a.total_sequence_length = seq_starts_h_[2 * static_cast<size_t>(c.hi)] - seq_starts_h_[2 * lo];
-    a.first_sequence_offset = seq_starts_h_[2 * lo];
+    a.total_sequence_length = c.span;
+    a.first_sequence_offset = c.first_offset;
     a.index_base            = c.lo;
     a.result_starts_base    = c.lo > 0 ? d_result_starts_ + lo : nullptr; // written by the chunk before this one
     a.scheduling_index      = d_order_ + lo;
@@ -395,7 +399,7 @@ void BandedAligner::fetch_head()
     // result offsets and metadata follow the kernels to the host (pinned), as the reference's align_all() does with its
     // result_starts (aligner_global_myers_banded.cpp:372-374): sync_alignments() and get_alignments_device() read
     // them after the stream has drained
-    const size_t un = static_cast<size_t>(num_alignments());
+    const size_t un = chunks_.empty() ? 0 : static_cast<size_t>(chunks_.back().hi);
     if (head_ == nullptr || head_cap_ < (2 * un + 1) * 4) // (sync_alignments() hands the buffer to the views' block)
     {
         if (head_ != nullptr) pinned_release(head_, head_cap_);
