@@ -656,7 +656,8 @@ def bench_reference_shapes(windows, local_rank, sync, steps):
               "cells": cells, "kernel_ms": round(k_ms, 2),
               "roofline": {"bound": "hbm", "kernel": "poa_window_kernel<int16,int16,full_band>", "achieved": round(cells * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9, 2),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(cells * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                           "algorithmic_bytes_per_cell": BYTES_PER_CELL, "kernel_ms": round(k_ms, 3)},
+                           "algorithmic_bytes_per_cell": BYTES_PER_CELL, "kernel_ms": round(k_ms, 3), "traffic": sub_traffic("full_band")},
+              "roofline_issue": roofline_issue("full_band"),
               "windows_equal_oracle_golden": int((fp == fgold["fingerprint"]).sum()) if len(windows) == fsum["windows"] else None,
               "equals_oracle_golden": bool(len(windows) == fsum["windows"] and G.band_gen.cell_digest(fp) == fsum["fingerprint_sha256"]
                                            and cells == fsum["cells"])}

@@ -10,6 +10,7 @@
 #   bench        the driver's bench line (BENCH_ARGS, default none = the full line with all sub-records)
 #   stats        rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline $STATS_ARGS` -> kernel_stats.csv
 #   pmc          tools/pmc_passes.sh with PASSES (default "insts waits lds fetch write") and SUBS (default none)
+#   pmcfull      the same passes over the full-band kernel alone (tools/profile_phases.py 1024 full_band) -> pmc_summary_full_band.csv
 #   traffic      derive pmc_profile.json (HBM traffic, issue and LDS counters per record) from the pmc step's summary; pass
 #                GW_COMMIT=$(git rev-parse --short HEAD) from the submitting side (the box has no .git)
 #   extra        run $EXTRA_CMD (one-off measurements)
@@ -64,8 +65,15 @@ if has pmc; then
     grep -c . $OUT/pmc_summary.csv
     grep -E "LDS|WAIT_ANY|WAVE_CYCLES|FETCH|WRITE_SIZE" $OUT/pmc_summary.csv | cut -c1-170 | head -60
 fi
+if has pmcfull; then
+    # the full-band kernel of the reference benchmarks' BatchConfig(1024, 200) on the 1024 metric windows, alone
+    PMC_CMD="python $REPO/tools/profile_phases.py 1024 full_band" PASSES="${PASSES:-insts waits lds fetch write}" bash tools/pmc_passes.sh $OUT/pmcfull > $OUT/pmcfull.log 2>&1
+    python tools/pmc_summary.py $OUT/pmcfull > $OUT/pmc_summary_full_band.csv 2>/dev/null
+    rm -rf $OUT/pmcfull
+    grep -E "WAVE_CYCLES|FETCH|WRITE_SIZE|WAIT_ANY" $OUT/pmc_summary_full_band.csv | cut -c1-170 | head -12
+fi
 if has traffic; then
-    python tools/pmc_profile.py $OUT/pmc_summary.csv "$TAG" $OUT "${GW_COMMIT:-unknown}"
+    python tools/pmc_profile.py $OUT/pmc_summary.csv "$TAG" $OUT "${GW_COMMIT:-unknown}" $OUT/pmc_summary_full_band.csv
 fi
 if has extra; then
     bash -c "${EXTRA_CMD:-true}" > $OUT/extra.log 2>&1; echo "extra rc=$?"; tail -${EXTRA_TAIL:-30} $OUT/extra.log

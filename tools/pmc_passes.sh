@@ -8,6 +8,8 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # SUBS: the sub-records whose kernels should run under the counters as well (aligner, default_aligner, long_reads)
 CMD="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --sub-configs ${SUBS:-none}"
+# PMC_CMD: another command to run under the counters instead (e.g. "python $REPO/tools/profile_phases.py 1024 full_band")
+[ -n "${PMC_CMD:-}" ] && CMD="$PMC_CMD"
 PASSES=${PASSES:-all}
 pass() { name=$1; shift; case " $PASSES " in *" all "*|*" $name "*) ;; *) return;; esac; timeout ${PASS_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$REPO/$OUT/$name" -o $name -- $CMD > "$REPO/$OUT/$name.log" 2>&1; echo "$name rc=$?"; }
 pass insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES

@@ -14,6 +14,11 @@ import sys
 rows = {}
 for r in csv.DictReader(open(sys.argv[1])):
     rows.setdefault(r["kernel"], {})[r["counter"]] = (float(r["mean_per_dispatch"]), int(r["dispatches"]))
+# optional fifth argument: the summary of the passes over the full-band kernel alone (gpu_session.sh step pmcfull); its kernel
+# names get a prefix so that they cannot mix with the main session's
+if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
+    for r in csv.DictReader(open(sys.argv[5])):
+        rows.setdefault("full_band_session::" + r["kernel"], {})[r["counter"]] = (float(r["mean_per_dispatch"]), int(r["dispatches"]))
 tag = sys.argv[2] if len(sys.argv) > 2 else "session"
 out_dir = sys.argv[3] if len(sys.argv) > 3 else "."
 commit = sys.argv[4] if len(sys.argv) > 4 else os.environ.get("GW_COMMIT", "unknown")
@@ -76,7 +81,9 @@ out = {"tag": tag, "commit": commit,
        "source": "rocprofv3 --kernel-trace --pmc, one counter group per pass (tools/pmc_passes.sh: insts, waits, lds, fetch, write) over "
                  "`bench.py --steps 1 --warmup 0 --no-cpu-baseline --sub-configs aligner,default_aligner,long_reads`; FETCH_SIZE x 2 and "
                  "WRITE_SIZE x 0.97 as calibrated in profiles/r03_pmc_traffic.json on microkernels of known size"}
-for key, e in (("headline", entry(lambda k: "poa_window_kernel<short, short, signed char, 1, false, tru" in k)),
+for key, e in (("headline", entry(lambda k: "poa_window_kernel<short, short, signed char, 1, false, tru" in k and not k.startswith("full_band_session::"))),
+               ("full_band", entry(lambda k: k.startswith("full_band_session::") and "poa_window_kernel<short, short, signed char, 0, false, tru" in k, "mean",
+                                   "the 1024 metric windows under BatchConfig(1024, 200), launches of the full batch only")),
                ("configs[1]", entry(lambda k: "myers_banded_group_kernel" in k)),
                ("configs[4]", entry(lambda k: "myers_banded_kernel<true>" in k)),
                ("default_aligner", entry(lambda k: "hirschberg_levels_kernel" in k or "hirschberg_wave_kernel" in k or "hb_span_" in k, "sum",
