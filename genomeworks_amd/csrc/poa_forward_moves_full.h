@@ -40,6 +40,33 @@ __device__ __forceinline__ void full_forward_moves(const GraphView<IdT>& g, RowI
 
     classify_kinds<kWdMaxDist>(rowinfo, graph_count, lane, xpred, dbg); // band starts are 0 in every row: kinds 0, 2, 3, 4
     wave_sync();
+    // Which rows' SCORES anybody will read back from HBM (bit 63 of the row word): the predecessors of general rows (they come
+    // from the HBM matrix), every row that may hold undecided cells -- general rows and rows with more than three predecessors --
+    // together with its predecessors (the walk steps such cells by recomputation from the row and its predecessor rows), and
+    // the sink rows (sink selection). Everything else -- 98 % of the rows of the metric windows -- keeps its score row out of
+    // HBM altogether: move bytes, ring and registers carry it. Column 0 is stored for every row (the walk along column 0).
+    // GWHIP_DEBUG bit 25 (debug instantiation): every row stores its scores (A/B).
+    {
+        auto mark = [&](int32_t row) {
+            __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(&rowinfo[row].w) + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        for (int32_t r = 1 + lane; r <= graph_count; r += kWave)
+        {
+            const uint64_t w    = rowinfo[r].w;
+            const uint32_t kind = (uint32_t)(w >> kKindShift) & 7u;
+            const int32_t cnt   = (int32_t)((w >> 8) & 0x3fu);
+            const bool reads_or_recomputes = kind >= 4u || cnt > 3;
+            if (reads_or_recomputes || ((w >> 14) & 1u) != 0 || (dbg & (1 << 25))) mark(r);
+            if (reads_or_recomputes)
+            {
+                const int32_t node_id = cnt > 3 ? (int32_t)g.sorted_poa[r - 1] : 0;
+                for (int32_t k = 0; k < cnt; k++)
+                    mark(k < 3 ? (int32_t)((w >> (24 + 12 * k)) & 0xfffu)
+                               : (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + k]] + 1);
+            }
+        }
+        wave_sync();
+    }
 
     const uint32_t GAP2   = pin_vgpr(pk_dup(gap_score));
     const uint32_t MAT2   = pin_vgpr(pk_dup(match_score));
@@ -127,30 +154,31 @@ __device__ __forceinline__ void full_forward_moves(const GraphView<IdT>& g, RowI
     // the finished row (P*) of row r with H[r][0] = c0: HBM score row, ring slot r & 3, move bytes. Both HBM stores are
     // streaming stores (round 5, same-box A/B on the 1024 windows: 59.0 -> 55.2 ms; the matrices of a full-band batch are 10 GB,
     // far beyond every cache level, and the walk reads a sliver of the move rows)
-    auto store_row = [&](int32_t r, int32_t c0, const uint32_t (&mv)[NP]) {
+    auto store_row = [&](int32_t r, int32_t c0, const uint32_t (&mv)[NP], bool need_scores) {
         score_ptr += stride2;
         move_ptr += stride;
         const uint32_t sbase = ring_base + (((uint32_t)r & (kWdSlots - 1)) * kWdSlotBytes);
+        if (need_scores && st_scores) // (wave-uniform: one row in fifty)
+        {
+#pragma unroll
+            for (int p = 0; p < NP - 1; p++) gstore_nt_u64(score_ptr + 512 * p, P01[p], P23[p]);
+            if (act) gstore_nt_u64(score_ptr + 512 * (NP - 1), P01[NP - 1], P23[NP - 1]);
+        }
 #pragma unroll
         for (int p = 0; p < NP - 1; p++)
         {
-            if (st_scores) gstore_nt_u64(score_ptr + 512 * p, P01[p], P23[p]);
             lds_store_u64(sbase + a1[p], P01[p], P23[p]);
             if (st_moves) __builtin_nontemporal_store(mv[p], reinterpret_cast<uint32_t*>(move_ptr + 256 * p));
         }
         lds_store_u64(sbase + a1[NP - 1], P01[NP - 1], P23[NP - 1]);
-        if (act)
-        {
-            if (st_scores) gstore_nt_u64(score_ptr + 512 * (NP - 1), P01[NP - 1], P23[NP - 1]);
-            if (st_moves) __builtin_nontemporal_store(mv[NP - 1], reinterpret_cast<uint32_t*>(move_ptr + 256 * (NP - 1)));
-        }
+        if (act && st_moves) __builtin_nontemporal_store(mv[NP - 1], reinterpret_cast<uint32_t*>(move_ptr + 256 * (NP - 1)));
         gstore_u16_lane0_below(score_ptr, (uint32_t)c0); // column 0
         c0ring  = lane == (int)((uint32_t)r & (kWdSlots - 1)) ? c0 : c0ring;
         prev_c0 = c0;
     };
 
     // ---------------- kind 0: one predecessor, the previous row, in registers ----------------
-    auto reg_row = [&](int32_t r, uint32_t base4) {
+    auto reg_row = [&](int32_t r, uint32_t base4, bool need_scores) {
         uint32_t s01[NP], s23[NP], D01[NP], D23[NP], V01[NP], V23[NP];
 #pragma unroll
         for (int p = 0; p < NP; p++)
@@ -175,7 +203,7 @@ __device__ __forceinline__ void full_forward_moves(const GraphView<IdT>& g, RowI
             const uint32_t m23 = pk_mad_u16(nz(P23[p], D23[p]), pk_mad_u16(nz(P23[p], V23[p]), NEG1, NEG1), THREE2);
             mv[p]              = pack_moves(m01, m23);
         }
-        store_row(r, c0, mv);
+        store_row(r, c0, mv, need_scores);
     };
 
     // ---------------- kind 4: any predecessors, from the HBM matrix, same packed arithmetic, moves undecided ----------------
@@ -222,7 +250,7 @@ __device__ __forceinline__ void full_forward_moves(const GraphView<IdT>& g, RowI
         uint32_t mv[NP];
 #pragma unroll
         for (int p = 0; p < NP; p++) mv[p] = 0u;
-        store_row(r, c0, mv);
+        store_row(r, c0, mv, true);
     };
 
     // ---------------- the rows ----------------
@@ -240,7 +268,7 @@ __device__ __forceinline__ void full_forward_moves(const GraphView<IdT>& g, RowI
             const uint32_t p0 = (uint32_t)(w >> 24) & 0xfffu, p1 = (uint32_t)(w >> 36) & 0xfffu, p2 = (uint32_t)(w >> 48) & 0xfffu;
             const uint32_t slots = (p0 & 3u) | ((p1 & 3u) << 3) | ((p2 & 3u) << 6);
             const uint32_t dists = (((uint32_t)rr - p0) & 7u) | ((((uint32_t)rr - p1) & 7u) << 3) | ((((uint32_t)rr - p2) & 7u) << 6);
-            D0v = kind | (slots << 12) | (dists << 21) | ((cnt <= 3 ? cnt : 0u) << 30);
+            D0v = kind | ((uint32_t)(w >> 63) << 3) | (slots << 12) | (dists << 21) | ((cnt <= 3 ? cnt : 0u) << 30); // bit 3: scores to HBM
             D1v = ((uint32_t)w & 0xffu) * 0x01010101u;
         }
         D0v = (r0 + lane <= graph_count) ? D0v : 7u; // rows past the end read as kind 7 = "end of block"
@@ -260,7 +288,7 @@ __device__ __forceinline__ void full_forward_moves(const GraphView<IdT>& g, RowI
         {
             while (kind == 0)
             {
-                reg_row(r, base4);
+                reg_row(r, base4, (d0 & 8u) != 0);
                 advance();
             }
             if (kind == 7u) break;
@@ -307,7 +335,7 @@ __device__ __forceinline__ void full_forward_moves(const GraphView<IdT>& g, RowI
                         const uint32_t m23 = pk_mad_u16_vvs(nz(P23[p], D23[p]), pk_mad_u16_vsv(nz(P23[p], V23[p]), cV, NEG1), cD);
                         mv[p]              = pack_moves(m01, m23);
                     }
-                    store_row(r, c0, mv);
+                    store_row(r, c0, mv, (d0 & 8u) != 0);
                 }
                 else
                 {
@@ -393,7 +421,7 @@ __device__ __forceinline__ void full_forward_moves(const GraphView<IdT>& g, RowI
 #pragma unroll
                     for (int p = 0; p < NP; p++)
                         mv[p] = pack_moves(move_of(P01[p], bD01[p], bV01[p], A01[p], B01[p]), move_of(P23[p], bD23[p], bV23[p], A23[p], B23[p]));
-                    store_row(r, c0, mv);
+                    store_row(r, c0, mv, (d0 & 8u) != 0);
                 }
             }
             else

@@ -733,7 +733,10 @@ def test_full_band_packed_pass_equals_the_generic_routine_and_the_oracle(monkeyp
     out = {}
     arms = (("production", None), ("registers_through_ring", str(1 << 10)), ("ring_through_general", str(1 << 9)),
             ("registers_through_general", str(1 << 11)), ("many_predecessors_general", str(1 << 30)),
-            ("everything_general", str((1 << 9) | (1 << 11) | (1 << 30))), ("generic_nw_full", str(1 << 8)))
+            ("everything_general", str((1 << 9) | (1 << 11) | (1 << 30))), ("generic_nw_full", str(1 << 8)),
+            # the production pass writes a score row to HBM only when somebody will read it back (general rows' predecessors,
+            # rows with undecided cells and their predecessors, sinks): bit 25 stores every row
+            ("every_row_stores_scores", str(1 << 25)), ("every_row_stores_scores_ring_through_general", str((1 << 25) | (1 << 9))))
     for name, flag in arms:
         if flag is None:
             monkeypatch.delenv("GWHIP_DEBUG", raising=False)
