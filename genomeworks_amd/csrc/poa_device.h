@@ -2044,6 +2044,7 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
 
     constexpr bool kFastOk = std::is_same<RowT, RowInfo<true>>::value && LDS_READ;
     bool fast_done = false, codes_valid = false, moves_valid = false;
+    bool packed_selective = false; // the packed pass of band 256 / 128 ran and kept the score rows nobody reads out of HBM
     bool wrapped = false; // a score did not fit the matrix type (narrow_chk)
     if constexpr (kFastOk && std::is_same<ScoreT, int16_t>::value)
     {
@@ -2072,13 +2073,19 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
                                                         reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score, dbg);
             }
             else if (band_width == 256)
+            {
                 banded_forward_moves<IdT, 256>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
                                                reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score,
-                                               dbg, pc.acc ? &pc.acc[kPhOther] : nullptr);
+                                               dbg, pc.acc ? &pc.acc[kPhOther] : nullptr, (dbg & (1 << 25)) != 0);
+                packed_selective = !(dbg & (1 << 25));
+            }
             else if constexpr (PV == 1)
+            {
                 banded_forward_moves<IdT, 128>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
                                                reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score,
-                                               dbg, pc.acc ? &pc.acc[kPhOther] : nullptr);
+                                               dbg, pc.acc ? &pc.acc[kPhOther] : nullptr, (dbg & (1 << 25)) != 0);
+                packed_selective = !(dbg & (1 << 25));
+            }
             fast_done   = true;
             moves_valid = true;
         }
@@ -2386,7 +2393,28 @@ __device__ __forceinline__ int32_t nw_banded(const GraphView<IdT>& g, RowT* rowi
         {
             aligned_nodes = traceback_moves<int16_t, IdT, RowInfo<true>, ADAPTIVE>(b, g, rowinfo, graph_count, lds_read, read_length, wave_first(best_i),
                                                            alignment_graph, alignment_read, gap_score, mismatch_score, match_score,
-                                                           rerun, reinterpret_cast<uint8_t*>(ring_base), codes);
+                                                           rerun, reinterpret_cast<uint8_t*>(ring_base), codes, nullptr,
+                                                           packed_selective ? ((dbg & (1 << 23)) ? 2 : 0) : 1);
+            if (aligned_nodes == kNwNeedScoreRows)
+            {
+                // the walk met a cell it has to step by recomputation in a row whose scores stayed out of HBM (the band's first
+                // cell, a chunk outside a predecessor's band): the same pass again with every row stored, then the same walk
+                // (GWHIP_DEBUG, debug instantiation: bit 24 counts these reruns into the "other" phase accumulator, bit 23 makes
+                // every recomputed step below row 0 take this path, bit 25 stores every row in the first place)
+                if (pc.acc && (dbg & (1 << 24))) pc.acc[kPhOther] += 1;
+                if (band_width == 256)
+                    banded_forward_moves<IdT, 256>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
+                                                   reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score,
+                                                   dbg, nullptr, true);
+                else if constexpr (PV == 1)
+                    banded_forward_moves<IdT, 128>(g, rowinfo, graph_count, lds_read, scores, codes, reinterpret_cast<uint8_t*>(ring_base),
+                                                   reinterpret_cast<const uint64_t*>(code_tile), max_column, gap_score, mismatch_score, match_score,
+                                                   dbg, nullptr, true);
+                wave_sync();
+                aligned_nodes = traceback_moves<int16_t, IdT, RowInfo<true>, ADAPTIVE>(b, g, rowinfo, graph_count, lds_read, read_length, wave_first(best_i),
+                                                               alignment_graph, alignment_read, gap_score, mismatch_score, match_score,
+                                                               rerun, reinterpret_cast<uint8_t*>(ring_base), codes, nullptr, 1);
+            }
             tb_done = true;
         }
     }

@@ -112,6 +112,44 @@ __device__ __forceinline__ int32_t classify_kinds(RowInfo<true>* rowinfo, int32_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Which rows' SCORES anybody will read back from HBM (round 5; bit 63 of the row word): the predecessors of general rows (they
+// come from the HBM matrix), every row whose cells the walk may have to step by recomputation -- general rows and rows with more
+// than three predecessors -- together with its predecessors, and the sink rows (sink selection). Every other row keeps its
+// score row out of HBM: move bytes, ring and registers carry it (a launch of the metric batch used to write 22.6 GB of score
+// rows of which well under 1 GB is ever read). Needs the row kinds in the table. all_rows: mark everything (A/B, reruns).
+// ------------------------------------------------------------------------------------------------
+constexpr uint64_t kRowScoresInHbm = 1ull << 63;
+template <typename IdT>
+__device__ __forceinline__ void mark_score_rows(const GraphView<IdT>& g, RowInfo<true>* rowinfo, int32_t graph_count, int lane, bool all_rows)
+{
+    auto mark = [&](int32_t row) {
+        __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(&rowinfo[row].w) + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    for (int32_t r = 1 + lane; r <= graph_count; r += kWave)
+    {
+        const uint64_t w    = rowinfo[r].w;
+        const uint32_t kind = (uint32_t)(w >> kKindShift) & 7u;
+        const int32_t cnt   = (int32_t)((w >> 8) & 0x3fu);
+        const bool reads_or_recomputes = kind >= 4u || cnt > 3;
+        if (reads_or_recomputes || ((w >> 14) & 1u) != 0 || all_rows) mark(r);
+        if (reads_or_recomputes)
+        {
+            const int32_t node_id = cnt > 3 ? (int32_t)g.sorted_poa[r - 1] : 0;
+            for (int32_t k = 0; k < cnt; k++)
+                mark(k < 3 ? (int32_t)((w >> (24 + 12 * k)) & 0xfffu) : (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + k]] + 1);
+        }
+    }
+    wave_sync();
+}
+// the walk may step a cell of this row by recomputation: the row and its predecessors have their scores in HBM -- marked
+// above, or a row whose band starts at column 0 (those store their scores anyway, and so do their predecessors, whose bands
+// cannot start further right; every walk ends there, in the band's first column)
+__device__ __forceinline__ bool row_recompute_safe(uint64_t w)
+{
+    return ((uint32_t)(w >> kKindShift) & 7u) >= 4u || ((w >> 8) & 0x3fu) > 3u || ((w >> 15) & 0x1ffu) == 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
 // The forward pass. `ring` is kPkSlots * kPkSlotBytes of LDS at LDS address 0 .. (the launcher's carve puts the ring
 // first); `scores` the HBM score matrix and `moves` the HBM move-byte matrix (row stride 264 elements / bytes);
 // lds_read the LDS copy of the read.
@@ -125,7 +163,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
                                                      const uint8_t* lds_read, int16_t* scores, uint8_t* moves, uint8_t* ring,
                                                      const uint64_t* xpred, int32_t max_column, int32_t gap_score,
                                                      int32_t mismatch_score, int32_t match_score, int32_t dbg,
-                                                     uint64_t* prof_acc)
+                                                     uint64_t* prof_acc, bool store_all = true)
 {
     // timing ablations (GWHIP_DEBUG, debug instantiation only; results are only meaningful on a relaunch over the
     // buffers of an unablated launch of the same batch): bit 26 no score-row stores, bit 27 no move-row stores
@@ -150,6 +188,9 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
 
     const int32_t first_moved = classify_kinds(rowinfo, graph_count, lane, xpred, dbg);
     wave_sync();
+    // rows past the first band move write their score row to HBM only when it will be read back (mark_score_rows); the rows
+    // whose band starts at column 0 (a tenth of them) keep storing theirs together with the real left-boundary value
+    mark_score_rows<IdT>(g, rowinfo, graph_count, lane, store_all);
 
     const uint32_t MIN2   = pin_vgpr(pk_dup(min_score));
     const uint32_t SENT2  = pin_vgpr(pk_dup(kPkSentinel));
@@ -189,7 +230,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
     uint32_t a1   = (uint32_t)lane8;
     uint32_t ga   = (a1 + guard_off) & (kPkSlotBytes - 1);
     // per-lane pointers to the lane's quad in the HBM score row / to its four bytes in the move row of the CURRENT row
-    uint8_t* score_ptr = reinterpret_cast<uint8_t*>(scores) + lane8 + 2 * (1 + kRelShift);
+    uint8_t* const score_base = reinterpret_cast<uint8_t*>(scores) + lane8 + 2 * (1 + kRelShift); // the lane's quad in row 0
     uint8_t* move_ptr  = moves + lane4 + (1 + kRelShift);
 
     // row 0 into ring slot 0
@@ -229,18 +270,21 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
         V23 = pk_add(q23, GAP2);
     };
     // the finished row (P01/P23) of row r: HBM score row, ring slot r & 7 with its guard quad, and its move bytes
-    auto store_row = [&](auto bs0_tag, int32_t r, int32_t rel0_val, uint32_t mv4) {
+    auto store_row = [&](auto bs0_tag, int32_t r, int32_t rel0_val, uint32_t mv4, bool scores_to_hbm) {
         constexpr bool BS0 = decltype(bs0_tag)::value;
-        score_ptr += stride * 2;
         move_ptr += stride;
         const uint32_t sbase = ring_base + (((uint32_t)r & (kPkSlots - 1)) * kPkSlotBytes);
-        if (st_scores && (BW == 256 || band_lane)) gstore_nt_u64(score_ptr, P01, P23);
+        if (BS0 || __builtin_expect(scores_to_hbm, 0)) // (wave-uniform)
+        {
+            uint8_t* score_ptr = score_base + (uint32_t)r * (uint32_t)(stride * 2);
+            if (st_scores && (BW == 256 || band_lane)) gstore_nt_u64(score_ptr, P01, P23);
+            if constexpr (BS0) gstore_u16_lane0_below(score_ptr, (uint32_t)rel0_val); // a real left-boundary value
+        }
         if (ab_ring && (BW == 256 || band_lane)) lds_store_u64(sbase + a1, P01, P23);
         if constexpr (BS0)
         {
             const uint32_t rel0pk = ((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)rel0_val << 16);
             if (ab_guard) lds_store_guard(sbase + ga, SENT2, is_lane16 ? rel0pk : SENT2);
-            gstore_u16_lane0_below(score_ptr, (uint32_t)rel0_val); // a real left-boundary value
             prev_rel0 = rel0_val;
         }
         else if (ab_guard)
@@ -344,7 +388,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
         }
         scan_row(pk_make(s0, s1), pk_make(s2, s3), fe + gap_score);
         // stores (either flavour of left boundary)
-        score_ptr += stride * 2;
+        uint8_t* score_ptr = score_base + (uint32_t)r * (uint32_t)(stride * 2);
         move_ptr += stride;
         const uint32_t sbase  = ring_base + (((uint32_t)r & (kPkSlots - 1)) * kPkSlotBytes);
         const uint32_t rel0pk = ((uint32_t)kPkSentinel & 0xffffu) | ((uint32_t)rel0_val << 16);
@@ -360,7 +404,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
     };
 
     // ---------------- kinds 0 / 1: one predecessor, the previous row, in registers ----------------
-    auto reg_row = [&](auto bs0_tag, auto moved_tag, int32_t r, uint32_t d0, uint32_t base4) {
+    auto reg_row = [&](auto bs0_tag, auto moved_tag, int32_t r, uint32_t d0, uint32_t base4, bool scores_to_hbm) {
         constexpr bool BS0   = decltype(bs0_tag)::value;
         constexpr bool MOVED = decltype(moved_tag)::value;
         uint32_t s0x, q01, q23;
@@ -401,7 +445,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
         const uint32_t m23 = pk_mad_u16(nz(P23, D23), pk_mad_u16(nz(P23, V23), NEG1, NEG1), THREE2);
         uint32_t mv4 = ab_moves ? pack_moves(m01, m23) : 0u;
         if constexpr (MOVED) mv4 = is_lane63 ? 0u : mv4;
-        store_row(bs0_tag, r, rel0_val, mv4);
+        store_row(bs0_tag, r, rel0_val, mv4, scores_to_hbm);
     };
 
     // ---------------- the rows of one phase ----------------
@@ -427,6 +471,8 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
             }
             // rows past the end of the phase read as kind 7 = "end of block"
             D0v = (r0 + lane <= r_to) ? D0v : 7u;
+            // bit j: row r0 + j writes its score row to HBM (mark_score_rows)
+            const uint64_t need64 = BS0 ? ~0ull : __ballot((rowinfo[min(r0 + lane, graph_count)].w & kRowScoresInHbm) != 0);
             int32_t k      = 0;
             uint32_t d0    = (uint32_t)__builtin_amdgcn_readlane((int32_t)D0v, 0);
             uint32_t base4 = (uint32_t)__builtin_amdgcn_readlane((int32_t)D1v, 0);
@@ -446,15 +492,16 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
                 const int32_t r_k0  = r;
                 while (kind == 0)
                 {
-                    reg_row(bs0_tag, std::false_type{}, r, d0, base4);
+                    reg_row(bs0_tag, std::false_type{}, r, d0, base4, ((need64 >> k) & 1ull) != 0);
                     advance();
                 }
                 if (ksel == 0) kacc += kcount ? (uint64_t)(r - r_k0) : clock64() - t_k0;
                 if (kind == 7u) break;
                 const int32_t kind_now = (int32_t)min(kind, 4u);
                 const uint64_t t_kx    = ksel == kind_now ? clock64() : 0;
+                const bool scores_to_hbm = ((need64 >> k) & 1ull) != 0;
                 if (kind == 1)
-                    reg_row(bs0_tag, std::true_type{}, r, d0, base4);
+                    reg_row(bs0_tag, std::true_type{}, r, d0, base4, scores_to_hbm);
                 else if (kind <= 3)
                 {
                     // ===== predecessors from the LDS ring =====
@@ -489,7 +536,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
                         const uint32_t m01 = pk_mad_u16_vvs(nz(P01, D01), pk_mad_u16_vsv(nz(P01, V01), cV, NEG1), cD);
                         const uint32_t m23 = pk_mad_u16_vvs(nz(P23, D23), pk_mad_u16_vsv(nz(P23, V23), cV, NEG1), cD);
                         const uint32_t mv4 = outside ? 0u : pack_moves(m01, m23);
-                        store_row(bs0_tag, r, rel0_val, mv4);
+                        store_row(bs0_tag, r, rel0_val, mv4, scores_to_hbm);
                     }
                     else
                     {
@@ -594,7 +641,7 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
                         const uint32_t m01 = move_of(P01, bD01, bV01, A01, B01);
                         const uint32_t m23 = move_of(P23, bD23, bV23, A23, B23);
                         const uint32_t mv4 = undecided ? 0u : pack_moves(m01, m23);
-                        store_row(bs0_tag, r, rel0_val, mv4);
+                        store_row(bs0_tag, r, rel0_val, mv4, scores_to_hbm);
                     }
                 }
                 else

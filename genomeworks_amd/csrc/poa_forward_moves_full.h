@@ -40,33 +40,10 @@ __device__ __forceinline__ void full_forward_moves(const GraphView<IdT>& g, RowI
 
     classify_kinds<kWdMaxDist>(rowinfo, graph_count, lane, xpred, dbg); // band starts are 0 in every row: kinds 0, 2, 3, 4
     wave_sync();
-    // Which rows' SCORES anybody will read back from HBM (bit 63 of the row word): the predecessors of general rows (they come
-    // from the HBM matrix), every row that may hold undecided cells -- general rows and rows with more than three predecessors --
-    // together with its predecessors (the walk steps such cells by recomputation from the row and its predecessor rows), and
-    // the sink rows (sink selection). Everything else -- 98 % of the rows of the metric windows -- keeps its score row out of
-    // HBM altogether: move bytes, ring and registers carry it. Column 0 is stored for every row (the walk along column 0).
-    // GWHIP_DEBUG bit 25 (debug instantiation): every row stores its scores (A/B).
-    {
-        auto mark = [&](int32_t row) {
-            __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(&rowinfo[row].w) + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        for (int32_t r = 1 + lane; r <= graph_count; r += kWave)
-        {
-            const uint64_t w    = rowinfo[r].w;
-            const uint32_t kind = (uint32_t)(w >> kKindShift) & 7u;
-            const int32_t cnt   = (int32_t)((w >> 8) & 0x3fu);
-            const bool reads_or_recomputes = kind >= 4u || cnt > 3;
-            if (reads_or_recomputes || ((w >> 14) & 1u) != 0 || (dbg & (1 << 25))) mark(r);
-            if (reads_or_recomputes)
-            {
-                const int32_t node_id = cnt > 3 ? (int32_t)g.sorted_poa[r - 1] : 0;
-                for (int32_t k = 0; k < cnt; k++)
-                    mark(k < 3 ? (int32_t)((w >> (24 + 12 * k)) & 0xfffu)
-                               : (int32_t)g.node_id_to_pos[g.incoming_edges[(int64_t)node_id * kEdges + k]] + 1);
-            }
-        }
-        wave_sync();
-    }
+    // a score row goes to HBM only when somebody will read it back (mark_score_rows, poa_forward_moves.h): 98 % of the rows of
+    // the metric windows keep theirs in move bytes, ring and registers. Column 0 is stored for every row (the walk along column
+    // 0). GWHIP_DEBUG bit 25 (debug instantiation): every row stores its scores (A/B).
+    mark_score_rows<IdT>(g, rowinfo, graph_count, lane, (dbg & (1 << 25)) != 0);
 
     const uint32_t GAP2   = pin_vgpr(pk_dup(gap_score));
     const uint32_t MAT2   = pin_vgpr(pk_dup(match_score));

@@ -25,6 +25,7 @@ constexpr int kMaxAdaptiveBand = 1536;
 constexpr int kShiftLeft = -10, kShiftRight = -11;
 constexpr int kNwLoopFailed = -1, kNwAdaptiveStorageFailed = -2, kNwTracebackBufferFailed = -3;
 constexpr int kNwScoreWrapped = -5;   // a score did not fit the int16 matrix (narrow_chk, poa_device.h): the reference's result would depend on its relaxation order
+constexpr int kNwNeedScoreRows = -6;  // the walk over move bytes needs a score row the forward pass kept out of HBM: nw_banded reruns the pass storing every row
 constexpr int kNwPipelineFailed = -4; // the multi-wave forward pass gave up on a bounded hand-over wait (protocol error, never expected)
 constexpr uint8_t kKernelError = 0xFF;
 

@@ -65,7 +65,7 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<ScoreT>& b, c
                                                    int32_t graph_count, const uint8_t* read, int32_t read_length, int32_t start_i,
                                                    int32_t* alignment_graph, int32_t* alignment_read, int32_t gap_score,
                                                    int32_t mismatch_score, int32_t match_score, int32_t rerun, uint8_t* tile_region,
-                                                   const uint8_t* moves, const uint8_t* plane1 = nullptr)
+                                                   const uint8_t* moves, const uint8_t* plane1 = nullptr, int32_t score_rows = 1)
 {
     constexpr bool kWide    = !std::is_same<RowT, RowInfo<true>>::value;
     constexpr int kMtStride = MtGeometry<kWide>::kStride, kMtZeroRows = MtGeometry<kWide>::kZeroRows;
@@ -325,6 +325,19 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<ScoreT>& b, c
             pred_count    = ri.cnt();
             pr0 = ri.pred(0); pr1 = ri.pred(1); pr2 = ri.pred(2);
         }
+        // score_rows: 1 = every score row is in HBM; 0 (round 5, the 256 / 128-column pass) = the forward pass kept the rows
+        // nobody was known to read out of HBM (mark_score_rows). A cell of such a row that must be stepped by recomputation --
+        // the band's first cell, a chunk outside a predecessor's band: the walk rarely passes through either outside the rows
+        // whose band starts at column 0 -- ends this walk; nw_banded reruns the forward pass with every row stored and walks
+        // again. 2 = as 0, but EVERY recomputed step below row 0 ends the walk (test arm: the rerun path on every read).
+        if constexpr (!kWide && MODE == 0)
+        {
+            if (score_rows != 1 && i != 0 && (score_rows == 2 || !row_recompute_safe(riw)))
+            {
+                n = kNwNeedScoreRows;
+                break;
+            }
+        }
         const uint32_t rch = j > 0 ? (uint32_t)wave_first((int32_t)read[j - 1]) : 0u;
         const int32_t np   = max(pred_count, 1);
         if (ADAPTIVE)
@@ -416,6 +429,7 @@ __device__ __forceinline__ int32_t traceback_moves(const BandedCtx<ScoreT>& b, c
     }
     if (n >= bound) n = kNwLoopFailed;
     wave_sync();
+    if (n == kNwNeedScoreRows) return n;
     for (int32_t k0 = lane; k0 < n; k0 += 4 * kWave) // 4 independent load chains per lane in flight
     {
         int32_t pos[4], node[4];

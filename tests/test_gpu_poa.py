@@ -441,7 +441,12 @@ def test_kernel_shortcuts_equal_the_plain_schedule(monkeypatch):
     arms = (("production", None), ("full_resort", str(1 << 21)), ("many_predecessors_general", str(1 << 30)),
             ("plain", str((1 << 21) | (1 << 30))), ("registers_through_ring", str(1 << 10)), ("moved_band_through_ring", str(1 << 15)),
             ("ring_through_general", str(1 << 9)), ("registers_through_general", str(1 << 11)),
-            ("everything_general", str((1 << 9) | (1 << 11) | (1 << 30))), ("consensus_node_by_node", str(1 << 4)))
+            ("everything_general", str((1 << 9) | (1 << 11) | (1 << 30))), ("consensus_node_by_node", str(1 << 4)),
+            # round 5: the production pass keeps the score rows nobody reads out of HBM and reruns a read whose walk needs one
+            # after all (kNwNeedScoreRows); bit 25 stores every row as rounds 1-4 did
+            ("every_row_stores_scores", str(1 << 25)), ("every_row_stores_scores_registers_through_ring", str((1 << 25) | (1 << 10))),
+            # ... and bit 23 sends EVERY read through that rerun (any recomputed step below row 0 ends the first walk)
+            ("score_row_rerun_on_every_read", str(1 << 23)))
     for name, flag in arms:
         if flag is None:
             monkeypatch.delenv("GWHIP_DEBUG", raising=False)
