@@ -29,6 +29,8 @@ namespace
                  "            device memory to preallocate, in GiB [2]\n"
                  "        -k, --kmer-size <int>\n"
                  "            factor applied to the residue-match column, as cudamapper prints it [1]\n"
+                 "        -S\n"
+                 "            print overlaps in SAM format (text; cudamapper's -S needs htslib, this writer does not)\n"
                  "        -h, --help\n";
     std::exit(exit_code);
 }
@@ -38,6 +40,7 @@ namespace
 int main(int argc, char** argv)
 {
     int32_t engines = 1, batch_size = 0, kmer_size = 1;
+    bool sam = false;
     int64_t cached_gib = 2;
     static const option long_options[] = {{"alignment-engines", required_argument, nullptr, 'a'},
                                           {"batch-size", required_argument, nullptr, 'b'},
@@ -46,7 +49,7 @@ int main(int argc, char** argv)
                                           {"help", no_argument, nullptr, 'h'},
                                           {nullptr, 0, nullptr, 0}};
     int c;
-    while ((c = getopt_long(argc, argv, "a:b:m:k:h", long_options, nullptr)) != -1)
+    while ((c = getopt_long(argc, argv, "a:b:m:k:Sh", long_options, nullptr)) != -1)
     {
         switch (c)
         {
@@ -54,6 +57,7 @@ int main(int argc, char** argv)
         case 'b': batch_size = std::atoi(optarg); break;
         case 'm': cached_gib = std::atoll(optarg); break;
         case 'k': kmer_size = std::atoi(optarg); break;
+        case 'S': sam = true; break;
         case 'h': usage(0);
         default: usage(1);
         }
@@ -71,7 +75,14 @@ int main(int argc, char** argv)
         DefaultDeviceAllocator allocator = create_default_device_allocator(static_cast<std::size_t>(cached_gib) << 30);
         std::vector<std::string> cigars;
         cudamapper::align_overlaps(allocator, overlaps, queries, targets, engines, cigars, batch_size);
-        cudamapper::print_paf(overlaps, cigars, queries, targets, kmer_size, stdout);
+        if (sam)
+        {
+            std::string command_line;
+            for (int k = 0; k < argc; ++k) command_line += (k ? " " : "") + std::string(argv[k]);
+            cudamapper::print_sam(overlaps, cigars, queries, targets, "0.6.0-mi355x", command_line, stdout);
+        }
+        else
+            cudamapper::print_paf(overlaps, cigars, queries, targets, kmer_size, stdout);
     }
     catch (const std::exception& e)
     {

@@ -226,6 +226,47 @@ void print_paf(const std::vector<Overlap>& overlaps, const std::vector<std::stri
     std::fwrite(buffer.data(), 1, buffer.size(), out);
 }
 
+void print_sam(const std::vector<Overlap>& overlaps, const std::vector<std::string>& cigars,
+               const std::vector<FastaSequence>& queries, const std::vector<FastaSequence>& targets,
+               const std::string& program_version, const std::string& command_line, std::FILE* out)
+{
+    if (!cigars.empty() && cigars.size() != overlaps.size()) throw std::invalid_argument("one CIGAR per overlap (or none)");
+    std::string buffer;
+    char num[96];
+    // header: @SQ of every target read an overlap names, in order of first appearance; @PG
+    std::vector<char> listed(targets.size(), 0);
+    for (const Overlap& o : overlaps)
+    {
+        const FastaSequence& t = targets.at(o.target_read_id_);
+        if (listed[o.target_read_id_]) continue;
+        listed[o.target_read_id_] = 1;
+        buffer += "@SQ\tSN:";
+        buffer += t.name;
+        std::snprintf(num, sizeof(num), "\tLN:%zu\n", t.seq.length());
+        buffer += num;
+    }
+    buffer += "@PG\tID:cudamapper\tPN:cudamapper\tVN:" + program_version;
+    if (!command_line.empty()) buffer += "\tCL:" + command_line;
+    buffer += '\n';
+    for (size_t i = 0; i < overlaps.size(); ++i)
+    {
+        const Overlap& o       = overlaps[i];
+        const FastaSequence& q = queries.at(o.query_read_id_);
+        const FastaSequence& t = targets.at(o.target_read_id_);
+        buffer += q.name;
+        std::snprintf(num, sizeof(num), "\t%d\t", o.relative_strand == RelativeStrand::Reverse ? 16 : 0);
+        buffer += num;
+        buffer += t.name;
+        std::snprintf(num, sizeof(num), "\t%u\t255\t", o.target_start_position_in_read_ + 1u); // SAM positions are 1-based
+        buffer += num;
+        buffer += (!cigars.empty() && !cigars[i].empty()) ? cigars[i] : std::string("*");
+        buffer += "\t*\t0\t0\t";
+        buffer += q.seq.empty() ? std::string("*") : q.seq;
+        buffer += "\t*\n";
+    }
+    std::fwrite(buffer.data(), 1, buffer.size(), out);
+}
+
 } // namespace cudamapper
 } // namespace genomeworks
 } // namespace claraparabricks

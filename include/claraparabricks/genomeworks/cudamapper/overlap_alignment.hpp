@@ -72,6 +72,17 @@ void print_paf(const std::vector<Overlap>& overlaps, const std::vector<std::stri
                const std::vector<FastaSequence>& queries, const std::vector<FastaSequence>& targets,
                std::int32_t kmer_size, std::FILE* out);
 
+/// SAM text records for the overlaps (cudamapper -S: print_sam, cudamapper/src/utils.cpp:190-318, which the reference only
+/// builds with htslib; this writer needs no library and emits text SAM only -- no BAM). Header: one @SQ line per distinct
+/// target read in order of first appearance (the reference adds one per overlap and htslib refuses the duplicates) and the
+/// @PG line of the tool; one record per overlap with the fields the reference fills: QNAME, FLAG 0 (16 for overlaps on the
+/// reverse strand), RNAME / POS of the TARGET read and start (the reference leaves the target index at 0 and writes the
+/// query start; a SAM consumer needs the position on RNAME), MAPQ 255 as in print_paf, the CIGAR when cigars is not empty
+/// (else *), RNEXT * / PNEXT 0 / TLEN 0, the whole query sequence, QUAL *.
+void print_sam(const std::vector<Overlap>& overlaps, const std::vector<std::string>& cigars,
+               const std::vector<FastaSequence>& queries, const std::vector<FastaSequence>& targets,
+               const std::string& program_version, const std::string& command_line, std::FILE* out);
+
 } // namespace cudamapper
 } // namespace genomeworks
 } // namespace claraparabricks

@@ -133,3 +133,40 @@ def test_paf_cigars_equal_direct_aligner_calls_for_any_engine_count(tmp_path):
         cigar = cols[12][5:]
         assert cigar == a.cigar
         assert cigar_lengths(cigar) == (len(q), len(t))
+
+
+@pytest.mark.gpu
+def test_sam_records_carry_the_paf_cigars(tmp_path):
+    """`align_overlaps -S` (cudamapper's -S / print_sam, cudamapper/src/utils.cpp:190-318, without htslib): one @SQ line per
+    distinct target read, the @PG line, and per overlap a record whose CIGAR is the `cg:Z:` tag of the PAF output, whose flag
+    says the strand, whose RNAME / POS are the target read and the 1-based target start, with the whole query sequence."""
+    fasta, paf, lines, _expect = make_case(tmp_path)
+    p = subprocess.run([TOOL, "-a", "2", fasta, fasta, paf], capture_output=True, text=True)
+    s = subprocess.run([TOOL, "-a", "2", "-S", fasta, fasta, paf], capture_output=True, text=True)
+    assert p.returncode == 0 and s.returncode == 0, (p.stderr, s.stderr)
+    paf_rows = [l.split("\t") for l in p.stdout.strip().split("\n")]
+    sam = s.stdout.strip().split("\n")
+    header = [l for l in sam if l.startswith("@")]
+    records = [l.split("\t") for l in sam if not l.startswith("@")]
+    targets_in_order = []
+    for row in paf_rows:
+        if row[5] not in targets_in_order:
+            targets_in_order.append(row[5])
+    assert [h.split("\t")[1][3:] for h in header if h.startswith("@SQ")] == targets_in_order
+    assert sum(1 for h in header if h.startswith("@PG\tID:cudamapper")) == 1 and header[-1].startswith("@PG")
+    assert len(records) == len(paf_rows)
+    seqs = {}
+    name = None
+    for line in open(fasta):
+        if line.startswith(">"):
+            name = line[1:].split()[0]
+            seqs[name] = ""
+        else:
+            seqs[name] += line.strip()
+    for rec, row in zip(records, paf_rows):
+        assert len(rec) == 11
+        assert rec[0] == row[0] and rec[2] == row[5]
+        assert rec[1] == ("16" if row[4] == "-" else "0")
+        assert int(rec[3]) == int(row[7]) + 1 and rec[4] == "255"
+        assert rec[5] == row[12][5:]
+        assert rec[6:9] == ["*", "0", "0"] and rec[9] == seqs[row[0]] and rec[10] == "*"
