@@ -362,7 +362,8 @@ def process_windows_multi_device(windows, max_sequences_per_poa, max_sequence_si
         raise RuntimeError(L.gw_last_error().decode())
     try:
         out = dict(status=[L.gw_poa_multi_status(h, w) for w in range(n)], worker=[L.gw_poa_multi_worker(h, w) for w in range(n)],
-                   launches=L.gw_poa_multi_launches(h), seconds=L.gw_poa_multi_seconds(h))
+                   launches=L.gw_poa_multi_launches(h), seconds=L.gw_poa_multi_seconds(h),
+                   seconds_after_creation=_multi_seconds_after_creation(L, h))
         ln = i32(0)
         if mask == 1:
             out["consensus"], out["coverage"] = [], []

@@ -244,8 +244,9 @@ PoaBatch::PoaBatch(int32_t device_id, cudaStream_t stream, DefaultDeviceAllocato
     h_coverage_       = reinterpret_cast<uint16_t*>(host_block_ + htake(cov_bytes));
     h_msa_            = msa_bytes ? reinterpret_cast<uint8_t*>(host_block_ + htake(msa_bytes)) : nullptr;
     h_cells_          = reinterpret_cast<uint64_t*>(host_block_ + htake(cell_bytes));
-    std::memset(h_sequences_, 0, seq_bytes);
-    std::memset(h_weights_, 0, seq_bytes);
+    // (the staging arrays are not cleared: an upload covers exactly the bytes add_seq_to_poa() wrote, padding included, and
+    // the read-ahead slack is zeroed on the device -- clearing 2 x 600 MB of pinned memory was most of the construction time of
+    // a BatchConfig(1024, 200) batch with tens of GB of device memory)
 
     debug_message(" Initializing batch on device ");
     reset();
@@ -306,7 +307,8 @@ bool PoaBatch::reserve_buf(int32_t max_seq_length)
                                       : cudautils::align<int32_t, 4>(max_seq_length + 1 + kCellsPerThread);
     size_t required_size        = static_cast<size_t>(matrix_width) * static_cast<size_t>(matrix_height);
     const bool tb               = batch_size_.band_mode == static_band_traceback || batch_size_.band_mode == adaptive_band_traceback;
-    required_size *= tb ? (cfg_.trace16 ? 2 : 1) : (cfg_.score32 ? 4 : 2);
+    // (full band with int16 scores: + one move byte per cell, as gwhip_poa_bytes_per_window counts it)
+    required_size *= tb ? (cfg_.trace16 ? 2 : 1) : (cfg_.score32 ? 4 : (batch_size_.band_mode == BandMode::full_band ? 3 : 2));
     if (required_size > avail_buf_mem_)
     {
         if (get_total_poas() == 0)

@@ -90,13 +90,35 @@ struct SharedCursor
 };
 
 // One worker: fills its batch from the cursor, runs it, stores by global index; until the windows run out.
+// Every worker's Batch exists before any of them fills: the clock of the reference's multi-batch benchmark starts there
+// (cudapoa/benchmarks/multi_batch.hpp: the batches are created in the constructor, process_batches() is what is timed).
+struct CreationGate
+{
+    int32_t workers = 0;
+    std::atomic<int32_t> arrived{0};
+    std::atomic<bool> abandoned{false}; // a worker thread could not be started: nobody waits for it
+    std::mutex m;
+    std::chrono::steady_clock::time_point all_created{};
+    void arrive()
+    {
+        if (arrived.fetch_add(1) + 1 == workers)
+        {
+            std::lock_guard<std::mutex> g(m);
+            all_created = std::chrono::steady_clock::now();
+        }
+        while (arrived.load() < workers && !abandoned.load()) std::this_thread::yield();
+    }
+};
+
 void worker_loop(int32_t worker, int32_t device, cudaStream_t stream, DefaultDeviceAllocator allocator, int64_t memory,
                  const BatchConfig& batch_size, const MultiDeviceConfig& config, const std::vector<std::vector<std::string>>& windows,
-                 SharedCursor& cursor, MultiDeviceOutput& out, std::atomic<int32_t>& launches)
+                 SharedCursor& cursor, MultiDeviceOutput& out, std::atomic<int32_t>& launches, CreationGate& gate, bool& arrived)
 {
     scoped_device_switch dev(device);
     std::unique_ptr<Batch> batch = create_batch(device, stream, allocator, memory, config.output_mask, batch_size, config.gap_score,
                                                 config.mismatch_score, config.match_score);
+    arrived = true;
+    gate.arrive();
     const bool want_msa = (config.output_mask & OutputType::msa) != 0;
     std::vector<size_t> in_batch;
     for (;;)
@@ -231,27 +253,42 @@ void process_windows_multi_device(MultiDeviceOutput& out, const std::vector<std:
         for (int32_t b = 0; b < config.batches_per_device; b++) streams.create(g.device);
     std::vector<std::exception_ptr> errors(groups.size() * static_cast<size_t>(config.batches_per_device));
     std::vector<std::thread> threads;
+    CreationGate gate;
+    gate.workers = static_cast<int32_t>(groups.size()) * config.batches_per_device;
+    threads.reserve(static_cast<size_t>(gate.workers));
     {
         JoinAll join{threads};
         int32_t worker = 0;
-        for (Group& g : groups)
-            for (int32_t b = 0; b < config.batches_per_device; b++, worker++)
-            {
-                cudaStream_t stream  = streams.items[static_cast<size_t>(worker)].second;
-                const int64_t memory = g.memory / config.batches_per_device;
-                threads.emplace_back([&, worker, stream, memory, device = g.device, allocator = g.allocator]() {
-                    try
-                    {
-                        worker_loop(worker, device, stream, allocator, memory, batch_size, config, windows, cursor, out, launches);
-                    }
-                    catch (...)
-                    {
-                        errors[static_cast<size_t>(worker)] = std::current_exception();
-                    }
-                });
-            }
+        try
+        {
+            for (Group& g : groups)
+                for (int32_t b = 0; b < config.batches_per_device; b++, worker++)
+                {
+                    cudaStream_t stream  = streams.items[static_cast<size_t>(worker)].second;
+                    const int64_t memory = g.memory / config.batches_per_device;
+                    threads.emplace_back([&, worker, stream, memory, device = g.device, allocator = g.allocator]() {
+                        bool arrived = false;
+                        try
+                        {
+                            worker_loop(worker, device, stream, allocator, memory, batch_size, config, windows, cursor, out, launches, gate, arrived);
+                        }
+                        catch (...)
+                        {
+                            errors[static_cast<size_t>(worker)] = std::current_exception();
+                            if (!arrived) gate.arrive(); // a failed creation releases the others
+                        }
+                    });
+                }
+        }
+        catch (...)
+        {
+            gate.abandoned.store(true); // std::thread could not start a worker: the started ones must not wait for it
+            throw;
+        }
     }
-    out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    const auto t_end = std::chrono::steady_clock::now();
+    out.seconds      = std::chrono::duration<double>(t_end - t_begin).count();
+    if (gate.arrived.load() == gate.workers) out.seconds_after_creation = std::chrono::duration<double>(t_end - gate.all_created).count();
     out.launches = launches.load();
     for (const std::exception_ptr& e : errors)
         if (e) std::rethrow_exception(e);

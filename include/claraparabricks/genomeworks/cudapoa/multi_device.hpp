@@ -46,7 +46,7 @@ struct MultiDeviceOutput
     int32_t launches = 0;                           ///< generate_poa() calls over all workers
     double seconds   = 0;                           ///< wall time from the first worker's start to the last worker's end
                                                     ///< (batch creation, filling, kernels, result unpacking)
-    double seconds_after_creation = 0;              ///< process_windows_size_classes: from the moment every class's Batch exists to the
+    double seconds_after_creation = 0;              ///< from the moment every worker's / class's Batch exists (process_windows_multi_device: to the end of the call) to the
                                                     ///< last results -- filling + generate_poa() + get_*(), the region the reference's
                                                     ///< multi-batch benchmark times (cudapoa/benchmarks/multi_batch.hpp:72-177)
 };
