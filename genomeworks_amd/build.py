@@ -24,6 +24,8 @@ HOST_SRCS = ["host/capi.cpp", "host/cudapoa_batch.cpp", "host/cudapoa_utils.cpp"
 # no fast-math, no FMA contraction: band placement is IEEE fp32
 KERNEL_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
                 "-fhip-fp32-correctly-rounded-divide-sqrt"]
+# experiments (same-box A/B of compiler options, tools/ab_headline.sh): extra hipcc flags for the kernel translation units
+KERNEL_FLAGS += [f for f in os.environ.get("GW_KERNEL_EXTRA_FLAGS", "").split() if f]
 HOST_FLAGS = ["-O2", "-g", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
               "-D__HIP_PLATFORM_AMD__", "-pthread"]
 
