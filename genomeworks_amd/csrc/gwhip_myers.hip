@@ -1310,27 +1310,26 @@ static WsPlan plan_fixed(int32_t n, int64_t total_len)
     return p;
 }
 
-// per-wave workspace sizes (64 slots of the processing order each): one thread per wave, then the same three-launch
-// exclusive scan as the run counts (64-bit: a million pairs need more than 2^31 workspace words)
-__global__ __launch_bounds__(kScanBlock) void ws_sizes_kernel(const int64_t* starts, const int32_t* max_bws, const int32_t* order,
-                                                              int64_t* sizes, int32_t* identity, int32_t n)
+// per-wave workspace sizes (64 slots of the processing order each): one lane per slot and a maximum over the wavefront, then the
+// same three-launch exclusive scan as the run counts (64-bit: a million pairs need more than 2^31 workspace words)
+__global__ __launch_bounds__(256) void ws_sizes_kernel(const int64_t* starts, const int32_t* max_bws, const int32_t* order,
+                                                       int64_t* sizes, int32_t* identity, int32_t n)
 {
-    const int32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int32_t i = gid; i < n; i += gridDim.x * blockDim.x) identity[i] = i;
-    const int32_t n_waves = (n + 63) / 64;
-    if (gid >= n_waves) return;
-    int64_t me_max = 0;
-    int32_t pw_max = 0;
-    for (int32_t s = gid * 64; s < min(n, gid * 64 + 64); s++)
+    const int32_t s = blockIdx.x * 256 + threadIdx.x; // slot; the 64 slots of a workspace region are one wavefront here
+    int64_t me      = 0;
+    int32_t pw      = 0;
+    if (s < n)
     {
-        const int32_t i = order[s];
-        int64_t me;
-        int32_t pw;
+        identity[s]     = s;
+        const int32_t i = order == identity ? s : order[s];
         pair_ws_dims((int32_t)(starts[2 * i + 1] - starts[2 * i]), (int32_t)(starts[2 * i + 2] - starts[2 * i + 1]), max_bws[i], me, pw);
-        me_max = max(me_max, me);
-        pw_max = max(pw_max, pw);
     }
-    sizes[gid] = 64 * (3 * me_max + pw_max);
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        me = max(me, (int64_t)__shfl_xor((long long)me, o));
+        pw = max(pw, __shfl_xor(pw, o));
+    }
+    if ((threadIdx.x & 63) == 0 && s < n) sizes[s >> 6] = 64 * (3 * me + pw);
 }
 
 __global__ __launch_bounds__(kScanBlock) void ws_block_totals_kernel(const int64_t* sizes, int64_t* block_totals, int32_t n_waves)
@@ -3183,18 +3182,15 @@ using namespace gwhip::myers;
 
 extern "C" {
 
-size_t gwhip_myers_banded_workspace_bytes_ordered(int32_t n_alignments, const int64_t* sequence_starts_host,
-                                                  const int32_t* max_bandwidths_host, const int32_t* scheduling_index_host)
+int64_t gwhip_myers_banded_workspace_words(int32_t first_slot, int32_t n_slots, const int64_t* sequence_starts_host,
+                                           const int32_t* max_bandwidths_host, const int32_t* scheduling_index_host)
 {
-    if (n_alignments <= 0) return 256;
-    // (the result slots are indexed relative to the first pair's offset: a chunk of a larger batch passes its own slice)
-    const WsPlan p = plan_fixed(n_alignments, sequence_starts_host[2 * (size_t)n_alignments] - sequence_starts_host[0]);
-    int64_t words  = 0;
-    for (int32_t w0 = 0; w0 < n_alignments; w0 += 64) // one interleaved region per wave of 64 slots
+    int64_t words = 0;
+    for (int32_t w0 = first_slot; w0 < first_slot + n_slots; w0 += 64) // one interleaved region per wave of 64 slots
     {
         int64_t me_max = 0;
         int32_t pw_max = 0;
-        for (int32_t s = w0; s < std::min(n_alignments, w0 + 64); s++)
+        for (int32_t s = w0; s < std::min(first_slot + n_slots, w0 + 64); s++)
         {
             const int32_t i = scheduling_index_host ? scheduling_index_host[s] : s;
             int64_t me;
@@ -3206,13 +3202,63 @@ size_t gwhip_myers_banded_workspace_bytes_ordered(int32_t n_alignments, const in
         }
         words += 64 * (3 * me_max + pw_max);
     }
+    return words;
+}
+
+size_t gwhip_myers_banded_workspace_bytes_of_words(int32_t n_alignments, int64_t total_sequence_length, int64_t words)
+{
+    if (n_alignments <= 0) return 256;
+    // (the result slots are indexed relative to the first pair's offset: a chunk of a larger batch passes its own slice)
+    const WsPlan p = plan_fixed(n_alignments, total_sequence_length);
     return p.off_ws + (size_t)words * 4 + 256;
+}
+
+size_t gwhip_myers_banded_workspace_bytes_ordered(int32_t n_alignments, const int64_t* sequence_starts_host,
+                                                  const int32_t* max_bandwidths_host, const int32_t* scheduling_index_host)
+{
+    if (n_alignments <= 0) return 256;
+    return gwhip_myers_banded_workspace_bytes_of_words(
+        n_alignments, sequence_starts_host[2 * (size_t)n_alignments] - sequence_starts_host[0],
+        gwhip_myers_banded_workspace_words(0, n_alignments, sequence_starts_host, max_bandwidths_host, scheduling_index_host));
 }
 
 size_t gwhip_myers_banded_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host,
                                           const int32_t* max_bandwidths_host)
 {
     return gwhip_myers_banded_workspace_bytes_ordered(n_alignments, sequence_starts_host, max_bandwidths_host, nullptr);
+}
+
+// two bases per byte -> one character per base (include/gwhip.h: gwhip_unpack_bases); a thread expands 8 packed bytes
+__global__ __launch_bounds__(256) void unpack_bases_kernel(const uint8_t* packed, char* out, int64_t first, int64_t last)
+{
+    // bytes 'A' 'C' 'T' 'G' 'N' 'N' 'N' 'N' of the codes 0..7 (5..7 never occur)
+    constexpr uint64_t kLut = 0x4e4e4e4e47544341ull;
+    const int64_t i0 = (first & ~int64_t(15)) + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; // 16 bases, 16-aligned
+    if (i0 >= last) return;
+    const uint64_t bits = *reinterpret_cast<const uint64_t*>(packed + (i0 >> 1)); // (the staging buffer is 8-byte padded)
+    char c[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c[k] = (char)(kLut >> (8 * ((bits >> (4 * k)) & 7u)));
+    if (i0 >= first && i0 + 16 <= last)
+        *reinterpret_cast<uint4*>(out + i0) = *reinterpret_cast<const uint4*>(c);
+    else
+        for (int k = 0; k < 16; ++k)
+            if (i0 + k >= first && i0 + k < last) out[i0 + k] = c[k];
+}
+
+int gwhip_unpack_bases(const uint8_t* packed, char* sequences, int64_t first, int64_t last, gwhip_stream_t stream_)
+{
+    if (!packed || !sequences || first < 0 || last < first)
+    {
+        g_last_error = "gwhip_unpack_bases: invalid arguments";
+        return (int)hipErrorInvalidValue;
+    }
+    if (last == first) return 0;
+    const int64_t groups = (last - (first & ~int64_t(15)) + 15) / 16;
+    hipLaunchKernelGGL(unpack_bases_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, packed, sequences, first, last);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(e, "unpack_bases_kernel launch");
+    return 0;
 }
 
 int gwhip_myers_occupancy(int device, int* blocks_per_cu)
@@ -3269,19 +3315,41 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
     ka.slot_base      = args->first_sequence_offset;
 
     ka.ws_capacity_words = ((int64_t)args->workspace_bytes - (int64_t)p.off_ws) / 4;
+    // sizing ahead of the alignment kernel and scan / compaction behind it go to the caller's side stream when it gave one
+    hipStream_t side = args->side_stream ? (hipStream_t)args->side_stream : stream;
+    auto hand_over   = [&](hipStream_t from, hipStream_t to) -> hipError_t {
+        if (from == to) return hipSuccess;
+        hipEvent_t ev = nullptr;
+        hipError_t e  = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        e = hipEventRecord(ev, from);
+        if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
+        (void)hipEventDestroy(ev); // (released once the recorded work has completed)
+        return e;
+    };
+    const bool do_sizing = args->phases == 0 || (args->phases & GWHIP_MYERS_SIZING) != 0;
+    const bool do_align  = args->phases == 0 || (args->phases & GWHIP_MYERS_ALIGN) != 0;
+    if (do_sizing)
     {
+        hipStream_t stream = side;
         const int32_t n_waves  = (n + 63) / 64;
         int64_t* offsets       = const_cast<int64_t*>(ka.ws_offsets);
         int64_t* block_totals  = reinterpret_cast<int64_t*>(ws + p.off_scan);
         const int32_t n_blocks = (n_waves + kScanChunk - 1) / kScanChunk;
-        const int32_t id_blocks = std::max(1, std::min((n + kScanBlock - 1) / kScanBlock, 4096));
-        hipLaunchKernelGGL(ws_sizes_kernel, dim3(std::max(id_blocks, (n_waves + kScanBlock - 1) / kScanBlock)), dim3(kScanBlock), 0, stream,
-                           args->sequence_starts, args->max_bandwidths, ka.order, offsets, identity, n);
+        hipLaunchKernelGGL(ws_sizes_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, args->sequence_starts, args->max_bandwidths, ka.order, offsets,
+                           identity, n);
         hipLaunchKernelGGL(ws_block_totals_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, offsets, block_totals, n_waves);
         hipLaunchKernelGGL(scan_totals_kernel<int64_t>, dim3(1), dim3(1024), 0, stream, block_totals, n_blocks, offsets + n_waves,
                            (const int64_t*)nullptr);
         hipLaunchKernelGGL(ws_apply_kernel, dim3(n_blocks), dim3(kScanBlock), 0, stream, offsets, block_totals, n_waves);
     }
+    if (!do_align)
+    {
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : fail(e, "myers workspace sizing launch");
+    }
+    if (do_sizing)
+        if (hipError_t e = hand_over(side, stream); e != hipSuccess) return fail(e, "gwhip_myers_banded: side stream -> stream");
     // LDS flavour when every pair's pattern table and column state fit one wave's share (<= 1 KiB per lane)
     bool use_lds = false;
     if (args->max_query_length > 0 && args->max_bandwidth_hint > 0)
@@ -3352,6 +3420,8 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
                            (size_t)(ka.lds_pattern_words + 3 * ka.lds_band_words + 16) * 64 * sizeof(uint32_t), stream, ka);
     else
         hipLaunchKernelGGL(myers_banded_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, stream, ka);
+    if (hipError_t e = hand_over(stream, side); e != hipSuccess) return fail(e, "gwhip_myers_banded: stream -> side stream");
+    stream = side; // (everything below)
     {
         int32_t* block_totals  = reinterpret_cast<int32_t*>(ws + p.off_scan);
         const int32_t n_blocks = (n + kScanChunk - 1) / kScanChunk;

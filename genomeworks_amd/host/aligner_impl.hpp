@@ -53,8 +53,13 @@ private:
     void free_device();
     struct Chunk;
     void launch(void* event_before = nullptr, void* event_after = nullptr); ///< every chunk's kernels again + fetch_head()
-    void launch_chunk(const Chunk& c);
-    void fetch_head();
+    void launch_chunk(const Chunk& c, int32_t phases = 0);
+    /// every chunk's kernels, pipelined over the aligner's stream and the side stream; `order` (host, pinned) goes up chunk by
+    /// chunk when given, and workspaces are allocated when `allocate`
+    void run_chunks(const int32_t* order, bool allocate);
+    void prepare_head();                                  ///< pinned [result_starts | metadata] of the launched batch
+    void fetch_head_slice(const Chunk& c, void* stream);  ///< the chunk's offsets and metadata follow its kernels to the host
+    void join_side_stream();                              ///< stream_ continues after everything queued on the side stream
 
     cudaStream_t stream_;
     int32_t device_id_;
@@ -66,6 +71,9 @@ private:
 
     // staging arrays in pinned host memory: uploaded asynchronously at link speed
     PinnedVector<char> seq_h_;
+    /// the same bases two per byte (include/gwhip.h, gwhip_unpack_bases): what align_all() uploads -- half the bytes over the
+    /// link; the characters above stay for the Alignment objects
+    PinnedVector<uint8_t> packed_h_;
     PinnedVector<int64_t> seq_starts_h_;
     PinnedVector<int32_t> max_bandwidths_h_;
     PinnedVector<int32_t> order_h_;
@@ -73,6 +81,7 @@ private:
     size_t workspace_bytes_estimate_ = 0;
     size_t largest_wave_ws_          = 0;
     int32_t longest_query_           = 0;
+    int64_t longest_pair_            = 0; ///< query + target of the longest pair (buckets of the counting sort in align_all())
     int32_t widest_band_             = 0;
     bool launched_                   = false;
     bool uploads_in_flight_          = false;
@@ -98,8 +107,10 @@ private:
     std::vector<Chunk> chunks_;
     int64_t launched_total_length_ = 0;   ///< bases of the launched batch (the host arrays move to the views at sync_alignments())
     void* upload_stream_ = nullptr;       ///< hipStream_t, created with the first chunked batch
+    void* side_stream_   = nullptr;       ///< hipStream_t of a chunked batch's sizing / compaction kernels and result offsets (gwhip_myers_args::side_stream)
     std::vector<void*> upload_events_;    ///< hipEvent_t pool (timing disabled)
     char* d_seq_               = nullptr;
+    uint8_t* d_packed_         = nullptr; ///< upload staging of packed_h_ (unpacked into d_seq_ on the device)
     int64_t* d_starts_         = nullptr;
     int32_t* d_bw_             = nullptr;
     int32_t* d_order_          = nullptr;

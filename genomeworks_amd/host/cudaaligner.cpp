@@ -26,6 +26,7 @@
 
 #include "../../include/gwhip.h"
 #include "aligner_impl.hpp"
+#include "host_common.hpp"
 #include "aligner_global.hpp"
 #include "alignment_impl.hpp"
 
@@ -46,6 +47,35 @@ namespace
 {
 constexpr int32_t kWordSize = 32;
 size_t up256(size_t v) { return (v + 255) & ~size_t(255); }
+// Two bases per byte for the upload (include/gwhip.h, gwhip_unpack_bases): base i of the batch in bits 4 (i & 1) .. + 3 of byte
+// i >> 1. A query base keeps what the kernels can tell apart -- 'A', 'C', 'T', 'G' (myers_gpu.cu:196-208 compares with exactly
+// these) or "anything else" -- a target base its pattern index (c >> 1) & 3 (myers_gpu.cu:210-241).
+struct QueryCodes
+{
+    uint8_t of[256];
+    QueryCodes()
+    {
+        for (int c = 0; c < 256; c++) of[c] = 4;
+        of['A'] = 0, of['C'] = 1, of['T'] = 2, of['G'] = 3;
+    }
+};
+const QueryCodes kQueryCodes;
+inline uint8_t query_code(char c) { return kQueryCodes.of[static_cast<unsigned char>(c)]; }
+inline uint8_t target_code(char c) { return static_cast<uint8_t>((static_cast<unsigned char>(c) >> 1) & 3u); }
+template <typename Code>
+void pack_bases(uint8_t* packed, int64_t first, const char* bases, int32_t n, Code code)
+{
+    int64_t i     = first;
+    int32_t k     = 0;
+    if (n > 0 && (i & 1)) // shares its byte with the base before it
+    {
+        packed[i >> 1] = static_cast<uint8_t>((packed[i >> 1] & 0x0f) | (code(bases[0]) << 4));
+        ++i;
+        ++k;
+    }
+    for (; k + 2 <= n; k += 2, i += 2) packed[i >> 1] = static_cast<uint8_t>(code(bases[k]) | (code(bases[k + 1]) << 4));
+    if (k < n) packed[i >> 1] = code(bases[k]);
+}
 // GW_ALIGNER_TRACE=1: host-side timeline of align_all() / sync_alignments() on stderr (debugging aid)
 struct Tracer
 {
@@ -87,6 +117,11 @@ BandedAligner::~BandedAligner()
         (void)hipStreamSynchronize(static_cast<hipStream_t>(upload_stream_));
         (void)hipStreamDestroy(static_cast<hipStream_t>(upload_stream_));
     }
+    if (side_stream_ != nullptr)
+    {
+        (void)hipStreamSynchronize(static_cast<hipStream_t>(side_stream_));
+        (void)hipStreamDestroy(static_cast<hipStream_t>(side_stream_));
+    }
     for (void* e : upload_events_) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
     free_device();
     if (head_ != nullptr) pinned_release(head_, head_cap_);
@@ -117,11 +152,13 @@ void BandedAligner::free_device()
 void BandedAligner::reset_data()
 {
     seq_h_.clear();
+    packed_h_.clear();
     seq_starts_h_.assign(1, 0);
     max_bandwidths_h_.clear();
     workspace_bytes_estimate_ = 0;
     largest_wave_ws_          = 0;
     longest_query_            = 0;
+    longest_pair_             = 0;
     widest_band_              = 0;
     launched_                 = false;
 }
@@ -131,6 +168,7 @@ void BandedAligner::reset()
     scoped_device_switch dev(device_id_);
     (void)hipStreamSynchronize(stream_);
     if (upload_stream_ != nullptr) (void)hipStreamSynchronize(static_cast<hipStream_t>(upload_stream_));
+    if (side_stream_ != nullptr) (void)hipStreamSynchronize(static_cast<hipStream_t>(side_stream_));
     uploads_in_flight_ = false;
     reset_data();
     free_device();
@@ -197,7 +235,7 @@ StatusType BandedAligner::add_alignment(int32_t max_bandwidth, const char* query
     // per base: sequences 1 + packed results 1 + 4 in the device block, per-pair result slots 1 + 4 inside the kernel
     // workspace (plan_fixed, gwhip_myers.hip); per pair: starts, band width, order, result start, metadata, cell and
     // run counters on both sides
-    const size_t per_pair_io  = static_cast<size_t>(query_length + target_length) * (1 + 1 + 4 + 1 + 4) + 160;
+    const size_t per_pair_io  = static_cast<size_t>(query_length + target_length) * (1 + 1 + 4 + 1 + 4) + (query_length + target_length) / 2 + 160;
     const size_t new_estimate = workspace_bytes_estimate_ + pair_ws + pair_ws / 4 + per_pair_io;
     if (static_cast<int64_t>(new_estimate + largest_wave_ws_) + (1 << 20) >= max_device_memory_)
     {
@@ -208,10 +246,14 @@ StatusType BandedAligner::add_alignment(int32_t max_bandwidth, const char* query
     seq_h_.resize(static_cast<size_t>(new_len_sum));
     genomeutils::copy_sequence(query, query_length, seq_h_.data() + seq_start, reverse_complement_query);
     genomeutils::copy_sequence(target, target_length, seq_h_.data() + seq_start + query_length, reverse_complement_target);
+    packed_h_.resize(static_cast<size_t>(new_len_sum + 1) / 2);
+    pack_bases(packed_h_.data(), seq_start, seq_h_.data() + seq_start, query_length, query_code);
+    pack_bases(packed_h_.data(), seq_start + query_length, seq_h_.data() + seq_start + query_length, target_length, target_code);
     seq_starts_h_.push_back(seq_start + query_length);
     seq_starts_h_.push_back(new_len_sum);
     max_bandwidths_h_.push_back(max_bandwidth);
     longest_query_            = std::max(longest_query_, query_length);
+    longest_pair_             = std::max<int64_t>(longest_pair_, static_cast<int64_t>(query_length) + target_length);
     widest_band_              = std::max(widest_band_, max_bandwidth);
     workspace_bytes_estimate_ = new_estimate;
     return StatusType::success;
@@ -235,6 +277,7 @@ StatusType BandedAligner::align_all()
     const size_t o_res = take(static_cast<size_t>(total_len) + 16), o_cnt = take((static_cast<size_t>(total_len) + 16) * 4);
     const size_t o_rs = take((static_cast<size_t>(n) + 1) * 4), o_meta = take(static_cast<size_t>(n) * 4);
     const size_t o_cells = take(static_cast<size_t>(n) * 8);
+    const size_t o_packed = take(static_cast<size_t>(total_len) / 2 + 64);
     // a previous align_all() without a sync in between may still be uploading from / computing on what this replaces
     if (uploads_in_flight_) GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
     // from here until launch() the object describes NO finished run: if an allocation below throws, a later
@@ -253,6 +296,7 @@ StatusType BandedAligner::align_all()
     d_result_starts_    = reinterpret_cast<int32_t*>(device_block_ + o_rs);
     d_metadata_         = reinterpret_cast<uint32_t*>(device_block_ + o_meta);
     d_cells_            = reinterpret_cast<uint64_t*>(device_block_ + o_cells);
+    d_packed_           = reinterpret_cast<uint8_t*>(device_block_ + o_packed);
 
     // Chunks of consecutive pairs for large batches (a million short reads: the upload is 2 / 3 of the call): the upload of
     // chunk k + 1 runs on a stream of its own under the kernels of chunk k. The pairs' results do not depend on how the
@@ -278,7 +322,13 @@ StatusType BandedAligner::align_all()
             GW_CU_CHECK_ERR(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
             upload_stream_ = s;
         }
-        while (upload_events_.size() < static_cast<size_t>(n_chunks) + 1)
+        if (side_stream_ == nullptr)
+        {
+            hipStream_t s = nullptr;
+            GW_CU_CHECK_ERR(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            side_stream_ = s;
+        }
+        while (upload_events_.size() < 2 * static_cast<size_t>(n_chunks) + 2)
         {
             hipEvent_t e = nullptr;
             GW_CU_CHECK_ERR(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -295,7 +345,17 @@ StatusType BandedAligner::align_all()
     auto enqueue_inputs = [&](const Chunk& c) {
         const int64_t b0 = seq_starts_h_[2 * static_cast<size_t>(c.lo)], b1 = seq_starts_h_[2 * static_cast<size_t>(c.hi)];
         const size_t m   = static_cast<size_t>(c.hi - c.lo);
-        if (b1 > b0) GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq_ + b0, seq_h_.data() + b0, static_cast<size_t>(b1 - b0), hipMemcpyHostToDevice, up));
+        static const bool raw_upload = std::getenv("GW_ALIGNER_RAW_UPLOAD") != nullptr; // A/B switch: one byte per base over the link
+        if (b1 > b0 && raw_upload)
+            GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq_ + b0, seq_h_.data() + b0, static_cast<size_t>(b1 - b0), hipMemcpyHostToDevice, up));
+        else if (b1 > b0)
+        {
+            // the bases go up two per byte and are expanded on the device (0.1 ms for 300 MB): half the bytes over the link
+            const int64_t p0 = b0 >> 1, p1 = (b1 + 1) >> 1;
+            GW_CU_CHECK_ERR(hipMemcpyAsync(d_packed_ + p0, packed_h_.data() + p0, static_cast<size_t>(p1 - p0), hipMemcpyHostToDevice, up));
+            const int rc = gwhip_unpack_bases(d_packed_, d_seq_, b0, b1, up);
+            if (rc != 0) GW_CU_CHECK_ERR(static_cast<hipError_t>(rc));
+        }
         GW_CU_CHECK_ERR(hipMemcpyAsync(d_starts_ + 2 * static_cast<size_t>(c.lo), seq_starts_h_.data() + 2 * static_cast<size_t>(c.lo), (2 * m + 1) * 8,
                                        hipMemcpyHostToDevice, up));
         GW_CU_CHECK_ERR(hipMemcpyAsync(d_bw_ + c.lo, max_bandwidths_h_.data() + c.lo, m * 4, hipMemcpyHostToDevice, up));
@@ -322,37 +382,154 @@ StatusType BandedAligner::align_all()
             std::stable_sort(ord, ord + m, [&](int32_t a, int32_t b) { return len_of(a) > len_of(b); });
         }
     };
-    enqueue_inputs(chunks_[0]);
-    uploads_in_flight_ = true;
-    trace.mark("align_all: device block, first uploads enqueued");
+    // Every chunk's inputs are queued on the upload stream right away (pinned sources: the calls return at once), one event per
+    // chunk; the link then runs back to back while the host orders and sizes the chunks -- on host threads, one chunk each:
+    // for a million short pairs that work (5 ms on one thread) would otherwise be longer than the uploads and the kernels.
     for (int32_t k = 0; k < n_chunks; ++k)
     {
         Chunk& c = chunks_[static_cast<size_t>(k)];
-        const size_t m = static_cast<size_t>(c.hi - c.lo);
-        sort_chunk(c);
-        // (the copy below reads the vector's storage, which order_h_ takes over at the end)
-        GW_CU_CHECK_ERR(hipMemcpyAsync(d_order_ + c.lo, order.data() + c.lo, m * 4, hipMemcpyHostToDevice, up));
+        enqueue_inputs(c);
         if (n_chunks > 1)
         {
             c.uploaded = upload_events_[static_cast<size_t>(k)];
             GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(c.uploaded), up));
-            if (k + 1 < n_chunks) enqueue_inputs(chunks_[static_cast<size_t>(k) + 1]); // keeps the copy engine busy while this chunk is sized
         }
-        c.workspace_bytes = gwhip_myers_banded_workspace_bytes_ordered(static_cast<int32_t>(m), seq_starts_h_.data() + 2 * static_cast<size_t>(c.lo),
-                                                                       max_bandwidths_h_.data() + c.lo, order.data() + c.lo);
-        c.block_bytes     = up256(c.workspace_bytes);
-        c.workspace       = allocator_.allocate(c.block_bytes, {stream_});
-        if (c.uploaded != nullptr) GW_CU_CHECK_ERR(hipStreamWaitEvent(stream_, static_cast<hipEvent_t>(c.uploaded), 0));
-        launch_chunk(c);
     }
+    uploads_in_flight_ = true;
+    trace.mark("align_all: device block, uploads enqueued");
+    // Large chunks are cut into pieces of whole waves (64 slots) for the host threads: a stable counting sort by descending pair
+    // length in three steps -- histogram per piece, first slot of every (length, piece) by a running sum, scatter per piece --
+    // gives exactly the order of the one-thread sort above; the workspace is then sized piece by piece.
+    struct Piece
+    {
+        int32_t chunk, lo, hi; // chunk-local indices, and the same range of slots
+        std::vector<int32_t> first;
+        int64_t words;
+    };
+    trace.mark("align_all:   (order buffer)");
+    const size_t host_threads = std::min<size_t>(32, std::max(1u, std::thread::hardware_concurrency()));
+    const int64_t buckets     = longest_pair_ + 1;
+    std::vector<Piece> pieces;
+    for (int32_t k = 0; k < n_chunks; ++k)
+    {
+        const int32_t m       = chunks_[static_cast<size_t>(k)].hi - chunks_[static_cast<size_t>(k)].lo;
+        const int32_t p_count = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(static_cast<int64_t>(host_threads) / n_chunks, m / 16384)));
+        const int32_t share   = ((m + p_count - 1) / p_count + 63) & ~63;
+        for (int32_t lo = 0; lo < m; lo += share) pieces.push_back(Piece{k, lo, std::min(m, lo + share), {}, 0});
+    }
+    const bool in_pieces = pieces.size() > static_cast<size_t>(n_chunks) && buckets * static_cast<int64_t>(pieces.size()) <= (int64_t(1) << 22);
+    auto len_in_chunk    = [&](const Chunk& c, int32_t i) { return seq_starts_h_[2 * static_cast<size_t>(c.lo + i) + 2] - seq_starts_h_[2 * static_cast<size_t>(c.lo + i)]; };
+    auto size_piece      = [&](Piece& pc) {
+        const Chunk& c = chunks_[static_cast<size_t>(pc.chunk)];
+        pc.words       = gwhip_myers_banded_workspace_words(pc.lo, pc.hi - pc.lo, seq_starts_h_.data() + 2 * static_cast<size_t>(c.lo), max_bandwidths_h_.data() + c.lo,
+                                                            order.data() + c.lo);
+    };
+    if (in_pieces)
+    {
+        gwhost::parallel_tasks(pieces.size(), pieces.size(), [&](size_t t) {
+            Piece& pc      = pieces[t];
+            const Chunk& c = chunks_[static_cast<size_t>(pc.chunk)];
+            pc.first.assign(static_cast<size_t>(buckets), 0);
+            for (int32_t i = pc.lo; i < pc.hi; ++i) pc.first[static_cast<size_t>(longest_pair_ - len_in_chunk(c, i))]++;
+        });
+        trace.mark("align_all:   histograms");
+        for (size_t t0 = 0; t0 < pieces.size();) // the pieces of one chunk are consecutive
+        {
+            size_t t1 = t0;
+            while (t1 < pieces.size() && pieces[t1].chunk == pieces[t0].chunk) ++t1;
+            int32_t running = 0;
+            for (int64_t b = 0; b < buckets; ++b)
+                for (size_t t = t0; t < t1; ++t)
+                {
+                    const int32_t count                   = pieces[t].first[static_cast<size_t>(b)];
+                    pieces[t].first[static_cast<size_t>(b)] = running;
+                    running += count;
+                }
+            t0 = t1;
+        }
+        gwhost::parallel_tasks(pieces.size(), pieces.size(), [&](size_t t) {
+            Piece& pc      = pieces[t];
+            const Chunk& c = chunks_[static_cast<size_t>(pc.chunk)];
+            int32_t* ord   = order.data() + c.lo;
+            for (int32_t i = pc.lo; i < pc.hi; ++i) ord[static_cast<size_t>(pc.first[static_cast<size_t>(longest_pair_ - len_in_chunk(c, i))]++)] = i;
+        });
+        trace.mark("align_all:   scatter");
+        gwhost::parallel_tasks(pieces.size(), pieces.size(), [&](size_t t) { size_piece(pieces[t]); });
+        trace.mark("align_all:   workspace words");
+    }
+    else
+    {
+        pieces.clear();
+        for (int32_t k = 0; k < n_chunks; ++k) pieces.push_back(Piece{k, 0, chunks_[static_cast<size_t>(k)].hi - chunks_[static_cast<size_t>(k)].lo, {}, 0});
+        gwhost::parallel_tasks(pieces.size(), pieces.size(), [&](size_t t) {
+            sort_chunk(chunks_[static_cast<size_t>(pieces[t].chunk)]);
+            size_piece(pieces[t]);
+        });
+    }
+    for (Chunk& c : chunks_) c.workspace_bytes = 0; // (the words of its pieces until the sum is complete)
+    for (const Piece& pc : pieces) chunks_[static_cast<size_t>(pc.chunk)].workspace_bytes += static_cast<size_t>(pc.words);
+    for (Chunk& c : chunks_) c.workspace_bytes = gwhip_myers_banded_workspace_bytes_of_words(c.hi - c.lo, c.span, static_cast<int64_t>(c.workspace_bytes));
+    trace.mark("align_all: chunks ordered and sized");
+    run_chunks(order.data(), true);
     order_h_ = std::move(order);
-    trace.mark("align_all: chunks sorted, sized, uploaded and launched");
-    fetch_head();
+    trace.mark("align_all: chunks launched");
     launched_ = true;
     return StatusType::success;
 }
 
-void BandedAligner::launch_chunk(const Chunk& c)
+void BandedAligner::run_chunks(const int32_t* order, bool allocate)
+{
+    // A chunked batch keeps three streams busy: the uploads; the alignment kernels, back to back on the aligner's stream; and on
+    // the side stream what surrounds them (gwhip_myers_args::side_stream, ::phases) -- the processing order going up and the
+    // workspace sizing of chunk k + 1 (queued ahead of) the run-offset scan and compaction of chunk k and its offsets' way to
+    // the host. Events: upload_events_[k] = chunk k's inputs are up, [n + 2 + k] = its workspace is sized.
+    const size_t n_chunks = chunks_.size();
+    prepare_head();
+    if (n_chunks <= 1)
+    {
+        for (Chunk& c : chunks_)
+        {
+            if (order != nullptr)
+                GW_CU_CHECK_ERR(hipMemcpyAsync(d_order_ + c.lo, order + c.lo, static_cast<size_t>(c.hi - c.lo) * 4, hipMemcpyHostToDevice, stream_));
+            if (allocate)
+            {
+                c.block_bytes = up256(c.workspace_bytes);
+                c.workspace   = allocator_.allocate(c.block_bytes, {stream_});
+            }
+            launch_chunk(c);
+            fetch_head_slice(c, stream_);
+        }
+        return;
+    }
+    hipStream_t side = static_cast<hipStream_t>(side_stream_);
+    auto size_chunk  = [&](size_t k) {
+        Chunk& c = chunks_[k];
+        if (c.uploaded != nullptr && order != nullptr) GW_CU_CHECK_ERR(hipStreamWaitEvent(side, static_cast<hipEvent_t>(c.uploaded), 0));
+        // (the copy reads the caller's vector, whose storage order_h_ takes over at the end of align_all())
+        if (order != nullptr)
+            GW_CU_CHECK_ERR(hipMemcpyAsync(d_order_ + c.lo, order + c.lo, static_cast<size_t>(c.hi - c.lo) * 4, hipMemcpyHostToDevice, side));
+        if (allocate)
+        {
+            c.block_bytes = up256(c.workspace_bytes);
+            c.workspace   = allocator_.allocate(c.block_bytes, {stream_});
+        }
+        launch_chunk(c, GWHIP_MYERS_SIZING);
+        GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(upload_events_[n_chunks + 2 + k]), side));
+    };
+    size_chunk(0);
+    for (size_t k = 0; k < n_chunks; ++k)
+    {
+        if (k + 1 < n_chunks) size_chunk(k + 1);
+        Chunk& c = chunks_[k];
+        if (c.uploaded != nullptr && order != nullptr) GW_CU_CHECK_ERR(hipStreamWaitEvent(stream_, static_cast<hipEvent_t>(c.uploaded), 0));
+        GW_CU_CHECK_ERR(hipStreamWaitEvent(stream_, static_cast<hipEvent_t>(upload_events_[n_chunks + 2 + k]), 0));
+        launch_chunk(c, GWHIP_MYERS_ALIGN);
+        fetch_head_slice(c, side);
+    }
+    join_side_stream();
+}
+
+void BandedAligner::launch_chunk(const Chunk& c, int32_t phases)
 {
     gwhip_myers_args a{};
     const size_t lo         = static_cast<size_t>(c.lo);
@@ -373,6 +550,8 @@ void BandedAligner::launch_chunk(const Chunk& c)
     a.result_starts_base    = c.lo > 0 ? d_result_starts_ + lo : nullptr; // written by the chunk before this one
     a.scheduling_index      = d_order_ + lo;
     a.band_cells            = d_cells_ + lo;
+    a.side_stream           = chunks_.size() > 1 ? side_stream_ : nullptr;
+    a.phases                = phases;
     // hints for the LDS-cached kernel variant: longest query and widest band of this batch
     a.max_query_length   = longest_query_;
     a.max_bandwidth_hint = widest_band_;
@@ -389,12 +568,25 @@ void BandedAligner::launch_chunk(const Chunk& c)
 void BandedAligner::launch(void* event_before, void* event_after)
 {
     if (event_before != nullptr) GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(event_before), stream_));
-    for (const Chunk& c : chunks_) launch_chunk(c);
+    if (chunks_.size() > 1) // the side stream's work of this round starts behind what the aligner's stream holds
+    {
+        hipEvent_t begin = static_cast<hipEvent_t>(upload_events_[chunks_.size()]);
+        GW_CU_CHECK_ERR(hipEventRecord(begin, stream_));
+        GW_CU_CHECK_ERR(hipStreamWaitEvent(static_cast<hipStream_t>(side_stream_), begin, 0));
+    }
+    run_chunks(nullptr, false);
     if (event_after != nullptr) GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(event_after), stream_));
-    fetch_head();
 }
 
-void BandedAligner::fetch_head()
+void BandedAligner::join_side_stream()
+{
+    if (chunks_.size() <= 1) return;
+    hipEvent_t done = static_cast<hipEvent_t>(upload_events_[chunks_.size() + 1]);
+    GW_CU_CHECK_ERR(hipEventRecord(done, static_cast<hipStream_t>(side_stream_)));
+    GW_CU_CHECK_ERR(hipStreamWaitEvent(stream_, done, 0));
+}
+
+void BandedAligner::prepare_head()
 {
     // result offsets and metadata follow the kernels to the host (pinned), as the reference's align_all() does with its
     // result_starts (aligner_global_myers_banded.cpp:372-374): sync_alignments() and get_alignments_device() read
@@ -405,10 +597,16 @@ void BandedAligner::fetch_head()
         if (head_ != nullptr) pinned_release(head_, head_cap_);
         head_ = pinned_acquire((2 * un + 1) * 4, &head_cap_);
     }
-    GW_CU_CHECK_ERR(hipMemcpyAsync(head_, d_result_starts_, (un + 1) * 4, hipMemcpyDeviceToHost, stream_));
-    GW_CU_CHECK_ERR(hipMemcpyAsync(head_ + (un + 1) * 4, d_metadata_, un * 4, hipMemcpyDeviceToHost, stream_));
     n_head_ = static_cast<int32_t>(un);
+}
 
+void BandedAligner::fetch_head_slice(const Chunk& c, void* stream)
+{
+    const size_t un = static_cast<size_t>(n_head_), lo = static_cast<size_t>(c.lo), m = static_cast<size_t>(c.hi - c.lo);
+    hipStream_t s   = static_cast<hipStream_t>(stream);
+    // entry hi of the offsets is the number of runs up to the chunk's end (the batch's total for the last chunk)
+    GW_CU_CHECK_ERR(hipMemcpyAsync(head_ + lo * 4, d_result_starts_ + lo, (m + 1) * 4, hipMemcpyDeviceToHost, s));
+    GW_CU_CHECK_ERR(hipMemcpyAsync(head_ + (un + 1 + lo) * 4, d_metadata_ + lo, m * 4, hipMemcpyDeviceToHost, s));
 }
 
 void BandedAligner::relaunch_resident()
@@ -495,40 +693,8 @@ StatusType BandedAligner::sync_alignments()
             }
         };
         const size_t n_threads = un >= 65536 ? std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
-        if (n_threads <= 1)
-            bind_range(0, un);
-        else
-        {
-            const size_t chunk = (un + n_threads - 1) / n_threads;
-            std::vector<std::thread> workers;
-            std::vector<std::exception_ptr> errors(n_threads);
-            {
-                struct JoinAll
-                {
-                    std::vector<std::thread>& threads;
-                    ~JoinAll()
-                    {
-                        for (std::thread& t : threads)
-                            if (t.joinable()) t.join();
-                    }
-                } join_on_exit{workers};
-                workers.reserve(n_threads);
-                for (size_t t = 1; t < n_threads; ++t)
-                    workers.emplace_back([&, t] {
-                        try
-                        {
-                            bind_range(std::min(un, t * chunk), std::min(un, (t + 1) * chunk));
-                        }
-                        catch (...)
-                        {
-                            errors[t] = std::current_exception();
-                        }
-                    });
-                bind_range(0, std::min(un, chunk));
-            }
-            for (const std::exception_ptr& e : errors)
-                if (e) std::rethrow_exception(e);
-        }
+        const size_t share = (un + n_threads - 1) / n_threads;
+        gwhost::parallel_tasks(n_threads, n_threads, [&](size_t t) { bind_range(std::min(un, t * share), std::min(un, (t + 1) * share)); });
         block->n_alignments = un;
         trace.mark("sync: views bound and published");
         GW_CU_CHECK_ERR(hipStreamSynchronize(stream_)); // uploads, kernels and the offsets / metadata copy queued by align_all()

@@ -202,7 +202,21 @@ typedef struct gwhip_myers_args
     int32_t index_base;
     int64_t first_sequence_offset;
     const int32_t* result_starts_base;
+    /* Optional second stream for what surrounds the alignment kernel: the workspace sizing ahead of it (reads sequence_starts,
+       max_bandwidths and scheduling_index only) and the run-offset scan, compaction and band_cells copy behind it. With chunked
+       calls the kernels of consecutive chunks then run back to back on `stream` while chunk k's compaction and chunk k + 1's
+       sizing run beside them. Ordering is by events inside the call; the caller passes the SAME side stream to every chunk
+       (result_starts_base is written there), has the inputs named above ordered before the side stream's work, and joins the
+       side stream into `stream` (or drains both) before it reads results. NULL = everything on `stream`. */
+    gwhip_stream_t side_stream;
+    /* 0 = the whole call. A caller that pipelines chunks can split it: GWHIP_MYERS_SIZING runs only the workspace sizing (on
+       side_stream, or stream when NULL); GWHIP_MYERS_ALIGN runs the alignment kernel on `stream` and what follows it, for the
+       same args, once the caller has ordered the SIZING call's work before `stream` (an event of its own: the call then adds no
+       hand-over from the side stream, so chunk k's kernel does not wait for sizing calls queued later). */
+    int32_t phases;
 } gwhip_myers_args;
+#define GWHIP_MYERS_SIZING 1
+#define GWHIP_MYERS_ALIGN 2
 
 size_t gwhip_myers_banded_workspace_bytes(int32_t n_alignments, const int64_t* sequence_starts_host,
                                           const int32_t* max_bandwidths_host);
@@ -210,12 +224,26 @@ size_t gwhip_myers_banded_workspace_bytes(int32_t n_alignments, const int64_t* s
    size it with the same order that gwhip_myers_banded will be given (pairs whose wave does not fit report no result). */
 size_t gwhip_myers_banded_workspace_bytes_ordered(int32_t n_alignments, const int64_t* sequence_starts_host,
                                                   const int32_t* max_bandwidths_host, const int32_t* scheduling_index_host);
+/* The same sum in pieces, for hosts that size a large batch on several threads: `..._workspace_words` is the part of the
+   slots [first_slot, first_slot + n_slots) of the processing order (first_slot a multiple of 64, n_slots too unless the
+   piece is the last); `..._workspace_bytes_of_words` turns the pieces' total into the byte count the call above returns
+   (total_sequence_length = sequence_starts_host[2 n] - sequence_starts_host[0]). */
+int64_t gwhip_myers_banded_workspace_words(int32_t first_slot, int32_t n_slots, const int64_t* sequence_starts_host,
+                                           const int32_t* max_bandwidths_host, const int32_t* scheduling_index_host);
+size_t gwhip_myers_banded_workspace_bytes_of_words(int32_t n_alignments, int64_t total_sequence_length, int64_t words);
 int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream);
 /* myers_banded_gpu_get_blocks_per_sm() (myers_gpu.cuh:53; the reference sizes its persistent launch with it,
    aligner_global_myers_banded.cpp:137-140): resident blocks of the one-lane-per-pair kernel per compute unit on `device`.
    Our launches are one block per wave of pairs, not persistent, so the host classes do not need it; exported for callers that
    size their batches by it. Returns a hipError_t as int. */
 int gwhip_myers_occupancy(int device, int* blocks_per_cu);
+
+/* Packed upload of the banded aligner's sequences (round 5): two bases per byte, base i in bits 4 (i & 1) .. 4 (i & 1) + 3 of
+   byte i >> 1, codes 0..4 = 'A', 'C', 'T', 'G', 'N'. The host encodes a QUERY base as A / C / T / G -> 0..3 and anything else
+   -> 4 (the kernels compare query characters with 'A', 'C', 'T', 'G' only, myers_gpu.cu:196-208) and a TARGET base c as
+   (c >> 1) & 3 (all the kernels use of a target character, myers_gpu.cu:210-241): the decoded batch behaves exactly like the
+   original one. Writes sequences[first .. last) from packed; asynchronous on `stream`. Returns a hipError_t as int. */
+int gwhip_unpack_bases(const uint8_t* packed, char* sequences, int64_t first, int64_t last, gwhip_stream_t stream);
 
 /* ---- cudaaligner: default aligner, Hirschberg + Myers (hirschberg_myers_gpu.cuh:45, hirschberg_myers_gpu.cu:684-701) ---- */
 typedef struct gwhip_hirschberg_args

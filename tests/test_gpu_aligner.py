@@ -76,6 +76,43 @@ def test_random_pairs_bit_exact_vs_oracle(max_bw):
             assert r.edit_distance == ref["edit_distance"]
 
 
+def test_bases_outside_acgt_and_odd_offsets_equal_the_oracle():
+    """The batch goes to the device two bases per byte (include/gwhip.h, gwhip_unpack_bases): a query base keeps what the
+    kernels can tell apart ('A', 'C', 'T', 'G' or anything else, myers_gpu.cu:196-208), a target base its pattern index
+    (c >> 1) & 3 (myers_gpu.cu:210-241). Lower case, 'N', IUPAC codes and arbitrary bytes in both sequences, odd lengths (so
+    queries and targets start on either half of a byte), in a batch large enough for the chunked upload when forced:
+    CIGARs, flags and distances equal the oracle, which follows the reference on the unpacked characters."""
+    import os
+    rng = random.Random(4242)
+    alphabet = "ACGTACGTACGTNnacgtRYKMSWBDHV-*xU@~ "
+    pairs = []
+    for k in range(700):
+        n = rng.choice([1, 2, 3, 15, 16, 17, 31, 33, 64, 65, 99, 150, 151, 301, 1000])
+        q = "".join(rng.choice(alphabet) for _ in range(n))
+        t = "".join(c if rng.random() > 0.06 else rng.choice(alphabet) for c in q)
+        if rng.random() < 0.3:
+            cut = rng.randrange(len(t))
+            t = t[:cut] + t[cut + 1:]
+        pairs.append((q, t or "n"))
+    ref = [A.align(q, t, 256) for q, t in pairs]
+    for chunks in (None, "5"):
+        if chunks is None:
+            os.environ.pop("GW_ALIGNER_CHUNKS", None)
+        else:
+            os.environ["GW_ALIGNER_CHUNKS"] = chunks
+        try:
+            res = run(pairs, max_bandwidth=256)
+        finally:
+            os.environ.pop("GW_ALIGNER_CHUNKS", None)
+        for (q, t), r, e in zip(pairs, res, ref):
+            assert (r.status == 0) == (e["status"] == 0), (q, t)
+            if e["status"] == 0:
+                assert r.cigar_extended == e["cigar_extended"], (q, t)
+                assert (r.is_optimal, r.edit_distance) == (e["optimal"], e["edit_distance"])
+        # the Alignment objects still hold the characters the caller passed
+        assert [(r.query, r.target) for r in res[:50]] == pairs[:50]
+
+
 def test_group_kernel_equals_one_lane_kernel(monkeypatch):
     """A/B of the two banded Myers kernels: eight lanes per pair (carry-lookahead over the lanes; picked for small batches
     of long pairs) against one lane per pair (GWHIP_MYERS_GROUP=0), and the group kernel forced on short queries too
