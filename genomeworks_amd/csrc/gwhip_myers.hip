@@ -1286,6 +1286,38 @@ __global__ __launch_bounds__(256) void compact_kernel(KernelArgs a, int8_t* resu
     }
 }
 
+// the call's packed runs [result_starts[0], result_starts[n]) also go to the caller's pinned host mirrors (entries below the
+// capacity): wavefront-wide consecutive stores, so the link sees whole lines
+__global__ __launch_bounds__(256) void mirror_runs_kernel(const int8_t* results, const int32_t* result_counts, const int32_t* result_starts, int32_t n,
+                                                          int8_t* results_host, int32_t* result_counts_host, int64_t capacity,
+                                                          const uint32_t* metadata, int32_t* result_starts_host, uint32_t* metadata_host)
+{
+    if (result_starts_host != nullptr)
+        for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x)
+        {
+            result_starts_host[i] = result_starts[i];
+            if (i < n && metadata_host != nullptr) metadata_host[i] = metadata[i];
+        }
+    if (results_host == nullptr || capacity <= 0) return;
+    const int64_t first = result_starts[0], last = min((int64_t)result_starts[n], capacity);
+    const int64_t step  = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < last; j += step) result_counts_host[j] = result_counts[j];
+    // the operations four per lane where the words are whole
+    const int64_t w0 = (first + 3) & ~int64_t(3), w1 = last & ~int64_t(3);
+    if (w0 < w1)
+    {
+        for (int64_t j = w0 + 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); j < w1; j += 4 * step)
+            *reinterpret_cast<uint32_t*>(results_host + j) = *reinterpret_cast<const uint32_t*>(results + j);
+        if (blockIdx.x == 0 && threadIdx.x < 8)
+        {
+            const int64_t j = threadIdx.x < 4 ? first + threadIdx.x : w1 + (threadIdx.x - 4);
+            if ((threadIdx.x < 4 && j < w0) || (threadIdx.x >= 4 && j < last)) results_host[j] = results[j];
+        }
+    }
+    else
+        for (int64_t j = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < last; j += step) results_host[j] = results[j];
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // fixed part of the workspace (depends on n and the total sequence length only), then the per-pair matrices
@@ -3432,6 +3464,15 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
     }
     hipLaunchKernelGGL(compact_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ka, args->results, args->result_counts,
                        args->result_starts);
+    {
+        const bool runs = args->results_host && args->result_counts_host && args->results_host_capacity > 0;
+        // (a small grid: the link needs few stores in flight, and a wide one slows the alignment kernel it runs beside)
+        static const int mirror_blocks = [] { const char* e = std::getenv("GWHIP_MIRROR_BLOCKS"); return e ? std::max(1, std::atoi(e)) : 16; }();
+        if (runs || args->result_starts_host)
+            hipLaunchKernelGGL(mirror_runs_kernel, dim3(std::max(1, std::min((n + 63) / 64, mirror_blocks))), dim3(256), 0, stream, args->results, args->result_counts,
+                               args->result_starts, n, runs ? args->results_host : nullptr, args->result_counts_host, args->results_host_capacity,
+                               args->result_metadata, args->result_starts_host, args->result_metadata_host);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(e, "myers kernels launch");
     if (args->band_cells)

@@ -57,6 +57,7 @@ private:
     /// every chunk's kernels, pipelined over the aligner's stream and the side stream; `order` (host, pinned) goes up chunk by
     /// chunk when given, and workspaces are allocated when `allocate`
     void run_chunks(const int32_t* order, bool allocate);
+    void enqueue_inputs(size_t k); ///< chunk k's bases, offsets and band widths on the upload stream, and its event
     void prepare_head();                                  ///< pinned [result_starts | metadata] of the launched batch
     void fetch_head_slice(const Chunk& c, void* stream);  ///< the chunk's offsets and metadata follow its kernels to the host
     void join_side_stream();                              ///< stream_ continues after everything queued on the side stream
@@ -87,6 +88,10 @@ private:
     bool uploads_in_flight_          = false;
     int64_t total_length_h_          = 0;
     int32_t n_last_                  = 0;
+    char* mirror_                    = nullptr; ///< pinned: operations[mirror_runs_] | run lengths[mirror_runs_] written by the chunks' kernels
+    size_t mirror_cap_               = 0;       ///< bytes (pinned_acquire)
+    int64_t mirror_runs_             = 0;       ///< capacity in runs; the run lengths start at byte up64(mirror_runs_)
+    bool raw_upload_                 = false;   ///< GW_ALIGNER_RAW_UPLOAD (A/B switch): characters instead of packed bases over the link
     char* head_                      = nullptr; ///< pinned: result_starts[n + 1] | metadata[n] of the last launch
     size_t head_cap_                 = 0;
     int32_t n_head_                  = 0;

@@ -125,6 +125,7 @@ BandedAligner::~BandedAligner()
     for (void* e : upload_events_) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
     free_device();
     if (head_ != nullptr) pinned_release(head_, head_cap_);
+    if (mirror_ != nullptr) pinned_release(mirror_, mirror_cap_);
 }
 
 void BandedAligner::reset_max_bandwidth(int32_t max_bandwidth)
@@ -313,6 +314,21 @@ StatusType BandedAligner::align_all()
         c.span         = seq_starts_h_[2 * static_cast<size_t>(c.hi)] - c.first_offset;
     }
     launched_total_length_ = total_len;
+    raw_upload_            = std::getenv("GW_ALIGNER_RAW_UPLOAD") != nullptr;
+    // a chunked batch's runs also arrive in a pinned mirror as the chunks finish (gwhip_myers_args::results_host): sized for 16 runs
+    // per pair or one per 16 bases; sync_alignments() copies for itself when a batch has more
+    if (n_chunks > 1)
+    {
+        const int64_t want = std::min<int64_t>(total_len, std::max<int64_t>(16 * static_cast<int64_t>(n), total_len / 16));
+        if (mirror_ == nullptr || mirror_runs_ < want)
+        {
+            if (mirror_ != nullptr) pinned_release(mirror_, mirror_cap_);
+            mirror_      = nullptr;
+            mirror_runs_ = 0;
+            mirror_      = pinned_acquire(static_cast<size_t>((want + 63) & ~int64_t(63)) + static_cast<size_t>(want) * 4 + 64, &mirror_cap_);
+            mirror_runs_ = want;
+        }
+    }
     hipStream_t up = stream_;
     if (n_chunks > 1)
     {
@@ -342,24 +358,6 @@ StatusType BandedAligner::align_all()
     }
     PinnedVector<int32_t> order;
     order.resize(static_cast<size_t>(n));
-    auto enqueue_inputs = [&](const Chunk& c) {
-        const int64_t b0 = seq_starts_h_[2 * static_cast<size_t>(c.lo)], b1 = seq_starts_h_[2 * static_cast<size_t>(c.hi)];
-        const size_t m   = static_cast<size_t>(c.hi - c.lo);
-        static const bool raw_upload = std::getenv("GW_ALIGNER_RAW_UPLOAD") != nullptr; // A/B switch: one byte per base over the link
-        if (b1 > b0 && raw_upload)
-            GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq_ + b0, seq_h_.data() + b0, static_cast<size_t>(b1 - b0), hipMemcpyHostToDevice, up));
-        else if (b1 > b0)
-        {
-            // the bases go up two per byte and are expanded on the device (0.1 ms for 300 MB): half the bytes over the link
-            const int64_t p0 = b0 >> 1, p1 = (b1 + 1) >> 1;
-            GW_CU_CHECK_ERR(hipMemcpyAsync(d_packed_ + p0, packed_h_.data() + p0, static_cast<size_t>(p1 - p0), hipMemcpyHostToDevice, up));
-            const int rc = gwhip_unpack_bases(d_packed_, d_seq_, b0, b1, up);
-            if (rc != 0) GW_CU_CHECK_ERR(static_cast<hipError_t>(rc));
-        }
-        GW_CU_CHECK_ERR(hipMemcpyAsync(d_starts_ + 2 * static_cast<size_t>(c.lo), seq_starts_h_.data() + 2 * static_cast<size_t>(c.lo), (2 * m + 1) * 8,
-                                       hipMemcpyHostToDevice, up));
-        GW_CU_CHECK_ERR(hipMemcpyAsync(d_bw_ + c.lo, max_bandwidths_h_.data() + c.lo, m * 4, hipMemcpyHostToDevice, up));
-    };
     // longest pairs first within a chunk (aligner_global_myers_banded.cpp:306-309): lanes of one wave get similar work;
     // indices are chunk-local
     auto sort_chunk = [&](const Chunk& c) {
@@ -382,19 +380,12 @@ StatusType BandedAligner::align_all()
             std::stable_sort(ord, ord + m, [&](int32_t a, int32_t b) { return len_of(a) > len_of(b); });
         }
     };
-    // Every chunk's inputs are queued on the upload stream right away (pinned sources: the calls return at once), one event per
-    // chunk; the link then runs back to back while the host orders and sizes the chunks -- on host threads, one chunk each:
-    // for a million short pairs that work (5 ms on one thread) would otherwise be longer than the uploads and the kernels.
-    for (int32_t k = 0; k < n_chunks; ++k)
-    {
-        Chunk& c = chunks_[static_cast<size_t>(k)];
-        enqueue_inputs(c);
-        if (n_chunks > 1)
-        {
-            c.uploaded = upload_events_[static_cast<size_t>(k)];
-            GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(c.uploaded), up));
-        }
-    }
+    // The first two chunks' inputs are queued on the upload stream right away (pinned sources: the calls return at once); the link
+    // runs while the host orders and sizes the chunks -- on host threads: for a million short pairs that work (5 ms on one
+    // thread) would otherwise be longer than the uploads and the kernels. run_chunks() queues the inputs of chunk k + 2 when it
+    // has queued chunk k + 1's processing order: copies of other streams are then never submitted behind uploads they do not need
+    // (copies of different streams can share an engine, which runs them in submission order).
+    for (int32_t k = 0; k < std::min(n_chunks, 2); ++k) enqueue_inputs(static_cast<size_t>(k));
     uploads_in_flight_ = true;
     trace.mark("align_all: device block, uploads enqueued");
     // Large chunks are cut into pieces of whole waves (64 slots) for the host threads: a stable counting sort by descending pair
@@ -477,6 +468,30 @@ StatusType BandedAligner::align_all()
     return StatusType::success;
 }
 
+void BandedAligner::enqueue_inputs(size_t k)
+{
+    Chunk& c         = chunks_[k];
+    hipStream_t up   = chunks_.size() > 1 ? static_cast<hipStream_t>(upload_stream_) : stream_;
+    const int64_t b0 = seq_starts_h_[2 * static_cast<size_t>(c.lo)], b1 = seq_starts_h_[2 * static_cast<size_t>(c.hi)];
+    const size_t m   = static_cast<size_t>(c.hi - c.lo);
+    if (b1 > b0 && raw_upload_)
+        GW_CU_CHECK_ERR(hipMemcpyAsync(d_seq_ + b0, seq_h_.data() + b0, static_cast<size_t>(b1 - b0), hipMemcpyHostToDevice, up));
+    else if (b1 > b0)
+    {
+        // the bases go up two per byte -- half the bytes over the link -- and are expanded on the device (run_chunks())
+        const int64_t p0 = b0 >> 1, p1 = (b1 + 1) >> 1;
+        GW_CU_CHECK_ERR(hipMemcpyAsync(d_packed_ + p0, packed_h_.data() + p0, static_cast<size_t>(p1 - p0), hipMemcpyHostToDevice, up));
+    }
+    GW_CU_CHECK_ERR(hipMemcpyAsync(d_starts_ + 2 * static_cast<size_t>(c.lo), seq_starts_h_.data() + 2 * static_cast<size_t>(c.lo), (2 * m + 1) * 8,
+                                   hipMemcpyHostToDevice, up));
+    GW_CU_CHECK_ERR(hipMemcpyAsync(d_bw_ + c.lo, max_bandwidths_h_.data() + c.lo, m * 4, hipMemcpyHostToDevice, up));
+    if (chunks_.size() > 1)
+    {
+        c.uploaded = upload_events_[k];
+        GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(c.uploaded), up));
+    }
+}
+
 void BandedAligner::run_chunks(const int32_t* order, bool allocate)
 {
     // A chunked batch keeps three streams busy: the uploads; the alignment kernels, back to back on the aligner's stream; and on
@@ -485,12 +500,21 @@ void BandedAligner::run_chunks(const int32_t* order, bool allocate)
     // the host. Events: upload_events_[k] = chunk k's inputs are up, [n + 2 + k] = its workspace is sized.
     const size_t n_chunks = chunks_.size();
     prepare_head();
+    // the chunk's bases from two per byte to characters (gwhip_unpack_bases), on the stream that has waited for its upload
+    auto unpack_chunk = [&](const Chunk& c, hipStream_t s) {
+        if (raw_upload_ || c.span == 0) return;
+        const int rc = gwhip_unpack_bases(d_packed_, d_seq_, c.first_offset, c.first_offset + c.span, s);
+        if (rc != 0) GW_CU_CHECK_ERR(static_cast<hipError_t>(rc));
+    };
     if (n_chunks <= 1)
     {
         for (Chunk& c : chunks_)
         {
             if (order != nullptr)
+            {
                 GW_CU_CHECK_ERR(hipMemcpyAsync(d_order_ + c.lo, order + c.lo, static_cast<size_t>(c.hi - c.lo) * 4, hipMemcpyHostToDevice, stream_));
+                unpack_chunk(c, stream_);
+            }
             if (allocate)
             {
                 c.block_bytes = up256(c.workspace_bytes);
@@ -507,7 +531,10 @@ void BandedAligner::run_chunks(const int32_t* order, bool allocate)
         if (c.uploaded != nullptr && order != nullptr) GW_CU_CHECK_ERR(hipStreamWaitEvent(side, static_cast<hipEvent_t>(c.uploaded), 0));
         // (the copy reads the caller's vector, whose storage order_h_ takes over at the end of align_all())
         if (order != nullptr)
+        {
             GW_CU_CHECK_ERR(hipMemcpyAsync(d_order_ + c.lo, order + c.lo, static_cast<size_t>(c.hi - c.lo) * 4, hipMemcpyHostToDevice, side));
+            unpack_chunk(c, side);
+        }
         if (allocate)
         {
             c.block_bytes = up256(c.workspace_bytes);
@@ -520,11 +547,11 @@ void BandedAligner::run_chunks(const int32_t* order, bool allocate)
     for (size_t k = 0; k < n_chunks; ++k)
     {
         if (k + 1 < n_chunks) size_chunk(k + 1);
+        if (order != nullptr && k + 2 < n_chunks) enqueue_inputs(k + 2);
         Chunk& c = chunks_[k];
         if (c.uploaded != nullptr && order != nullptr) GW_CU_CHECK_ERR(hipStreamWaitEvent(stream_, static_cast<hipEvent_t>(c.uploaded), 0));
         GW_CU_CHECK_ERR(hipStreamWaitEvent(stream_, static_cast<hipEvent_t>(upload_events_[n_chunks + 2 + k]), 0));
         launch_chunk(c, GWHIP_MYERS_ALIGN);
-        fetch_head_slice(c, side);
     }
     join_side_stream();
 }
@@ -552,6 +579,18 @@ void BandedAligner::launch_chunk(const Chunk& c, int32_t phases)
     a.band_cells            = d_cells_ + lo;
     a.side_stream           = chunks_.size() > 1 ? side_stream_ : nullptr;
     a.phases                = phases;
+    if (chunks_.size() > 1)
+    {
+        // the chunk's offsets and metadata reach the pinned head by a kernel of the call (no copies queued behind the uploads)
+        a.result_starts_host   = reinterpret_cast<int32_t*>(head_) + lo;
+        a.result_metadata_host = reinterpret_cast<uint32_t*>(head_) + static_cast<size_t>(n_head_) + 1 + lo;
+    }
+    if (chunks_.size() > 1 && mirror_ != nullptr)
+    {
+        a.results_host          = reinterpret_cast<int8_t*>(mirror_);
+        a.result_counts_host    = reinterpret_cast<int32_t*>(mirror_ + static_cast<size_t>((mirror_runs_ + 63) & ~int64_t(63)));
+        a.results_host_capacity = mirror_runs_;
+    }
     // hints for the LDS-cached kernel variant: longest query and widest band of this batch
     a.max_query_length   = longest_query_;
     a.max_bandwidth_hint = widest_band_;
@@ -700,18 +739,32 @@ StatusType BandedAligner::sync_alignments()
         GW_CU_CHECK_ERR(hipStreamSynchronize(stream_)); // uploads, kernels and the offsets / metadata copy queued by align_all()
         uploads_in_flight_ = false;
         trace.mark("sync: stream drained (H2D + kernels)");
-        const size_t total     = static_cast<size_t>(block->run_starts[un]);
-        const size_t counts_at = (total + 63) & ~size_t(63);
-        block->pinned          = pinned_acquire(counts_at + total * 4 + 64, &block->pinned_bytes);
-        block->ops             = reinterpret_cast<const int8_t*>(block->pinned);
-        block->counts          = reinterpret_cast<const int32_t*>(block->pinned + counts_at);
-        if (total > 0)
+        const size_t total = static_cast<size_t>(block->run_starts[un]);
+        if (chunks_.size() > 1 && mirror_ != nullptr && static_cast<int64_t>(total) <= mirror_runs_)
         {
-            GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned, d_results_, total, hipMemcpyDeviceToHost, stream_));
-            GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned + counts_at, d_result_counts_, total * 4, hipMemcpyDeviceToHost, stream_));
-            GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+            // the chunks' kernels have put the runs there already: the block takes the buffer over
+            block->pinned       = mirror_;
+            block->pinned_bytes = mirror_cap_;
+            block->ops          = reinterpret_cast<const int8_t*>(mirror_);
+            block->counts       = reinterpret_cast<const int32_t*>(mirror_ + static_cast<size_t>((mirror_runs_ + 63) & ~int64_t(63)));
+            mirror_             = nullptr;
+            mirror_cap_         = 0;
+            mirror_runs_        = 0;
         }
-        trace.mark("sync: D2H of the runs done");
+        else
+        {
+            const size_t counts_at = (total + 63) & ~size_t(63);
+            block->pinned          = pinned_acquire(counts_at + total * 4 + 64, &block->pinned_bytes);
+            block->ops             = reinterpret_cast<const int8_t*>(block->pinned);
+            block->counts          = reinterpret_cast<const int32_t*>(block->pinned + counts_at);
+            if (total > 0)
+            {
+                GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned, d_results_, total, hipMemcpyDeviceToHost, stream_));
+                GW_CU_CHECK_ERR(hipMemcpyAsync(block->pinned + counts_at, d_result_counts_, total * 4, hipMemcpyDeviceToHost, stream_));
+                GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+            }
+        }
+        trace.mark("sync: runs on the host");
         total_length_h_ = static_cast<int64_t>(total);
     }
     catch (...)

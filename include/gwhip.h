@@ -214,6 +214,17 @@ typedef struct gwhip_myers_args
        same args, once the caller has ordered the SIZING call's work before `stream` (an event of its own: the call then adds no
        hand-over from the side stream, so chunk k's kernel does not wait for sizing calls queued later). */
     int32_t phases;
+    /* Optional mirrors of the packed runs in pinned (device-accessible) host memory: once the call's runs are in `results` /
+       `result_counts`, entries below results_host_capacity are also copied there by a kernel of the same call (the device
+       knows the range; the host would have to wait for the offsets first). When the batch's total stays below the capacity the
+       host needs no copy of its own after the streams have drained. NULL / 0 = none. */
+    int8_t* results_host;
+    int32_t* result_counts_host;
+    int64_t results_host_capacity;
+    /* The same for the call's n_alignments + 1 entries of result_starts and its n_alignments entries of result_metadata (host
+       pointers that correspond to the device pointers above; independent of the capacity). NULL = none. */
+    int32_t* result_starts_host;
+    uint32_t* result_metadata_host;
 } gwhip_myers_args;
 #define GWHIP_MYERS_SIZING 1
 #define GWHIP_MYERS_ALIGN 2
