@@ -319,8 +319,10 @@ StatusType BandedAligner::align_all()
     // per pair or one per 16 bases; sync_alignments() copies for itself when a batch has more
     if (n_chunks > 1)
     {
-        const int64_t want = std::min<int64_t>(total_len, std::max<int64_t>(16 * static_cast<int64_t>(n), total_len / 16));
-        if (mirror_ == nullptr || mirror_runs_ < want)
+        int64_t want     = std::min<int64_t>(total_len, std::max<int64_t>(16 * static_cast<int64_t>(n), total_len / 16));
+        const char* runs = std::getenv("GW_ALIGNER_MIRROR_RUNS"); // tests: a capacity the batch exceeds
+        if (runs != nullptr) want = std::max<int64_t>(1, std::min<int64_t>(std::atoll(runs), total_len));
+        if (mirror_ == nullptr || mirror_runs_ < want || runs != nullptr)
         {
             if (mirror_ != nullptr) pinned_release(mirror_, mirror_cap_);
             mirror_      = nullptr;

@@ -113,6 +113,37 @@ def test_bases_outside_acgt_and_odd_offsets_equal_the_oracle():
         assert [(r.query, r.target) for r in res[:50]] == pairs[:50]
 
 
+def test_chunked_batch_runs_reach_the_host_through_the_mirror_or_the_copy(monkeypatch):
+    """A chunked batch's runs are written to a pinned mirror by the chunks' kernels (gwhip_myers_args::results_host);
+    sync_alignments() copies for itself when the batch has more runs than the mirror holds. Both ways, and one chunk, give the
+    same alignments as the oracle: pairs with a run per base (every other base substituted) next to identical pairs, so that
+    the capacity cut falls inside a chunk, and a batch that fits."""
+    rng = random.Random(99)
+    swap = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    pairs = []
+    for k in range(640):
+        n = rng.choice([40, 97, 150, 151, 300])
+        q = "".join(rng.choice("ACGT") for _ in range(n))
+        if k % 3 == 0:
+            t = "".join(swap[c] if i % 2 else c for i, c in enumerate(q))
+        elif k % 3 == 1:
+            t = q
+        else:
+            t = _mutate(rng, q, 3) or "A"
+        pairs.append((q, t))
+    ref = [A.align(q, t, 512) for q, t in pairs]
+    want = [(e["status"], e["cigar_extended"], e["optimal"], e["edit_distance"]) for e in ref]
+    assert sum(len(e["runs"]) for e in ref) > 16 * len(pairs)  # more than the default capacity of a small batch
+    for chunks, mirror_runs in (("1", None), ("5", None), ("5", "1000"), ("5", "10000000"), ("7", "3")):
+        monkeypatch.setenv("GW_ALIGNER_CHUNKS", chunks)
+        if mirror_runs is None:
+            monkeypatch.delenv("GW_ALIGNER_MIRROR_RUNS", raising=False)
+        else:
+            monkeypatch.setenv("GW_ALIGNER_MIRROR_RUNS", mirror_runs)
+        got = [(r.status, r.cigar_extended, r.is_optimal, r.edit_distance) for r in run(pairs, max_bandwidth=512)]
+        assert got == want, (chunks, mirror_runs)
+
+
 def test_group_kernel_equals_one_lane_kernel(monkeypatch):
     """A/B of the two banded Myers kernels: eight lanes per pair (carry-lookahead over the lanes; picked for small batches
     of long pairs) against one lane per pair (GWHIP_MYERS_GROUP=0), and the group kernel forced on short queries too
