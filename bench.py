@@ -194,6 +194,39 @@ def reduce_scalars(dist, torch, values, op):
     return [float(x) for x in t.tolist()]
 
 
+def aligner_golden_verdict(key, runs, lo, hi):
+    """The checker of a banded-aligner record: `runs` (CudaAlignerBatch.get_runs() of the pairs [lo, hi) of the config) against
+    the committed oracle golden of BASELINE configs[1] (`key` "config2": a CIGAR fingerprint, the optimality flag and the edit
+    distance of every pair) or configs[4] ("config5": flags and edit distances of every pair, digests of the fingerprints in
+    blocks of 1024 pairs -- the blocks that lie inside [lo, hi) -- and one digest over all pairs when the range is the whole
+    config). tests/golden/make_config_goldens.py wrote them; tests/test_gpu_config_goldens.py makes the same comparison.
+    -> (ok, what was compared)"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_io as G  # the checker
+    s = G.summary()[key]
+    g = G.config2_pairs() if key == "config2" else G.config5_pairs()
+    n = hi - lo
+    ok = len(runs["status"]) == n and bool((np.asarray(runs["status"]) == 0).all())
+    ok = ok and bool((np.asarray(runs["optimal"]) == g["optimal"][lo:hi]).all())
+    ok = ok and bool((G.edit_distances(runs["offsets"], runs["ops"], runs["counts"]) == g["edit_distance"][lo:hi]).all())
+    fp = G.run_fingerprints(runs["offsets"], runs["ops"], runs["counts"])
+    if key == "config2":
+        ok = ok and bool((fp == g["fingerprint"][lo:hi]).all())
+        return ok, "CIGAR fingerprint, optimality flag and edit distance of each of the %d pairs" % n
+    block = int(s["block"])
+    first, last = (lo + block - 1) // block, hi // block  # whole blocks inside the range
+    if hi == int(s["pairs"]) and hi % block:
+        last += 1  # the config's short last block
+    for b in range(first, last):
+        part = fp[b * block - lo:min((b + 1) * block, hi) - lo]
+        ok = ok and hashlib.sha256(np.ascontiguousarray(part).tobytes()).hexdigest()[:32] == str(g["block_sha"][b])
+    if lo == 0 and hi == int(s["pairs"]):
+        ok = ok and hashlib.sha256(fp.tobytes()).hexdigest() == s["fingerprint_sha256"]
+    return ok, ("optimality flag and edit distance of each of the %d pairs, CIGAR fingerprints in %d blocks of %d pairs"
+                % (n, max(0, last - first), block))
+
+
 def bench_aligner(name, cfg, rank, world, local_rank, sync, dist, torch, reps, cpu_budget_s, cpu_all_cores=None):
     """One aligner config, index-split over the ranks. Timed regions: align_all() + sync_alignments() (the reference
     benchmark's, cudaaligner/benchmarks/main.cpp:96-143), align_all() + stream sync with the results left on the
@@ -242,8 +275,19 @@ def bench_aligner(name, cfg, rank, world, local_rank, sync, dist, torch, reps, c
         sync()
         t_full.append(time.perf_counter() - t0)
         assert n_host == len(mine)
+    # outside the clock: this rank's pairs once more, every alignment against the committed oracle golden
+    golden_flag, golden_what = -1.0, None
+    try:
+        al.reset()
+        fill()
+        al.align_all()
+        ok, golden_what = aligner_golden_verdict("config2" if cfg is CONFIG2 else "config5", al.get_runs(), lo, hi)
+        golden_flag = 1.0 if ok else 0.0
+    except Exception as e:  # the record then says that the check did not run, and why
+        golden_what = "golden check failed to run: %r" % (e,)
     al.reset()
     full, dev = min(t_full), min(t_dev)
+    (golden_all,) = reduce_scalars(dist, torch, [golden_flag], "MIN")
     full, dev, k_max = reduce_scalars(dist, torch, [full, dev, k_ms], "MAX")
     (cells_all,) = reduce_scalars(dist, torch, [float(cells)], "SUM")
     if rank != 0:
@@ -263,6 +307,8 @@ def bench_aligner(name, cfg, rank, world, local_rank, sync, dist, torch, reps, c
                         "traffic": sub_traffic("configs[1]" if cfg is CONFIG2 else "configs[4]"),
                         "algorithmic_bytes_per_cell": BYTES_PER_MYERS_CELL, "kernel_ms": round(k_ms, 3)},
            "roofline_issue": roofline_issue("configs[1]" if cfg is CONFIG2 else "configs[4]")}
+    out["equals_oracle_golden"] = None if golden_all < 0 else bool(golden_all > 0.5)
+    out["golden_compared"] = golden_what  # (rank 0's words; every rank compared its own pairs)
     if cpu is not None:
         out["cpu_baseline"] = cpu
     return out

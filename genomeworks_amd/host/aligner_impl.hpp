@@ -60,6 +60,7 @@ private:
     void enqueue_inputs(size_t k); ///< chunk k's bases, offsets and band widths on the upload stream, and its event
     void prepare_head();                                  ///< pinned [result_starts | metadata] of the launched batch
     void fetch_head_slice(const Chunk& c, void* stream);  ///< the chunk's offsets and metadata follow its kernels to the host
+    void drain_streams();                                 ///< host waits for the aligner's, the upload and the side stream
     void join_side_stream();                              ///< stream_ continues after everything queued on the side stream
 
     cudaStream_t stream_;

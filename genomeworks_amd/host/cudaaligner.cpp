@@ -181,6 +181,14 @@ void BandedAligner::free_temporary_device_buffers()
     // everything but the packed results could go; we keep one block per batch, so this is a no-op until reset()
 }
 
+void BandedAligner::drain_streams()
+{
+    // the aligner's stream has waited for the other two by the end of align_all(); after a call that threw in between it has not
+    (void)hipStreamSynchronize(stream_);
+    if (upload_stream_ != nullptr) (void)hipStreamSynchronize(static_cast<hipStream_t>(upload_stream_));
+    if (side_stream_ != nullptr) (void)hipStreamSynchronize(static_cast<hipStream_t>(side_stream_));
+}
+
 StatusType BandedAligner::add_alignment(const char* query, int32_t query_length, const char* target, int32_t target_length,
                                         bool reverse_complement_query, bool reverse_complement_target)
 {
@@ -197,6 +205,7 @@ StatusType BandedAligner::add_alignment(int32_t max_bandwidth, const char* query
         // the staging arrays may be read by copies queued in align_all(): let them drain before the arrays can move
         scoped_device_switch dev(device_id_);
         GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+        drain_streams();
         uploads_in_flight_ = false;
     }
     if (max_bandwidth < 0 || query_length < 0 || target_length < 0 || query == nullptr || target == nullptr)
@@ -280,7 +289,11 @@ StatusType BandedAligner::align_all()
     const size_t o_cells = take(static_cast<size_t>(n) * 8);
     const size_t o_packed = take(static_cast<size_t>(total_len) / 2 + 64);
     // a previous align_all() without a sync in between may still be uploading from / computing on what this replaces
-    if (uploads_in_flight_) GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+    if (uploads_in_flight_)
+    {
+        GW_CU_CHECK_ERR(hipStreamSynchronize(stream_));
+        drain_streams();
+    }
     // from here until launch() the object describes NO finished run: if an allocation below throws, a later
     // sync_alignments() must not read the previous run's offsets against the fresh, never-written result block
     launched_ = false;
@@ -463,7 +476,16 @@ StatusType BandedAligner::align_all()
     for (const Piece& pc : pieces) chunks_[static_cast<size_t>(pc.chunk)].workspace_bytes += static_cast<size_t>(pc.words);
     for (Chunk& c : chunks_) c.workspace_bytes = gwhip_myers_banded_workspace_bytes_of_words(c.hi - c.lo, c.span, static_cast<int64_t>(c.workspace_bytes));
     trace.mark("align_all: chunks ordered and sized");
-    run_chunks(order.data(), true);
+    try
+    {
+        run_chunks(order.data(), true);
+    }
+    catch (...)
+    {
+        // copies queued so far read `order` and the staging arrays; kernels queued so far use the device block
+        drain_streams();
+        throw;
+    }
     order_h_ = std::move(order);
     trace.mark("align_all: chunks launched");
     launched_ = true;

@@ -165,3 +165,46 @@ def test_aligner_matrix_golden_file_matches_oracle_sample():
         assert all(r[1] >= 0 and r[2] >= 2048 for r in recs)
     # all four classes are optimal on these pairs: equal edit-distance sums
     assert len({gold[G.matrix_gen.cell_key(a, 1024, 2048)]["edit_distance_sum"] for a in ("ukkonen", "myers", "myers_banded", "hirschberg_myers")}) == 1
+
+
+def _oracle_runs(name, lo, hi):
+    """What CudaAlignerBatch.get_runs() returns for the pairs [lo, hi) of a config, from the oracle."""
+    import oracle_aligner as A
+    pairs = G.gen.pairs_of(name)[lo:hi]
+    c = G.gen.CONFIG2 if name == "config2" else G.gen.CONFIG5
+    offs, ops, cnts, status, opt = [0], [], [], [], []
+    for q, t in pairs:
+        r = A.align(q, t, c["max_bandwidth"])
+        status.append(r["status"])
+        opt.append(1 if r["optimal"] else 0)
+        for o, k in r["runs"]:
+            ops.append(o)
+            cnts.append(k)
+        offs.append(len(ops))
+    return {"offsets": np.array(offs, np.int64), "ops": np.array(ops, np.int8), "counts": np.array(cnts, np.int32),
+            "status": np.array(status, np.int8), "optimal": np.array(opt, np.uint8)}
+
+
+def test_bench_aligner_golden_verdict_accepts_the_oracle_and_rejects_a_changed_run():
+    """bench.py's checker of the configs[1] / configs[4] records (aligner_golden_verdict): a rank's range of pairs -- block
+    aligned or not, the start, the middle or the end of the config -- passes with the oracle's runs and fails when one run
+    length, one operation, one flag or one status differs."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for key, lo, hi in (("config2", 0, 40), ("config2", 9990, 10000), ("config5", 0, 2048), ("config5", 1000, 3100),
+                        ("config5", 1000000 - 1700, 1000000)):
+        runs = _oracle_runs(key, lo, hi)
+        ok, what = bench.aligner_golden_verdict(key, runs, lo, hi)
+        assert ok, (key, lo, hi, what)
+        for field, at in (("counts", len(runs["counts"]) // 2), ("ops", len(runs["ops"]) // 3), ("optimal", 5), ("status", 7)):
+            bad = {k: v.copy() for k, v in runs.items()}
+            bad[field][at] = bad[field][at] + 1 if field == "counts" else (bad[field][at] + 1) % 3 if field == "ops" else bad[field][at] ^ 1
+            assert not bench.aligner_golden_verdict(key, bad, lo, hi)[0], (key, lo, hi, field)
+    # a block that is wrong in the middle of an unaligned range
+    runs = _oracle_runs("config5", 1000, 3100)
+    i = int(runs["offsets"][1500])
+    runs["ops"][i] = (runs["ops"][i] + 1) % 3
+    assert not bench.aligner_golden_verdict("config5", runs, 1000, 3100)[0]

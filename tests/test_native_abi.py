@@ -83,3 +83,37 @@ def test_synthetic_generator_is_seed_stable(libs):
     assert a == b and a != c
     assert len(a) == 32 and len(a[0]) == 960 and all(900 <= len(r) <= 984 for r in a)
     assert set(b"".join(a)) <= set(b"ACGT")
+
+
+def test_banded_myers_workspace_sized_in_pieces_equals_the_whole(libs):
+    """gwhip_myers_banded_workspace_words over pieces of whole waves (64 slots) + ..._bytes_of_words is what
+    gwhip_myers_banded_workspace_bytes_ordered returns for the batch: align_all() sizes a chunk's workspace piece by piece on
+    host threads (host functions, no device call)."""
+    import random
+    import numpy as np
+    gwhip, _ = libs
+    gwhip.gwhip_myers_banded_workspace_bytes_ordered.restype = C.c_size_t
+    gwhip.gwhip_myers_banded_workspace_bytes_of_words.restype = C.c_size_t
+    gwhip.gwhip_myers_banded_workspace_words.restype = C.c_int64
+    p64, p32 = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+    gwhip.gwhip_myers_banded_workspace_bytes_ordered.argtypes = [C.c_int32, p64, p32, p32]
+    gwhip.gwhip_myers_banded_workspace_words.argtypes = [C.c_int32, C.c_int32, p64, p32, p32]
+    gwhip.gwhip_myers_banded_workspace_bytes_of_words.argtypes = [C.c_int32, C.c_int64, C.c_int64]
+    rng = random.Random(5)
+    for n in (1, 63, 64, 65, 1000, 4099):
+        starts = [0]
+        for _ in range(n):
+            q = rng.choice([1, 31, 32, 150, 151, 1000])
+            starts.append(starts[-1] + q)
+            starts.append(starts[-1] + max(1, q + rng.randint(-3, 3)))
+        starts = np.array(starts, np.int64)
+        bws = np.array([rng.choice([7, 150, 512, 1024]) for _ in range(n)], np.int32)
+        order = np.array(sorted(range(n), key=lambda i: -(starts[2 * i + 2] - starts[2 * i])), np.int32)
+        for sched in (order, None):
+            so = sched.ctypes.data_as(p32) if sched is not None else None
+            whole = gwhip.gwhip_myers_banded_workspace_bytes_ordered(n, starts.ctypes.data_as(p64), bws.ctypes.data_as(p32), so)
+            for share in (64, 192, 4096):
+                words = 0
+                for lo in range(0, n, share):
+                    words += gwhip.gwhip_myers_banded_workspace_words(lo, min(n, lo + share) - lo, starts.ctypes.data_as(p64), bws.ctypes.data_as(p32), so)
+                assert gwhip.gwhip_myers_banded_workspace_bytes_of_words(n, int(starts[-1] - starts[0]), words) == whole
