@@ -26,6 +26,7 @@
 
 #include "../../include/gwhip.h"
 #include "aligner_impl.hpp"
+#include "base_packing.hpp"
 #include "host_common.hpp"
 #include "aligner_global.hpp"
 #include "alignment_impl.hpp"
@@ -47,35 +48,9 @@ namespace
 {
 constexpr int32_t kWordSize = 32;
 size_t up256(size_t v) { return (v + 255) & ~size_t(255); }
-// Two bases per byte for the upload (include/gwhip.h, gwhip_unpack_bases): base i of the batch in bits 4 (i & 1) .. + 3 of byte
-// i >> 1. A query base keeps what the kernels can tell apart -- 'A', 'C', 'T', 'G' (myers_gpu.cu:196-208 compares with exactly
-// these) or "anything else" -- a target base its pattern index (c >> 1) & 3 (myers_gpu.cu:210-241).
-struct QueryCodes
-{
-    uint8_t of[256];
-    QueryCodes()
-    {
-        for (int c = 0; c < 256; c++) of[c] = 4;
-        of['A'] = 0, of['C'] = 1, of['T'] = 2, of['G'] = 3;
-    }
-};
-const QueryCodes kQueryCodes;
-inline uint8_t query_code(char c) { return kQueryCodes.of[static_cast<unsigned char>(c)]; }
-inline uint8_t target_code(char c) { return static_cast<uint8_t>((static_cast<unsigned char>(c) >> 1) & 3u); }
-template <typename Code>
-void pack_bases(uint8_t* packed, int64_t first, const char* bases, int32_t n, Code code)
-{
-    int64_t i     = first;
-    int32_t k     = 0;
-    if (n > 0 && (i & 1)) // shares its byte with the base before it
-    {
-        packed[i >> 1] = static_cast<uint8_t>((packed[i >> 1] & 0x0f) | (code(bases[0]) << 4));
-        ++i;
-        ++k;
-    }
-    for (; k + 2 <= n; k += 2, i += 2) packed[i >> 1] = static_cast<uint8_t>(code(bases[k]) | (code(bases[k + 1]) << 4));
-    if (k < n) packed[i >> 1] = code(bases[k]);
-}
+using gwhost::pack_bases;
+using gwhost::query_code;
+using gwhost::target_code;
 // GW_ALIGNER_TRACE=1: host-side timeline of align_all() / sync_alignments() on stderr (debugging aid)
 struct Tracer
 {

@@ -79,3 +79,13 @@ def test_worker_pool_runs_every_task_once(tmp_path):
                     "-pthread"], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+def test_two_bases_per_byte_round_trip(tmp_path):
+    """The banded aligner's upload format (genomeworks_amd/host/base_packing.hpp) against a restatement of the device-side
+    expansion: tests/cpp/base_packing_driver.cpp."""
+    exe = str(tmp_path / "base_packing_driver")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "genomeworks_amd", "host"), "-o", exe,
+                    os.path.join(ROOT, "tests", "cpp", "base_packing_driver.cpp")], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
