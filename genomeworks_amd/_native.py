@@ -39,7 +39,10 @@ class MyersArgs(C.Structure):
                 ("scheduling_index", C.c_void_p), ("band_cells", C.c_void_p), ("run_counts_out", C.c_void_p),
                 ("max_query_length", C.c_int32), ("max_bandwidth_hint", C.c_int32),
                 # chunked batches (include/gwhip.h); all zero = one call for the whole batch
-                ("index_base", C.c_int32), ("first_sequence_offset", C.c_int64), ("result_starts_base", C.c_void_p)]
+                ("index_base", C.c_int32), ("first_sequence_offset", C.c_int64), ("result_starts_base", C.c_void_p),
+                # pipelined chunks: second stream, phases of the call, pinned host mirrors of the results; all zero = none
+                ("side_stream", C.c_void_p), ("phases", C.c_int32), ("results_host", C.c_void_p), ("result_counts_host", C.c_void_p),
+                ("results_host_capacity", C.c_int64), ("result_starts_host", C.c_void_p), ("result_metadata_host", C.c_void_p)]
 
 
 class PoaBatchConfig(C.Structure):

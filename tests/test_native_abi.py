@@ -117,3 +117,18 @@ def test_banded_myers_workspace_sized_in_pieces_equals_the_whole(libs):
                 for lo in range(0, n, share):
                     words += gwhip.gwhip_myers_banded_workspace_words(lo, min(n, lo + share) - lo, starts.ctypes.data_as(p64), bws.ctypes.data_as(p32), so)
                 assert gwhip.gwhip_myers_banded_workspace_bytes_of_words(n, int(starts[-1] - starts[0]), words) == whole
+
+
+def test_python_mirror_of_gwhip_myers_args_has_the_layout_of_the_header(tmp_path):
+    """_native.MyersArgs (ctypes) against include/gwhip.h compiled by gcc: size and the offset of every field."""
+    import subprocess
+    from genomeworks_amd import _native
+    names = [f[0] for f in _native.MyersArgs._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gwhip.h"\nint main(void) {\n  printf("%zu", sizeof(gwhip_myers_args));\n'
+                   + "".join('  printf(" %%zu", offsetof(gwhip_myers_args, %s));\n' % n for n in names) + '  return 0;\n}\n')
+    exe = str(tmp_path / "layout")
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, str(src)], check=True)
+    got = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    assert got[0] == C.sizeof(_native.MyersArgs)
+    assert got[1:] == [getattr(_native.MyersArgs, n).offset for n in names]
