@@ -27,6 +27,7 @@
 #include "../../include/gwhip.h"
 #include "aligner_impl.hpp"
 #include "base_packing.hpp"
+#include "chunk_order.hpp"
 #include "host_common.hpp"
 #include "aligner_global.hpp"
 #include "alignment_impl.hpp"
@@ -348,28 +349,6 @@ StatusType BandedAligner::align_all()
     }
     PinnedVector<int32_t> order;
     order.resize(static_cast<size_t>(n));
-    // longest pairs first within a chunk (aligner_global_myers_banded.cpp:306-309): lanes of one wave get similar work;
-    // indices are chunk-local
-    auto sort_chunk = [&](const Chunk& c) {
-        const int32_t m = c.hi - c.lo;
-        int32_t* ord    = order.data() + c.lo;
-        auto len_of     = [&](int32_t i) { return seq_starts_h_[2 * static_cast<size_t>(c.lo + i) + 2] - seq_starts_h_[2 * static_cast<size_t>(c.lo + i)]; };
-        int64_t longest = 0;
-        for (int32_t i = 0; i < m; ++i) longest = std::max(longest, len_of(i));
-        if (m >= 4096 && longest < (int64_t(1) << 22))
-        {
-            // a stable counting sort by descending pair length: linear in m (a million short pairs sort in a few ms)
-            std::vector<int32_t> first(static_cast<size_t>(longest) + 2, 0);
-            for (int32_t i = 0; i < m; ++i) first[static_cast<size_t>(longest - len_of(i)) + 1]++;
-            for (size_t k = 1; k < first.size(); ++k) first[k] += first[k - 1];
-            for (int32_t i = 0; i < m; ++i) ord[static_cast<size_t>(first[static_cast<size_t>(longest - len_of(i))]++)] = i;
-        }
-        else
-        {
-            std::iota(ord, ord + m, 0);
-            std::stable_sort(ord, ord + m, [&](int32_t a, int32_t b) { return len_of(a) > len_of(b); });
-        }
-    };
     // The first two chunks' inputs are queued on the upload stream right away (pinned sources: the calls return at once); the link
     // runs while the host orders and sizes the chunks -- on host threads: for a million short pairs that work (5 ms on one
     // thread) would otherwise be longer than the uploads and the kernels. run_chunks() queues the inputs of chunk k + 2 when it
@@ -378,78 +357,17 @@ StatusType BandedAligner::align_all()
     for (int32_t k = 0; k < std::min(n_chunks, 2); ++k) enqueue_inputs(static_cast<size_t>(k));
     uploads_in_flight_ = true;
     trace.mark("align_all: device block, uploads enqueued");
-    // Large chunks are cut into pieces of whole waves (64 slots) for the host threads: a stable counting sort by descending pair
-    // length in three steps -- histogram per piece, first slot of every (length, piece) by a running sum, scatter per piece --
-    // gives exactly the order of the one-thread sort above; the workspace is then sized piece by piece.
-    struct Piece
+    // processing order (longest pairs first within a chunk, aligner_global_myers_banded.cpp:306-309) and workspace words of every
+    // chunk, on host threads (chunk_order.hpp)
     {
-        int32_t chunk, lo, hi; // chunk-local indices, and the same range of slots
-        std::vector<int32_t> first;
-        int64_t words;
-    };
-    trace.mark("align_all:   (order buffer)");
-    const size_t host_threads = std::min<size_t>(32, std::max(1u, std::thread::hardware_concurrency()));
-    const int64_t buckets     = longest_pair_ + 1;
-    std::vector<Piece> pieces;
-    for (int32_t k = 0; k < n_chunks; ++k)
-    {
-        const int32_t m       = chunks_[static_cast<size_t>(k)].hi - chunks_[static_cast<size_t>(k)].lo;
-        const int32_t p_count = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(static_cast<int64_t>(host_threads) / n_chunks, m / 16384)));
-        const int32_t share   = ((m + p_count - 1) / p_count + 63) & ~63;
-        for (int32_t lo = 0; lo < m; lo += share) pieces.push_back(Piece{k, lo, std::min(m, lo + share), {}, 0});
+        std::vector<gwhost::PairRange> ranges;
+        for (const Chunk& c : chunks_) ranges.push_back(gwhost::PairRange{c.lo, c.hi});
+        const size_t host_threads      = std::min<size_t>(32, std::max(1u, std::thread::hardware_concurrency()));
+        const std::vector<int64_t> words = gwhost::order_and_size_chunks(ranges, seq_starts_h_.data(), max_bandwidths_h_.data(), longest_pair_, host_threads,
+                                                                         order.data(), &gwhip_myers_banded_workspace_words);
+        for (size_t k = 0; k < chunks_.size(); ++k)
+            chunks_[k].workspace_bytes = gwhip_myers_banded_workspace_bytes_of_words(chunks_[k].hi - chunks_[k].lo, chunks_[k].span, words[k]);
     }
-    const bool in_pieces = pieces.size() > static_cast<size_t>(n_chunks) && buckets * static_cast<int64_t>(pieces.size()) <= (int64_t(1) << 22);
-    auto len_in_chunk    = [&](const Chunk& c, int32_t i) { return seq_starts_h_[2 * static_cast<size_t>(c.lo + i) + 2] - seq_starts_h_[2 * static_cast<size_t>(c.lo + i)]; };
-    auto size_piece      = [&](Piece& pc) {
-        const Chunk& c = chunks_[static_cast<size_t>(pc.chunk)];
-        pc.words       = gwhip_myers_banded_workspace_words(pc.lo, pc.hi - pc.lo, seq_starts_h_.data() + 2 * static_cast<size_t>(c.lo), max_bandwidths_h_.data() + c.lo,
-                                                            order.data() + c.lo);
-    };
-    if (in_pieces)
-    {
-        gwhost::parallel_tasks(pieces.size(), pieces.size(), [&](size_t t) {
-            Piece& pc      = pieces[t];
-            const Chunk& c = chunks_[static_cast<size_t>(pc.chunk)];
-            pc.first.assign(static_cast<size_t>(buckets), 0);
-            for (int32_t i = pc.lo; i < pc.hi; ++i) pc.first[static_cast<size_t>(longest_pair_ - len_in_chunk(c, i))]++;
-        });
-        trace.mark("align_all:   histograms");
-        for (size_t t0 = 0; t0 < pieces.size();) // the pieces of one chunk are consecutive
-        {
-            size_t t1 = t0;
-            while (t1 < pieces.size() && pieces[t1].chunk == pieces[t0].chunk) ++t1;
-            int32_t running = 0;
-            for (int64_t b = 0; b < buckets; ++b)
-                for (size_t t = t0; t < t1; ++t)
-                {
-                    const int32_t count                   = pieces[t].first[static_cast<size_t>(b)];
-                    pieces[t].first[static_cast<size_t>(b)] = running;
-                    running += count;
-                }
-            t0 = t1;
-        }
-        gwhost::parallel_tasks(pieces.size(), pieces.size(), [&](size_t t) {
-            Piece& pc      = pieces[t];
-            const Chunk& c = chunks_[static_cast<size_t>(pc.chunk)];
-            int32_t* ord   = order.data() + c.lo;
-            for (int32_t i = pc.lo; i < pc.hi; ++i) ord[static_cast<size_t>(pc.first[static_cast<size_t>(longest_pair_ - len_in_chunk(c, i))]++)] = i;
-        });
-        trace.mark("align_all:   scatter");
-        gwhost::parallel_tasks(pieces.size(), pieces.size(), [&](size_t t) { size_piece(pieces[t]); });
-        trace.mark("align_all:   workspace words");
-    }
-    else
-    {
-        pieces.clear();
-        for (int32_t k = 0; k < n_chunks; ++k) pieces.push_back(Piece{k, 0, chunks_[static_cast<size_t>(k)].hi - chunks_[static_cast<size_t>(k)].lo, {}, 0});
-        gwhost::parallel_tasks(pieces.size(), pieces.size(), [&](size_t t) {
-            sort_chunk(chunks_[static_cast<size_t>(pieces[t].chunk)]);
-            size_piece(pieces[t]);
-        });
-    }
-    for (Chunk& c : chunks_) c.workspace_bytes = 0; // (the words of its pieces until the sum is complete)
-    for (const Piece& pc : pieces) chunks_[static_cast<size_t>(pc.chunk)].workspace_bytes += static_cast<size_t>(pc.words);
-    for (Chunk& c : chunks_) c.workspace_bytes = gwhip_myers_banded_workspace_bytes_of_words(c.hi - c.lo, c.span, static_cast<int64_t>(c.workspace_bytes));
     trace.mark("align_all: chunks ordered and sized");
     try
     {

@@ -89,3 +89,18 @@ def test_two_bases_per_byte_round_trip(tmp_path):
                     os.path.join(ROOT, "tests", "cpp", "base_packing_driver.cpp")], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+def test_chunk_order_on_host_threads_equals_a_plain_stable_sort(tmp_path):
+    """The banded aligner's processing order and workspace sizing in pieces on pool threads (genomeworks_amd/host/chunk_order.hpp)
+    against one stable sort and one sizing call per chunk: tests/cpp/chunk_order_driver.cpp."""
+    from genomeworks_amd import build
+    build.build_all()
+    exe = str(tmp_path / "chunk_order_driver")
+    lib = os.path.join(ROOT, "genomeworks_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "genomeworks_amd", "host"), "-o", exe,
+                    os.path.join(ROOT, "tests", "cpp", "chunk_order_driver.cpp"), "-L", lib, "-lgenomeworks_amd", "-lgwhip",
+                    "-L", os.path.join(ROCM, "lib"), "-lamdhip64", "-Wl,-rpath," + lib, "-Wl,-rpath," + os.path.join(ROCM, "lib"),
+                    "-pthread"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
