@@ -1,0 +1,93 @@
+"""bench.py's banded-aligner record (bench_aligner) end to end on the CPU: the aligner is a double that answers from the oracle,
+so the record's flow -- fill, timed loops, the golden verdict outside the clock, the reductions -- runs without a GPU. The double
+is test infrastructure only; the real record is produced by genomeworks_amd.cudaaligner.CudaAlignerBatch on the device."""
+import importlib.util
+import os
+
+import numpy as np
+
+import oracle_aligner as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_bench():
+    spec = importlib.util.spec_from_file_location("bench_for_aligner_record", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+class FakeLib:
+    @staticmethod
+    def gw_aligner_add_alignment(handle, q, lq, t, lt, rq, rt):
+        assert lq == len(q) and lt == len(t)
+        handle.pairs.append((q, t))
+        return 0
+
+
+class FakeAligner:
+    """The calls bench_aligner makes on CudaAlignerBatch, answered by the oracle."""
+    spoil = None  # (pair, field) to falsify in get_runs(); "raise" to fail there
+
+    def __init__(self, max_bandwidth, **kwargs):
+        self.bw, self._L, self._h, self.pairs, self.res = max_bandwidth, FakeLib, self, [], None
+
+    def align_all(self):
+        self.res = [A.align(q, t, self.bw) for q, t in self.pairs]
+
+    def band_cells(self):
+        return sum(r["cells"] for r in self.res)
+
+    def relaunch_timed(self):
+        return 1.0
+
+    def reset(self):
+        self.pairs, self.res = [], None
+
+    def device_sync(self):
+        return len(self.res), sum(len(r["runs"]) for r in self.res)
+
+    def sync(self):
+        return len(self.res)
+
+    def get_runs(self):
+        if FakeAligner.spoil == "raise":
+            raise RuntimeError("no runs today")
+        offs, ops, cnts = [0], [], []
+        for r in self.res:
+            for o, k in r["runs"]:
+                ops.append(o)
+                cnts.append(k)
+            offs.append(len(ops))
+        out = dict(offsets=np.array(offs, np.int64), ops=np.array(ops, np.int8), counts=np.array(cnts, np.int32),
+                   status=np.array([r["status"] for r in self.res], np.int32), optimal=np.array([1 if r["optimal"] else 0 for r in self.res], np.int32))
+        if FakeAligner.spoil is not None:
+            pair, field = FakeAligner.spoil
+            at = pair if field in ("status", "optimal") else int(out["offsets"][pair])
+            out[field][at] = out[field][at] + 1 if field == "counts" else out[field][at] ^ 1
+        return out
+
+
+def run_record(bench, monkeypatch, cfg, pairs):
+    from genomeworks_amd import cudaaligner
+    monkeypatch.setattr(cudaaligner, "CudaAlignerBatch", FakeAligner)
+    monkeypatch.setitem(cfg, "pairs", pairs)
+    return bench.bench_aligner("record under test", cfg, 0, 1, 0, lambda: None, None, None, 2, 0.0)
+
+
+def test_aligner_record_reports_the_golden_verdict(monkeypatch):
+    bench = load_bench()
+    for cfg, pairs in ((bench.CONFIG2, 24), (bench.CONFIG5, 2048)):
+        FakeAligner.spoil = None
+        rec = run_record(bench, monkeypatch, cfg, pairs)
+        assert rec["equals_oracle_golden"] is True, rec["golden_compared"]
+        assert rec["pairs"] == pairs and rec["value"] > 0 and rec["kernel_only"]["ms"] == 1.0
+        assert str(pairs) in rec["golden_compared"]
+        for field in ("counts", "ops", "optimal", "status"):
+            FakeAligner.spoil = (pairs // 2, field)
+            assert run_record(bench, monkeypatch, cfg, pairs)["equals_oracle_golden"] is False, field
+        FakeAligner.spoil = "raise"
+        rec = run_record(bench, monkeypatch, cfg, pairs)
+        assert rec["equals_oracle_golden"] is None and "no runs today" in rec["golden_compared"]
+    FakeAligner.spoil = None
