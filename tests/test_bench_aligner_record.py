@@ -91,3 +91,72 @@ def test_aligner_record_reports_the_golden_verdict(monkeypatch):
         rec = run_record(bench, monkeypatch, cfg, pairs)
         assert rec["equals_oracle_golden"] is None and "no runs today" in rec["golden_compared"]
     FakeAligner.spoil = None
+
+
+def _rank(rank, world, port, q):
+    import contextlib
+    import io
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      GW_BENCH_RANKS_PER_DEVICE=str(world))
+    import torch
+    import golden_io
+    import test_bench_eight_ranks as E
+    from genomeworks_amd import cuda, cudaaligner, cudapoa, synthetic
+    rows, _ = golden_io.config3_windows()
+    E.FakeBatch.rows = rows
+    E.FakeBatch.by_first_read = {synthetic.generate_window(1000 + w)[0].decode(): w for w in range(len(rows))}
+    cudapoa.CudaPoaBatch = E.FakeBatch
+    cudaaligner.CudaAlignerBatch = FakeAligner
+    cuda.cuda_set_device = lambda d: None
+    torch.cuda.is_available = lambda: True
+    torch.cuda.set_device = lambda d: None
+    torch.cuda.synchronize = lambda *a: None
+    import bench
+    bench.CONFIG2["pairs"], bench.CONFIG5["pairs"] = 25, 3001  # odd counts: the ranks' ranges are uneven and not block aligned
+    if rank == 1 and os.environ.get("GW_TEST_SPOIL_RANK1"):
+        FakeAligner.spoil = (3, "ops")  # (an operation: seen by the edit distances, which the golden holds for every pair)
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--sub-configs", "aligner"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    q.put((rank, buf.getvalue()))
+
+
+def _two_ranks(spoil):
+    import json
+    import torch.multiprocessing as mp
+    world = 2
+    if spoil:
+        os.environ["GW_TEST_SPOIL_RANK1"] = "1"
+    else:
+        os.environ.pop("GW_TEST_SPOIL_RANK1", None)
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = 29950 + (os.getpid() % 40) + (7 if spoil else 0)
+        procs = [ctx.Process(target=_rank, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = dict(q.get(timeout=600) for _ in range(world))
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        os.environ.pop("GW_TEST_SPOIL_RANK1", None)
+    assert got[1].strip() == ""
+    lines = [l for l in got[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])["sub_records"]
+
+
+def test_aligner_records_with_two_gloo_ranks_reduce_the_verdict():
+    """bench.py --gpus 2 --sub-configs aligner over gloo with the doubles: every rank compares its own range of pairs with the
+    golden, the record says True only when all do (one falsified run on rank 1 turns it False)."""
+    sub = _two_ranks(False)
+    assert sub["configs[1]"]["equals_oracle_golden"] is True and sub["configs[4]"]["equals_oracle_golden"] is True
+    assert sub["configs[1]"]["pairs"] == 25 and sub["configs[4]"]["pairs_per_gpu"] in (1500, 1501)
+    sub = _two_ranks(True)
+    assert sub["configs[1]"]["equals_oracle_golden"] is False and sub["configs[4]"]["equals_oracle_golden"] is False
