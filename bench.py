@@ -237,6 +237,12 @@ def bench_aligner(name, cfg, rank, world, local_rank, sync, dist, torch, reps, c
     cpu = cpu_all_cores if cpu_all_cores is not None else (
         cpu_baseline_pairs(pairs, cfg["max_bandwidth"], cpu_budget_s) if (rank == 0 and cpu_budget_s > 0) else None)
     lo, hi = multi_gpu.shard_range(len(pairs), rank, world)
+    if cfg is CONFIG5 and world > 1:
+        # the ranks' ranges on the grid of the golden's fingerprint blocks (1024 pairs; under 1 % of a rank's pairs at N = 8):
+        # every pair's CIGAR then lies in a block that aligner_golden_verdict() compares
+        block = 1024
+        lo = 0 if rank == 0 else min(len(pairs), (lo + block - 1) // block * block)
+        hi = len(pairs) if rank == world - 1 else min(len(pairs), (hi + block - 1) // block * block)
     mine = pairs[lo:hi]
     al = cudaaligner.CudaAlignerBatch(max_bandwidth=cfg["max_bandwidth"], max_device_memory_allocator_caching_size=32 << 30,
                                       device_id=local_rank)
