@@ -125,6 +125,35 @@ class CudaPoaBatch:
         if not self._h:
             raise RuntimeError(self._L.gw_last_error().decode())
 
+    @classmethod
+    def from_batch_config(cls, max_sequence_size, max_sequences_per_poa, alignment_band_width, band_mode, max_gpu_mem,
+                          output_type="consensus", device_id=0, stream=None, gap_score=-8, mismatch_score=-6, match_score=8,
+                          adaptive_storage_factor=2.0, graph_length_factor=3.0, max_banded_pred_distance=0):
+        """A batch sized by the first BatchConfig constructor of batch.hpp -- BatchConfig(max_seq_sz, max_seq_per_poa,
+        band_width, banding, adaptive_storage_factor, graph_length_factor, max_pred_dist), which derives the consensus, graph
+        and matrix dimensions and, unlike the all-explicit constructor that __init__ (and cudapoa.pyx) uses, accepts a band
+        wider than the longest sequence. What C++ callers of the reference write."""
+        if output_type not in ("consensus", "msa"):
+            raise RuntimeError("Unknown output_type provided. Must be consensus/msa.")
+        if band_mode not in _BAND_MODES:
+            raise RuntimeError("Unknown band_mode provided. Must be full_band/static_band/adaptive_band.")
+        if stream is not None and not isinstance(stream, CudaStream):
+            raise RuntimeError("Type for stream option must be CudaStream")
+        self = cls.__new__(cls)
+        self._L = _bind(_native.host())
+        self.stream = stream
+        cfg = _native.PoaBatchConfig()
+        if self._L.gw_poa_batch_config_default(C.byref(cfg), max_sequence_size, max_sequences_per_poa, alignment_band_width,
+                                               _BAND_MODES[band_mode], adaptive_storage_factor, graph_length_factor,
+                                               max_banded_pred_distance) != 0:
+            raise ValueError(self._L.gw_last_error().decode())
+        self.batch_size = cfg
+        self._h = self._L.gw_poa_create_batch(device_id, stream.stream if stream is not None else None, int(max_gpu_mem),
+                                              1 if output_type == "consensus" else 2, C.byref(cfg), gap_score, mismatch_score, match_score)
+        if not self._h:
+            raise RuntimeError(self._L.gw_last_error().decode())
+        return self
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

@@ -766,3 +766,46 @@ def test_full_band_packed_pass_equals_the_generic_routine_and_the_oracle(monkeyp
                 assert cons[i] == ref["consensus"] and cov[i] == list(ref["coverage"]), i
         assert ws.overflow_events() == 0
     assert cells == cells_ref
+
+
+def test_hip_path_equals_the_reference_itself_on_the_simt_goldens():
+    """tests/golden/reference_simt_windows.json.gz holds what the REFERENCE's own cudapoa library answered (its CUDA sources
+    compiled from /root/reference and run on the CPU by the SIMT emulator of oracle/simt; tests/golden/make_reference_simt_goldens.py):
+    every band mode, consensus and MSA, other scores, per-base weights, graphs that outgrow max_nodes_per_graph, reads that
+    add_poa_group refuses. The HIP path through the Python API, with the batch sized by the same BatchConfig constructor,
+    gives the same add_poa_group statuses, window statuses, consensus, coverage and MSA rows."""
+    import gzip
+    import json
+    import os
+    from genomeworks_amd import cudapoa
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_simt_windows.json.gz"), "rb") as f:
+        rows = json.loads(f.read().decode())["windows"]
+    names = {v: k for k, v in BAND.items()}
+    assert len(rows) >= 77
+    bad = []
+    for i, r in enumerate(rows):
+        c, ref, bc = r["case"], r["reference"], r["reference"]["batch_config"]
+        msa = bool(c["output_mask"] & 2)
+        # the constructor the generator used on the reference: BatchConfig(max_seq_sz, max_seq_per_poa, band_width, banding)
+        b = cudapoa.CudaPoaBatch.from_batch_config(c["max_seq"], c["max_seqs"], c["band_width"], names[c["band_mode"]], 1 << 30,
+                                                   output_type="msa" if msa else "consensus", gap_score=c["gap"], mismatch_score=c["mismatch"],
+                                                   match_score=c["match"])
+        got = b.batch_size
+        assert [got.max_sequence_size, got.max_consensus_size, got.max_nodes_per_graph, got.matrix_sequence_dimension, got.alignment_band_width,
+                got.max_sequences_per_poa, got.band_mode, got.max_banded_pred_distance] == [bc[k] for k in (
+                    "max_sequence_size", "max_consensus_size", "max_nodes_per_graph", "matrix_sequence_dimension", "alignment_band_width",
+                    "max_sequences_per_poa", "band_mode", "max_banded_pred_distance")], i
+        st, seq_st = b.add_poa_group(c["reads"], c["weights"])
+        if (st, list(seq_st)) != (ref["add_status"], ref["read_status"]):
+            bad.append((i, "add_poa_group", st, list(seq_st)))
+            continue
+        b.generate_poa()
+        if msa:
+            rows_msa, status = b.get_msa()
+            if status[0] != ref["status"] or (status[0] == 0 and rows_msa[0] != ref["msa"]):
+                bad.append((i, "msa", status[0]))
+        else:
+            cons, cov, status = b.get_consensus()
+            if status[0] != ref["status"] or (status[0] == 0 and (cons[0], list(cov[0])) != (ref["consensus"], ref["coverage"])):
+                bad.append((i, "consensus", status[0]))
+    assert not bad, "windows where the HIP path differs from the reference: %s" % bad[:10]

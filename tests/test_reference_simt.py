@@ -1,0 +1,111 @@
+"""The oracle against THE REFERENCE ITSELF: the reference's cudapoa library (its CUDA sources compiled by g++ from where they lie,
+kernels run on the CPU by the SIMT emulator oracle/simt) answered the windows of tests/golden/reference_simt_windows.json.gz
+(tests/golden/make_reference_simt_goldens.py). The oracle must give the same statuses, consensus, coverage and MSA rows for every
+window; where the reference library is present (oracle/_ref/libref_cudapoa_simt.so: this container, and the GPU box when the
+prebuilt file travelled) a sample of the file is regenerated and fresh random windows are compared as well."""
+import gzip
+import json
+import os
+import random
+
+import pytest
+
+import oracle_poa as O
+import ref_cudapoa as R
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def golden():
+    with gzip.open(os.path.join(HERE, "golden", "reference_simt_windows.json.gz"), "rb") as f:
+        return json.loads(f.read().decode())["windows"]
+
+
+def accepted_reads(c, ref):
+    """add_poa_group refuses single reads (too long, too many: its per-read statuses say which); the window is what it accepted"""
+    keep = [i for i, st in enumerate(ref["read_status"]) if st == 0]
+    return dict(c, reads=[c["reads"][i] for i in keep], weights=None if c["weights"] is None else [c["weights"][i] for i in keep])
+
+
+def oracle_answer(c):
+    cfg = O.make_cfg(c["max_seq"], c["max_seqs"], c["band_width"], c["band_mode"], gap=c["gap"], mismatch=c["mismatch"], match=c["match"],
+                     output_mask=c["output_mask"])
+    with O.Workspace(cfg) as ws:
+        return ws.process(c["reads"], c["weights"])
+
+
+def same(c, ref, mine):
+    if ref["status"] != mine["status"]:
+        return False
+    if mine["status"] != 0:
+        return True
+    if c["output_mask"] & 1:
+        return ref["consensus"] == mine["consensus"] and list(ref["coverage"]) == [int(x) for x in mine["coverage"]]
+    return ref["msa"] == mine["msa"]
+
+
+def test_oracle_equals_the_reference_on_every_golden_window():
+    rows = golden()
+    assert len(rows) >= 70 and {r["case"]["band_mode"] for r in rows} == {0, 1, 2, 3, 4}
+    assert any(r["case"]["weights"] for r in rows) and {r["case"]["output_mask"] for r in rows} == {1, 2}
+    assert sum(r["reference"]["status"] == 4 for r in rows) >= 3          # node_count_exceeded_maximum_graph_size
+    assert any(2 in r["reference"]["read_status"] for r in rows)          # exceeded_maximum_sequence_size
+    assert any(3 in r["reference"]["read_status"] for r in rows)          # exceeded_maximum_sequences_per_poa
+    bad = [i for i, r in enumerate(rows)
+           if r["reference"]["add_status"] == 0 and not same(r["case"], r["reference"], oracle_answer(accepted_reads(r["case"], r["reference"])))]
+    assert not bad, "windows where the oracle differs from the reference: %s" % bad
+
+
+@pytest.mark.skipif(not R.available(), reason="the reference library (oracle/_ref/libref_cudapoa_simt.so) is not built here")
+def test_reference_library_reproduces_a_sample_of_the_golden_file():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_reference_simt_goldens", os.path.join(HERE, "golden", "make_reference_simt_goldens.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    rows, cases = golden(), gen.cases()
+    assert [r["case"] for r in rows] == cases  # the generator still describes the file
+    for i in (0, 9, 17, 30, 44, 58, 70, 72, 75, 76):
+        assert gen.run_reference(cases[i]) == rows[i]["reference"], i
+
+
+@pytest.mark.skipif(not R.available(), reason="the reference library (oracle/_ref/libref_cudapoa_simt.so) is not built here")
+def test_oracle_equals_the_reference_on_fresh_random_windows():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_reference_simt_goldens", os.path.join(HERE, "golden", "make_reference_simt_goldens.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    rng = random.Random(os.getpid())  # different windows on every run; the seed is in the failure message
+    seed = rng.randrange(1 << 30)
+    rng = random.Random(seed)
+    for k in range(12):
+        L = rng.choice([20, 70, 130, 220])
+        base = "".join(rng.choice("ACGT") for _ in range(L))
+        div = rng.choice([0, 15, 8, 5])
+        c = dict(max_seq=256, max_seqs=12, band_width=rng.choice([128, 256]), band_mode=rng.randint(0, 4), output_mask=rng.choice([1, 2]),
+                 gap=-8, mismatch=-6, match=8, reads=[gen.mutate(rng, base, L // div if div else 0) for _ in range(rng.randint(1, 10))], weights=None)
+        ref = gen.run_reference(c)
+        assert ref["add_status"] == 0
+        assert same(c, ref, oracle_answer(c)), "seed %d window %d: %s" % (seed, k, c)
+
+
+@pytest.mark.skipif(not R.available(), reason="the reference library (oracle/_ref/libref_cudapoa_simt.so) is not built here")
+def test_batch_config_constructor_equals_the_reference():
+    """BatchConfig(max_seq_sz, max_seq_per_poa, band_width, banding, adaptive_storage_factor, graph_length_factor, max_pred_dist):
+    the host library's constructor (gw_poa_batch_config_default, no device call) against the reference's own, field by field,
+    over band modes, widths that are and are not multiples of 128, the factors and predecessor distances."""
+    import ctypes as C
+    from genomeworks_amd import _native, cudapoa
+    L = cudapoa._bind(_native.host())
+    keys = ("max_sequence_size", "max_consensus_size", "max_nodes_per_graph", "matrix_sequence_dimension", "alignment_band_width",
+            "max_sequences_per_poa", "band_mode", "max_banded_pred_distance")
+    checked = 0
+    for mode in range(5):
+        for max_seq in (32, 100, 1024, 5000, 40000):
+            for band in (1, 128, 200, 256, 1000):
+                for sf, gf, pred in ((2.0, 3.0, 0), (1.5, 4.0, 0), (4.0, 3.0, 100), (2.0, 2.5, 1000)):
+                    ref = R.config(max_seq, 31, band, mode, sf, gf, pred)
+                    cfg = _native.PoaBatchConfig()
+                    assert L.gw_poa_batch_config_default(C.byref(cfg), max_seq, 31, band, mode, sf, gf, pred) == 0
+                    assert [getattr(cfg, k) for k in keys] == [ref[k] for k in keys], (mode, max_seq, band, sf, gf, pred)
+                    checked += 1
+    assert checked == 500
