@@ -24,6 +24,7 @@ struct RefPoa
     std::vector<StatusType> msa_status;
 };
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 // BatchConfig(max_seq_sz, max_seq_per_poa, band_width, banding, adaptive_storage_factor, graph_length_factor, max_pred_dist) of batch.hpp
@@ -116,3 +117,4 @@ void ref_poa_msa_row(void* handle, int w, int r, char* out)
     std::memcpy(out, s.data(), s.size());
 }
 }
+#pragma GCC visibility pop
