@@ -78,6 +78,23 @@ inline cudaError_t cudaMemGetInfo(size_t* free_bytes, size_t* total)
     *total      = size_t(8) << 30;
     return cudaSuccess;
 }
+enum cudaDeviceAttr
+{
+    cudaDevAttrMultiProcessorCount = 16,
+    cudaDevAttrMaxThreadsPerBlock  = 1,
+    cudaDevAttrWarpSize            = 10
+};
+inline cudaError_t cudaDeviceGetAttribute(int* value, cudaDeviceAttr attr, int)
+{
+    *value = attr == cudaDevAttrMultiProcessorCount ? 2 : (attr == cudaDevAttrWarpSize ? 32 : 1024);
+    return cudaSuccess;
+}
+template <typename F>
+inline cudaError_t cudaOccupancyMaxActiveBlocksPerMultiprocessor(int* blocks, F, int, size_t)
+{
+    *blocks = 2;
+    return cudaSuccess;
+}
 enum cudaFuncCache
 {
     cudaFuncCachePreferNone,

@@ -1,13 +1,14 @@
 """TEST INFRASTRUCTURE (oracle/simt): two rewrites of a reference source, nothing else is touched.
 1. The CUDA kernel-launch syntax, so that g++ can parse it:
     kernel<T...> <<<grid, block, shmem, stream>>>(args);   ->   simt::launch(grid, block, [&]() { kernel<T...>(args); });
-2. Reconvergence points around one-lane sections:
+2. With --converge (the cudapoa sources; the cudaaligner sources name the participating lanes in every *_sync call and put one-lane
+   sections inside divergent code, where a full-warp meeting point would be wrong). Reconvergence points around one-lane sections:
     if (lane_idx == 0) {...} [else ...]   ->   { simt::converge(); if (lane_idx == 0) {...} [else ...] simt::converge(); }
    A warp of the GPU executes converged code in lockstep: every lane has finished the statements before a divergent `if` when the
    first lane enters it, and the other lanes wait at its end. The reference relies on that without a __syncwarp() (e.g.
    cudapoa_nw_banded.cuh: all lanes' initialize_band() stores land before lane 0's set_score() of the same cell). The emulator
    runs a lane until its next rendezvous, so the two implicit reconvergence points are made explicit.
-usage: python cuda_to_simt.py <in> <out>. The output is a build intermediate under oracle/_ref/ that
+usage: python cuda_to_simt.py [--converge] <in> <out>. The output is a build intermediate under oracle/_ref/ that
 oracle/Makefile.ref deletes after compiling (reference sources are never copied into the repository)."""
 import re
 import sys
@@ -115,5 +116,8 @@ def add_convergence(text):
 
 
 if __name__ == "__main__":
-    src = open(sys.argv[1]).read()
-    open(sys.argv[2], "w").write(add_convergence(rewrite(src)))
+    args = [a for a in sys.argv[1:] if a != "--converge"]
+    text = rewrite(open(args[0]).read())
+    if "--converge" in sys.argv[1:]:
+        text = add_convergence(text)
+    open(args[1], "w").write(text)

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <type_traits>
 #include <vector>
 
@@ -35,6 +36,16 @@ struct uint3
 {
     unsigned x, y, z;
 };
+struct int2
+{
+    int x, y;
+};
+struct int4
+{
+    int x, y, z, w;
+};
+inline int2 make_int2(int x, int y) { return int2{x, y}; }
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 struct dim3
 {
     unsigned x, y, z;
@@ -70,7 +81,7 @@ struct Block
         int arrived = 0;
         uint64_t generation = 0;
     };
-    std::vector<Rendezvous> warp_sync;
+    std::vector<std::map<unsigned, Rendezvous>> warp_sync; // per warp, per participation mask of the *_sync primitive
     Rendezvous block_sync;
     std::vector<uint64_t> slot;
     uint64_t progress = 0; // (deadlock detection: rounds completed + fibers finished)
@@ -84,16 +95,18 @@ inline void yield()
     swapcontext(&f.ctx, &b.scheduler);
 }
 
-inline int live_in_range(const Block& b, int first, int last)
+// the lanes of [first, last) that have not left the kernel and are named in `mask` (bit i = lane first + i)
+inline int live_in_range(const Block& b, int first, int last, unsigned mask = 0xffffffffu)
 {
     int n = 0;
-    for (int i = first; i < last; ++i) n += b.fibers[static_cast<size_t>(i)].done ? 0 : 1;
+    for (int i = first; i < last; ++i)
+        if (!b.fibers[static_cast<size_t>(i)].done && (last - first > 32 || ((mask >> (i - first)) & 1u))) n++;
     return n;
 }
 
-// all live fibers of [first, last) meet here; fibers that have left the kernel are not waited for (CUDA: exited threads do not
-// take part in *_sync primitives)
-inline void rendezvous(Block::Rendezvous& r, int first, int last)
+// the live fibers of [first, last) named in `mask` meet here; fibers that have left the kernel are not waited for (CUDA: exited
+// threads do not take part in *_sync primitives)
+inline void rendezvous(Block::Rendezvous& r, int first, int last, unsigned mask = 0xffffffffu)
 {
     Block& b            = *g_block;
     const uint64_t mine = r.generation;
@@ -101,7 +114,7 @@ inline void rendezvous(Block::Rendezvous& r, int first, int last)
     for (;;)
     {
         if (r.generation != mine) return;
-        if (r.arrived >= live_in_range(b, first, last))
+        if (r.arrived >= live_in_range(b, first, last, mask))
         {
             r.arrived = 0;
             r.generation++;
@@ -112,10 +125,16 @@ inline void rendezvous(Block::Rendezvous& r, int first, int last)
     }
 }
 
-inline int lane_id() { return static_cast<int>(threadIdx.x % 32); }
-inline int warp_first() { return static_cast<int>(threadIdx.x / 32 * 32); }
+// (a warp is 32 consecutive threads of the block in linear order x + y * blockDim.x + z * blockDim.x * blockDim.y)
+inline int linear_tid() { return g_block->current; }
+inline int lane_id() { return linear_tid() % 32; }
+inline int warp_first() { return linear_tid() / 32 * 32; }
 inline int warp_last() { return std::min<int>(warp_first() + 32, static_cast<int>(g_block->fibers.size())); }
-inline void warp_rendezvous() { rendezvous(g_block->warp_sync[threadIdx.x / 32], warp_first(), warp_last()); }
+// the lanes named in `mask` meet (a primitive called with a partial mask is called by exactly those lanes)
+inline void warp_rendezvous(unsigned mask = 0xffffffffu)
+{
+    rendezvous(g_block->warp_sync[static_cast<size_t>(linear_tid() / 32)][mask], warp_first(), warp_last(), mask);
+}
 /// reconvergence point of a divergent section (cuda_to_simt.py puts one on either side of `if (lane_idx == 0) ...`)
 inline void converge()
 {
@@ -141,13 +160,13 @@ inline T from_bits(uint64_t u)
 // every live lane of the warp publishes `v`; returns after all have, `read` picks what this lane wants, and a second rendezvous
 // keeps the slots until everyone has read
 template <typename T, typename Read>
-inline T exchange(T v, Read read)
+inline T exchange(unsigned mask, T v, Read read)
 {
-    Block& b                                 = *g_block;
-    b.slot[threadIdx.x]                      = to_bits(v);
-    warp_rendezvous();
+    Block& b                                  = *g_block;
+    b.slot[static_cast<size_t>(linear_tid())] = to_bits(v);
+    warp_rendezvous(mask);
     const T out = read(b.slot.data() + warp_first());
-    warp_rendezvous();
+    warp_rendezvous(mask);
     return out;
 }
 
@@ -155,7 +174,7 @@ inline void run_block(unsigned threads, const std::function<void()>& body)
 {
     Block b;
     b.fibers.resize(threads);
-    b.warp_sync.assign((threads + 31) / 32, Block::Rendezvous{});
+    b.warp_sync.assign((threads + 31) / 32, {});
     b.slot.assign(threads, 0);
     b.body  = &body;
     g_block = &b;
@@ -185,8 +204,8 @@ inline void run_block(unsigned threads, const std::function<void()>& body)
         {
             Fiber& f = b.fibers[t];
             if (f.done) continue;
-            b.current   = static_cast<int>(t);
-            threadIdx.x = t;
+            b.current = static_cast<int>(t);
+            threadIdx = uint3{t % blockDim.x, t / blockDim.x % blockDim.y, t / (blockDim.x * blockDim.y)};
             swapcontext(&b.scheduler, &f.ctx);
             if (!f.done) remaining++;
         }
@@ -195,7 +214,8 @@ inline void run_block(unsigned threads, const std::function<void()>& body)
             // one more full round without any rendezvous completing or fiber finishing: the live fibers wait for each other at
             // different primitives (divergent *_sync calls)
             bool waiting_somewhere = false;
-            for (const Block::Rendezvous& r : b.warp_sync) waiting_somewhere |= r.arrived > 0;
+            for (const auto& by_mask : b.warp_sync)
+                for (const auto& r : by_mask) waiting_somewhere |= r.second.arrived > 0;
             waiting_somewhere |= b.block_sync.arrived > 0;
             if (waiting_somewhere)
             {
@@ -215,19 +235,18 @@ inline void run_block(unsigned threads, const std::function<void()>& body)
 template <typename Body>
 inline void launch(dim3 grid, dim3 block, Body body)
 {
-    if (block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1)
-    {
-        std::fprintf(stderr, "simt: only one-dimensional launches\n");
-        std::abort();
-    }
     const std::function<void()> fn = body;
     gridDim  = grid;
     blockDim = block;
-    for (unsigned bx = 0; bx < grid.x; ++bx)
-    {
-        blockIdx = uint3{bx, 0, 0};
-        run_block(block.x, fn);
-    }
+    static const bool trace = std::getenv("SIMT_TRACE") != nullptr;
+    if (trace) std::fprintf(stderr, "simt: launch grid (%u, %u, %u) block (%u, %u, %u)\n", grid.x, grid.y, grid.z, block.x, block.y, block.z);
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx)
+            {
+                blockIdx = uint3{bx, by, bz};
+                run_block(block.x * block.y * block.z, fn);
+            }
 }
 template <typename Body, typename A>
 inline void launch(dim3 grid, dim3 block, A, Body body)
@@ -242,53 +261,53 @@ inline void launch(dim3 grid, dim3 block, A, B, Body body)
 } // namespace simt
 
 // ---- warp-level and block-level primitives -------------------------------------------------------------------------
-inline void __syncwarp(unsigned = 0xffffffffu) { simt::warp_rendezvous(); }
+inline void __syncwarp(unsigned mask = 0xffffffffu) { simt::warp_rendezvous(mask); }
 inline void __syncthreads() { simt::rendezvous(simt::g_block->block_sync, 0, static_cast<int>(simt::g_block->fibers.size())); }
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 
 template <typename T>
-inline T __shfl_sync(unsigned, T v, int src_lane, int width = 32)
+inline T __shfl_sync(unsigned mask, T v, int src_lane, int width = 32)
 {
     const int lane = simt::lane_id();
-    return simt::exchange(v, [&](const uint64_t* s) { return simt::from_bits<T>(s[(lane & ~(width - 1)) + (src_lane & (width - 1))]); });
+    return simt::exchange(mask, v, [&](const uint64_t* s) { return simt::from_bits<T>(s[(lane & ~(width - 1)) + (src_lane & (width - 1))]); });
 }
 template <typename T>
-inline T __shfl_up_sync(unsigned, T v, unsigned delta, int width = 32)
+inline T __shfl_up_sync(unsigned mask, T v, unsigned delta, int width = 32)
 {
     const int lane = simt::lane_id();
-    return simt::exchange(v, [&](const uint64_t* s) {
+    return simt::exchange(mask, v, [&](const uint64_t* s) {
         const int src = lane - static_cast<int>(delta);
         return src >= (lane & ~(width - 1)) ? simt::from_bits<T>(s[src]) : v;
     });
 }
 template <typename T>
-inline T __shfl_down_sync(unsigned, T v, unsigned delta, int width = 32)
+inline T __shfl_down_sync(unsigned mask, T v, unsigned delta, int width = 32)
 {
     const int lane = simt::lane_id();
-    return simt::exchange(v, [&](const uint64_t* s) {
+    return simt::exchange(mask, v, [&](const uint64_t* s) {
         const int src = lane + static_cast<int>(delta);
         return src < (lane & ~(width - 1)) + width ? simt::from_bits<T>(s[src]) : v;
     });
 }
 template <typename T>
-inline T __shfl_xor_sync(unsigned, T v, int lane_mask, int width = 32)
+inline T __shfl_xor_sync(unsigned mask, T v, int lane_mask, int width = 32)
 {
     const int lane = simt::lane_id();
-    return simt::exchange(v, [&](const uint64_t* s) {
+    return simt::exchange(mask, v, [&](const uint64_t* s) {
         const int src = lane ^ lane_mask;
         return src < (lane & ~(width - 1)) + width ? simt::from_bits<T>(s[src]) : v;
     });
 }
-inline unsigned __ballot_sync(unsigned, int predicate)
+inline unsigned __ballot_sync(unsigned mask, int predicate)
 {
     // lanes that have left the kernel contribute 0 (their slot is cleared when they publish nothing: cleared below)
     simt::Block& b = *simt::g_block;
     const int first = simt::warp_first(), last = simt::warp_last();
-    return simt::exchange(static_cast<uint32_t>(predicate != 0), [&](const uint64_t* s) {
+    return simt::exchange(mask, static_cast<uint32_t>(predicate != 0), [&](const uint64_t* s) {
         unsigned m = 0;
         for (int i = first; i < last; ++i)
-            if (!b.fibers[static_cast<size_t>(i)].done && s[i - first] != 0) m |= 1u << (i - first);
+            if (!b.fibers[static_cast<size_t>(i)].done && ((mask >> (i - first)) & 1u) && s[i - first] != 0) m |= 1u << (i - first);
         return m;
     });
 }
@@ -299,7 +318,7 @@ inline int __all_sync(unsigned mask, int predicate)
     const int first = simt::warp_first(), last = simt::warp_last();
     unsigned live = 0;
     for (int i = first; i < last; ++i)
-        if (!b.fibers[static_cast<size_t>(i)].done) live |= 1u << (i - first);
+        if (!b.fibers[static_cast<size_t>(i)].done && ((mask >> (i - first)) & 1u)) live |= 1u << (i - first);
     return (__ballot_sync(mask, predicate) & live) == live;
 }
 inline unsigned __activemask() { return 0xffffffffu; }

@@ -535,3 +535,48 @@ def test_aligner_matrix_cells_equal_the_golden():
         assert len(res) == n and all(r.status == 0 for r in res), (algorithm, n, size)
         assert sum(sum(1 for x in r.alignment if x != 0) for r in res) == g["edit_distance_sum"], (algorithm, n, size)
         assert G.aligner_gen.digest(G.aligner_gen.pair_record(r.status, r.alignment) for r in res) == g["states_sha256"], (algorithm, n, size)
+
+
+def test_hip_aligners_equal_the_reference_itself_on_the_simt_goldens():
+    """tests/golden/reference_simt_alignments.json.gz holds what the REFERENCE's own cudaaligner library answered (its CUDA sources
+    compiled from /root/reference and run on the CPU by the SIMT emulator of oracle/simt;
+    tests/golden/make_reference_simt_alignments.py): the default aligner (Hirschberg + Myers) up to 5 kbp, the banded Myers aligner
+    at five band widths with pairs the band rejects or only approximates, the Ukkonen and the full-matrix Myers classes. The HIP
+    aligners give the same statuses, optimality flags and alignment states, pair by pair."""
+    import gzip
+    import importlib.util
+    import json
+    import os
+    from genomeworks_amd import cudaaligner
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_reference_simt_alignments", os.path.join(here, "golden", "make_reference_simt_alignments.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with gzip.open(os.path.join(here, "golden", "reference_simt_alignments.json.gz"), "rb") as f:
+        rows = json.loads(f.read().decode())["batches"]
+    assert len(rows) >= 12
+    bad = []
+    for k, row in enumerate(rows):
+        b, ref = row["batch"], row["reference"]
+        pairs = [tuple(p) for p in b["pairs"]]
+        max_len = max(max(len(q), len(t)) for q, t in pairs)
+        if b["kind"] == "banded":
+            al = cudaaligner.CudaAlignerBatch(max_bandwidth=b["max_bandwidth"], max_device_memory_allocator_caching_size=2 << 30)
+        elif b["kind"] == "default":
+            al = cudaaligner.CudaAlignerBatch(max_len, max_len, len(pairs), max_device_memory_allocator_caching_size=2 << 30)
+        else:
+            al = cudaaligner.CudaAlignerBatch(max_len, max_len, len(pairs), algorithm=b["kind"], max_device_memory_allocator_caching_size=2 << 30)
+        added = [al.add_alignment(q, t) for q, t in pairs]
+        if added != [r["add_status"] for r in ref]:
+            bad.append((k, "add_alignment", added))
+            continue
+        al.align_all()
+        got = al.get_alignments()
+        kept = [r for r in ref if r["add_status"] == 0]
+        assert len(got) == len(kept)
+        for i, (g, r) in enumerate(zip(got, kept)):
+            if g.status != r["status"]:
+                bad.append((k, i, "status", g.status, r["status"]))
+            elif r["status"] == 0 and (list(g.alignment) != gen.unrle(r["alignment"]) or bool(g.is_optimal) != bool(r["optimal"])):
+                bad.append((k, i, "alignment"))
+    assert not bad, "pairs where a HIP aligner differs from the reference: %s" % bad[:10]

@@ -109,3 +109,77 @@ def test_batch_config_constructor_equals_the_reference():
                     assert [getattr(cfg, k) for k in keys] == [ref[k] for k in keys], (mode, max_seq, band, sf, gf, pred)
                     checked += 1
     assert checked == 500
+
+
+# ---- cudaaligner: the reference's own aligners (tests/golden/make_reference_simt_alignments.py) ------------------------------
+import oracle_aligner as A
+import ref_cudaaligner as RA
+
+
+def alignment_golden():
+    with gzip.open(os.path.join(HERE, "golden", "reference_simt_alignments.json.gz"), "rb") as f:
+        return json.loads(f.read().decode())["batches"]
+
+
+def _aligner_generator():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_reference_simt_alignments", os.path.join(HERE, "golden", "make_reference_simt_alignments.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    return gen
+
+
+def oracle_alignment(kind, q, t, max_bandwidth=None, max_len=None):
+    """-> (status == success, optimal, [AlignmentState...]) of the oracle that restates that aligner"""
+    if kind == "banded":
+        r = A.align(q, t, max_bandwidth)
+        states = [o for o, k in r["runs"] for _ in range(k)] if r["status"] == 0 else None
+        return r["status"] == 0, r["optimal"] if r["status"] == 0 else None, states
+    if kind in ("default", "hirschberg_myers"):
+        r = A.hirschberg(q, t, max_len)
+    elif kind == "ukkonen":
+        r = A.ukkonen(q, t, 100)
+    else:
+        r = A.myers_full(q, t)
+    return True, True, list(r["states"])
+
+
+def differences(gen, b, ref):
+    max_len = max(max(len(q), len(t)) for q, t in b["pairs"])
+    bad = []
+    for i, ((q, t), r) in enumerate(zip(b["pairs"], ref)):
+        ok, optimal, states = oracle_alignment(b["kind"], q, t, b.get("max_bandwidth"), max_len)
+        if r["add_status"] != 0:
+            continue  # refused by add_alignment: the host classes are compared on the GPU
+        ref_ok = r["status"] == 0 and r["alignment"] is not None and (r["alignment"] != "" or (q == "" and t == ""))
+        if ok != ref_ok or (ok and (states != gen.unrle(r["alignment"]) or bool(optimal) != bool(r["optimal"]))):
+            bad.append(i)
+    return bad
+
+
+def test_aligner_oracles_equal_the_reference_on_every_golden_batch():
+    gen, rows = _aligner_generator(), alignment_golden()
+    assert {r["batch"]["kind"] for r in rows} == {"default", "banded", "ukkonen", "myers"}
+    assert sum(len(r["batch"]["pairs"]) for r in rows) >= 220
+    assert any(max(len(q) for q, _ in r["batch"]["pairs"]) >= 5000 for r in rows)           # the Hirschberg recursion, several levels
+    assert any(x["status"] != 0 for r in rows for x in r["reference"])                      # pairs a band rejected
+    assert any(x["optimal"] is False for r in rows for x in r["reference"] if x["status"] == 0)  # approximate results of a narrow band
+    for k, r in enumerate(rows):
+        bad = differences(gen, r["batch"], r["reference"])
+        assert not bad, "batch %d (%s, max_bandwidth %s): pairs where the oracle differs from the reference: %s" % (
+            k, r["batch"]["kind"], r["batch"].get("max_bandwidth"), bad)
+
+
+@pytest.mark.skipif(not RA.available(), reason="the reference library (oracle/_ref/libref_cudaaligner_simt.so) is not built here")
+def test_reference_aligner_library_reproduces_the_golden_file_and_fresh_pairs():
+    gen, rows = _aligner_generator(), alignment_golden()
+    assert [r["batch"] for r in rows] == gen.batches()
+    for k in (1, 2, 6, 10, 11):
+        assert gen.run_reference(rows[k]["batch"]) == rows[k]["reference"], k
+    seed = random.Random(os.getpid()).randrange(1 << 30)
+    rng = random.Random(seed)
+    for kind, bw in (("default", None), ("banded", 31), ("banded", 256), ("ukkonen", None), ("myers", None)):
+        b = dict(kind=kind, pairs=gen.random_pairs(rng, 16, [3, 30, 64, 129, 260], 300))
+        if bw:
+            b["max_bandwidth"] = bw
+        assert not differences(gen, b, gen.run_reference(b)), "seed %d %s %s" % (seed, kind, bw)
