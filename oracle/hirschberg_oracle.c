@@ -14,9 +14,10 @@
  *   - the split: query midpoint len/2, target midpoint = argmin_t F[t] + R[T - t] (:412-481) found the way the
  *     32 lanes of the reference's warp find it (strided first-minimum per lane, then a strict-less shuffle-down
  *     tree), which fixes the choice among equal sums.
- * PINNING: the reference has no CPU implementation of this aligner; the restatement is pinned by the reference's
- * known-answer CIGARs (cudaaligner/tests/Test_AlignerGlobal.cpp:73-155, tests/golden) and by optimality of the
- * edit distance against the reference's CPU NW (oracle/_ref) -- ties beyond those vectors are "parity unpinned".
+ * PINNING: the restatement is pinned by the reference's known-answer CIGARs (cudaaligner/tests/Test_AlignerGlobal.cpp:73-155,
+ * tests/golden), by optimality of the edit distance against the reference's CPU NW (oracle/_ref), and -- tie-breaking
+ * included -- by the reference's own hirschberg_myers_gpu.cu run on the CPU (oracle/simt, oracle/_ref/libref_cudaaligner_simt.so):
+ * tests/golden/reference_simt_alignments.json.gz (pairs up to 5 kbp) and fresh random pairs, tests/test_reference_simt.py.
  */
 #include "hirschberg_oracle.h"
 

@@ -7,9 +7,12 @@
  * Every function cites the reference file:line (relative to /root/reference) it restates.
  * Parity status: pinned by the reference's inline known-answer vectors:
  * NW1-NW5, the 493-node banded==full case, topsort x3, addAlignment x5, consensus x5,
- * batch-level cases. spoa itself is an empty un-vendored submodule in the reference checkout
- * and cudapoa/data/sample-windows.txt is stripped, so parity vs spoa / the End2End golden
- * is unpinned (stated in DESIGN.md).
+ * batch-level cases; and by the reference's own cudapoa library run on the CPU (its CUDA sources under
+ * the SIMT emulator of oracle/simt -> oracle/_ref/libref_cudapoa_simt.so): the 77 windows of
+ * tests/golden/reference_simt_windows.json.gz and fresh random windows, tests/test_reference_simt.py.
+ * spoa itself is an empty un-vendored submodule in the reference checkout and
+ * cudapoa/data/sample-windows.txt is stripped, so parity vs spoa / the End2End golden cannot be
+ * had here (stated in DESIGN.md).
  */
 #ifndef POA_ORACLE_H
 #define POA_ORACLE_H
