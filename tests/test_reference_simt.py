@@ -2,7 +2,7 @@
 kernels run on the CPU by the SIMT emulator oracle/simt) answered the windows of tests/golden/reference_simt_windows.json.gz
 (tests/golden/make_reference_simt_goldens.py). The oracle must give the same statuses, consensus, coverage and MSA rows for every
 window; where the reference library is present (oracle/_ref/libref_cudapoa_simt.so: this container, and the GPU box when the
-prebuilt file travelled) a sample of the file is regenerated and fresh random windows are compared as well."""
+prebuilt file travelled) a sample of the file is regenerated and windows that are not in the file are compared as well (a fixed seed; GW_SIMT_SEED picks others)."""
 import gzip
 import json
 import os
@@ -74,8 +74,7 @@ def test_oracle_equals_the_reference_on_fresh_random_windows():
     spec = importlib.util.spec_from_file_location("make_reference_simt_goldens", os.path.join(HERE, "golden", "make_reference_simt_goldens.py"))
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
-    rng = random.Random(os.getpid())  # different windows on every run; the seed is in the failure message
-    seed = rng.randrange(1 << 30)
+    seed = int(os.environ.get("GW_SIMT_SEED", "424242"))  # (GW_SIMT_SEED=<n>: other windows; tools/explore_reference_simt.py sweeps seeds)
     rng = random.Random(seed)
     for k in range(12):
         L = rng.choice([20, 70, 130, 220])
@@ -176,7 +175,7 @@ def test_reference_aligner_library_reproduces_the_golden_file_and_fresh_pairs():
     assert [r["batch"] for r in rows] == gen.batches()
     for k in (1, 2, 6, 10, 11):
         assert gen.run_reference(rows[k]["batch"]) == rows[k]["reference"], k
-    seed = random.Random(os.getpid()).randrange(1 << 30)
+    seed = int(os.environ.get("GW_SIMT_SEED", "434343"))
     rng = random.Random(seed)
     for kind, bw in (("default", None), ("banded", 31), ("banded", 256), ("ukkonen", None), ("myers", None)):
         b = dict(kind=kind, pairs=gen.random_pairs(rng, 16, [3, 30, 64, 129, 260], 300))
