@@ -182,3 +182,20 @@ def test_reference_aligner_library_reproduces_the_golden_file_and_fresh_pairs():
         if bw:
             b["max_bandwidth"] = bw
         assert not differences(gen, b, gen.run_reference(b)), "seed %d %s %s" % (seed, kind, bw)
+
+
+def test_config_goldens_were_checked_against_the_reference():
+    """tests/golden/reference_simt_config_check.json is the record of tests/golden/check_goldens_against_reference.py: which units
+    of the committed BASELINE-config goldens the reference itself (on the SIMT emulator) was asked for, and that none differed.
+    Where the reference library is present, a few pairs of configs[1] are asked again."""
+    with open(os.path.join(HERE, "golden", "reference_simt_config_check.json")) as f:
+        rec = json.load(f)
+    assert len(rec["config3"]["windows_checked"]) >= 256 and rec["config3"]["windows_differing"] == []
+    assert sum(hi - lo for lo, hi in rec["config2"]["pair_ranges_checked"]) == 10000 and rec["config2"]["ranges_differing"] == []
+    assert sum(hi - lo for lo, hi in rec["config5"]["pair_ranges_checked"]) >= 64 * 1024 and rec["config5"]["ranges_differing"] == []
+    if RA.available():
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("check_goldens_against_reference", os.path.join(HERE, "golden", "check_goldens_against_reference.py"))
+        chk = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(chk)
+        assert chk.check_pairs(("config2", 5000, 5012)) == ("config2", [5000, 5012], [])
