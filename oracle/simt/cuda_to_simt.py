@@ -1,8 +1,9 @@
 """TEST INFRASTRUCTURE (oracle/simt): two rewrites of a reference source, nothing else is touched.
 1. The CUDA kernel-launch syntax, so that g++ can parse it:
     kernel<T...> <<<grid, block, shmem, stream>>>(args);   ->   simt::launch(grid, block, [&]() { kernel<T...>(args); });
-2. With --converge (the cudapoa sources; the cudaaligner sources name the participating lanes in every *_sync call and put one-lane
-   sections inside divergent code, where a full-warp meeting point would be wrong). Reconvergence points around one-lane sections:
+2. With --converge (every one-lane section of the file: the cudapoa sources) or --converge-lines=<file>:<lines> (the named sections:
+   hirschberg_myers_gpu.cu, whose other one-lane sections sit inside divergent code, where a full-warp meeting point would be
+   wrong). Reconvergence points around one-lane sections:
     if (lane_idx == 0) {...} [else ...]   ->   { simt::converge(); if (lane_idx == 0) {...} [else ...] simt::converge(); }
    A warp of the GPU executes converged code in lockstep: every lane has finished the statements before a divergent `if` when the
    first lane enters it, and the other lanes wait at its end. The reference relies on that without a __syncwarp() (e.g.
@@ -10,6 +11,7 @@
    runs a lane until its next rendezvous, so the two implicit reconvergence points are made explicit.
 usage: python cuda_to_simt.py [--converge] <in> <out>. The output is a build intermediate under oracle/_ref/ that
 oracle/Makefile.ref deletes after compiling (reference sources are never copied into the repository)."""
+import os
 import re
 import sys
 
@@ -99,10 +101,12 @@ def statement_end(text, i):
     return text.index(";", i) + 1
 
 
-def add_convergence(text):
+def add_convergence(text, only_lines=None):
     out, pos = [], 0
     for m in ONE_LANE.finditer(text):
         if m.start() < pos:
+            continue
+        if only_lines is not None and text.count("\n", 0, m.start()) + 1 not in only_lines:
             continue
         line_start = text.rfind("\n", 0, m.start()) + 1
         if "//" in text[line_start:m.start()]:
@@ -116,8 +120,14 @@ def add_convergence(text):
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[1:] if a != "--converge"]
-    text = rewrite(open(args[0]).read())
-    if "--converge" in sys.argv[1:]:
-        text = add_convergence(text)
-    open(args[1], "w").write(text)
+    args = [a for a in sys.argv[1:] if not a.startswith("--converge")]
+    text = open(args[0]).read()
+    # (line numbers of --converge-lines are those of the reference source: convergence first, the launch rewrite keeps lines)
+    for a in sys.argv[1:]:
+        if a == "--converge":
+            text = add_convergence(text)
+        elif a.startswith("--converge-lines="):  # --converge-lines=<source file name>:<line>,<line>,... (other files are left alone)
+            name, lines = a.split("=")[1].split(":")
+            if os.path.basename(args[0]) == name:
+                text = add_convergence(text, set(int(x) for x in lines.split(",") if x))
+    open(args[1], "w").write(rewrite(text))

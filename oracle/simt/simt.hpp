@@ -200,9 +200,13 @@ inline void run_block(unsigned threads, const std::function<void()>& body)
     {
         const uint64_t before = b.progress;
         remaining             = 0;
-        for (unsigned t = 0; t < threads; ++t)
+        // SIMT_ORDER=reverse: the lanes of a round run from the last to the first -- a result that depends on the order depends on a
+        // race between lanes that the GPU resolves by executing them in lockstep
+        static const bool reverse_order = [] { const char* e = std::getenv("SIMT_ORDER"); return e != nullptr && e[0] == 'r'; }();
+        for (unsigned k = 0; k < threads; ++k)
         {
-            Fiber& f = b.fibers[t];
+            const unsigned t = reverse_order ? threads - 1 - k : k;
+            Fiber& f         = b.fibers[t];
             if (f.done) continue;
             b.current = static_cast<int>(t);
             threadIdx = uint3{t % blockDim.x, t / blockDim.x % blockDim.y, t / (blockDim.x * blockDim.y)};
