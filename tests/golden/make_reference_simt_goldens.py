@@ -70,16 +70,38 @@ def cases():
     # more reads than max_sequences_per_poa
     out.append(dict(max_seq=128, max_seqs=4, band_width=128, band_mode=2, output_mask=2, gap=-8, mismatch=-6, match=8,
                     reads=[mutate(rng2, base, 5) for _ in range(7)], weights=None))
+    # traceback-buffer modes with a predecessor window of 8 and 16 rows and indel-heavy reads: first predecessors at a multiple of
+    # the window alias the row's own ring slot (cudapoa_nw_tb_banded.cuh:456; oracle/poa_nw_tb.inc on the pass order). The HIP
+    # path has not met these windows on a GPU yet: the GPU test of this file leaves out the cases marked "gpu": False.
+    rng3 = random.Random(88)
+
+    def indels(s, k):
+        s = list(s)
+        for _ in range(k):
+            i = rng3.randrange(len(s))
+            op = rng3.random()
+            if op < 0.3:
+                s[i] = rng3.choice("ACGT")
+            elif op < 0.65:
+                s[i:i] = [rng3.choice("ACGT") for _ in range(rng3.choice([1, 1, 2, 8, 30]))]
+            else:
+                del s[i:i + rng3.choice([1, 1, 2, 8, 30])]
+        return ("".join(s) or "A")[:500]
+    for k in range(10):
+        L = rng3.choice([100, 200, 350])
+        base = "".join(rng3.choice("ACGT") for _ in range(L))
+        out.append(dict(max_seq=512, max_seqs=16, band_width=128, band_mode=3 + k % 2, output_mask=1 + k % 2, gap=-8, mismatch=-6, match=8,
+                        reads=[indels(base, L // 8) for _ in range(rng3.randint(4, 10))], weights=None, max_pred=8 if k < 7 else 16, gpu=False))
     return out
 
 
 def run_reference(c):
     import ref_cudapoa as R
     with R.RefBatch(c["max_seq"], c["max_seqs"], c["band_width"], c["band_mode"], gap=c["gap"], mismatch=c["mismatch"], match=c["match"],
-                    output_mask=c["output_mask"]) as b:
+                    output_mask=c["output_mask"], max_pred=c.get("max_pred", 0)) as b:
         add_status, read_status = b.add_poa_group(c["reads"], c["weights"])
         # (the eight fields the reference's BatchConfig constructor derived: what a caller of the explicit constructor passes)
-        res = dict(add_status=add_status, read_status=read_status, batch_config=R.config(c["max_seq"], c["max_seqs"], c["band_width"], c["band_mode"]))
+        res = dict(add_status=add_status, read_status=read_status, batch_config=R.config(c["max_seq"], c["max_seqs"], c["band_width"], c["band_mode"], max_pred=c.get("max_pred", 0)))
         if add_status == 0:
             b.generate_poa()
             if c["output_mask"] & 1:

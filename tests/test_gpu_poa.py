@@ -785,6 +785,8 @@ def test_hip_path_equals_the_reference_itself_on_the_simt_goldens():
     bad = []
     for i, r in enumerate(rows):
         c, ref, bc = r["case"], r["reference"], r["reference"]["batch_config"]
+        if c.get("gpu") is False:
+            continue  # (the short-predecessor-window cases of the traceback modes: compared with the oracle on the CPU so far)
         msa = bool(c["output_mask"] & 2)
         # the constructor the generator used on the reference: BatchConfig(max_seq_sz, max_seq_per_poa, band_width, banding)
         b = cudapoa.CudaPoaBatch.from_batch_config(c["max_seq"], c["max_seqs"], c["band_width"], names[c["band_mode"]], 1 << 30,
