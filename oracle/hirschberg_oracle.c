@@ -137,8 +137,12 @@ static int32_t single_char(char qc, const char* tb, const char* te, int8_t* path
 
 typedef struct { const char *qb, *qe, *tb, *te; } range_t;
 
-int32_t hirschberg_oracle_align(const char* query, int32_t query_size, const char* target, int32_t target_size,
-                                int32_t max_query_length, int8_t* path, int32_t* path_length)
+/* `query` / `target` are what the bit-vector parts see of the pair (tests/oracle_aligner.py, pattern_view(): the four query
+   patterns and the target's pattern index; the identity over ACGT); the single-character leaf compares the characters themselves
+   (:483-515), so it gets the caller's own sequences. */
+int32_t hirschberg_oracle_align_raw(const char* query, int32_t query_size, const char* target, int32_t target_size,
+                                    const char* raw_query, const char* raw_target, int32_t max_query_length, int8_t* path,
+                                    int32_t* path_length)
 {
     /* per-alignment matrix capacity of the reference's workspace: max_n_words * (switch size + 1) elements (:40-41) */
     const int64_t max_elems = (int64_t)ceil_div(max_query_length, kWord) * (kSwitchToMyers + 1);
@@ -165,7 +169,7 @@ int32_t hirschberg_oracle_align(const char* query, int32_t query_size, const cha
             len += tn;
         }
         else if (qn == 1)
-            len += single_char(*e.qb, e.tb, e.te, path + len);
+            len += single_char(raw_query[e.qb - query], raw_target + (e.tb - target), raw_target + (e.te - target), path + len);
         else
         {
             if (qn < kSwitchToMyers)
@@ -189,4 +193,10 @@ int32_t hirschberg_oracle_align(const char* query, int32_t query_size, const cha
     if (!ok) len = 0;
     *path_length = len;
     return ok ? 0 : 1;
+}
+
+int32_t hirschberg_oracle_align(const char* query, int32_t query_size, const char* target, int32_t target_size,
+                                int32_t max_query_length, int8_t* path, int32_t* path_length)
+{
+    return hirschberg_oracle_align_raw(query, query_size, target, target_size, query, target, max_query_length, path, path_length);
 }

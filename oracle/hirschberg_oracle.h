@@ -18,6 +18,11 @@ enum { HO_MATCH = 0, HO_MISMATCH = 1, HO_INSERTION = 2, HO_DELETION = 3 };
    (length 0, alignment stays uninitialized unless both sequences are empty). */
 int32_t hirschberg_oracle_align(const char* query, int32_t query_size, const char* target, int32_t target_size,
                                 int32_t max_query_length, int8_t* path, int32_t* path_length);
+/* The same with the bit-vector kernels' view of the pair in query / target and the caller's characters in raw_query / raw_target
+   (same lengths): the single-character leaf compares characters, everything else goes through the pattern tables. */
+int32_t hirschberg_oracle_align_raw(const char* query, int32_t query_size, const char* target, int32_t target_size,
+                                    const char* raw_query, const char* raw_target, int32_t max_query_length, int8_t* path,
+                                    int32_t* path_length);
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,32 @@ def batches():
         out.append(dict(kind="banded", max_bandwidth=bw, pairs=pairs))
     out.append(dict(kind="ukkonen", pairs=random_pairs(rng, 24, [2, 5, 31, 33, 64, 100, 199, 250], 300)))
     out.append(dict(kind="myers", pairs=random_pairs(rng, 24, [1, 2, 5, 31, 33, 64, 100, 199, 250], 300)))
+    # characters outside ACGT ('N', lower case, IUPAC codes): the bit-vector kernels see the query through four patterns and the target
+    # through its pattern index (c >> 1) & 3; the Hirschberg kernel's single-character leaf and the Ukkonen kernel compare the
+    # characters themselves. (The reference's debug build asserts ACGT-only targets, myers_gpu.cu:214; its release build does this.)
+    # The HIP default and full-Myers aligners have not met such input on a GPU yet: those batches are marked "gpu": False.
+    rng2 = random.Random(77)
+
+    def odd_pairs(n):
+        alphabet, pairs = "ACGTNacgtRY", []
+        for _ in range(n):
+            L = rng2.choice([1, 2, 7, 33, 64, 130, 260])
+            q = [rng2.choice(alphabet) for _ in range(L)]
+            t = list(q)
+            for _ in range(rng2.choice([0, 1, 3, L // 10 + 1])):
+                i, op = rng2.randrange(len(t)), rng2.random()
+                if op < 0.4:
+                    t[i] = rng2.choice(alphabet)
+                elif op < 0.7:
+                    t.insert(i, rng2.choice(alphabet))
+                elif len(t) > 1:
+                    del t[i]
+            pairs.append(["".join(q), "".join(t)])
+        return pairs
+    out.append(dict(kind="banded", max_bandwidth=256, pairs=odd_pairs(20)))
+    out.append(dict(kind="default", pairs=odd_pairs(30), gpu=False))
+    out.append(dict(kind="myers", pairs=odd_pairs(20), gpu=False))
+    out.append(dict(kind="ukkonen", pairs=[p for p in odd_pairs(40) if abs(len(p[0]) - len(p[1])) <= 2][:16], gpu=False))
     return out
 
 

@@ -84,20 +84,31 @@ def cigar(runs, extended):
     return "".join(out)
 
 
+def pattern_view(query, target):
+    """What the Myers bit-vector kernels see of a pair (myers_gpu.cu:196-241, hirschberg_myers_gpu.cu: the same tables): the query
+    through four patterns -- 'A', 'C', 'T', 'G'; any other query character matches nothing -- and a target character through its
+    pattern index (c >> 1) & 3, i.e. as one of those four letters. The value-level oracles below compare characters, so they are
+    given this view of the pair; for sequences over ACGT it is the identity."""
+    q = query.encode() if isinstance(query, str) else bytes(query)
+    t = target.encode() if isinstance(target, str) else bytes(target)
+    return bytes(c if c in b"ACGT" else 0 for c in q), bytes(b"ACTG"[(c >> 1) & 3] for c in t)
+
+
 def hirschberg(query, target, max_query_length=None):
     """The default aligner (Hirschberg + Myers restatement, oracle/hirschberg_oracle.c):
     dict(status, states (forward order), cigar, cigar_extended, edit_distance)."""
     L = lib()
-    L.hirschberg_oracle_align.restype = C.c_int32
-    L.hirschberg_oracle_align.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p,
-                                          C.POINTER(C.c_int32)]
-    q = query.encode() if isinstance(query, str) else bytes(query)
-    t = target.encode() if isinstance(target, str) else bytes(target)
+    L.hirschberg_oracle_align_raw.restype = C.c_int32
+    L.hirschberg_oracle_align_raw.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p,
+                                              C.POINTER(C.c_int32)]
+    raw_q = query.encode() if isinstance(query, str) else bytes(query)
+    raw_t = target.encode() if isinstance(target, str) else bytes(target)
+    q, t = pattern_view(query, target)
     if max_query_length is None:
         max_query_length = max(len(q), len(t)) + 1
     path = np.zeros(len(q) + len(t) + 8, np.int8)
     n = C.c_int32(0)
-    rc = L.hirschberg_oracle_align(q, len(q), t, len(t), max_query_length, path.ctypes.data, C.byref(n))
+    rc = L.hirschberg_oracle_align_raw(q, len(q), t, len(t), raw_q, raw_t, max_query_length, path.ctypes.data, C.byref(n))
     states = [int(x) for x in path[:n.value]][::-1]  # the host reverses (aligner_global.cpp:180)
     runs = []
     for s in states:
@@ -140,7 +151,7 @@ def ukkonen(query, target, p=100):
 
 def myers_full(query, target):
     """AlignerGlobalMyers restatement (oracle/global_oracle.c)."""
-    return _global("myers_full_oracle_align", query, target)
+    return _global("myers_full_oracle_align", *pattern_view(query, target))
 
 
 def ref_ukkonen_cpu(query, target, p):
