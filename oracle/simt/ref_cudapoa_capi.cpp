@@ -5,6 +5,9 @@
 // get_consensus, get_msa. Used by tests/ref_cudapoa.py to check oracle/poa_oracle.c and to write tests/golden/reference_simt_*.
 #include <claraparabricks/genomeworks/cudapoa/batch.hpp>
 #include <claraparabricks/genomeworks/cudapoa/cudapoa.hpp>
+#include <claraparabricks/genomeworks/cudapoa/utils.hpp>
+
+#include "allocate_block.hpp"
 
 #include <cstring>
 #include <memory>
@@ -56,6 +59,48 @@ void ref_poa_config(int max_sequence_size, int max_sequences_per_poa, int band_w
 }
 
 void ref_poa_destroy(void* handle) { delete static_cast<RefPoa*>(handle); }
+
+// BatchBlock<int32_t, int32_t, int16_t>::estimate_max_poas (allocate_block.hpp:403) for the BatchConfig of a group of `reads` sequences
+// whose longest has `longest` bases -- what get_multi_batch_sizes() computes per group (utils.cu:52-58); the "free device memory" is
+// what the stub's cudaMemGetInfo() reports
+long long ref_poa_estimate_max_poas(int longest, int reads, int band_width, int band_mode, float adaptive_storage_factor, float graph_length_factor,
+                                    int max_pred_distance, int msa_flag, float quota, int mismatch, int gap, int match)
+{
+    BatchConfig cfg(longest, reads, band_width, static_cast<BandMode>(band_mode), adaptive_storage_factor, graph_length_factor, max_pred_distance);
+    return BatchBlock<int32_t, int32_t, int16_t>::estimate_max_poas(cfg, msa_flag != 0, quota, mismatch, gap, match);
+}
+
+// get_multi_batch_sizes (utils.cu:30-135) for groups given by their longest sequence and number of sequences (all it looks at).
+// Out: n_batches; per batch eight BatchConfig fields in cfg8[8 b ..], its number of groups in per_batch[b], the group ids of all
+// batches back to back in ids[].
+int ref_poa_multi_batch_sizes(int n_groups, const int* longest, const int* reads, int msa_flag, int band_width, int band_mode,
+                              float adaptive_storage_factor, float graph_length_factor, int max_pred_distance, float quota, int mismatch, int gap,
+                              int match, int* cfg8, int* per_batch, int* ids)
+{
+    std::vector<Group> groups(static_cast<size_t>(n_groups));
+    for (int g = 0; g < n_groups; ++g)
+        for (int r = 0; r < reads[g]; ++r)
+        {
+            Entry e{};
+            e.length = r == 0 ? longest[g] : std::max(1, longest[g] / 2);
+            groups[static_cast<size_t>(g)].push_back(e);
+        }
+    std::vector<BatchConfig> cfgs;
+    std::vector<std::vector<int32_t>> per;
+    get_multi_batch_sizes(cfgs, per, groups, msa_flag != 0, band_width, static_cast<BandMode>(band_mode), adaptive_storage_factor, graph_length_factor,
+                          max_pred_distance, nullptr, quota, mismatch, gap, match);
+    int at = 0;
+    for (size_t b = 0; b < cfgs.size(); ++b)
+    {
+        const BatchConfig& c = cfgs[b];
+        int* o               = cfg8 + 8 * b;
+        o[0] = c.max_sequence_size, o[1] = c.max_consensus_size, o[2] = c.max_nodes_per_graph, o[3] = c.matrix_sequence_dimension;
+        o[4] = c.alignment_band_width, o[5] = c.max_sequences_per_poa, o[6] = static_cast<int>(c.band_mode), o[7] = c.max_banded_pred_distance;
+        per_batch[b] = static_cast<int>(per[b].size());
+        for (int32_t g : per[b]) ids[at++] = g;
+    }
+    return static_cast<int>(cfgs.size());
+}
 
 // -> StatusType of add_poa_group; per-read statuses into read_status[n_reads]; weights may be NULL (or weights[i] NULL)
 int ref_poa_add_group(void* handle, int n_reads, const char** reads, const int* lengths, const signed char** weights, int* read_status)

@@ -200,3 +200,39 @@ def test_config_goldens_were_checked_against_the_reference():
         chk = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(chk)
         assert chk.check_pairs(("config2", 5000, 5012)) == ("config2", [5000, 5012], [])
+
+
+@pytest.mark.skipif(not R.available(), reason="the reference library (oracle/_ref/libref_cudapoa_simt.so) is not built here")
+def test_multi_batch_binning_equals_the_reference():
+    """get_multi_batch_sizes (cudapoa/src/utils.cu:30-135): the host library's binning rule (gw_poa_bin_groups, no device call) fed
+    with the per-group capacities the reference itself estimates (BatchBlock::estimate_max_poas over the stub's 8 GB of free
+    memory) gives the reference's batches: the same BatchConfig per batch and the same groups in the same order. (The capacities
+    themselves differ by design -- our device layout has other byte counts per window)"""
+    import ctypes as C
+    from genomeworks_amd import cudapoa
+    L = R.lib()
+    L.ref_poa_estimate_max_poas.restype = C.c_longlong
+    L.ref_poa_estimate_max_poas.argtypes = [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_float] + [C.c_int] * 3
+    pi = C.POINTER(C.c_int)
+    L.ref_poa_multi_batch_sizes.argtypes = [C.c_int, pi, pi] + [C.c_int] * 3 + [C.c_float, C.c_float, C.c_int, C.c_float] + [C.c_int] * 3 + [pi, pi, pi]
+    rng = random.Random(2718)
+    keys = ("max_sequence_size", "max_consensus_size", "max_nodes_per_graph", "matrix_sequence_dimension", "alignment_band_width",
+            "max_sequences_per_poa", "band_mode", "max_banded_pred_distance")
+    modes = {0: "full_band", 1: "static_band", 2: "adaptive_band", 3: "static_band_traceback", 4: "adaptive_band_traceback"}
+    for trial in range(40):
+        n = rng.randint(1, 60)
+        longest = [rng.choice([100, 300, 1000, 3000, 9000, 20000, 30000]) + rng.randint(0, 99) for _ in range(n)]
+        reads = [rng.randint(1, 60) for _ in range(n)]
+        mode, msa = rng.randint(0, 4), rng.randint(0, 1)
+        band = rng.choice([128, 256, 512])
+        cfg8, per, ids = (C.c_int * (8 * n))(), (C.c_int * n)(), (C.c_int * n)()
+        nb = L.ref_poa_multi_batch_sizes(n, (C.c_int * n)(*longest), (C.c_int * n)(*reads), msa, band, mode, 2.0, 3.0, 0, 0.9, -6, -8, 8, cfg8, per, ids)
+        ref_cfgs = [dict(zip(keys, list(cfg8[8 * b:8 * b + 8]))) for b in range(nb)]
+        ref_groups, at = [], 0
+        for b in range(nb):
+            ref_groups.append(list(ids[at:at + per[b]]))
+            at += per[b]
+        capacity = [int(min(L.ref_poa_estimate_max_poas(longest[g], reads[g], band, mode, 2.0, 3.0, 0, msa, 0.9, -6, -8, 8), 2 ** 31 - 1)) for g in range(n)]
+        cfgs, groups = cudapoa.bin_poa_groups(capacity, longest, reads, band, modes[mode])
+        assert groups == ref_groups, (trial, capacity)
+        assert [{k: c[k] for k in keys} for c in cfgs] == ref_cfgs, trial
