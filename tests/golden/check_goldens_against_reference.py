@@ -121,8 +121,8 @@ def main():
     windows = sorted(set(windows) - done_w)
     jobs = [("w", windows[i::procs * 4]) for i in range(procs * 4) if windows[i::procs * 4]]
     jobs += [("p", ("config2", lo, min(10000, lo + 250))) for lo in range(0, n_pairs2, 250) if (lo, min(10000, lo + 250)) not in done_2]
-    blocks5 = sorted(set(int(b) for b in np.linspace(0, 975, n_blocks5).round())) if n_blocks5 else []
-    jobs += [("p", ("config5", b * 1024, b * 1024 + 1024)) for b in blocks5 if (b * 1024, b * 1024 + 1024) not in done_5]
+    blocks5 = (list(range(977)) if n_blocks5 >= 977 else sorted(set(int(b) for b in np.linspace(0, 975, n_blocks5).round()))) if n_blocks5 else []
+    jobs += [("p", ("config5", b * 1024, min(1000000, b * 1024 + 1024))) for b in blocks5 if (b * 1024, min(1000000, b * 1024 + 1024)) not in done_5]
     n_long = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     done_4 = set(old["config4"]["windows_checked"]) if old and "config4" in old else set()
     if n_long:
