@@ -5,7 +5,9 @@
  * 32-bit words, "warp iterations" of 32 words with the cross-lane add / shift helpers emulated lane by lane,
  * so that band geometry, the implicit worst-case row 0 and the three-phase backtrace are literal.
  * Pinned by Test_AlignerGlobal.cpp:79-148, Test_ApproximateBandedMyers.cpp:72-170 and, for edit distances of
- * optimal results, by the reference's own CPU code built into oracle/_ref (Makefile.ref).
+ * optimal results, by the reference's own CPU code built into oracle/_ref (Makefile.ref); and by the reference's own myers_gpu.cu
+ * run on the CPU (oracle/simt -> oracle/_ref/libref_cudaaligner_simt.so): tests/golden/reference_simt_alignments.json.gz, and every
+ * pair of the configs[1] and configs[4] goldens (tests/golden/reference_simt_config_check.json), tests/test_reference_simt.py.
  */
 #include "aligner_oracle.h"
 

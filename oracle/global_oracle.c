@@ -6,7 +6,8 @@
  * (cudaaligner/tests/Test_AlignerGlobal.cpp:79-153: the table is run for the Ukkonen and Myers classes too; the
  * empty-sequence cases only for Myers) and, when oracle/_ref is built, against the reference's own CPU code
  * compiled in place: ukkonen_cpu() (ukkonen_cpu.cpp, the function the reference's own tests compare the GPU
- * Ukkonen path with) and the naive NW edit distance for optimality of both.
+ * Ukkonen path with) and the naive NW edit distance for optimality of both; and against the reference's own ukkonen_gpu.cu /
+ * myers_gpu.cu run on the CPU (oracle/simt): tests/golden/reference_simt_alignments.json.gz, tests/test_reference_simt.py.
  *
  * Ukkonen: the reference stores the band in anti-diagonal coordinates, slot (k, l) = ((j - i + p) / 2, i + j) with C
  * integer division, and its backtrace indexes that storage directly -- including the slot aliasing of the
