@@ -132,34 +132,43 @@ _PMC_PROFILE = None
 
 
 def pmc_profile():
-    """The committed PMC session of this round (tools/gpu_session.sh steps pmc + traffic -> tools/pmc_profile.py): HBM traffic,
-    issued instructions, wave cycles, wait share and LDS bank conflicts per launch of every record's kernels, stamped with the
-    commit it was taken at. rocprofv3 cannot run inside the timed region, so these come from their own passes."""
+    """The committed PMC session of this round (tools/gpu_session.sh steps pmc + issue + traffic -> tools/pmc_profile.py): HBM
+    traffic, issued instructions, wave cycles, wait share and LDS bank conflicts per launch of every record's kernels. rocprofv3
+    cannot run inside the timed region, so these come from their own passes -- and they only describe THESE kernels if the device
+    sources have not changed since: the session stamps `kernel_source_sha256` (genomeworks_amd.build.kernel_source_digest()),
+    which is recomputed here. A profile without the stamp or with another one is STALE: nothing of it is attached to a line
+    (`"traffic": null, "stale": true`)."""
     global _PMC_PROFILE
     if _PMC_PROFILE is None:
+        _PMC_PROFILE = {}
         try:
-            _PMC_PROFILE = {}
-            for name in ("r05_pmc_profile.json", "r04_pmc_profile.json"):
+            from genomeworks_amd.build import kernel_source_digest
+            now = kernel_source_digest()
+            for name in ("r06_pmc_profile.json", "r05_pmc_profile.json", "r04_pmc_profile.json"):
                 path = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(path):
-                    _PMC_PROFILE = json.load(open(path))
-                    _PMC_PROFILE["file"] = "profiles/" + name
+                    prof = json.load(open(path))
+                    if prof.get("kernel_source_sha256") == now:
+                        _PMC_PROFILE = prof
+                        _PMC_PROFILE["file"] = "profiles/" + name
+                    else:
+                        _PMC_PROFILE = {"stale": True, "file": "profiles/" + name, "stale_commit": prof.get("commit")}
                     break
         except (OSError, ValueError):
             _PMC_PROFILE = {}
     return _PMC_PROFILE
 
 
+def pmc_stale():
+    return bool(pmc_profile().get("stale"))
+
+
 def sub_traffic(key):
-    """HBM bytes of a record's kernels from the committed PMC passes (this round's profile, else round 3's files); None if
-    neither has an entry."""
+    """HBM bytes of a record's kernels from the committed PMC session when it describes these kernels (pmc_profile()); else None."""
     e = pmc_profile().get(key)
     if isinstance(e, dict) and "hbm_bytes" in e:
         return e["hbm_bytes"]
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_sub.json")))[key]["hbm_bytes"]
-    except (OSError, ValueError, KeyError):
-        return None
+    return None
 
 
 def roofline_issue(key):
@@ -177,7 +186,7 @@ def roofline_issue(key):
            "cycles_per_instruction": e["issue"]["cycles_per_instruction"],
            "lone_wave_cycles_per_instruction": e["issue"]["lone_wave_cycles_per_instruction"],
            "frac": e["issue"]["frac_of_lone_wave_issue_bound"], "wait_share": e.get("wait_share"),
-           "lone_wave_cycles_per_instruction_source": "constant from a round-3 microbenchmark (profiles/r03_microbench_instruction_size.json)",
+           "lone_wave_cycles_per_instruction_source": e["issue"].get("lone_wave_cycles_per_instruction_source"),
            "source": "%s (commit %s, tag %s)" % (p.get("file"), p.get("commit"), p.get("tag"))}
     if "lds" in e:
         out["lds_bank_conflict_share_of_lds_active"] = e["lds"]["bank_conflict_share_of_lds_active"]
@@ -738,6 +747,84 @@ def bench_reference_shapes(windows, local_rank, sync, steps):
                             "runs": multi}}
 
 
+FINAL_LINE_LIMIT = 4096   # bytes: the driver keeps a bounded tail of stdout and parses the LAST line
+
+
+def emit(headline, strong, strong8, sub, record_dir):
+    """Output protocol. Every sub-record goes out FIRST, one `{"sub_record": name, ...}` JSON line each, and the whole run
+    (headline + sub-records) is also written to <record_dir>/bench_full_record.json. The LAST line of stdout is the headline
+    alone -- the reference benchmark prints one number per benchmark (cudapoa/benchmarks/single_batch.hpp:86-93) -- and is
+    kept under FINAL_LINE_LIMIT bytes: metric, value, unit, n_gpus, steps, warmup, ms_per_step, dtype, config, roofline,
+    cpu_baseline, the golden verdict and a pointer to the file. Returns the final line."""
+    extras = {}
+    if strong is not None:
+        extras["strong_scaling"] = strong
+    if strong8 is not None:
+        extras["strong_scaling_8x"] = strong8
+    extras.update(sub or {})
+    for name, rec in extras.items():
+        print(json.dumps({"sub_record": name, "record": rec}), flush=True)
+    full = dict(headline)
+    if extras:
+        full["sub_records"] = extras
+    pointer = None
+    try:
+        os.makedirs(record_dir, exist_ok=True)
+        pointer = os.path.join(record_dir, "bench_full_record.json")
+        with open(pointer, "w") as f:
+            json.dump(full, f, indent=1)
+        pointer = os.path.relpath(pointer, ROOT)
+    except OSError as e:
+        print("bench.py: could not write the full record (%s)" % e, file=sys.stderr)
+        pointer = None
+    final = dict(headline)
+    # what the sub-records said, in one small object: name -> golden verdict (every row of the record ANDed) + its value
+    final["sub_records"] = {"file": pointer, "lines": "one {\"sub_record\": ...} stdout line each, before this line",
+                            "summary": {k: sub_summary(v) for k, v in extras.items()}}
+    line = json.dumps(final, separators=(",", ":"))
+    # shed the optional members (never metric / roofline / cpu_baseline) until the line fits
+    for victim in ("roofline_issue", "extension_get_consensus_in_place", "kernel_only", "timed_region", "scaling_note",
+                   "consensus_sha256", "cold_first_pass_ms"):
+        if len(line.encode()) < FINAL_LINE_LIMIT:
+            break
+        final.pop(victim, None)
+        line = json.dumps(final, separators=(",", ":"))
+    if len(line.encode()) >= FINAL_LINE_LIMIT:
+        final["sub_records"] = {"file": pointer}
+        line = json.dumps(final, separators=(",", ":"))
+    assert len(line.encode()) < FINAL_LINE_LIMIT, len(line)
+    sys.stdout.flush()
+    print(line, flush=True)
+    return line
+
+
+def golden_verdicts(rec):
+    """Every `equals_oracle_golden` found anywhere inside a record."""
+    found = []
+    if isinstance(rec, dict):
+        for k, v in rec.items():
+            if k == "equals_oracle_golden":
+                found.append(v)
+            else:
+                found.extend(golden_verdicts(v))
+    elif isinstance(rec, (list, tuple)):
+        for v in rec:
+            found.extend(golden_verdicts(v))
+    return found
+
+
+def sub_summary(rec):
+    v = golden_verdicts(rec)
+    out = {"golden": [sum(1 for x in v if x is True), len(v)]}   # [rows equal to the golden, rows checked]
+    if isinstance(rec, dict):
+        for k in ("value", "gcups", "ms", "ms_per_step"):
+            if isinstance(rec.get(k), (int, float)):
+                out[k] = rec[k]
+        if isinstance(rec.get("unit"), str):
+            out["unit"] = rec["unit"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -749,6 +836,8 @@ def main():
                     help="comma list of the sub-records to measure next to the metric config: aligner, default_aligner, "
                          "aligner_matrix, long_reads, reference_shapes, band_modes, none")
     ap.add_argument("--long-read-windows", type=int, default=598)
+    ap.add_argument("--record-dir", default=os.path.join(ROOT, "gpurun_out"),
+                    help="where bench_full_record.json (headline + every sub-record) is written; stdout's last line is the headline")
     args = ap.parse_args()
     subs = set(x for x in args.sub_configs.split(",") if x and x != "none")
 
@@ -959,15 +1048,7 @@ def main():
         achieved = cells * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed PMC pass of this same workload (rocprofv3 cannot run inside the
         # timed region; tools/pmc_passes.sh collects FETCH_SIZE / WRITE_SIZE in their own runs)
-        traffic = pmc_profile().get("headline", {}).get("hbm_bytes") if args.windows == WINDOWS else None
-        for name in (() if traffic is not None else ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")):
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-                if pmc.get("windows") == args.windows:
-                    traffic = pmc["hbm_bytes_per_launch"]
-                    break
-            except (OSError, ValueError, KeyError):
-                continue
+        traffic = sub_traffic("headline") if args.windows == WINDOWS else None
         out = {
             "metric": "cudapoa consensus GCUPS, 1024-window short-read batch (static band 256, 32 reads <= 1024 bp)",
             "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -985,7 +1066,8 @@ def main():
                        "windows_per_gpu": args.windows, "cells_per_gpu": cells, "parallelism": "index-split x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "poa_window_kernel<int16,int16,static_band>",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "stale": pmc_stale(),
+                         "traffic_source": pmc_profile().get("file"),
                          "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL,
                          "kernel_ms": round(k_ms, 3), "output_kernel_ms": round(o_ms, 3),
                          "algorithmic_bytes_per_cell": BYTES_PER_CELL},
@@ -1002,19 +1084,12 @@ def main():
             "cold_first_pass_ms": round(t_cold * 1e3, 3),
         }
         if world > 1:
-            out["scaling_note"] = ("weak scaling by construction: every rank runs the same 1024-window batch (one window is one "
-                                   "chain of 31 dependent alignments, and a launch lasts as long as its slowest window, so one "
-                                   "1024-window batch does not split: see strong_scaling); the comparable strong-scaling record "
-                                   "is strong_scaling_8x (8 x 1024 windows index-split over the ranks)")
+            out["scaling_note"] = ("weak scaling by construction: every rank runs the same 1024-window batch; the comparable "
+                                   "strong-scaling records are strong_scaling (1024 windows) and strong_scaling_8x (8 x 1024 windows "
+                                   "index-split over the ranks), see the sub-record lines / file")
         if cpu is not None:  # timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu
-        if strong is not None:
-            out["strong_scaling"] = strong
-        if strong8 is not None:
-            out["strong_scaling_8x"] = strong8
-        if sub:
-            out["sub_records"] = sub
-        print(json.dumps(out))
+        emit(out, strong, strong8, sub, args.record_dir)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -39,6 +39,20 @@ def _digest(paths, extra):
     return h.hexdigest()
 
 
+def kernel_source_digest():
+    """sha256 over the device sources (csrc/*.hip, *.h) and include/gwhip.h by repo-relative name and content: what a measurement
+    session stamps into its PMC profile and bench.py recomputes at run time, so counters taken on other kernels are never
+    attached to a line (the GPU box has no .git to ask)."""
+    h = hashlib.sha256()
+    base = os.path.join(PKG, "csrc")
+    paths = [os.path.join(base, f) for f in os.listdir(base) if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "gwhip.h")]
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(os.path.relpath(p, ROOT).encode())
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _deps(subdir, exts):
     out = []
     for base in (os.path.join(PKG, subdir), os.path.join(ROOT, "include")):

@@ -3351,12 +3351,43 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
     hipStream_t side = args->side_stream ? (hipStream_t)args->side_stream : stream;
     auto hand_over   = [&](hipStream_t from, hipStream_t to) -> hipError_t {
         if (from == to) return hipSuccess;
+        // events of this host thread and device, made once and reused round robin (a wait refers to the record that preceded
+        // it, so recording the event again later does not disturb it); two creations + destructions per chunk and launch
+        // were on the timed path of every align_all() before
+        struct EventRing
+        {
+            int device = -1;
+            hipEvent_t ev[8] = {};
+            unsigned next = 0; // (never destroyed: a thread's exit may come after the runtime's own teardown)
+        };
+        thread_local EventRing rings[4];
+        int device = 0;
+        if (hipError_t e = hipGetDevice(&device); e != hipSuccess) return e;
+        EventRing* ring = nullptr;
+        for (EventRing& r : rings)
+            if (r.device == device || r.device < 0)
+            {
+                ring = &r;
+                break;
+            }
         hipEvent_t ev = nullptr;
-        hipError_t e  = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        if (e != hipSuccess) return e;
-        e = hipEventRecord(ev, from);
+        bool own      = false;
+        if (ring != nullptr)
+        {
+            ring->device   = device;
+            hipEvent_t& slot = ring->ev[ring->next++ & 7];
+            if (slot == nullptr)
+                if (hipError_t e = hipEventCreateWithFlags(&slot, hipEventDisableTiming); e != hipSuccess) return e;
+            ev = slot;
+        }
+        else // (a thread that has visited more than four devices)
+        {
+            if (hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); e != hipSuccess) return e;
+            own = true;
+        }
+        hipError_t e = hipEventRecord(ev, from);
         if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
-        (void)hipEventDestroy(ev); // (released once the recorded work has completed)
+        if (own) (void)hipEventDestroy(ev); // (released once the recorded work has completed)
         return e;
     };
     const bool do_sizing = args->phases == 0 || (args->phases & GWHIP_MYERS_SIZING) != 0;
@@ -3402,51 +3433,70 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
     }
     const char* myers_dbg = std::getenv("GWHIP_MYERS_HBM_STATE"); // debugging: force the HBM-state kernel
     if (myers_dbg && myers_dbg[0] == '1') use_lds = false;
-    // Small batches of long pairs: eight lanes per pair (myers_banded_group_kernel). Worth it while the one-lane kernel
+    // Small batches of long pairs: G lanes per pair (myers_banded_group_kernel). Worth it while the one-lane kernel
     // would leave SIMDs empty (fewer wavefronts than SIMDs) and a pair is a long chain (queries of 256 bases and more).
-    bool use_group = false;
+    // G = 6 / 8 for batches that then fill the SIMDs (BASELINE configs[1]); G = 16 / 32 / 64 (round 6) while the batch still
+    // fits one wavefront per SIMD AND a band attempt may need more words than lanes -- an attempt wider than the group falls
+    // back to the one-lane stripes on the group's first lane, which is what made 1024 pairs of 2 kbp at max_bandwidth 1024
+    // (band attempts of 5, 9 and 13+ words; the reference benchmark's shape, cudaaligner/benchmarks/main.cpp:81-95) take
+    // 15.7 ms: every column of a 13-word attempt was 13 dependent word steps of one lane.
+    int group_lanes = 0; // 0: not the group kernel
     {
         const char* gdbg = std::getenv("GWHIP_MYERS_GROUP"); // debugging: 0 = never, 1 = whenever the LDS tables fit
         int cus = 0, dev = 0;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        const int32_t simds  = 4 * cus;
         const int32_t qwords = args->max_query_length > 0 ? (args->max_query_length + kWord - 1) / kWord : 0;
-        const bool fits      = qwords > 0 && (size_t)(40 * (4 * qwords + 1) + 40 * 17 + 64 * 224) * 4 <= 80 * 1024; // two blocks per CU
-        use_group = fits && (n + 63) / 64 < 4 * cus && args->max_query_length >= 256;
+        // LDS of a block of four wavefronts with G lanes per pair: per pair the pattern table (+ 1: odd stride) and 17 words of
+        // target characters, plus the backtrace's column window (224 words for each of the 64 slots of a workspace region)
+        auto lds_bytes = [&](int G) {
+            const size_t pairs = G == 6 ? 40 : 256 / (size_t)G;
+            return (pairs * (size_t)(4 * qwords + 1) + pairs * 17 + 64 * 224) * sizeof(uint32_t);
+        };
+        auto fits = [&](int G) { return qwords > 0 && lds_bytes(G) <= (G <= 8 ? (size_t)80 * 1024 : (size_t)156 * 1024); }; // two blocks / one block per CU
+        bool use_group = (n + 63) / 64 < simds && args->max_query_length >= 256;
         if (gdbg && gdbg[0] == '0') use_group = false;
-        if (gdbg && gdbg[0] == '1') use_group = fits;
+        if (gdbg && gdbg[0] == '1') use_group = true;
         if (use_group)
+        {
+            // (four lanes per pair with two words per lane -- half the wavefronts for 10 000 pairs -- was measured and is no
+            // faster: 1.71 vs 1.68 ms on configs[1], profiles/r03_h_aligner_group_lanes.txt.) Six lanes per pair (ten pairs per
+            // wavefront) when that is what puts the batch on one wavefront per SIMD.
+            int G = (n > 8 * simds && n <= 10 * simds) ? 6 : 8;
+            // the widest band an attempt can reach, in words
+            const int32_t bw_cap      = args->max_bandwidth_hint > 0 ? std::min(args->max_bandwidth_hint, args->max_query_length) : args->max_query_length;
+            const int32_t worst_words = (bw_cap + kWord - 1) / kWord;
+            while (G >= 8 && G < 64 && G < worst_words && (int64_t)n * (2 * G) / 64 <= simds) G *= 2;
+            if (const char* gl = std::getenv("GWHIP_MYERS_GROUP_LANES")) // forces the choice (6, 8, 16, 32, 64)
+            {
+                const int v = std::atoi(gl);
+                if (v == 6 || v == 8 || v == 16 || v == 32 || v == 64) G = v;
+            }
+            // tables that do not fit: fewer pairs per block (more lanes per pair) until they do, if the batch allows it
+            for (int g = G; g <= 64 && group_lanes == 0; g = g == 6 ? 8 : 2 * g)
+                if (fits(g) && (g == G || (int64_t)n * g / 64 <= 2 * simds)) group_lanes = g;
+        }
+        if (group_lanes != 0)
         {
             ka.lds_pattern_words = 4 * qwords;
             ka.lds_band_words    = 224; // words of the backtrace's column window per pair
+            const size_t lds     = lds_bytes(group_lanes);
+            auto launch = [&](auto kernel, int pairs) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 80 * 1024));
+                hipLaunchKernelGGL(kernel, dim3((n + pairs - 1) / pairs), dim3(256), lds, stream, ka);
+            };
+            switch (group_lanes)
+            {
+            case 6: launch(&myers_banded_group_kernel<6, 4>, 40); break;
+            case 8: launch(&myers_banded_group_kernel<8, 4>, 32); break;
+            case 16: launch(&myers_banded_group_kernel<16, 4>, 16); break;
+            case 32: launch(&myers_banded_group_kernel<32, 4>, 8); break;
+            default: launch(&myers_banded_group_kernel<64, 4>, 4); break;
+            }
         }
     }
-    // (four lanes per pair with two words per lane -- half the wavefronts for 10 000 pairs -- was measured and is no faster:
-    // 1.71 vs 1.68 ms on configs[1], profiles/r03_h_aligner_group_lanes.txt: twice the vector work per column and wavefront.)
-    // Six lanes per pair (ten pairs per wavefront) when that is what puts the batch on one wavefront per SIMD: a band attempt
-    // of up to six words still runs across the lanes (GWHIP_MYERS_GROUP_LANES = 6 / 8 forces the choice).
-    if (use_group)
-    {
-        int cus = 0, dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        bool six = n > 8 * 4 * cus && n <= 10 * 4 * cus;
-        const char* gl = std::getenv("GWHIP_MYERS_GROUP_LANES");
-        if (gl && gl[0] == '6') six = true;
-        if (gl && gl[0] == '8') six = false;
-        const int pairs  = six ? 40 : 32;
-        const size_t lds = (size_t)(pairs * (ka.lds_pattern_words + 1) + pairs * 17 + 64 * ka.lds_band_words) * sizeof(uint32_t);
-        if (six)
-        {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&myers_banded_group_kernel<6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            hipLaunchKernelGGL((myers_banded_group_kernel<6, 4>), dim3((n + 39) / 40), dim3(256), lds, stream, ka);
-        }
-        else
-        {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&myers_banded_group_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            hipLaunchKernelGGL((myers_banded_group_kernel<8, 4>), dim3((n + 31) / 32), dim3(256), lds, stream, ka);
-        }
-    }
+    if (group_lanes != 0) {}
     else if (use_lds)
         hipLaunchKernelGGL(myers_banded_kernel<true>, dim3((n + 63) / 64), dim3(64),
                            (size_t)(ka.lds_pattern_words + 3 * ka.lds_band_words + 16) * 64 * sizeof(uint32_t), stream, ka);

@@ -530,7 +530,18 @@ void BandedAligner::launch(void* event_before, void* event_after)
         GW_CU_CHECK_ERR(hipEventRecord(begin, stream_));
         GW_CU_CHECK_ERR(hipStreamWaitEvent(static_cast<hipStream_t>(side_stream_), begin, 0));
     }
-    run_chunks(nullptr, false);
+    try
+    {
+        run_chunks(nullptr, false);
+    }
+    catch (...)
+    {
+        // a HIP call failed in the middle of a chunked batch: the side / upload streams hold work nobody joins, and head_ and the
+        // pinned mirror may still be written; drain all three streams and take the batch out of its launched state, as align_all() does
+        drain_streams();
+        launched_ = false;
+        throw;
+    }
     if (event_after != nullptr) GW_CU_CHECK_ERR(hipEventRecord(static_cast<hipEvent_t>(event_after), stream_));
 }
 
@@ -686,7 +697,7 @@ StatusType BandedAligner::sync_alignments()
     }
     catch (...)
     {
-        (void)hipStreamSynchronize(stream_);
+        drain_streams(); // all three: the side stream's mirror kernels write the pinned buffers the block is about to release
         uploads_in_flight_ = false;
         alignments_.clear();
         reset_data();

@@ -259,9 +259,66 @@ void print_sam(const std::vector<Overlap>& overlaps, const std::vector<std::stri
         buffer += t.name;
         std::snprintf(num, sizeof(num), "\t%u\t255\t", o.target_start_position_in_read_ + 1u); // SAM positions are 1-based
         buffer += num;
-        buffer += (!cigars.empty() && !cigars[i].empty()) ? cigars[i] : std::string("*");
+        // SEQ is the whole read on the strand it aligns in (flag 16: its reverse complement), and the CIGAR covers only
+        // query_start..query_end of it: the unaligned ends become soft clips, so that the CIGAR's query length equals
+        // len(SEQ) as the SAM specification asks (the reference hands htslib the forward read and the bare CIGAR,
+        // cudamapper/src/utils.cpp:253-300; samtools rejects such a record for partial overlaps)
+        const bool reverse  = o.relative_strand == RelativeStrand::Reverse;
+        const bool has_cg   = !cigars.empty() && !cigars[i].empty();
+        if (has_cg)
+        {
+            const int64_t qlen  = static_cast<int64_t>(q.seq.length());
+            const int64_t head  = std::max<int64_t>(0, std::min<int64_t>(o.query_start_position_in_read_, qlen));
+            const int64_t tail  = std::max<int64_t>(0, qlen - std::min<int64_t>(o.query_end_position_in_read_, qlen));
+            const int64_t left  = reverse ? tail : head;
+            const int64_t right = reverse ? head : tail;
+            if (left > 0)
+            {
+                std::snprintf(num, sizeof(num), "%" PRId64 "S", left);
+                buffer += num;
+            }
+            // cudaaligner's 'I' is a base present in the TARGET only and its 'D' one present in the query only
+            // (cudaaligner.hpp:47-53), the opposite of SAM's operators, which are named from the reference sequence's side
+            // (RNAME = the target read): swapped here, in the SAM text only (the PAF cg:Z: tag stays cudaaligner's)
+            {
+                const size_t at = buffer.size();
+                buffer += cigars[i];
+                for (size_t k = at; k < buffer.size(); ++k)
+                    buffer[k] = buffer[k] == 'I' ? 'D' : (buffer[k] == 'D' ? 'I' : buffer[k]);
+            }
+            if (right > 0)
+            {
+                std::snprintf(num, sizeof(num), "%" PRId64 "S", right);
+                buffer += num;
+            }
+        }
+        else
+            buffer += '*';
         buffer += "\t*\t0\t0\t";
-        buffer += q.seq.empty() ? std::string("*") : q.seq;
+        if (q.seq.empty())
+            buffer += '*';
+        else if (!reverse)
+            buffer += q.seq;
+        else
+        {
+            const size_t at = buffer.size();
+            buffer.append(q.seq.rbegin(), q.seq.rend());
+            for (size_t k = at; k < buffer.size(); ++k)
+            {
+                switch (buffer[k])
+                {
+                case 'A': buffer[k] = 'T'; break;
+                case 'C': buffer[k] = 'G'; break;
+                case 'G': buffer[k] = 'C'; break;
+                case 'T': buffer[k] = 'A'; break;
+                case 'a': buffer[k] = 't'; break;
+                case 'c': buffer[k] = 'g'; break;
+                case 'g': buffer[k] = 'c'; break;
+                case 't': buffer[k] = 'a'; break;
+                default: break; // N and the IUPAC codes that are their own complement stay
+                }
+            }
+        }
         buffer += "\t*\n";
     }
     std::fwrite(buffer.data(), 1, buffer.size(), out);

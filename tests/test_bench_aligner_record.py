@@ -118,7 +118,9 @@ def _rank(rank, world, port, q):
     bench.CONFIG2["pairs"], bench.CONFIG5["pairs"] = 25, 3001  # odd counts: the ranks' ranges are uneven and not block aligned
     if rank == 1 and os.environ.get("GW_TEST_SPOIL_RANK1"):
         FakeAligner.spoil = (3, "ops")  # (an operation: seen by the edit distances, which the golden holds for every pair)
-    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--sub-configs", "aligner"]
+    import tempfile
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--sub-configs", "aligner",
+                "--record-dir", tempfile.mkdtemp(prefix="gw_bench_")]
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         bench.main()
@@ -148,8 +150,9 @@ def _two_ranks(spoil):
         os.environ.pop("GW_TEST_SPOIL_RANK1", None)
     assert got[1].strip() == ""
     lines = [l for l in got[0].splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    return json.loads(lines[0])["sub_records"]
+    # every sub-record on a line of its own, the small headline line last (bench.emit)
+    assert len(lines[-1].encode()) < 4096 and "metric" in json.loads(lines[-1])
+    return {json.loads(l)["sub_record"]: json.loads(l)["record"] for l in lines[:-1]}
 
 
 def test_aligner_records_with_two_gloo_ranks_reduce_the_verdict():

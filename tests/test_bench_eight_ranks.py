@@ -60,7 +60,9 @@ def _rank(rank, world, port, q):
     torch.cuda.set_device = lambda d: None
     torch.cuda.synchronize = lambda *a: None
     import bench
-    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--sub-configs", "none"]
+    import tempfile
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--sub-configs", "none",
+                "--record-dir", tempfile.mkdtemp(prefix="gw_bench_")]
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         bench.main()
@@ -81,11 +83,18 @@ def test_bench_line_with_eight_gloo_ranks_and_a_device_double():
         assert p.exitcode == 0
     assert all(got[r].strip() == "" for r in range(1, world))      # one line, from rank 0
     lines = [l for l in got[0].splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    line = json.loads(lines[0])
+    # the sub-records first (one line each), the headline LAST and small enough for the driver's tail
+    assert len(lines) == 3 and got[0].rstrip().splitlines()[-1] == lines[-1]
+    assert len(lines[-1].encode()) < 4096
+    line = json.loads(lines[-1])
     assert line["n_gpus"] == world and line["scaling"] == "weak"
     assert line["equals_oracle_golden"] is True                      # every rank hashed its own last step
     assert line["config"]["cells_per_gpu"] == 10990578176
-    s1, s8 = line["strong_scaling"], line["strong_scaling_8x"]
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["bound"] == "hbm"
+    assert line["sub_records"]["summary"]["strong_scaling_8x"]["golden"] == [1, 1]
+    subs = {json.loads(l)["sub_record"]: json.loads(l)["record"] for l in lines[:-1]}
+    s1, s8 = subs["strong_scaling"], subs["strong_scaling_8x"]
+    full = json.load(open(os.path.join(ROOT, line["sub_records"]["file"])))
+    assert full["sub_records"]["strong_scaling_8x"] == s8 and full["value"] == line["value"]
     assert s1["windows"] == 1024 and s1["equals_oracle_golden"] is True
     assert s8["windows"] == 8192 and s8["equals_oracle_golden"] is True

@@ -558,8 +558,6 @@ def test_hip_aligners_equal_the_reference_itself_on_the_simt_goldens():
     bad = []
     for k, row in enumerate(rows):
         b, ref = row["batch"], row["reference"]
-        if b.get("gpu") is False:
-            continue  # (characters outside ACGT through the default / Myers / Ukkonen classes: compared with the oracles on the CPU so far)
         pairs = [tuple(p) for p in b["pairs"]]
         max_len = max(max(len(q), len(t)) for q, t in pairs)
         if b["kind"] == "banded":

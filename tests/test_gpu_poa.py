@@ -785,13 +785,11 @@ def test_hip_path_equals_the_reference_itself_on_the_simt_goldens():
     bad = []
     for i, r in enumerate(rows):
         c, ref, bc = r["case"], r["reference"], r["reference"]["batch_config"]
-        if c.get("gpu") is False:
-            continue  # (the short-predecessor-window cases of the traceback modes: compared with the oracle on the CPU so far)
         msa = bool(c["output_mask"] & 2)
         # the constructor the generator used on the reference: BatchConfig(max_seq_sz, max_seq_per_poa, band_width, banding)
         b = cudapoa.CudaPoaBatch.from_batch_config(c["max_seq"], c["max_seqs"], c["band_width"], names[c["band_mode"]], 1 << 30,
                                                    output_type="msa" if msa else "consensus", gap_score=c["gap"], mismatch_score=c["mismatch"],
-                                                   match_score=c["match"])
+                                                   match_score=c["match"], max_banded_pred_distance=c.get("max_pred", 0))
         got = b.batch_size
         assert [got.max_sequence_size, got.max_consensus_size, got.max_nodes_per_graph, got.matrix_sequence_dimension, got.alignment_band_width,
                 got.max_sequences_per_poa, got.band_mode, got.max_banded_pred_distance] == [bc[k] for k in (

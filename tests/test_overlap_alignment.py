@@ -168,5 +168,17 @@ def test_sam_records_carry_the_paf_cigars(tmp_path):
         assert rec[0] == row[0] and rec[2] == row[5]
         assert rec[1] == ("16" if row[4] == "-" else "0")
         assert int(rec[3]) == int(row[7]) + 1 and rec[4] == "255"
-        assert rec[5] == row[12][5:]
-        assert rec[6:9] == ["*", "0", "0"] and rec[9] == seqs[row[0]] and rec[10] == "*"
+        # the PAF CIGAR between soft clips for the unaligned ends of the read, with I / D in SAM's sense (cudaaligner names them
+        # from the other sequence's side); on the reverse strand SEQ is the reverse complement and the clips swap sides
+        qlen, qs, qe = int(row[1]), int(row[2]), int(row[3])
+        head, tail = (qs, qlen - qe) if row[4] == "+" else (qlen - qe, qs)
+        swapped = row[12][5:].translate(str.maketrans("ID", "DI"))
+        assert rec[5] == ("%dS" % head if head else "") + swapped + ("%dS" % tail if tail else "")
+        seq = seqs[row[0]] if row[4] == "+" else seqs[row[0]][::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
+        assert rec[6:9] == ["*", "0", "0"] and rec[9] == seq and rec[10] == "*"
+        # SAM validity: the operators that consume the query (M I S = X) add up to len(SEQ), those that consume the reference
+        # (M D N = X) to the aligned target span
+        ops = re.findall(r"(\d+)([MIDNSHP=X])", rec[5])
+        assert "".join(n + o for n, o in ops) == rec[5]
+        assert sum(int(n) for n, o in ops if o in "MIS=X") == len(rec[9])
+        assert sum(int(n) for n, o in ops if o in "MDN=X") == int(row[8]) - int(row[7])

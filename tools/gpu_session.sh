@@ -11,6 +11,8 @@
 #   stats        rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline $STATS_ARGS` -> kernel_stats.csv
 #   pmc          tools/pmc_passes.sh with PASSES (default "insts waits lds fetch write") and SUBS (default none)
 #   pmcfull      the same passes over the full-band kernel alone (tools/profile_phases.py 1024 full_band) -> pmc_summary_full_band.csv
+#   issue        measure the lone-wavefront issue rate (tools/microbench_fetch.hip) -> microbench_issue.json, which the traffic step
+#                writes into pmc_profile.json instead of the round-3 constant
 #   traffic      derive pmc_profile.json (HBM traffic, issue and LDS counters per record) from the pmc step's summary; pass
 #                GW_COMMIT=$(git rev-parse --short HEAD) from the submitting side (the box has no .git)
 #   extra        run $EXTRA_CMD (one-off measurements)
@@ -34,13 +36,18 @@ if has phases; then
     cut -c1-900 $OUT/phase_breakdown.json; echo
 fi
 if has bench; then
-    ( timeout ${BENCH_TIMEOUT:-1500} python bench.py ${BENCH_ARGS:-} > $OUT/bench.json 2> $OUT/bench.err ); echo "bench rc=$?"; tail -3 $OUT/bench.err
+    ( timeout ${BENCH_TIMEOUT:-1500} python bench.py --record-dir $OUT ${BENCH_ARGS:-} > $OUT/bench.json 2> $OUT/bench.err ); echo "bench rc=$?"; tail -3 $OUT/bench.err
     python - $OUT/bench.json <<'PY'
 import json, sys
+import os
 lines = [x for x in open(sys.argv[1]) if x.startswith('{')]
 if not lines:
     sys.exit("no bench line")
-d = json.loads(lines[0])
+d = json.loads(lines[-1])
+print("final line bytes:", len(lines[-1].encode()))
+full = os.path.join(os.path.dirname(sys.argv[1]), "bench_full_record.json")
+if os.path.exists(full):
+    d = json.load(open(full))
 print("headline", d['value'], d['unit'], "step ms", d['ms_per_step'], "kernel ms", d['roofline']['kernel_ms'], "frac", d['roofline']['frac'],
       "golden", d.get('equals_oracle_golden'))
 s = d.get('sub_records', {})
@@ -71,6 +78,21 @@ if has pmcfull; then
     python tools/pmc_summary.py $OUT/pmcfull > $OUT/pmc_summary_full_band.csv 2>/dev/null
     rm -rf $OUT/pmcfull
     grep -E "WAVE_CYCLES|FETCH|WRITE_SIZE|WAIT_ANY" $OUT/pmc_summary_full_band.csv | cut -c1-170 | head -12
+fi
+if has issue; then
+    # the lone-wavefront issue rate that roofline_issue prices instructions with, measured in THIS session
+    mkdir -p tools/bin
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/microbench_fetch.hip -o tools/bin/microbench_fetch 2> $OUT/issue_build.log \
+        && timeout 300 tools/bin/microbench_fetch > $OUT/microbench_instruction_size.json
+    python - $OUT <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1] + "/microbench_instruction_size.json"))["cycles_per_instruction"]
+lone = [r for r in d if r["waves_per_simd"] == 1]
+pick = next(r for r in lone if r["chain"].startswith("v_add_u32 e32, 4 independent"))
+json.dump({"lone_wave_cycles_per_instruction": pick["cycles"], "what": pick["chain"] + ", one wavefront per SIMD",
+           "all_lone_wave_rows": lone}, open(sys.argv[1] + "/microbench_issue.json", "w"), indent=1)
+print("lone-wave cycles per instruction:", pick["cycles"])
+PY
 fi
 if has traffic; then
     python tools/pmc_profile.py $OUT/pmc_summary.csv "$TAG" $OUT "${GW_COMMIT:-unknown}" $OUT/pmc_summary_full_band.csv

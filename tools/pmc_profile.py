@@ -26,6 +26,7 @@ commit = sys.argv[4] if len(sys.argv) > 4 else os.environ.get("GW_COMMIT", "unkn
 # a CONSTANT, not a counter: the issue rate of a lone wavefront measured once by a microbenchmark in the production launch geometry
 # (profiles/r03_microbench_instruction_size.json: 4.1-4.2 cycles per 4-byte instruction); every record says so
 LONE_WAVE_CYCLES_PER_INST = 4.1
+LONE_WAVE_SOURCE = "constant from the round-3 microbenchmark profiles/r03_microbench_instruction_size.json, not measured in this session"
 
 
 def entry(match, what="mean", note=None, launches_per_call=1):
@@ -66,7 +67,7 @@ def entry(match, what="mean", note=None, launches_per_call=1):
             e["issue"] = {"instructions_per_wave": round(per_wave, 1), "cycles_per_wave": round(wc * 4 / waves, 1),
                           "cycles_per_instruction": round(wc * 4 / waves / per_wave, 2),
                           "lone_wave_cycles_per_instruction": LONE_WAVE_CYCLES_PER_INST,
-                          "lone_wave_cycles_per_instruction_source": "constant from the round-3 microbenchmark profiles/r03_microbench_instruction_size.json, not measured in this session",
+                          "lone_wave_cycles_per_instruction_source": LONE_WAVE_SOURCE,
                           "frac_of_lone_wave_issue_bound": round(per_wave * LONE_WAVE_CYCLES_PER_INST / (wc * 4 / waves), 4)}
     bc, ia = tot("SQ_LDS_BANK_CONFLICT"), tot("SQ_LDS_IDX_ACTIVE")
     if bc is not None and ia:
@@ -78,7 +79,20 @@ def entry(match, what="mean", note=None, launches_per_call=1):
     return e
 
 
-out = {"tag": tag, "commit": commit,
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from genomeworks_amd.build import kernel_source_digest  # noqa: E402
+
+# optional: the lone-wave issue constant measured in THIS session (tools/microbench_issue.hip, gpu_session.sh step issue)
+issue_json = os.path.join(out_dir, "microbench_issue.json")
+if os.path.exists(issue_json):
+    try:
+        m = json.load(open(issue_json))
+        LONE_WAVE_SOURCE = "measured in this session by tools/microbench_issue.hip (%s)" % m.get("what", "independent 4-byte VALU instructions, one wavefront per SIMD")
+        LONE_WAVE_CYCLES_PER_INST = float(m["lone_wave_cycles_per_instruction"])
+    except (OSError, ValueError, KeyError):
+        pass
+
+out = {"tag": tag, "commit": commit, "kernel_source_sha256": kernel_source_digest(),
        "source": "rocprofv3 --kernel-trace --pmc, one counter group per pass (tools/pmc_passes.sh: insts, waits, lds, fetch, write) over "
                  "`bench.py --steps 1 --warmup 0 --no-cpu-baseline --sub-configs aligner,default_aligner,long_reads`; FETCH_SIZE x 2 and "
                  "WRITE_SIZE x 0.97 as calibrated in profiles/r03_pmc_traffic.json on microkernels of known size"}
