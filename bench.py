@@ -722,9 +722,63 @@ def bench_reference_shapes(windows, local_rank, sync, steps):
               "windows_equal_oracle_golden": int((fp == fgold["fingerprint"]).sum()) if len(windows) == fsum["windows"] else None,
               "equals_oracle_golden": bool(len(windows) == fsum["windows"] and G.band_gen.cell_digest(fp) == fsum["fingerprint_sha256"]
                                            and cells == fsum["cells"])}
+    # BM_SingleBatchTest's own sweep (cudapoa/benchmarks/main.cpp:68-71: RangeMultiplier(4), Range(1, 1024)): the first n windows
+    # as one batch, in the benchmark's full band and in the metric configuration (static band 256). One window is one chain of
+    # 31 dependent alignments on ONE wavefront, so a batch that leaves SIMDs empty takes as long as a full one: the sweep is the
+    # measured form of "a 1024-window batch does not strong-scale" (DESIGN.md 5).
+    sweep = []
+    for n in (1, 4, 16, 64, 256, 1024):
+        if n > len(windows):
+            break
+        row = {"windows": n}
+        for label, mk in (("full_band", lambda: cudapoa.CudaPoaBatch(200, 1024, 16 << 30, output_type="consensus", band_mode="full_band",
+                                                                     device_id=local_rank, max_nodes_per_graph=3072, matrix_sequence_dimension=1024)),
+                          ("static_band_256", lambda: cudapoa.CudaPoaBatch(32, 1024, 8 << 30, output_type="consensus", band_mode="static_band",
+                                                                           alignment_band_width=256, device_id=local_rank, max_nodes_per_graph=3072))):
+            sb = mk()
+            for w in windows[:n]:
+                st, _ = sb.add_poa_group(w)
+                assert st == 0, st
+            sb.generate_poa()
+            sb.get_consensus_native()
+            c_n = sb.total_cells()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                sb.generate_poa()
+                sb.get_consensus_native()
+            sync()
+            dt_n = (time.perf_counter() - t0) / steps
+            cons, cov, status = sb.get_consensus()
+            del sb
+            if label == "full_band":
+                ok = bool(len(windows) == fsum["windows"] and (G.band_mode_fingerprints(cons, cov, status) == fgold["fingerprint"][:n]).all())
+            else:
+                rows3, _ = G.config3_windows()
+                ok = all(c == rows3[i]["consensus"] and list(v) == list(rows3[i]["coverage"]) and int(stt) == rows3[i]["status"]
+                         for i, (c, v, stt) in enumerate(zip(cons, cov, status)))
+            row[label] = {"ms": round(dt_n * 1e3, 3), "gcups": round(c_n / dt_n / 1e9, 2), "windows_per_s": round(n / dt_n, 1),
+                          "equals_oracle_golden": ok}
+        sweep.append(row)
     multi = []
     twice = windows + windows
     gold_fp = fgold["fingerprint"]
+    # the reference's own size: 5 500 windows over 1 .. 16 batches (cudapoa/benchmarks/main.cpp:48-66), here the 1024 config-3
+    # windows cyclically; every block of results is compared with the same golden fingerprints
+    big = [windows[i % len(windows)] for i in range(5500)]
+    multi_5500 = []
+    for nb in (1, 2, 4, 8, 16):
+        sync()
+        out = cudapoa.process_windows_multi_device(big, 200, 1024, devices=(local_rank,), batches_per_device=nb,
+                                                   memory_per_device=int(96e9), band_mode="full_band",
+                                                   max_nodes_per_graph=3072, matrix_sequence_dimension=1024)
+        fp5 = G.band_mode_fingerprints(out["consensus"], out["coverage"], out["status"])
+        ok = bool(len(windows) == fsum["windows"] and all(s == 0 for s in out["status"])
+                  and all((fp5[k:k + len(windows)] == gold_fp[:len(fp5[k:k + len(windows)])]).all() for k in range(0, len(big), len(windows))))
+        multi_5500.append({"batches": nb, "ms": round(out["seconds_after_creation"] * 1e3, 1),
+                           "windows_per_s": round(len(big) / out["seconds_after_creation"], 1), "launches": out["launches"],
+                           "gcups": round(cells * len(big) / len(windows) / out["seconds_after_creation"] / 1e9, 1),
+                           "ms_with_batch_creation": round(out["seconds"] * 1e3, 1), "equals_oracle_golden": ok})
     for nb in (1, 2, 4, 8):
         sync()
         # BatchConfig(1024, 200) = full band and one share of the device's memory split evenly over the batches, as the
@@ -740,6 +794,12 @@ def bench_reference_shapes(windows, local_rank, sync, steps):
         multi.append({"batches": nb, "ms": round(dt * 1e3, 1), "windows_per_s": round(len(twice) / dt, 1), "launches": out["launches"],
                       "gcups": round(2 * cells / dt / 1e9, 1), "ms_with_batch_creation": round(dt_all * 1e3, 1), "equals_oracle_golden": ok})
     return {"single_batch_full_band": single,
+            "single_batch_sweep": {"shape": "BM_SingleBatchTest sweep: the first n of the 1024 config-3 windows as one batch, generate_poa() + "
+                                            "get_consensus(); full band = BatchConfig(1024, 200) as in the reference, static_band_256 = the metric "
+                                            "configuration (cudapoa/benchmarks/main.cpp:68-71)", "rows": sweep},
+            "multi_batch_5500": {"shape": "BM_MultiBatchTest: 5500 windows (the 1024 config-3 windows cyclically), BatchConfig(1024, 200) full band, "
+                                          "1 .. 16 batches on host threads sharing the device and 96 GB of it (cudapoa/benchmarks/main.cpp:48-66, "
+                                          "multi_batch.hpp:41-61,165-176); timed like process_batches()", "runs": multi_5500},
             "multi_batch": {"shape": "BM_MultiBatchTest pattern: %d windows (the 1024 config-3 windows twice), BatchConfig(1024, 200) full "
                                      "band as in the reference, N batches on host threads sharing the device and 32 GB of it split evenly "
                                      "(multi_batch.hpp:49-57); timed like process_batches() there: filling (under the window mutex), kernels, "

@@ -69,6 +69,7 @@ struct KernelArgs
     int32_t debug_flags;    // profiling ablations (GWHIP_DEBUG env var); 0 in production
     int32_t cons_lds_nodes; // node capacity of the consensus kernel's LDS tables (poa_graph_device.h)
     int32_t wide_ring_bytes; // HBM-table layout: bytes of the LDS ring of score rows (the other regions follow it)
+    uint32_t* work_counters; // persistent grid (fewer blocks than windows): [0] windows handed out beyond the first gridDim.x, [1] blocks done
 };
 
 template <typename IdT>
@@ -126,7 +127,10 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane       = threadIdx.x & (kWave - 1);
     const int wave       = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int32_t w      = blockIdx.x;
+    // One block per window -- or, when the launcher put fewer blocks than windows on the device (a persistent grid of one block
+    // per SIMD, single-wave kernels only), window after window from a shared counter: block b starts with window b.
+    for (int32_t w = blockIdx.x; w < a.total_windows;)
+    {
     const gwhip_poa_config& c = a.cfg;
     uint8_t* slab        = a.workspace + (size_t)w * a.L.per_window;
     GraphView<IdT> g     = carve_graph<IdT>(slab, a.L);
@@ -498,7 +502,30 @@ __global__ __launch_bounds__(kWave * NW) void poa_window_kernel(KernelArgs a)
     {
         if (lane == 0) mw_args->op = 2; // the helper wavefronts leave
         block_barrier();
+        break;
     }
+    else
+    {
+        if ((int32_t)gridDim.x >= a.total_windows || a.work_counters == nullptr) break; // one block per window
+        wave_sync();
+        int32_t next = 0;
+        if (lane == 0) next = (int32_t)gridDim.x + (int32_t)atomicAdd(a.work_counters, 1u);
+        w = wave_first(next);
+    }
+    }
+    if constexpr (NW == 1)
+        if ((int32_t)gridDim.x < a.total_windows && a.work_counters != nullptr && threadIdx.x == 0)
+        {
+            // the last block to leave puts the counters back to zero for the next launch (every other block has made its last
+            // request by then)
+            __threadfence();
+            if (atomicAdd(a.work_counters + 1, 1u) == gridDim.x - 1)
+            {
+                a.work_counters[0] = 0;
+                a.work_counters[1] = 0;
+                __threadfence();
+            }
+        }
 }
 
 #ifndef GWHIP_POA_PART
@@ -695,6 +722,18 @@ static hipError_t launch_window_kernel(const KernelArgs& ka_in, hipStream_t stre
     ka.wide_ring_bytes = 5 * (kMaxAdaptiveBand + kRightPad) * 4;
     const size_t lds   = LDS_TABLES ? (size_t)kRingBytes + kRowInfoBytes + kReadLds + kCodeTileLds : (size_t)ka.wide_ring_bytes + wide_rest;
     dim3 grid(ka.total_windows);
+    // more windows than one wavefront per SIMD (LDS-table kernels: 39 KB of LDS = four one-wave blocks per CU): a persistent grid
+    if (LDS_TABLES && ka.work_counters != nullptr)
+    {
+        static const int simds = [] {
+            int cus = 0, dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            return 4 * cus;
+        }();
+        if (ka.total_windows > simds) grid = dim3(simds);
+    }
+    if (grid.x >= (unsigned)ka.total_windows) ka.work_counters = nullptr;
 #define GW_LAUNCH(BM)                                                                                              \
     {                                                                                                              \
         constexpr int NW = (!LDS_TABLES && BM == GWHIP_ADAPTIVE_BAND) ? kSkWaves : 1;                              \
@@ -824,6 +863,9 @@ static KernelArgs make_kernel_args(const gwhip_poa_args* args)
     ka.full_scores     = ka.workspace + (size_t)args->total_windows * ka.L.per_window;
     ka.cells           = args->cells;
     ka.phase_cycles    = args->phase_cycles;
+    ka.work_counters   = args->work_counters;
+    if (const char* pg = std::getenv("GWHIP_POA_PERSISTENT")) // A/B: 0 = always one block per window
+        if (pg[0] == '0') ka.work_counters = nullptr;
     {
         const char* dbg = std::getenv("GWHIP_DEBUG");
         ka.debug_flags  = dbg ? std::atoi(dbg) : 0;
@@ -868,6 +910,21 @@ void gwhip_poa_bytes_per_window(const gwhip_poa_config* cfg, int64_t* per_poa, i
     *per_poa += (int64_t)cfg->max_consensus_size * 3;
     if (cfg->output_mask & 2) *per_poa += (int64_t)cfg->max_consensus_size * cfg->max_sequences_per_poa;
     *per_poa += (int64_t)cfg->max_sequences_per_poa * cfg->max_sequence_size * 2 + (int64_t)cfg->max_sequences_per_poa * 4 + 32;
+}
+
+int32_t gwhip_poa_resident_windows(const gwhip_poa_config* cfg)
+{
+    if (cfg == nullptr) return 0;
+    // the condition of launch_msa_split() for the LDS-table kernels (one 64-lane block per window, 39 KB of LDS: four per CU)
+    const bool lds = !cfg->size32 && cfg->max_nodes_per_graph + 2 <= kRowInfoLds && cfg->max_sequence_size + 16 <= kReadLds;
+    if (!lds) return 0;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    {
+        (void)hipGetLastError();
+        cus = 256;
+    }
+    return 4 * cus;
 }
 
 int gwhip_poa_generate(const gwhip_poa_args* args, gwhip_stream_t stream_)

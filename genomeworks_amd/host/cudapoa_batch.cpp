@@ -24,6 +24,7 @@
 #include <tuple>
 
 #include "../../include/gwhip.h"
+#include "alignment_impl.hpp" // pinned_acquire / pinned_release (the process-wide cache of pinned buffers, runtime.cpp)
 #include "host_common.hpp"
 #include "poa_batch_impl.hpp"
 
@@ -225,15 +226,19 @@ PoaBatch::PoaBatch(int32_t device_id, cudaStream_t stream, DefaultDeviceAllocato
     d_coverage_   = reinterpret_cast<uint16_t*>(device_block_ + o_cov);
     d_msa_        = msa_bytes ? reinterpret_cast<uint8_t*>(device_block_ + o_msa) : nullptr;
     d_cells_      = reinterpret_cast<uint64_t*>(device_block_ + o_cells);
+    d_work_counters_ = reinterpret_cast<uint32_t*>(device_block_ + o_ws - 256);
     d_workspace_  = device_block_ + o_ws;
     input_capacity_ = seq_bytes - 4096;
     // the kernels read up to 2 KiB past a read (never consumed): keep that slack zero
     GW_CU_CHECK_ERR(hipMemsetAsync(d_sequences_, 0, seq_bytes, stream_));
     GW_CU_CHECK_ERR(hipMemsetAsync(d_weights_, 0, seq_bytes, stream_));
+    GW_CU_CHECK_ERR(hipMemsetAsync(d_work_counters_, 0, 256, stream_)); // (a launch leaves them at zero again)
 
     // ---- pinned staging block ----
     host_block_bytes_ = seq_bytes * 2 + len_bytes + wd_bytes + cons_bytes + cov_bytes + msa_bytes + cell_bytes;
-    GW_CU_CHECK_ERR(hipHostMalloc(reinterpret_cast<void**>(&host_block_), host_block_bytes_, hipHostMallocDefault));
+    // from the process-wide cache of pinned buffers (runtime.cpp): pinning and unpinning 1.2 GB took 200 and 100 ms of every
+    // construction and destruction of a BatchConfig(1024, 200) batch with 32 GB of device memory
+    host_block_ = cudaaligner::pinned_acquire(host_block_bytes_, &host_block_capacity_);
     size_t h          = 0;
     auto htake        = [&](size_t b) { size_t o = h; h += b; return o; };
     h_sequences_      = reinterpret_cast<uint8_t*>(host_block_ + htake(seq_bytes));
@@ -257,7 +262,7 @@ PoaBatch::~PoaBatch()
     debug_message(" Destroyed buffers on device ");
     scoped_device_switch dev(device_id_);
     (void)hipStreamSynchronize(stream_);
-    if (host_block_ != nullptr) (void)hipHostFree(host_block_);
+    if (host_block_ != nullptr) cudaaligner::pinned_release(host_block_, host_block_capacity_);
     if (device_block_ != nullptr) allocator_.deallocate(device_block_, device_block_bytes_);
 }
 
@@ -283,7 +288,7 @@ size_t PoaBatch::plan(int32_t n_poas, size_t* o) const
     o[4] = take(up(n * batch_size_.max_consensus_size));
     o[5] = take(up(n * batch_size_.max_consensus_size * sizeof(uint16_t)));
     o[6] = take((output_mask_ & OutputType::msa) ? up(n * max_sequences_per_poa_ * batch_size_.max_consensus_size) : 0);
-    o[7] = take(up(n * sizeof(uint64_t)));
+    o[7] = take(up(n * sizeof(uint64_t)) + 256); // + the two work counters of a persistent launch (gwhip_poa_args::work_counters)
     o[8] = take(up(gwhip_poa_workspace_bytes(&cfg_, n_poas, 0)));
     return off;
 }
@@ -433,6 +438,7 @@ gwhip_poa_args PoaBatch::kernel_args() const
     a.workspace        = d_workspace_;
     a.workspace_bytes  = workspace_bytes_;
     a.cells            = d_cells_;
+    a.work_counters    = d_work_counters_;
     return a;
 }
 
@@ -456,6 +462,9 @@ void PoaBatch::launch(void* event_after_graph_build, uint64_t* phase_cycles)
     gwhip_poa_args a          = kernel_args();
     a.event_after_graph_build = event_after_graph_build;
     a.phase_cycles            = phase_cycles;
+    // (A launch gate that kept concurrent batches from overlapping on the device beyond one wavefront per SIMD was built and
+    // measured in round 6 -- it loses: 2048 windows over four batches 154 ms gated, 108-126 ms with the launches left to the
+    // hardware; what did matter is the size of a fill, host/multi_device.cpp.)
     const int rc     = gwhip_poa_generate(&a, stream_);
     if (rc != 0)
     {

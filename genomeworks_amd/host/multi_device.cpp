@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <chrono>
 #include <exception>
 #include <map>
@@ -99,6 +100,13 @@ struct CreationGate
     std::atomic<bool> abandoned{false}; // a worker thread could not be started: nobody waits for it
     std::mutex m;
     std::chrono::steady_clock::time_point all_created{};
+    std::chrono::steady_clock::time_point last_done{}; // the moment the last worker had stored its last results (before its Batch is destroyed)
+    void done()
+    {
+        const auto t = std::chrono::steady_clock::now();
+        std::lock_guard<std::mutex> g(m);
+        if (t > last_done) last_done = t;
+    }
     void arrive()
     {
         if (arrived.fetch_add(1) + 1 == workers)
@@ -120,6 +128,17 @@ void worker_loop(int32_t worker, int32_t device, cudaStream_t stream, DefaultDev
     arrived = true;
     gate.arrive();
     const bool want_msa = (config.output_mask & OutputType::msa) != 0;
+    // A fill stops at a whole number of device rounds: the device runs `resident` windows side by side (one wavefront per SIMD;
+    // 0 = a configuration that is not one wavefront per window), and a launch of 1400 windows lasts two rounds like one of 2048
+    // -- the 376 windows of its second round would have filled the SIMDs together with another worker's. Measured
+    // (profiles/r06_multibatch_timeline.txt): 2048 full-band windows over two batches of 16 GB, 1400 + 648: 145 ms; 1024 + 1024: 1xx ms.
+    int32_t fill_cap = INT32_MAX;
+    {
+        const gwhip_poa_config dc = make_device_config(batch_size, config.output_mask, config.gap_score, config.mismatch_score, config.match_score);
+        const int32_t resident    = gwhip_poa_resident_windows(&dc);
+        if (const char* e = std::getenv("GW_POA_FILL_ROUNDS"); e != nullptr && e[0] == '0') {}
+        else if (resident > 0) fill_cap = resident; // (a batch that holds less fills up as before)
+    }
     std::vector<size_t> in_batch;
     for (;;)
     {
@@ -128,7 +147,7 @@ void worker_loop(int32_t worker, int32_t device, cudaStream_t stream, DefaultDev
         {
             // the cursor only moves under the lock: a window is taken by exactly one worker
             std::lock_guard<std::mutex> guard(cursor.mutex);
-            while (cursor.next < windows.size())
+            while (cursor.next < windows.size() && batch->get_total_poas() < fill_cap)
             {
                 const std::vector<std::string>& window = windows[cursor.next];
                 Group group;
@@ -156,7 +175,13 @@ void worker_loop(int32_t worker, int32_t device, cudaStream_t stream, DefaultDev
                 cursor.next++;
             }
         }
-        if (batch->get_total_poas() == 0) break;
+        if (batch->get_total_poas() == 0)
+        {
+            // everything this worker took is stored: the timed region of the reference's multi-batch benchmark ends here (its
+            // batches outlive process_batches(); releasing a Batch -- its pinned staging block above all -- is not part of it)
+            gate.done();
+            break;
+        }
         batch->generate_poa();
         launches++;
         std::vector<StatusType> status;
@@ -288,7 +313,8 @@ void process_windows_multi_device(MultiDeviceOutput& out, const std::vector<std:
     }
     const auto t_end = std::chrono::steady_clock::now();
     out.seconds      = std::chrono::duration<double>(t_end - t_begin).count();
-    if (gate.arrived.load() == gate.workers) out.seconds_after_creation = std::chrono::duration<double>(t_end - gate.all_created).count();
+    if (gate.arrived.load() == gate.workers)
+        out.seconds_after_creation = std::chrono::duration<double>((gate.last_done > gate.all_created ? gate.last_done : t_end) - gate.all_created).count();
     out.launches = launches.load();
     for (const std::exception_ptr& e : errors)
         if (e) std::rethrow_exception(e);

@@ -97,11 +97,13 @@ private:
     uint16_t* d_coverage_      = nullptr;
     uint8_t* d_msa_            = nullptr;
     uint64_t* d_cells_         = nullptr;
+    uint32_t* d_work_counters_ = nullptr; // two zeroed words behind the cell counters: the window counter of a persistent launch
     char* d_workspace_         = nullptr;
 
     // pinned staging block
     char* host_block_        = nullptr;
     size_t host_block_bytes_ = 0;
+    size_t host_block_capacity_ = 0; // what the pinned cache handed out (pinned_release wants it back)
     uint8_t* h_sequences_    = nullptr;
     int8_t* h_weights_       = nullptr;
     int32_t* h_seq_lens_     = nullptr;

@@ -235,6 +235,28 @@ void pinned_release(char* p, size_t capacity)
         }
     }
     if (drop != nullptr) (void)hipHostFree(drop);
+    // a cap in bytes as well (cudapoa batches stage GBs): beyond it the LARGEST idle buffers go back to the system
+    static const size_t byte_cap = [] {
+        const char* e = std::getenv("GW_PINNED_CACHE_BYTES");
+        return e ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : (size_t(24) << 30);
+    }();
+    for (;;)
+    {
+        char* big = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(c.m);
+            size_t total = 0, largest = 0;
+            for (size_t i = 0; i < c.free_list.size(); ++i)
+            {
+                total += c.free_list[i].second;
+                if (c.free_list[i].second > c.free_list[largest].second) largest = i;
+            }
+            if (total <= byte_cap || c.free_list.empty()) break;
+            big = c.free_list[largest].first;
+            c.free_list.erase(c.free_list.begin() + static_cast<long>(largest));
+        }
+        (void)hipHostFree(big);
+    }
 }
 
 // ---- pageable host buffers, recycled the same way (the views of a million-pair batch: a recycled buffer is already mapped) ----

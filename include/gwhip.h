@@ -100,6 +100,11 @@ typedef struct gwhip_poa_args
     /* optional profiling aid: per-window cycle totals (s_memtime ticks) of the graph-build phases,
        uint64[total_windows][6] = {row table, NW forward, sink+traceback, graph merge, topsort, other} */
     uint64_t* phase_cycles;
+    /* optional: two zeroed uint32 words, device. With them a batch of more windows than the device holds at one wavefront per
+       SIMD runs as a PERSISTENT grid -- one block per SIMD, each taking the next window from the counter when it has finished
+       one -- instead of one block per window (replacement blocks land on SIMDs that are still busy: 2048 full-band windows
+       took 2.47 x the time of 1024). The last block to finish zeroes both words again. NULL: one block per window. */
+    uint32_t* work_counters;
 } gwhip_poa_args;
 
 /* Bytes of scratch needed for `windows` windows under cfg (host function, no GPU needed).
@@ -110,6 +115,14 @@ size_t gwhip_poa_workspace_bytes(const gwhip_poa_config* cfg, int32_t windows, u
 /* Device bytes per window excluding the score/trace matrix, and bytes of the matrix: the two terms of
    max_poas = avail / (per_poa + matrix) (allocate_block.hpp:75-89), for OUR layout. Host function. */
 void gwhip_poa_bytes_per_window(const gwhip_poa_config* cfg, int64_t* per_poa, int64_t* per_matrix);
+
+/* How many windows of this configuration the current device runs side by side at full speed: one wavefront per SIMD
+   (4 x compute units) for the configurations whose graph-build kernel is one wavefront per window with its tables in LDS
+   (16-bit ids, <= 3072 graph rows, reads that fit the LDS copy), 0 for the others (long reads: blocks of eight wavefronts
+   that are admitted by residency, host/multi_device.cpp). A launch lasts a whole number of such rounds, so a host that
+   spreads windows over several batches fills them in multiples of it (2048 full-band windows as 1400 + 648: 145 ms; as
+   1024 + 1024: 107 ms; profiles/r06_multibatch_timeline.txt). */
+int32_t gwhip_poa_resident_windows(const gwhip_poa_config* cfg);
 
 int gwhip_poa_generate(const gwhip_poa_args* args, gwhip_stream_t stream);
 

@@ -101,6 +101,39 @@ def test_config4_plan_is_reproducible_and_oracle_sample_matches():
     assert O.Workspace.msa_scatter_mismatches() == 0
 
 
+def test_long_read_prefix_fixture_of_the_reference_and_oracle_sample():
+    """tests/golden/reference_simt_long_prefixes.json (the reference's own answers for cut-down windows of the two largest
+    size classes of configs[3]): the file covers both classes with windows that the whole-window check has not, every row was
+    equal to the oracle when it was written, and the oracle still reproduces the cheapest rows of every set."""
+    import importlib.util
+    import json
+    import os
+    from genomeworks_amd import synthetic
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_long_read_goldens", os.path.join(here, "make_long_read_goldens.py"))
+    lr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lr)
+    with open(os.path.join(here, "reference_simt_long_prefixes.json")) as f:
+        fixture = json.load(f)
+    with open(os.path.join(here, "config4_long_reads.json")) as f:
+        golden = json.load(f)
+    with open(os.path.join(here, "reference_simt_config_check.json")) as f:
+        whole = set(json.load(f)["config4"]["windows_checked"])
+    rows = fixture["windows"]
+    assert fixture["batch_configs"] == golden["batch_configs"][:2]
+    assert len(rows) >= 60 and all(r["oracle_equal"] and r["add_status"] == 0 for r in rows)
+    assert not whole & {r["w"] for r in rows}
+    assert all(golden["windows_detail"][r["w"]]["cfg"] == r["cfg"] for r in rows)
+    for n_reads in sorted({r["reads"] for r in rows}):
+        cheapest = min((r for r in rows if r["reads"] == n_reads), key=lambda r: r["cells"])
+        if cheapest["cells"] > 150e6:
+            continue
+        with O.Workspace(lr.oracle_cfg(fixture["batch_configs"][cheapest["cfg"]])) as ws:
+            ref = ws.process(synthetic.long_read_window(cheapest["w"], golden["max_len"])[:n_reads])
+        assert ref["status"] == cheapest["status"] and ref["cells"] == cheapest["cells"]
+        assert lr.msa_digest(ref["msa"]) == cheapest["msa_sha"] and len(ref["msa"]) == cheapest["msa_rows"]
+
+
 def test_band_mode_table_file_matches_summary_and_oracle_sample():
     """tests/golden/band_mode_goldens.{npz,json}: 4 banded modes x 4 band widths x 1024 windows. The file is what its
     summary says, the static-band / 256 cell is the config-3 golden, and the oracle still reproduces two windows of

@@ -153,3 +153,86 @@ def test_long_read_windows_through_the_sequential_multi_batch_loop():
             assert got == golden[w]["msa_sha"], w
             both += 1
     assert both >= len(ids) // 2
+
+
+def test_long_read_prefixes_equal_the_reference_itself():
+    """tests/golden/reference_simt_long_prefixes.json: windows of the two LARGEST size classes of configs[3] (reads of 7.6-30 kbp:
+    32-bit scores and ids, HBM row tables, the adaptive band growing from 256 towards its 1536-column cap) cut to their first 4, 8
+    or 12 reads and answered by the REFERENCE's own cudapoa library on the SIMT emulator
+    (tests/golden/make_reference_simt_long_prefixes.py). None of them is among the 245 whole windows that
+    reference_simt_config_check.json covers. The HIP path, in a batch of the class's BatchConfig, gives the same statuses and MSA rows."""
+    import importlib.util
+    import json
+    import os
+    from genomeworks_amd import cudapoa, synthetic
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_long_read_goldens", os.path.join(here, "make_long_read_goldens.py"))
+    lr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lr)
+    with open(os.path.join(here, "reference_simt_long_prefixes.json")) as f:
+        fixture = json.load(f)
+    rows = fixture["windows"]
+    assert len(rows) >= 60 and {r["cfg"] for r in rows} == {0, 1} and all(r["oracle_equal"] for r in rows)
+    assert max(r["reads"] for r in rows) >= 8  # (sets in which the band has grown)
+    bad = []
+    for k, c in enumerate(fixture["batch_configs"]):
+        mine = [r for r in rows if r["cfg"] == k]
+        b = cudapoa.CudaPoaBatch.from_batch_config(c["max_sequence_size"], c["max_sequences_per_poa"], c["alignment_band_width"], "adaptive_band",
+                                                   96 << 30, output_type="msa", adaptive_storage_factor=fixture["storage_factor"])
+        got = b.batch_size
+        assert (got.max_nodes_per_graph, got.matrix_sequence_dimension, got.max_consensus_size) == (
+            c["max_nodes_per_graph"], c["matrix_sequence_dimension"], c["max_consensus_size"])
+        for r in mine:
+            st, _ = b.add_poa_group(synthetic.long_read_window(r["w"], 32768)[:r["reads"]])
+            assert st == r["add_status"] == 0, (r["w"], st)
+        b.generate_poa()
+        n = b.get_msa_native()
+        assert n == len(mine)
+        for i, r in enumerate(mine):
+            msa, status = b.collect_msa_one(i)
+            if status != r["status"] or (status == 0 and (lr.msa_digest(msa) != r["msa_sha"] or len(msa) != r["msa_rows"])):
+                bad.append((r["w"], r["reads"], status))
+        del b
+    assert not bad, "prefix windows where the HIP path differs from the reference: %s" % bad[:10]
+
+
+def test_more_windows_than_simds_run_as_a_persistent_grid_and_equal_the_golden(monkeypatch):
+    """A batch of more windows than the device holds at one wavefront per SIMD (gwhip_poa_args::work_counters): blocks take
+    window after window from a device counter. 2300 windows (the 1024 metric windows cyclically) in the metric configuration and
+    in the benchmarks' full band, twice each on the same Batch (the last block of a launch has to leave the counters at zero),
+    against the committed goldens; then once more with one block per window (GWHIP_POA_PERSISTENT=0)."""
+    import golden_io as G
+    from genomeworks_amd import cudapoa, synthetic
+    rows, _ = G.config3_windows()
+    fgold = G.full_band_goldens()["fingerprint"]
+    n = 2300
+    windows = [[r.decode() for r in synthetic.generate_window(1000 + (w % 1024))] for w in range(n)]
+
+    def run(make, check):
+        b = make()
+        for w in windows:
+            st, _ = b.add_poa_group(w)
+            assert st == 0, st
+        for _ in range(2):
+            b.generate_poa()
+            cons, cov, status = b.get_consensus()
+            assert len(cons) == n
+            check(cons, cov, status)
+
+    def check_static(cons, cov, status):
+        bad = [w for w in range(n) if status[w] != rows[w % 1024]["status"] or cons[w] != rows[w % 1024]["consensus"]
+               or list(cov[w]) != list(rows[w % 1024]["coverage"])]
+        assert not bad, bad[:10]
+
+    def check_full(cons, cov, status):
+        fp = G.band_mode_fingerprints(cons, cov, status)
+        assert all((fp[k:k + 1024] == fgold[:len(fp[k:k + 1024])]).all() for k in range(0, n, 1024))
+
+    static = lambda: cudapoa.CudaPoaBatch(32, 1024, 24 << 30, output_type="consensus", band_mode="static_band", alignment_band_width=256,
+                                          max_nodes_per_graph=3072)
+    full = lambda: cudapoa.CudaPoaBatch(200, 1024, 48 << 30, output_type="consensus", band_mode="full_band", max_nodes_per_graph=3072,
+                                        matrix_sequence_dimension=1024)
+    run(static, check_static)
+    run(full, check_full)
+    monkeypatch.setenv("GWHIP_POA_PERSISTENT", "0")
+    run(static, check_static)

@@ -4,8 +4,11 @@
 // window), of generate_poa() and of get_consensus(), each on the wall clock; then the same fill again (warm), and the fill's
 // bytes written into ordinary heap memory for comparison.
 //   g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include tools/fill_probe.cpp -L genomeworks_amd/lib \
+//   usage: fill_probe [windows=2048] [GB=32] [window file]
 //       -lgenomeworks_amd -lgwhip -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/genomeworks_amd/lib -Wl,-rpath,/opt/rocm/lib -o tools/bin/fill_probe
 #include <claraparabricks/genomeworks/cudapoa/batch.hpp>
+#include <claraparabricks/genomeworks/cudapoa/utils.hpp>
+#include <claraparabricks/genomeworks/cudapoa/multi_device.hpp>
 
 #include <chrono>
 #include <cstdio>
@@ -30,6 +33,13 @@ int main(int argc, char** argv)
     const double gb   = argc > 2 ? std::atof(argv[2]) : 32.0;
     std::mt19937 rng(7);
     std::vector<std::vector<std::string>> windows(static_cast<size_t>(W));
+    if (argc > 3) // a window file (cudapoa's text format); repeated cyclically up to W windows
+    {
+        std::vector<std::vector<std::string>> file_windows;
+        parse_cudapoa_file(file_windows, argv[3], -1);
+        for (size_t i = 0; i < windows.size(); ++i) windows[i] = file_windows[i % file_windows.size()];
+    }
+    else
     for (auto& w : windows)
     {
         std::string backbone(960, 'A');
@@ -44,6 +54,33 @@ int main(int argc, char** argv)
         }
     }
     Init();
+    if (argc > 4) // fill_probe W GB file BATCHES: the multi-batch runner itself (cudapoa::process_windows_multi_device)
+    {
+        BatchConfig shape(1024, 200);
+        std::printf("{\"windows\": %d, \"multi_device\": [", W);
+        bool first = true;
+        for (const char* p = argv[4]; *p; ++p)
+        {
+            const int nb = *p - '0';
+            if (nb < 1 || nb > 9) continue;
+            for (int rep = 0; rep < 2; ++rep)
+            {
+                MultiDeviceConfig mc;
+                mc.devices            = {0};
+                mc.batches_per_device = nb;
+                mc.memory_per_device  = static_cast<int64_t>(gb * 1e9);
+                MultiDeviceOutput out;
+                const double a = now();
+                process_windows_multi_device(out, windows, shape, mc);
+                const double b = now();
+                std::printf("%s{\"batches\": %d, \"call_ms\": %.1f, \"ms\": %.1f, \"ms_after_creation\": %.1f, \"launches\": %d}", first ? "" : ", ", nb,
+                            (b - a) * 1e3, out.seconds * 1e3, out.seconds_after_creation * 1e3, out.launches);
+                first = false;
+            }
+        }
+        std::printf("]}\n");
+        return 0;
+    }
     double t0 = now();
     BatchConfig shape(1024, 200); // the reference benchmarks' shape: full band, 200 reads per POA
     std::unique_ptr<Batch> batch = create_batch(0, nullptr, static_cast<int64_t>(gb * 1e9), OutputType::consensus, shape, -8, -6, 8);
