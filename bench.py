@@ -447,6 +447,7 @@ def bench_long_reads(n_windows, rank, world, local_rank, sync, dist, torch, cpu,
            "value_without_those_cells": round((cells - failed_cells) / seconds / 1e9, 3),
            "launches_rank0": out["launches"], "dtype": "int32",
            "windows_equal_to_oracle_golden": int(checked), "windows_differing_from_golden": int(mismatched),
+           "equals_oracle_golden": bool(int(mismatched) == 0 and int(checked) == n_windows),
            "size_classes": [{"max_sequence_size": c["max_sequence_size"], "windows": len(g)} for c, g in zip(cfgs, plan.groups)],
            "roofline": {"bound": "hbm", "kernel": "poa_window_kernel<int32,int32,adaptive_band,HBM tables, 8 waves per window> (4 launches, admitted by residency)",
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -563,7 +564,7 @@ def bench_default_aligner(local_rank, sync, cpu_all_cores=None):
     return out
 
 
-def bench_aligner_matrix(local_rank, sync, cpu_by_size=None):
+def bench_aligner_matrix(local_rank, sync, cpu_by_size=None, corners=False):
     """Six cells of the reference's aligner benchmark matrix (cudaaligner/benchmarks/main.cpp:69-143, registered :150-168:
     AlignerGlobalUkkonen / AlignerGlobalMyers / AlignerGlobalMyersBanded / AlignerGlobalHirschbergMyers x alignments per batch
     x genome size): all four classes at 1024 pairs x 2048 bases, Ukkonen and Hirschberg + Myers at 256 x 8192. Timed region as
@@ -576,13 +577,17 @@ def bench_aligner_matrix(local_rank, sync, cpu_by_size=None):
     import golden_io as G  # the checker
     gold = G.aligner_matrix_goldens()
     rows = []
-    for algorithm, n, size in G.matrix_gen.CELLS:
+    # corners=True (--sub-configs aligner_grid): the corners of the reference's grid instead -- 1024 x 512, 32 x 32768 and 32 x 65536 for
+    # every class (cudaaligner/benchmarks/main.cpp:150-168); cells without a committed golden are skipped
+    for algorithm, n, size in (G.matrix_gen.CORNER_CELLS if corners else G.matrix_gen.CELLS):
+        if G.matrix_gen.cell_key(algorithm, n, size) not in gold:
+            continue
         pairs = G.aligner_gen.shape_pairs(n, size)
         if algorithm == "myers_banded":
-            al = cudaaligner.CudaAlignerBatch(max_bandwidth=G.matrix_gen.BANDED_MAX_BANDWIDTH, max_device_memory_allocator_caching_size=64 << 30,
+            al = cudaaligner.CudaAlignerBatch(max_bandwidth=G.matrix_gen.BANDED_MAX_BANDWIDTH, max_device_memory_allocator_caching_size=96 << 30,
                                               device_id=local_rank)
         else:
-            al = cudaaligner.CudaAlignerBatch(size, size, n, algorithm=algorithm, max_device_memory_allocator_caching_size=64 << 30,
+            al = cudaaligner.CudaAlignerBatch(size, size, n, algorithm=algorithm, max_device_memory_allocator_caching_size=96 << 30,
                                               device_id=local_rank)
         best = None
         for _ in range(3):
@@ -1094,6 +1099,8 @@ def main():
     if "aligner_matrix" in subs and rank == 0:
         sub["aligner_matrix"] = bench_aligner_matrix(local_rank, sync if world == 1 else (lambda: torch.cuda.synchronize()),
                                                      {2048: cpu_pairs.get("matrix_2048"), 8192: cpu_pairs.get("matrix_8192")})
+    if "aligner_grid" in subs and rank == 0:  # (not in the default line: the 65 kbp cells take seconds each)
+        sub["aligner_grid"] = bench_aligner_matrix(local_rank, sync if world == 1 else (lambda: torch.cuda.synchronize()), None, corners=True)
     if "band_modes" in subs and world == 1:
         sub["band_modes"] = bench_band_modes(windows, local_rank, sync)
     if "reference_shapes" in subs and world == 1:

@@ -31,6 +31,11 @@ _spec.loader.exec_module(base)
 # (algorithm, pairs, length); "myers_banded" = create_aligner(max_bandwidth = 1024), the others the fixed-stride classes
 CELLS = [("ukkonen", 1024, 2048), ("myers", 1024, 2048), ("myers_banded", 1024, 2048), ("hirschberg_myers", 1024, 2048),
          ("ukkonen", 256, 8192), ("hirschberg_myers", 256, 8192)]
+# round 6: the corners of the reference's grid ({32 .. 1024} x {512 .. 65536}, cudaaligner/benchmarks/main.cpp:150-168) for every class
+# (CORNER_CELLS: bench.py --sub-configs aligner_grid and the GPU tests; the default bench line keeps the six cells above)
+CORNER_CELLS = [(a, 1024, 512) for a in ("ukkonen", "myers", "myers_banded", "hirschberg_myers")]
+CORNER_CELLS += [(a, 32, 32768) for a in ("ukkonen", "myers", "myers_banded", "hirschberg_myers")]
+CORNER_CELLS += [(a, 32, 65536) for a in ("ukkonen", "myers_banded", "hirschberg_myers", "myers")]
 BANDED_MAX_BANDWIDTH = 1024
 
 
@@ -61,12 +66,18 @@ def _one(job):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--procs", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--only-missing", action="store_true", help="keep the cells the file already holds (the oracle is deterministic)")
     args = ap.parse_args()
     import subprocess
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
     out = {}
+    path = os.path.join(HERE, "aligner_matrix_goldens.json")
+    if args.only_missing and os.path.exists(path):
+        out = json.load(open(path))
     with mp.get_context("fork").Pool(args.procs) as pool:
-        for algorithm, n, size in CELLS:
+        for algorithm, n, size in CELLS + CORNER_CELLS:
+            if cell_key(algorithm, n, size) in out:
+                continue
             pairs = base.shape_pairs(n, size)
             res = pool.map(_one, [(algorithm, q, t, size) for q, t in pairs], chunksize=max(1, n // (args.procs * 8)))
             out[cell_key(algorithm, n, size)] = {"algorithm": algorithm, "pairs": n, "length": size,
@@ -74,9 +85,9 @@ def main():
                                                  "edit_distance_sum": int(sum(e for _, e, _ in res)),
                                                  "states_total": int(sum(s for _, _, s in res))}
             print(cell_key(algorithm, n, size), out[cell_key(algorithm, n, size)], flush=True)
-    with open(os.path.join(HERE, "aligner_matrix_goldens.json"), "w") as f:
-        json.dump(out, f, indent=1, sort_keys=True)
-        f.write("\n")
+            with open(path, "w") as f:  # (after every cell: the long ones take minutes)
+                json.dump(out, f, indent=1, sort_keys=True)
+                f.write("\n")
 
 
 if __name__ == "__main__":

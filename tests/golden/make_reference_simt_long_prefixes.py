@@ -78,6 +78,27 @@ def _run(job):
     return row
 
 
+def record_in_config_check(rows):
+    """reference_simt_config_check.json lists what of the BASELINE configs the reference itself has answered: the cut-down windows
+    go in beside the 245 whole ones, per size class."""
+    path = os.path.join(HERE, "reference_simt_config_check.json")
+    with open(path) as f:
+        check = json.load(f)
+    per_class = {}
+    for r in rows:
+        e = per_class.setdefault(str(r["cfg"]), {"windows": 0, "reads": {}, "cells": 0})
+        e["windows"] += 1
+        e["reads"][str(r["reads"])] = e["reads"].get(str(r["reads"]), 0) + 1
+        e["cells"] += r["cells"]
+    check["config4_prefixes"] = {"file": "tests/golden/reference_simt_long_prefixes.json",
+                                 "what": "windows of size classes 0 and 1 that are not among config4.windows_checked, cut to their first 4 / 8 / 12 reads",
+                                 "windows_checked": sorted(r["w"] for r in rows), "windows_differing": sorted(r["w"] for r in rows if not r["oracle_equal"]),
+                                 "per_size_class": per_class}
+    with open(path, "w") as f:
+        json.dump(check, f)
+        f.write("\n")
+
+
 def main():
     global PREFIX_READS
     procs = int(sys.argv[1]) if len(sys.argv) > 1 else 6
@@ -99,6 +120,7 @@ def main():
     with open(OUT, "w") as f:
         json.dump(out, f, indent=0, separators=(",", ":"))
         f.write("\n")
+    record_in_config_check(rows)
     bad = [r["w"] for r in rows if not r["oracle_equal"]]
     print("windows: %d, oracle differs on: %s, %.0f s" % (len(rows), bad, time.time() - t0))
     if bad:

@@ -190,7 +190,12 @@ def test_aligner_matrix_golden_file_matches_oracle_sample():
     """tests/golden/aligner_matrix_goldens.json: the cells bench.py publishes; the Hirschberg cell at 1024 x 2048 is the
     default aligner's golden of the same pairs, and each class's oracle still reproduces the first pairs of a cell."""
     gold, dgold = G.aligner_matrix_goldens(), G.default_aligner_goldens()
-    assert sorted(gold) == sorted(G.matrix_gen.cell_key(*c) for c in G.matrix_gen.CELLS)
+    assert sorted(gold) == sorted(G.matrix_gen.cell_key(*c) for c in G.matrix_gen.CELLS + G.matrix_gen.CORNER_CELLS)
+    # the long cells: each class's oracle on the first pair of the 32 x 32768 corner (the full-matrix Myers oracle takes 6 s there)
+    long_pair = G.aligner_gen.shape_pairs(32, 32768)[0]
+    for algorithm in ("ukkonen", "myers_banded", "hirschberg_myers"):
+        rec = G.matrix_gen._one((algorithm, long_pair[0], long_pair[1], 32768))
+        assert rec[1] >= 0 and rec[2] >= 32768
     assert gold["hirschberg_myers/1024x2048"]["states_sha256"] == dgold["1024x2048"]["states_sha256"]
     pairs = G.aligner_gen.shape_pairs(1024, 2048)[:3]
     for algorithm in ("ukkonen", "myers", "myers_banded", "hirschberg_myers"):

@@ -521,18 +521,22 @@ def test_aligner_matrix_cells_equal_the_golden():
     import golden_io as G
     from genomeworks_amd import cudaaligner
     gold = G.aligner_matrix_goldens()
-    for algorithm, n, size in G.matrix_gen.CELLS:
+    assert all(G.matrix_gen.cell_key(*c) in gold for c in G.matrix_gen.CELLS + G.matrix_gen.CORNER_CELLS)
+    # (round 6: + the corners of the reference's grid -- 1024 x 512, 32 x 32768 and 32 x 65536 for every class)
+    for algorithm, n, size in G.matrix_gen.CELLS + G.matrix_gen.CORNER_CELLS:
         pairs = G.aligner_gen.shape_pairs(n, size)
         if algorithm == "myers_banded":
-            al = cudaaligner.CudaAlignerBatch(max_bandwidth=G.matrix_gen.BANDED_MAX_BANDWIDTH, max_device_memory_allocator_caching_size=64 << 30)
+            al = cudaaligner.CudaAlignerBatch(max_bandwidth=G.matrix_gen.BANDED_MAX_BANDWIDTH, max_device_memory_allocator_caching_size=96 << 30)
         else:
-            al = cudaaligner.CudaAlignerBatch(size, size, n, algorithm=algorithm, max_device_memory_allocator_caching_size=64 << 30)
+            al = cudaaligner.CudaAlignerBatch(size, size, n, algorithm=algorithm, max_device_memory_allocator_caching_size=96 << 30)
         for q, t in pairs:
             assert al.add_alignment(q, t) == 0
         al.align_all()
         res = al.get_alignments()
         g = gold[G.matrix_gen.cell_key(algorithm, n, size)]
-        assert len(res) == n and all(r.status == 0 for r in res), (algorithm, n, size)
+        assert len(res) == n, (algorithm, n, size)
+        if size <= 8192:
+            assert all(r.status == 0 for r in res), (algorithm, n, size)
         assert sum(sum(1 for x in r.alignment if x != 0) for r in res) == g["edit_distance_sum"], (algorithm, n, size)
         assert G.aligner_gen.digest(G.aligner_gen.pair_record(r.status, r.alignment) for r in res) == g["states_sha256"], (algorithm, n, size)
 
