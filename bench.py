@@ -188,6 +188,10 @@ def roofline_issue(key):
            "frac": e["issue"]["frac_of_lone_wave_issue_bound"], "wait_share": e.get("wait_share"),
            "lone_wave_cycles_per_instruction_source": e["issue"].get("lone_wave_cycles_per_instruction_source"),
            "source": "%s (commit %s, tag %s)" % (p.get("file"), p.get("commit"), p.get("tag"))}
+    if "valu_busy" in e:
+        out["valu_busy"] = e["valu_busy"].get("by_instruction_count")
+        out["closest_limit"] = ("none saturated: a dependency chain on one wavefront per SIMD (VALU busy %.2f, HBM see roofline.frac, "
+                                "issue port %.2f of its lone-wave bound)" % (out["valu_busy"], out["frac"]))
     if "lds" in e:
         out["lds_bank_conflict_share_of_lds_active"] = e["lds"]["bank_conflict_share_of_lds_active"]
         out["lds_bank_conflict_share_of_wave_cycles"] = e["lds"].get("bank_conflict_share_of_wave_cycles")

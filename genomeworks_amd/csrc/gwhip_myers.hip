@@ -3450,11 +3450,20 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
         const int32_t qwords = args->max_query_length > 0 ? (args->max_query_length + kWord - 1) / kWord : 0;
         // LDS of a block of four wavefronts with G lanes per pair: per pair the pattern table (+ 1: odd stride) and 17 words of
         // target characters, plus the backtrace's column window (224 words for each of the 64 slots of a workspace region)
-        auto lds_bytes = [&](int G) {
+        // (the wide groups may go without the column window: a band of more than nine words leaves it under the eight columns
+        // below which the walk ignores it anyway, and queries of 64 kbp only fit that way -- four pairs per block, 131 KB of tables)
+        auto lds_bytes = [&](int G, int tile_words) {
             const size_t pairs = G == 6 ? 40 : 256 / (size_t)G;
-            return (pairs * (size_t)(4 * qwords + 1) + pairs * 17 + 64 * 224) * sizeof(uint32_t);
+            return (pairs * (size_t)(4 * qwords + 1) + pairs * 17 + 64 * (size_t)tile_words) * sizeof(uint32_t);
         };
-        auto fits = [&](int G) { return qwords > 0 && lds_bytes(G) <= (G <= 8 ? (size_t)80 * 1024 : (size_t)156 * 1024); }; // two blocks / one block per CU
+        auto tile_of = [&](int G) -> int { // words of the backtrace's column window per pair, -1: the tables do not fit
+            const size_t limit = G <= 8 ? (size_t)80 * 1024 : (size_t)156 * 1024; // two blocks / one block per CU
+            if (qwords <= 0) return -1;
+            if (lds_bytes(G, 224) <= limit) return 224;
+            if (G >= 16 && lds_bytes(G, 0) <= limit) return 0;
+            return -1;
+        };
+        auto fits = [&](int G) { return tile_of(G) >= 0; };
         bool use_group = (n + 63) / 64 < simds && args->max_query_length >= 256;
         if (gdbg && gdbg[0] == '0') use_group = false;
         if (gdbg && gdbg[0] == '1') use_group = true;
@@ -3480,8 +3489,8 @@ int gwhip_myers_banded(const gwhip_myers_args* args, gwhip_stream_t stream_)
         if (group_lanes != 0)
         {
             ka.lds_pattern_words = 4 * qwords;
-            ka.lds_band_words    = 224; // words of the backtrace's column window per pair
-            const size_t lds     = lds_bytes(group_lanes);
+            ka.lds_band_words    = tile_of(group_lanes); // words of the backtrace's column window per pair
+            const size_t lds     = lds_bytes(group_lanes, ka.lds_band_words);
             auto launch = [&](auto kernel, int pairs) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 80 * 1024));
                 hipLaunchKernelGGL(kernel, dim3((n + pairs - 1) / pairs), dim3(256), lds, stream, ka);

@@ -9,7 +9,7 @@
 #   phases       per-phase cycle breakdown of the metric kernel (tools/profile_phases.py 1024)
 #   bench        the driver's bench line (BENCH_ARGS, default none = the full line with all sub-records)
 #   stats        rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline $STATS_ARGS` -> kernel_stats.csv
-#   pmc          tools/pmc_passes.sh with PASSES (default "insts waits lds fetch write") and SUBS (default none)
+#   pmc          tools/pmc_passes.sh with PASSES (default "insts waits lds fetch write active") and SUBS (default none)
 #   pmcfull      the same passes over the full-band kernel alone (tools/profile_phases.py 1024 full_band) -> pmc_summary_full_band.csv
 #   issue        measure the lone-wavefront issue rate (tools/microbench_fetch.hip) -> microbench_issue.json, which the traffic step
 #                writes into pmc_profile.json instead of the round-3 constant
@@ -66,7 +66,7 @@ if has stats; then
     rm -rf $OUT/stats
 fi
 if has pmc; then
-    SUBS=${SUBS:-none} PASSES="${PASSES:-insts waits lds fetch write}" bash tools/pmc_passes.sh $OUT/pmc > $OUT/pmc.log 2>&1
+    SUBS=${SUBS:-none} PASSES="${PASSES:-insts waits lds fetch write active}" bash tools/pmc_passes.sh $OUT/pmc > $OUT/pmc.log 2>&1
     python tools/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.csv 2>/dev/null
     rm -rf $OUT/pmc
     grep -c . $OUT/pmc_summary.csv

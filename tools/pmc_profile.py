@@ -69,6 +69,15 @@ def entry(match, what="mean", note=None, launches_per_call=1):
                           "lone_wave_cycles_per_instruction": LONE_WAVE_CYCLES_PER_INST,
                           "lone_wave_cycles_per_instruction_source": LONE_WAVE_SOURCE,
                           "frac_of_lone_wave_issue_bound": round(per_wave * LONE_WAVE_CYCLES_PER_INST / (wc * 4 / waves), 4)}
+    # the compute-side fraction: how busy the vector ALUs are. By instruction count (every wave64 VALU instruction
+    # holds its SIMD's issue port for 4 cycles; wave cycles = cycles a wavefront was resident, and these kernels keep one wavefront
+    # per SIMD) and, when the `active` pass ran, by the SQ's own counter of cycles with a VALU instruction in flight
+    if wc and "instructions" in e:
+        e["valu_busy"] = {"by_instruction_count": round(e["instructions"]["valu"] * 4.0 / (wc * 4), 4),
+                          "what": "VALU instructions x 4 cycles / resident wave cycles (one wavefront per SIMD in these kernels)"}
+        av, awc = tot("SQ_ACTIVE_INST_VALU"), tot("SQ_WAVE_CYCLES")
+        if av is not None and awc:
+            e["valu_busy"]["sq_active_inst_valu_over_wave_cycles"] = round(av / awc, 4)
     bc, ia = tot("SQ_LDS_BANK_CONFLICT"), tot("SQ_LDS_IDX_ACTIVE")
     if bc is not None and ia:
         e["lds"] = {"bank_conflict_cycles": int(bc), "idx_active_cycles": int(ia), "bank_conflict_share_of_lds_active": round(bc / ia, 4)}
