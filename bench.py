@@ -591,7 +591,8 @@ def bench_aligner_matrix(local_rank, sync, cpu_by_size=None, corners=False):
             al = cudaaligner.CudaAlignerBatch(max_bandwidth=G.matrix_gen.BANDED_MAX_BANDWIDTH, max_device_memory_allocator_caching_size=96 << 30,
                                               device_id=local_rank)
         else:
-            al = cudaaligner.CudaAlignerBatch(size, size, n, algorithm=algorithm, max_device_memory_allocator_caching_size=96 << 30,
+            # (full-matrix Myers at 32 x 65 536: 103 GB of workspace, a region is 64 slots wide whatever the number of pairs)
+            al = cudaaligner.CudaAlignerBatch(size, size, n, algorithm=algorithm, max_device_memory_allocator_caching_size=(160 if size > 32768 else 96) << 30,
                                               device_id=local_rank)
         best = None
         for _ in range(3):

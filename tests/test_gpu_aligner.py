@@ -528,7 +528,9 @@ def test_aligner_matrix_cells_equal_the_golden():
         if algorithm == "myers_banded":
             al = cudaaligner.CudaAlignerBatch(max_bandwidth=G.matrix_gen.BANDED_MAX_BANDWIDTH, max_device_memory_allocator_caching_size=96 << 30)
         else:
-            al = cudaaligner.CudaAlignerBatch(size, size, n, algorithm=algorithm, max_device_memory_allocator_caching_size=96 << 30)
+            # (the full-matrix Myers class at 32 x 65 536: 2 048 band words x 65 537 columns x 12 B for each of the 64 slots of a
+            # workspace region, whatever the number of pairs: 103 GB)
+            al = cudaaligner.CudaAlignerBatch(size, size, n, algorithm=algorithm, max_device_memory_allocator_caching_size=(160 if size > 32768 else 96) << 30)
         for q, t in pairs:
             assert al.add_alignment(q, t) == 0
         al.align_all()
@@ -539,6 +541,7 @@ def test_aligner_matrix_cells_equal_the_golden():
             assert all(r.status == 0 for r in res), (algorithm, n, size)
         assert sum(sum(1 for x in r.alignment if x != 0) for r in res) == g["edit_distance_sum"], (algorithm, n, size)
         assert G.aligner_gen.digest(G.aligner_gen.pair_record(r.status, r.alignment) for r in res) == g["states_sha256"], (algorithm, n, size)
+        del res, al  # (before the next cell's aligner asks for its memory)
 
 
 def test_hip_aligners_equal_the_reference_itself_on_the_simt_goldens():

@@ -39,7 +39,10 @@ def entry(match, what="mean", note=None, launches_per_call=1):
         for k in ks:
             if counter in rows[k]:
                 m, n = rows[k][counter]
-                v += m * (n if what == "sum" else launches_per_call)
+                # (summaries written before round 6 counted a counter once per pass that collected it: the launches of the set are
+                # those of SQ_WAVES, which one pass collects)
+                n_set = rows[k]["SQ_WAVES"][1] if "SQ_WAVES" in rows[k] else n
+                v += m * (min(n, n_set) if what == "sum" else launches_per_call)
                 seen = True
         return v if seen else None
     e = {"kernel": " + ".join(k.replace("void ", "").replace("full_band_session::", "") for k in ks),
