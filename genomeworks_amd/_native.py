@@ -28,7 +28,7 @@ class PoaArgs(C.Structure):
     _fields_ = [("cfg", PoaConfig), ("total_windows", C.c_int32), ("sequences", C.c_void_p),
                 ("base_weights", C.c_void_p), ("sequence_lengths", C.c_void_p), ("window_details", C.c_void_p),
                 ("consensus", C.c_void_p), ("coverage", C.c_void_p), ("msa", C.c_void_p), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t), ("cells", C.c_void_p), ("event_after_graph_build", C.c_void_p), ("phase_cycles", C.c_void_p), ("work_counters", C.c_void_p)]
+                ("workspace_bytes", C.c_size_t), ("cells", C.c_void_p), ("event_after_graph_build", C.c_void_p), ("phase_cycles", C.c_void_p), ("work_counters", C.c_void_p), ("shared_device", C.c_int32)]
 
 
 class MyersArgs(C.Structure):

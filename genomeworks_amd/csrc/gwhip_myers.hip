@@ -912,6 +912,262 @@ __device__ __forceinline__ void group_diagonal_band(Band& b, GroupCtx<G>& c, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bands wider than the group (round 6; one pair per wavefront, G = 64): W ROUNDS per column. Lane l owns band words l, 64 + l,
+// 128 + l, ...; round j advances words 64 j .. 64 j + 63 across the lanes exactly as group_advance does, and what the one-lane
+// form chains from word to word crosses the round boundary as three wave-uniform values: the carry of the multi-word addition
+// (out of lane 63 into lane 0 of the next round: the look-ahead sum takes it as its carry-in) and the top bits of ph / mh that the
+// shift moves into the next word. The sliding stripe shifts every word down by one bit first, word w taking the low bit of word
+// w + 1 -- lane 63 of round j that of lane 0 of round j + 1 -- from the values of the previous column. State (pv, mv, score of W
+// words) stays in registers; the pattern words come from the pair's table in LDS (two loads per word and column, all of a
+// column's independent of each other). Before this a band of more than 64 words ran on ONE lane: the full-matrix Myers class
+// on 32 pairs of 65 536 bases (band attempts of 103 words) took 2.8 s.
+// ------------------------------------------------------------------------------------------------
+template <int W> struct MultiState
+{
+    uint32_t pv[W], mv[W];
+    int32_t sc[W];
+};
+
+// one round: like group_advance<64>, with the chain values of the round below (cin01: carry into lane 0; ph_in / mh_in: bits
+// shifted into lane 0's word) and those for the round above
+__device__ __forceinline__ void multi_advance(uint32_t eq, uint32_t& pv, uint32_t& mv, uint32_t& ph_out, uint32_t& mh_out, uint32_t& carry,
+                                              uint32_t& ph_top, uint32_t& mh_top)
+{
+    const int lane     = threadIdx.x & 63;
+    const uint32_t xv  = eq | mv;
+    const uint32_t a   = eq & pv;
+    const uint32_t s0  = a + pv;
+    const uint64_t gen = __ballot(s0 < a), prp = __ballot(s0 == 0xffffffffu);
+    // carries into every lane at once: (gen | prp) + gen + carry-in ripples like the word carries do; bit 63 is kept out of the
+    // addition (its carry-out is the next round's carry-in, taken separately)
+    const uint64_t top = 1ull << 63;
+    const uint64_t A = (gen | prp) & ~top, B = gen & ~top;
+    const uint64_t cin = (A + B + (uint64_t)carry) ^ (prp & ~top);
+    const uint32_t c_me = (uint32_t)((cin >> lane) & 1u);
+    const uint32_t sum = s0 + c_me;
+    // carry out of lane 63: generated there, or propagated from its carry-in
+    carry = (uint32_t)(((gen >> 63) | ((prp >> 63) & (cin >> 63))) & 1u);
+    const uint32_t xh  = (sum ^ pv) | eq;
+    const uint32_t ph  = mv | ~(xh | pv);
+    const uint32_t mh  = pv & xh;
+    uint32_t ph_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(ph >> 31), 0x138, 0xf, 0xf, false); // wave_shr:1
+    uint32_t mh_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)(mh >> 31), 0x138, 0xf, 0xf, false);
+    if (lane == 0)
+    {
+        ph_lo = ph_top;
+        mh_lo = mh_top;
+    }
+    ph_top = (uint32_t)__builtin_amdgcn_readlane((int32_t)(ph >> 31), 63);
+    mh_top = (uint32_t)__builtin_amdgcn_readlane((int32_t)(mh >> 31), 63);
+    const uint32_t phs = (ph << 1) | ph_lo, mhs = (mh << 1) | mh_lo;
+    pv     = mhs | ~(xv | phs);
+    mv     = phs & xv;
+    ph_out = ph;
+    mh_out = mh;
+}
+
+// the 32 pattern bits of band word w for base ci when the band's window starts `begin` bits into the query
+__device__ __forceinline__ uint32_t multi_eq(const PairTable& patterns, int32_t n_words_query, int32_t w, int32_t begin, uint32_t ci)
+{
+    const int32_t q   = w + begin / kWord;
+    const uint32_t lo = (q >= 0 && q < n_words_query) ? patterns[q * 4 + (int32_t)ci] : 0u;
+    const uint32_t hi = (q + 1 >= 0 && q + 1 < n_words_query) ? patterns[(q + 1) * 4 + (int32_t)ci] : 0u;
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(begin % kWord));
+}
+
+template <int W>
+__device__ __forceinline__ void multi_horizontal_band(Band& b, GroupCtx<64>& c, const PairTable& patterns, int32_t n_words_query, int32_t t_begin,
+                                                      int32_t t_end, int32_t width, int32_t n_words, int32_t pattern_offset, MultiState<W>& st)
+{
+    const int lane = threadIdx.x & 63;
+    TargetWords<64> tw{0u, INT32_MIN};
+    const size_t step = (size_t)b.n_rows * b.stride;
+    size_t at0        = b.at(lane, t_begin);
+    for (int32_t t = t_begin; t < t_end; ++t, at0 += step)
+    {
+        const uint32_t ci = group_target_code<64>(c, tw, t - 1);
+        uint32_t carry = 0u, ph_top = 1u, mh_top = 0u; // the band's top border is the worst case: +1
+#pragma unroll
+        for (int j = 0; j < W; j++)
+        {
+            const int32_t w   = j * 64 + lane;
+            const uint32_t eq = multi_eq(patterns, n_words_query, w, pattern_offset, ci);
+            uint32_t ph, mh;
+            multi_advance(eq, st.pv[j], st.mv[j], ph, mh, carry, ph_top, mh_top);
+            const uint32_t hbit = 1u << (w == n_words - 1 ? width - (n_words - 1) * kWord - 1 : kWord - 1);
+            st.sc[j] += ((ph & hbit) ? 1 : 0) - ((mh & hbit) ? 1 : 0);
+            if (w < n_words)
+            {
+                const size_t at = at0 + (size_t)(j * 64) * b.stride;
+                b.pv[at]    = st.pv[j];
+                b.mv[at]    = st.mv[j];
+                b.score[at] = st.sc[j];
+            }
+        }
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void multi_diagonal_band(Band& b, GroupCtx<64>& c, const PairTable& patterns, int32_t n_words_query, int32_t t_begin,
+                                                    int32_t t_end, int32_t band_width, int32_t n_words, int32_t pattern_offset, MultiState<W>& st)
+{
+    const int lane = threadIdx.x & 63;
+    TargetWords<64> tw{0u, INT32_MIN};
+    const size_t step = (size_t)b.n_rows * b.stride;
+    size_t at0        = b.at(lane, t_begin);
+    int32_t begin     = pattern_offset + 1; // the window slides one bit per column
+    for (int32_t t = t_begin; t < t_end; ++t, ++begin, at0 += step)
+    {
+        const uint32_t ci = group_target_code<64>(c, tw, t - 1);
+        // the band slides one row down: word w takes the low bit of word w + 1 (of the previous column) as its top bit
+#pragma unroll
+        for (int j = 0; j < W; j++)
+        {
+            const int32_t w = j * 64 + lane;
+            uint32_t pv_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)st.pv[j], 0x130, 0xf, 0xf, false); // wave_shl:1
+            uint32_t mv_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)st.mv[j], 0x130, 0xf, 0xf, false);
+            if (j + 1 < W) // lane 63's neighbour is lane 0 of the round above (still the previous column's value)
+            {
+                const int jn      = j + 1 < W ? j + 1 : j; // (a constant once the loop is unrolled)
+                const uint32_t pn = (uint32_t)__builtin_amdgcn_readlane((int32_t)st.pv[jn], 0);
+                const uint32_t mn = (uint32_t)__builtin_amdgcn_readlane((int32_t)st.mv[jn], 0);
+                if (lane == 63)
+                {
+                    pv_up = pn;
+                    mv_up = mn;
+                }
+            }
+            uint32_t pv = st.pv[j] >> 1, mv = st.mv[j] >> 1;
+            if (w + 1 < n_words)
+            {
+                pv |= pv_up << (kWord - 1);
+                mv |= mv_up << (kWord - 1);
+            }
+            if (w == n_words - 1)
+            {
+                const uint32_t ddb = 2u << (band_width - (n_words - 1) * kWord - 2);
+                pv |= ddb; // bottom bit has no left neighbour: assume the worst case (+1)
+                mv &= ~ddb;
+            }
+            st.pv[j] = pv;
+            st.mv[j] = mv;
+        }
+        uint32_t carry = 0u, ph_top = 1u, mh_top = 0u;
+#pragma unroll
+        for (int j = 0; j < W; j++)
+        {
+            const int32_t w   = j * 64 + lane;
+            const uint32_t eq = multi_eq(patterns, n_words_query, w, begin, ci);
+            uint32_t ph, mh;
+            multi_advance(eq, st.pv[j], st.mv[j], ph, mh, carry, ph_top, mh_top);
+            const uint32_t drb = 1u << (w == n_words - 1 ? band_width - (n_words - 1) * kWord - 2 : kWord - 2);
+            const uint32_t ddb = drb << 1;
+            const int32_t hx   = ((ph & drb) ? 1 : 0) - ((mh & drb) ? 1 : 0);
+            const int32_t down = ((st.pv[j] & ddb) ? 1 : 0) - ((st.mv[j] & ddb) ? 1 : 0);
+            st.sc[j] += hx + down;
+            if (w < n_words)
+            {
+                const size_t at = at0 + (size_t)(j * 64) * b.stride;
+                b.pv[at]    = st.pv[j];
+                b.mv[at]    = st.mv[j];
+                b.score[at] = st.sc[j];
+            }
+        }
+    }
+}
+
+// one band attempt of n_words_band <= 64 W words on the whole wavefront; returns the last word's score in the last column
+template <int W>
+__device__ __forceinline__ int32_t multi_attempt(Band& b, GroupCtx<64>& c, const PairTable& patterns, int32_t n_words, int32_t query_size,
+                                                 int32_t target_size, int32_t p, int32_t dlen, int32_t n_words_band, int32_t band_width,
+                                                 int32_t& diagonal_begin, int32_t& diagonal_end)
+{
+    const int lane = threadIdx.x & 63;
+    MultiState<W> st;
+#pragma unroll
+    for (int j = 0; j < W; j++)
+    {
+        const int32_t w = j * 64 + lane;
+        st.pv[j] = ~0u;
+        st.mv[j] = 0u;
+        st.sc[j] = min((w + 1) * kWord, band_width);
+        if (w < n_words_band)
+        {
+            const size_t at = b.at(w, 0);
+            b.pv[at]    = st.pv[j];
+            b.mv[at]    = st.mv[j];
+            b.score[at] = st.sc[j];
+        }
+    }
+    c.lo = -(1 << 30);
+    if (band_width >= query_size)
+    {
+        diagonal_begin = target_size + 1;
+        diagonal_end   = target_size + 1;
+        multi_horizontal_band<W>(b, c, patterns, n_words, 1, target_size + 1, query_size, n_words_band, 0, st);
+    }
+    else
+    {
+        const int32_t symmetric = (band_width - min(1 + 2 * p + dlen, query_size) == 0) ? 1 : 0;
+        diagonal_begin = query_size < target_size ? target_size - query_size + p + 2 : p + 2 + (1 - symmetric);
+        diagonal_end   = query_size < target_size ? query_size - p + symmetric : query_size - (query_size - target_size) - p + 1;
+        multi_horizontal_band<W>(b, c, patterns, n_words, 1, diagonal_begin, band_width, n_words_band, 0, st);
+        multi_diagonal_band<W>(b, c, patterns, n_words, diagonal_begin, diagonal_end, band_width, n_words_band, 0, st);
+        multi_horizontal_band<W>(b, c, patterns, n_words, diagonal_end, target_size + 1, band_width, n_words_band, query_size - band_width, st);
+    }
+    // the last word's score in the last column: word n_words_band - 1 = round (n - 1) / 64, lane (n - 1) % 64
+    int32_t dist = 0;
+#pragma unroll
+    for (int j = 0; j < W; j++)
+    {
+        const int32_t v = __shfl(st.sc[j], (n_words_band - 1) % 64); // (every lane takes part in every shuffle)
+        if ((n_words_band - 1) / 64 == j) dist = v;
+    }
+    return dist;
+}
+
+// The group kernel's door to it: only a whole wavefront per pair (G = 64) can take a band of more than G words this way. A
+// function of its own, NOT inlined: with the 32-round instantiation's ~100 state registers inside the kernel's body the
+// ordinary one-word-per-lane stripes of the same kernel lost 20 % (myers_banded at 64 kbp: 67 -> 82 ms); everything goes in and
+// out by value.
+struct MultiResult
+{
+    int32_t dist, diagonal_begin, diagonal_end;
+};
+__device__ __attribute__((noinline)) MultiResult multi_attempt_any(Band b, GroupCtx<64> c, PairTable patterns, int32_t n_words, int32_t query_size,
+                                                                   int32_t target_size, int32_t p, int32_t dlen, int32_t n_words_band,
+                                                                   int32_t band_width)
+{
+    MultiResult r{0, -1, -1};
+    const int32_t rounds = (n_words_band + 63) / 64;
+#define GW_MULTI(W) r.dist = multi_attempt<W>(b, c, patterns, n_words, query_size, target_size, p, dlen, n_words_band, band_width, r.diagonal_begin, r.diagonal_end)
+    if (rounds <= 2) GW_MULTI(2);
+    else if (rounds <= 4) GW_MULTI(4);
+    else if (rounds <= 8) GW_MULTI(8);
+    else if (rounds <= 16) GW_MULTI(16);
+    else GW_MULTI(32);
+#undef GW_MULTI
+    return r;
+}
+template <int G>
+__device__ __forceinline__ bool multi_attempt_for_group(const Band& b, const GroupCtx<G>& ctx, const PairTable& patterns, int32_t n_words,
+                                                        int32_t query_size, int32_t target_size, int32_t p, int32_t dlen, int32_t n_words_band,
+                                                        int32_t band_width, int32_t& diagonal_begin, int32_t& diagonal_end, int32_t& dist)
+{
+    if constexpr (G == 64)
+    {
+        if (n_words_band > 64 * 32) return false;
+        const MultiResult r = multi_attempt_any(b, ctx, patterns, n_words, query_size, target_size, p, dlen, n_words_band, band_width);
+        dist           = r.dist;
+        diagonal_begin = r.diagonal_begin;
+        diagonal_end   = r.diagonal_end;
+        return true;
+    }
+    else
+        return false;
+}
+
 // PAIRS pairs per block (a divisor of 64): the workspace regions stay those of 64 slots -- block j works on slots
 // [PAIRS j, PAIRS j + PAIRS) of region PAIRS j / 64 -- but a block is PAIRS G / 64 wavefronts, so that a small batch spreads
 // over all CUs with one busy wavefront per SIMD (the column step is vector work back to back: two such wavefronts on one
@@ -1115,6 +1371,13 @@ __global__ __launch_bounds__(WAVES * 64) void myers_banded_group_kernel(KernelAr
             // the last word's score in the last column, to every lane of the group
             dist = __shfl(sc, gbase + n_words_band - 1);
             if (a.debug_skip & 2) dist = b.score[b.at(n_words_band - 1, target_size)];
+        }
+        else if (!(a.debug_skip & (2 | 8)) &&
+                 multi_attempt_for_group<G>(b, ctx, patterns, n_words, query_size, target_size, p, dlen, n_words_band, band_width, diagonal_begin,
+                                            diagonal_end, dist))
+        {
+            // a band wider than the wavefront that owns the pair: several words per lane (multi_attempt above; GWHIP_MYERS_SKIP
+            // bit 3 sends it down the one-lane stripes below instead, for A/B runs)
         }
         else
         {

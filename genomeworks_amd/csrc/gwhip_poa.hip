@@ -979,7 +979,7 @@ int gwhip_poa_generate(const gwhip_poa_args* args, gwhip_stream_t stream_)
             int cus = 0, dev = 0;
             (void)hipGetDevice(&dev);
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-            const int32_t cap = (args->cfg.max_nodes_per_graph > kConsLdsNodesSmall && args->total_windows > 2 * cus &&
+            const int32_t cap = (args->cfg.max_nodes_per_graph > kConsLdsNodesSmall && (args->total_windows > 2 * cus || args->shared_device != 0) &&
                                  !(cons_dbg && cons_dbg[0] == '2'))
                                     ? kConsLdsNodesSmall
                                     : std::min<int32_t>(args->cfg.max_nodes_per_graph, kConsLdsNodes);

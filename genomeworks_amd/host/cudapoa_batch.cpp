@@ -169,6 +169,17 @@ gwhip_poa_config make_device_config(const BatchConfig& b, int8_t output_mask, in
     return c;
 }
 
+// Batch objects alive per device: with more than one, kernels of different batches may share the device
+// (gwhip_poa_args::shared_device).
+namespace
+{
+std::atomic<int32_t>& live_batches(int32_t device)
+{
+    static std::atomic<int32_t> table[64];
+    return table[static_cast<uint32_t>(device) & 63u];
+}
+} // namespace
+
 // ---- PoaBatch ------------------------------------------------------------------------------------------
 PoaBatch::PoaBatch(int32_t device_id, cudaStream_t stream, DefaultDeviceAllocator allocator, int64_t max_mem,
                    int8_t output_mask, const BatchConfig& batch_size, int32_t gap_score, int32_t mismatch_score,
@@ -253,6 +264,7 @@ PoaBatch::PoaBatch(int32_t device_id, cudaStream_t stream, DefaultDeviceAllocato
     // the read-ahead slack is zeroed on the device -- clearing 2 x 600 MB of pinned memory was most of the construction time of
     // a BatchConfig(1024, 200) batch with tens of GB of device memory)
 
+    live_batches(device_id_).fetch_add(1);
     debug_message(" Initializing batch on device ");
     reset();
 }
@@ -262,6 +274,7 @@ PoaBatch::~PoaBatch()
     debug_message(" Destroyed buffers on device ");
     scoped_device_switch dev(device_id_);
     (void)hipStreamSynchronize(stream_);
+    live_batches(device_id_).fetch_sub(1);
     if (host_block_ != nullptr) cudaaligner::pinned_release(host_block_, host_block_capacity_);
     if (device_block_ != nullptr) allocator_.deallocate(device_block_, device_block_bytes_);
 }
@@ -439,6 +452,7 @@ gwhip_poa_args PoaBatch::kernel_args() const
     a.workspace_bytes  = workspace_bytes_;
     a.cells            = d_cells_;
     a.work_counters    = d_work_counters_;
+    a.shared_device    = live_batches(device_id_).load(std::memory_order_relaxed) > 1 ? 1 : 0;
     return a;
 }
 

@@ -105,6 +105,11 @@ typedef struct gwhip_poa_args
        one -- instead of one block per window (replacement blocks land on SIMDs that are still busy: 2048 full-band windows
        took 2.47 x the time of 1024). The last block to finish zeroes both words again. NULL: one block per window. */
     uint32_t* work_counters;
+    /* non-zero: other batches' kernels may run on the device at the same time (several Batch objects on host threads). The
+       consensus kernel then keeps to the LDS footprint of the graph-build kernel's blocks (tables for 2176 nodes, larger graphs
+       through the HBM routine) even for small batches: a 55 KB block needs two neighbouring slots of a CU to fall free at once
+       and was seen waiting 46 ms for them behind another batch's window kernel (profiles/r06_multibatch_timeline.txt). */
+    int32_t shared_device;
 } gwhip_poa_args;
 
 /* Bytes of scratch needed for `windows` windows under cfg (host function, no GPU needed).

@@ -513,6 +513,41 @@ def test_myers_class_bit_exact_vs_oracle():
         assert r.cigar == ref["cigar"]
 
 
+def test_myers_class_bands_wider_than_a_wavefront_equal_the_oracle(monkeypatch):
+    """Band attempts of more than 64 words (round 6: several words per lane of the wavefront that owns the pair,
+    multi_attempt in gwhip_myers.hip; before: one lane). Long pairs whose first attempts fail -- unrelated sequences, pairs at
+    30 % divergence, different lengths -- so that the doubling reaches bands of 2 .. 8 rounds of 64 words, horizontal stripes
+    alone (band = query) and with the sliding stripe; against the full-matrix oracle, and against the one-lane stripes
+    (GWHIP_MYERS_SKIP=8) on the same pairs."""
+    from genomeworks_amd import cudaaligner
+    rng = random.Random(66)
+    rand = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    pairs = []
+    q = rand(8192)
+    pairs.append((q, _mutate(rng, q, 2400)[:8192]))           # 30 % divergence: attempts of 13, 26, 52, 103 words
+    pairs.append((rand(9000), rand(12000)))                    # unrelated, |dlen| 3000: the band ends up covering the query
+    pairs.append((rand(16000), rand(15000)))                   # unrelated: 500 words, eight rounds
+    q = rand(5000)
+    pairs.append((q, _mutate(rng, q, 2000)[:6000]))
+    pairs.append((rand(4200), rand(4100)))
+    max_len = 16384
+
+    def run():
+        al = cudaaligner.CudaAlignerBatch(max_len, max_len, len(pairs), algorithm="myers", max_device_memory_allocator_caching_size=64 << 30)
+        for a, b in pairs:
+            assert al.add_alignment(a, b) == 0
+        al.align_all()
+        return [(r.status, bool(r.is_optimal), list(r.alignment)) for r in al.get_alignments()]
+
+    got = run()
+    for (st, opt, states), (a, b) in zip(got, pairs):
+        ref = A.myers_full(a, b)
+        assert st == 0 and opt
+        assert states == ref["states"], (len(a), len(b))
+    monkeypatch.setenv("GWHIP_MYERS_SKIP", "8")
+    assert run() == got
+
+
 def test_aligner_matrix_cells_equal_the_golden():
     """The cells of the reference's aligner benchmark matrix that bench.py publishes (cudaaligner/benchmarks/main.cpp:69-168:
     AlignerGlobalUkkonen, AlignerGlobalMyers, AlignerGlobalMyersBanded, AlignerGlobalHirschbergMyers at 1024 x 2048 bases;
