@@ -848,6 +848,10 @@ def emit(headline, strong, strong8, sub, record_dir):
         print("bench.py: could not write the full record (%s)" % e, file=sys.stderr)
         pointer = None
     final = dict(headline)
+    if isinstance(final.get("roofline_issue"), dict):  # (the whole object is in the file; the line keeps the ratios)
+        keep = ("bound", "instructions_per_wave", "cycles_per_wave", "cycles_per_instruction", "lone_wave_cycles_per_instruction", "frac",
+                "wait_share", "valu_busy", "closest_limit", "source")
+        final["roofline_issue"] = {k: final["roofline_issue"][k] for k in keep if k in final["roofline_issue"]}
     # what the sub-records said, in one small object: name -> golden verdict (every row of the record ANDed) + its value
     final["sub_records"] = {"file": pointer, "lines": "one {\"sub_record\": ...} stdout line each, before this line",
                             "summary": {k: sub_summary(v) for k, v in extras.items()}}
