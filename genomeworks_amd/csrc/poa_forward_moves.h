@@ -169,9 +169,12 @@ __device__ __forceinline__ void banded_forward_moves(const GraphView<IdT>& g, Ro
     // buffers of an unablated launch of the same batch): bit 26 no score-row stores, bit 27 no move-row stores
     // (tools/microbench_rows.hip only, results are garbage: bit 20 no ring write, 19 no guard write, 18 no cross-lane scan,
     // 17 no move bytes, 16 no rows at all)
-    const bool st_scores = !(dbg & (1 << 26)), st_moves = !(dbg & (1 << 27));
-    const bool ab_ring = !(dbg & (1 << 20)), ab_guard = !(dbg & (1 << 19)), ab_scan = !(dbg & (1 << 18)), ab_moves = !(dbg & (1 << 17)),
-               ab_rows = !(dbg & (1 << 16));
+    // (all of them only with bit 14 set: the same bits are the merge / topsort profiling selectors of the window kernel, 16-18 and
+    // 25-27 -- tools/profile_subphases.sh's topsort selectors 2, 3 and 6 switched the row stores off until round 6)
+    const bool abl       = (dbg & (1 << 14)) != 0;
+    const bool st_scores = !(abl && (dbg & (1 << 26))), st_moves = !(abl && (dbg & (1 << 27)));
+    const bool ab_ring = !(abl && (dbg & (1 << 20))), ab_guard = !(abl && (dbg & (1 << 19))), ab_scan = !(abl && (dbg & (1 << 18))),
+               ab_moves = !(abl && (dbg & (1 << 17))), ab_rows = !(abl && (dbg & (1 << 16)));
     // profiling (GWHIP_DEBUG bits 28-30 = row kind + 1): cycles spent in rows of that kind, or with bit 12 their number;
     // arrives in the "other" phase accumulator
     const int32_t ksel = prof_acc ? ((dbg >> 28) & 7) - 1 : -1;

@@ -127,7 +127,8 @@ __device__ __forceinline__ void full_forward_moves(const GraphView<IdT>& g, RowI
     auto pack_moves = [&](uint32_t m01, uint32_t m23) -> uint32_t { return __builtin_amdgcn_perm(m23, m01, 0x06040200u); };
     // timing ablations (GWHIP_DEBUG, debug instantiation only; results are garbage): bit 26 no score-row stores, bit 27 no
     // move-row stores
-    const bool st_scores = !(dbg & (1 << 26)), st_moves = !(dbg & (1 << 27));
+    const bool abl       = (dbg & (1 << 14)) != 0; // (the store ablations only with bit 14: bits 26 / 27 are topsort selectors too)
+    const bool st_scores = !(abl && (dbg & (1 << 26))), st_moves = !(abl && (dbg & (1 << 27)));
     // the finished row (P*) of row r with H[r][0] = c0: HBM score row, ring slot r & 3, move bytes. Both HBM stores are
     // streaming stores (round 5, same-box A/B on the 1024 windows: 59.0 -> 55.2 ms; the matrices of a full-band batch are 10 GB,
     // far beyond every cache level, and the walk reads a sliver of the move rows)

@@ -125,7 +125,7 @@ int main(int argc, char** argv)
         {
             if (p != 0 && p != 5 && ab.bits != 0 && ab.bits != ((1 << 26) | (1 << 27)) && ab.bits != (1 << 16)) continue; // full ablation table for kind 0 and the mix
             a.pattern = p;
-            a.dbg     = ab.bits;
+            a.dbg     = ab.bits ? (ab.bits | (1 << 14)) : 0; // (bit 14 enables the ablation bits, poa_forward_moves.h)
             double best_ms = 1e30, cyc = 0;
             for (int it = 0; it < 3; it++)
             {

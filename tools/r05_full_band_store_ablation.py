@@ -17,8 +17,8 @@ for w in windows:
 b.generate_poa()
 b.get_consensus_native()
 out = {}
-for name, flag in (("production", None), ("debug_instantiation", 32), ("no_score_rows", 1 << 26), ("no_move_rows", 1 << 27),
-                   ("neither", (1 << 26) | (1 << 27)), ("debug_instantiation_again", 32), ("production_again", None)):
+for name, flag in (("production", None), ("debug_instantiation", 32), ("no_score_rows", (1 << 14) | (1 << 26)), ("no_move_rows", (1 << 14) | (1 << 27)),
+                   ("neither", (1 << 14) | (1 << 26) | (1 << 27)), ("debug_instantiation_again", 32), ("production_again", None)):
     if flag is None:
         os.environ.pop("GWHIP_DEBUG", None)
     else:
