@@ -103,8 +103,9 @@ def test_config4_plan_is_reproducible_and_oracle_sample_matches():
 
 def test_long_read_prefix_fixture_of_the_reference_and_oracle_sample():
     """tests/golden/reference_simt_long_prefixes.json (the reference's own answers for cut-down windows of the two largest
-    size classes of configs[3]): the file covers both classes with windows that the whole-window check has not, every row was
-    equal to the oracle when it was written, and the oracle still reproduces the cheapest rows of every set."""
+    size classes of configs[3]): the file covers both classes, every row was equal to the oracle when it was written, the oracle
+    still reproduces the cheapest rows of every set, and reference_simt_config_check.json lists these windows beside the 424 whole
+    windows of all four size classes that the reference has answered."""
     import importlib.util
     import json
     import os
@@ -118,11 +119,17 @@ def test_long_read_prefix_fixture_of_the_reference_and_oracle_sample():
     with open(os.path.join(here, "config4_long_reads.json")) as f:
         golden = json.load(f)
     with open(os.path.join(here, "reference_simt_config_check.json")) as f:
-        whole = set(json.load(f)["config4"]["windows_checked"])
+        check = json.load(f)
     rows = fixture["windows"]
     assert fixture["batch_configs"] == golden["batch_configs"][:2]
     assert len(rows) >= 60 and all(r["oracle_equal"] and r["add_status"] == 0 for r in rows)
-    assert not whole & {r["w"] for r in rows}
+    # the record of what the reference has answered lists them (beside the whole windows: 245 when these were cut, 424 since)
+    assert sorted(r["w"] for r in rows) == check["config4_prefixes"]["windows_checked"] and not check["config4_prefixes"]["windows_differing"]
+    assert len(check["config4"]["windows_checked"]) >= 424 and not check["config4"]["windows_differing"]
+    by_class = {}
+    for w in check["config4"]["windows_checked"]:
+        by_class[golden["windows_detail"][w]["cfg"]] = by_class.get(golden["windows_detail"][w]["cfg"], 0) + 1
+    assert by_class[3] == 130 and by_class[2] == 160 and by_class[1] >= 93 and by_class[0] >= 41  # every size class
     assert all(golden["windows_detail"][r["w"]]["cfg"] == r["cfg"] for r in rows)
     for n_reads in sorted({r["reads"] for r in rows}):
         cheapest = min((r for r in rows if r["reads"] == n_reads), key=lambda r: r["cells"])

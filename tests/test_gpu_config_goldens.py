@@ -159,8 +159,8 @@ def test_long_read_prefixes_equal_the_reference_itself():
     """tests/golden/reference_simt_long_prefixes.json: windows of the two LARGEST size classes of configs[3] (reads of 7.6-30 kbp:
     32-bit scores and ids, HBM row tables, the adaptive band growing from 256 towards its 1536-column cap) cut to their first 4, 8
     or 12 reads and answered by the REFERENCE's own cudapoa library on the SIMT emulator
-    (tests/golden/make_reference_simt_long_prefixes.py). None of them is among the 245 whole windows that
-    reference_simt_config_check.json covers. The HIP path, in a batch of the class's BatchConfig, gives the same statuses and MSA rows."""
+    (tests/golden/make_reference_simt_long_prefixes.py). None of them was among the 245 whole windows that
+    reference_simt_config_check.json covered when they were cut (424 since). The HIP path, in a batch of the class's BatchConfig, gives the same statuses and MSA rows."""
     import importlib.util
     import json
     import os
